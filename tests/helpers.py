@@ -1,0 +1,49 @@
+"""Shared test helpers: golden loading and oracle parameter construction."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        return {k: torch.from_numpy(z[k]) if z[k].ndim > 0 else z[k].item() for k in z.files}
+
+
+def t(x, requires_grad=False):
+    x = x.clone()
+    x.requires_grad_(requires_grad)
+    return x
+
+
+def oracle_field_params(g, prefix="", log2t_key="log2t", requires_grad=False, static_scale=100.0):
+    from oracle.field import FieldParams, GridParams
+
+    def layers(tag):
+        out, i = [], 0
+        while f"{prefix}{tag}_w{i}" in g:
+            out.append((t(g[f"{prefix}{tag}_w{i}"], requires_grad), t(g[f"{prefix}{tag}_b{i}"], requires_grad)))
+            i += 1
+        return out
+
+    grid = GridParams(t(g[f"{prefix}table"], requires_grad), g[f"{prefix}scalings"], int(g[log2t_key]))
+    return FieldParams(grid, layers("geo"), layers("feat"), t(g[f"{prefix}beta"], requires_grad), static_scale)
+
+
+def oracle_prop_params(g, prefix="prop_", log2t_key="prop_log2t", requires_grad=False, static_scale=100.0):
+    from oracle.field import GridParams, ProposalParams
+
+    grid = GridParams(t(g[f"{prefix}table"], requires_grad), g[f"{prefix}scalings"], int(g[log2t_key]))
+    return ProposalParams(grid, t(g[f"{prefix}decoder"], requires_grad), static_scale)
+
+
+def assert_close(actual, expected, rtol=1e-4, atol_scale=1e-5, what=""):
+    """rel tolerance `rtol` with an absolute floor of atol_scale * max|expected| (the north-star's
+    "within 1e-4 rel" is meaningless for entries that are ~0 against O(1) neighbours)."""
+    if not isinstance(expected, torch.Tensor):
+        expected = torch.as_tensor(expected, dtype=actual.dtype).reshape(actual.shape)
+    expected = expected.to(actual.dtype)
+    scale = float(expected.abs().max()) if expected.numel() else 1.0
+    torch.testing.assert_close(actual, expected, rtol=rtol, atol=atol_scale * max(scale, 1e-30), msg=lambda m: f"{what}: {m}")
