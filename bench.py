@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Benchmark of the NeuRadar hot path on MI355X: training rays/s.
+
+One "step" = one pass of the hot path over one batch of synthetic sensor poses, everything resident
+in HBM: on-device patch sampling + camera ray generation -> proposal sampling (2 rounds) -> hash-grid
+encoding -> MFMA field MLP -> alpha compositing -> bench loss -> backward (scatter-add into the
+tables, MLP weight grads) -> dense Adam on every parameter.  Weak scaling: every rank draws its own
+full batch (the reference's semantics), gradients are mean-all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant hash-grid
+kernel, HIP-event timed on its launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: camera-only, L=16/F=2 hash + 64-wide MLP, 4096 rays
+    "cam4096_l16f2_w64": dict(rays=4096, grid=dict(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024,
+                                                   log2_hashmap_size=19), hidden=64),
+    # NeuRadar's own field dims: L=8/F=4/T=2^22, 32-wide
+    "cam4096_neuradar": dict(rays=4096, grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192,
+                                                  log2_hashmap_size=22), hidden=32),
+    "cam16384_neuradar": dict(rays=16384, grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192,
+                                                    log2_hashmap_size=22), hidden=32),
+    "cam16384_l16f2_w64": dict(rays=16384, grid=dict(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024,
+                                                     log2_hashmap_size=19), hidden=64),
+}
+
+
+def build_model(wl, device):
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
+
+    cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(**wl["grid"])),
+                                                geo_hidden_dim=wl["hidden"], nff_hidden_dim=wl["hidden"]))
+    torch.manual_seed(0)  # identical replicas on every rank
+    return NeuRadarHotPath(cfg).to(device).train()
+
+
+class SyntheticScene:
+    """Seeded synthetic sensor rig: ego drives 0->100 m in 20 s, 10 Hz forward camera,
+    1920x1080 pinhole with fx=fy=2000, rolling shutter; 32x32 patches at stride 3."""
+
+    H, W, PATCH, STRIDE = 1080, 1920, 32, 3
+
+    def __init__(self, device, seed):
+        from neuradar_amd.sensors import Cameras
+
+        g = torch.Generator().manual_seed(seed)
+        n = 200
+        t = torch.linspace(0, 20, n)
+        c2w = torch.zeros(n, 3, 4)
+        # camera looks along +x (OpenGL: -z is forward, +y up): columns = right, up, back
+        c2w[:, :, 0] = torch.tensor([0.0, -1.0, 0.0])
+        c2w[:, :, 1] = torch.tensor([0.0, 0.0, 1.0])
+        c2w[:, :, 2] = torch.tensor([-1.0, 0.0, 0.0])
+        c2w[:, 0, 3] = -50.0 + 5.0 * t
+        c2w[:, 1, 3] = 0.5 * torch.randn(n, generator=g)
+        c2w[:, 2, 3] = 1.6
+        ones = torch.ones(n)
+        self.cameras = Cameras(c2w.to(device), (2000.0 * ones).to(device), (2000.0 * ones).to(device),
+                               (self.W / 2 * ones).to(device), (self.H / 2 * ones).to(device),
+                               (self.H * ones).to(device), t.to(device),
+                               torch.tensor([[5.0, 0.0, 0.0]]).repeat(n, 1).to(device),
+                               torch.tensor([[-0.015, 0.015]]).repeat(n, 1).to(device))
+        self.n_cams = n
+        self.device = device
+        ar = torch.arange(self.PATCH, device=device) * self.STRIDE
+        self.dy, self.dx = torch.meshgrid(ar, ar, indexing="ij")
+
+    def sample_ray_indices(self, n_rays):
+        """On-device patch sampler: n_rays/1024 random (camera, y0, x0) patches -> [n_rays,3] int64."""
+        n_p = n_rays // (self.PATCH * self.PATCH)
+        span = self.PATCH * self.STRIDE
+        cam = torch.randint(0, self.n_cams, (n_p, 1, 1), device=self.device)
+        y0 = torch.randint(0, self.H - span, (n_p, 1, 1), device=self.device)
+        x0 = torch.randint(0, self.W - span, (n_p, 1, 1), device=self.device)
+        idx = torch.stack([cam.expand(-1, self.PATCH, self.PATCH), y0 + self.dy, x0 + self.dx], dim=-1)
+        return idx.reshape(-1, 3)
+
+
+def make_step(model, scene, opts, reducer, targets, n_rays):
+    """Returns (fwd_bwd, optim) closures; together they are one training step."""
+    from neuradar_amd.sensors import scale_pixel_area
+
+    tgt_f, tgt_d = targets
+
+    def fwd_bwd():
+        bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
+        scale_pixel_area(bundle)
+        out = model.get_nff_outputs(bundle)
+        loss = model.bench_loss(out, tgt_f, tgt_d)
+        loss.backward()
+        return loss.detach()
+
+    def optim():
+        reducer.all_reduce()
+        for o in opts:
+            o.step()
+
+    return fwd_bwd, optim
+
+
+def time_kernel(fn, iters=20):
+    """Average device time of `fn` (launches on torch's current stream) via HIP events."""
+    for _ in range(3):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters * 1e-3
+
+
+def roofline_probe(model, scene, n_rays):
+    """HIP-event timing of every hash-grid launch of one step, on the stream they run on.
+    Algorithmic bytes: fwd = N*L*8*F*4 B gathered; bwd = 2x (read-modify-write)."""
+    from neuradar_amd import ops
+    from neuradar_amd.sensors import scale_pixel_area
+
+    with torch.no_grad():
+        bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
+        scale_pixel_area(bundle)
+        out = model.get_nff_outputs(bundle)
+    rows = []
+    fields = [("prop_s128", model.proposal_fields[1], out["ray_samples_list"][0]),
+              ("prop_s64", model.proposal_fields[1], out["ray_samples_list"][1]),
+              ("main_s32", model.field, out["ray_samples"])]
+    for tag, fld, rs in fields:
+        g = fld.hashgrid.static_grid
+        B, S = rs.shape
+        n, L, F = B * S, g.num_levels, g.features_per_level
+        x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, fld.hashgrid.static_scale)
+        buf = torch.empty((L, n, F), device=x01.device)
+        gbuf = torch.randn_like(buf)
+        gtab = torch.zeros_like(g.hash_table)
+        lib, p, st = ops._lib.lib(), ops._p, ops._stream
+        fwd = lambda: lib.nr_hash_encode_fwd(p(x01), p(std01), p(g.hash_table), p(g.scalings), L, F,  # noqa: E731
+                                             g.log2_hashmap_size, p(buf), F, n * F, n, S, st())
+        bwd = lambda: lib.nr_hash_encode_bwd(p(x01), p(std01), p(g.scalings), L, F, g.log2_hashmap_size,  # noqa: E731
+                                             p(gbuf), F, n * F, p(gtab), n, S, st())
+        bytes_fwd = n * L * 8 * F * 4
+        rows.append(dict(kernel=f"hash_encode_fwd[{tag}]", seconds=time_kernel(fwd), bytes=bytes_fwd))
+        rows.append(dict(kernel=f"hash_encode_bwd[{tag}]", seconds=time_kernel(bwd), bytes=2 * bytes_fwd))
+    return rows
+
+
+def cpu_baseline(wl, n_rays_sample, threads):
+    """The CPU oracle (port of the reference's torch path) on a bounded sample of the same workload:
+    fwd + bwd of the bench loss, median of 3 after 1 warm-up."""
+    from oracle import field as of, hashgrid as oh, pipeline as op
+
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    gc = wl["grid"]
+
+    def grid(L, F, lo, hi, log2t):
+        return of.GridParams((oh.init_table(L, log2t, F, generator=g)).requires_grad_(True), oh.level_scalings(L, lo, hi), log2t)
+
+    def lin(o, i):
+        k = 1 / math.sqrt(i)
+        return ((torch.rand(o, i, generator=g) * 2 - 1).mul_(k).requires_grad_(True),
+                (torch.rand(o, generator=g) * 2 - 1).mul_(k).requires_grad_(True))
+
+    H = wl["hidden"]
+    fp = of.FieldParams(grid(gc["num_levels"], gc["hashgrid_dim"], gc["base_res"], gc["max_res"], gc["log2_hashmap_size"]),
+                        [lin(H, 32), lin(33, H)], [lin(H, 48), lin(H, H), lin(32, H)], torch.full((1,), 20.0, requires_grad=True))
+    pp = of.ProposalParams(grid(6, 1, 128, 4096, 20), (torch.rand(1, 6, generator=g) - 0.5).requires_grad_(True))
+    B = n_rays_sample
+    o = torch.cat([-50 + 100 * torch.rand(B, 1, generator=g), torch.randn(B, 1, generator=g), torch.full((B, 1), 1.6)], -1)
+    d = torch.nn.functional.normalize(torch.cat([torch.ones(B, 1), 0.4 * torch.randn(B, 2, generator=g)], -1), dim=-1)
+    bundle = {"origins": o, "directions": d, "pixel_area": torch.full((B, 1), 2.25e-6), "fars": torch.full((B, 1), 1e6)}
+    tf, td = torch.zeros(B, 32), torch.full((B, 1), 20.0)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        out = op.nff_outputs(fp, [pp, pp], bundle, torch.rand(B, 129, generator=g), (torch.rand(B, 1, generator=g),) * 2)
+        loss = op.train_loss(out, tf, td)
+        torch.autograd.grad(loss, fp.tensors() + pp.tensors())
+        times.append(time.perf_counter() - t0)
+    return B / statistics.median(times[1:])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cam4096_l16f2_w64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=int, default=1024)
+    ap.add_argument("--bf16-allreduce", action="store_true", help="all-reduce the table gradients in bf16")
+    args = ap.parse_args()
+
+    from neuradar_amd import _lib
+    from neuradar_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
+    from neuradar_amd.step import FlatAdam
+
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    wl = WORKLOADS[args.workload]
+    n_rays = wl["rays"]
+
+    model = build_model(wl, device)
+    broadcast_parameters(model)
+    groups = model.get_param_groups()
+    # configs/method_configs.py:384-409: hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
+    opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, lr_final=1e-3, max_steps=20001, warmup_steps=500),
+            FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3,
+                     max_steps=20001, warmup_steps=500)]
+    reducer = GradAllReducer([p for grp in groups.values() for p in grp],
+                             table_dtype=torch.bfloat16 if args.bf16_allreduce else None)
+    scene = SyntheticScene(device, seed=1000 + rank)  # seed + rank, like scripts/train.py:104
+    torch.manual_seed(1234 + rank)
+    targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
+    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays)
+
+    use_graph = not args.no_graph
+    graphs = []
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd()
+                    optim()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                static_loss = fwd_bwd()
+            if world == 1:
+                with torch.cuda.graph(g1 if False else torch.cuda.CUDAGraph()) as _:
+                    pass
+            graphs = [g1]
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph, graphs = False, []
+            torch.cuda.synchronize()
+
+    if use_graph:
+        g_opt = None
+        if world == 1:
+            try:
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_opt):
+                    optim()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] optimizer graph capture failed ({e}); optimizer runs eagerly", file=sys.stderr)
+                g_opt = None
+                torch.cuda.synchronize()
+
+        def step():
+            graphs[0].replay()
+            if g_opt is not None:
+                g_opt.replay()
+            else:
+                optim()
+    else:
+        def step():
+            fwd_bwd()
+            optim()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_rays * args.steps / elapsed
+
+    roof, cpu = None, None
+    if rank == 0 and not args.no_roofline:
+        rows = roofline_probe(model, scene, n_rays)
+        dom = max(rows, key=lambda r: r["seconds"])
+        achieved = dom["bytes"] / dom["seconds"] / 1e9
+        roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_us": round(dom["seconds"] * 1e6, 2), "bytes_per_launch": dom["bytes"],
+                "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
+                                      "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = os.cpu_count() or 1
+        cpu_rate = cpu_baseline(wl, args.cpu_sample_rays, threads)
+        cpu = {"value": round(cpu_rate, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+               "sample": f"{args.cpu_sample_rays} rays of the same workload, fwd+bwd of the bench loss (no optimizer), "
+                         f"median of 3 after 1 warm-up, torch CPU oracle with {threads} threads"}
+    if rank == 0:
+        line = {
+            "metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
+                       "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
+                       "graph": bool(use_graph), "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": reducer.bytes_per_step() if world > 1 else 0},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

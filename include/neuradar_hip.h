@@ -1,0 +1,235 @@
+/*
+ * neuradar_hip.h -- C ABI of libneuradar_hip.so: the MI355X (gfx950) volumetric-rendering hot path
+ * of NeuRadar.  This is the drop-in boundary: each entry point stands in for a
+ * call the reference makes into tiny-cuda-nn / nerfacc / torch on this path, and is what a binding
+ * behind the reference's `implementation=` switch would call (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (torch); the library allocates nothing
+ *     persistent and keeps no global state.  All tensors are contiguous fp32 unless stated.
+ *   - `stream` is a hipStream_t passed as void* (torch's current stream); calls are asynchronous.
+ *   - Return value: 0 on success, a hipError_t (>0) for a runtime failure, NR_EINVAL (-1) for a bad
+ *     argument.  Nothing is thrown across the boundary.
+ *   - "+=" outputs accumulate (atomically) into caller-zeroed buffers -- parameter gradients keep
+ *     the torch layouts (hash_table [L*T,F]; Linear.weight [out,in]; bias [out]) so optimizers,
+ *     state_dict and DDP-style all-reduce see ordinary nn.Parameters.
+ *   - Paths cited as file:line are relative to /root/reference/nerfstudio/.
+ */
+#ifndef NEURADAR_HIP_H
+#define NEURADAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NR_EINVAL (-1)
+#define NR_MAX_LAYERS 8
+#define NR_ABI_VERSION 1
+
+typedef void* nr_stream_t;
+
+/* Library / ABI version (NR_ABI_VERSION) and the code-object target ("gfx950"). */
+int nr_abi_version(void);
+const char* nr_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multiresolution hash grid   -- replaces tcnn.Encoding{HashGrid} fwd/bwd reached from
+ * field_components/encodings.py:370-373,468-471 (K1/K2/K3 in SURVEY 2a) with the semantics of the
+ * torch path encodings.py:406-466: every level hashed, ceil/floor corners, primes
+ * {1, 2654435761, 805459861}, one [L*T, F] table, `scalings[l] = floor(min_res * g^l)` (fp32).
+ *
+ *   x         [n,3]   positions in [0,1]
+ *   std       [n] or NULL.  When given, level l of the output is multiplied by
+ *             1/max(1, 2*scalings[l]*std)  (NeuRADHashEncoding._rescale_grid_features,
+ *             field_components/neurad_encoding.py:309-316), fused into the gather.
+ *   table     [L*T, F], T = 2^log2_hashmap_size, F in {1,2,4,8}
+ *   out       element (i, l, f) at out[i*out_stride_n + l*out_stride_l + f]; the torch layout
+ *             [n, L*F] is (out_stride_n = L*F, out_stride_l = F); the level-major layout the fused
+ *             kernels prefer is (F, n*F).
+ *   sample_major  0: thread i handles sample i.  S>0: samples are (ray b, sample s) pairs stored
+ *             ray-major (i = b*S + s) and lanes are assigned to consecutive RAYS of one sample slot,
+ *             which makes the lanes of a wave spatially coherent for camera patches.  Results are
+ *             identical either way.
+ * ---------------------------------------------------------------------------------------------- */
+int nr_hash_encode_fwd(const float* x, const float* std, const float* table, const float* scalings,
+                       int num_levels, int features_per_level, int log2_hashmap_size,
+                       float* out, int64_t out_stride_n, int64_t out_stride_l,
+                       int64_t n, int sample_major, nr_stream_t stream);
+
+/* grad_table [L*T, F] += scatter of grad_out (same strides as `out`).  Backward of the gather
+ * (torch autograd of encodings.py:445-466; tcnn's kernel_grid_backward).  Positions get no grad
+ * (static scene: sample positions are detached, model_components/ray_samplers.py:364). */
+int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings,
+                       int num_levels, int features_per_level, int log2_hashmap_size,
+                       const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
+                       float* grad_table, int64_t n, int sample_major, nr_stream_t stream);
+
+/* Frustums.get_fast_isotropic_gaussian(1) (cameras/rays.py:109-124) followed by
+ * ScaledSceneContraction(order=inf, scale) on the GaussiansStd
+ * (field_components/spatial_distortions.py:103-113,126-136):
+ *   origins, directions [n_rays,3]; pixel_area [n_rays]; edges [n_rays, n_samples+1] (metres)
+ *   -> x01 [n_rays*n_samples, 3] in [0,1], std01 [n_rays*n_samples]. */
+int nr_contract_gaussians(const float* origins, const float* directions, const float* pixel_area,
+                          const float* edges, int64_t n_rays, int n_samples, float scale,
+                          float* x01, float* std01, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small MLPs on MFMA  -- replaces tcnn.Network{FullyFusedMLP} (field_components/mlp.py:109-113,
+ * 180-183; K4/K5/K7) with the torch semantics mlp.py:159-178: Linear+ReLU hidden layers, linear
+ * output.  weight[i] is [out_i, in_i] row-major, bias[i] is [out_i] (nn.Linear layouts).
+ * Widths: in_dim <= 64, layer width in {16,32,64}, out_dim <= 64.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nr_mlp {
+  int num_layers;                         /* number of Linear layers (>=1) */
+  int in_dim, width, out_dim;             /* MLP(in_dim, num_layers, layer_width, out_dim) */
+  const float* weight[NR_MAX_LAYERS];
+  const float* bias[NR_MAX_LAYERS];
+} nr_mlp_t;
+
+typedef struct nr_mlp_grads {             /* all "+=" */
+  float* weight[NR_MAX_LAYERS];
+  float* bias[NR_MAX_LAYERS];
+} nr_mlp_grads_t;
+
+/* y [n,out_dim] = MLP(x [n,in_dim]).  MLP.forward, mlp.py:180-183. */
+int nr_mlp_fwd(const nr_mlp_t* mlp, const float* x, int64_t n, float* y, nr_stream_t stream);
+/* grad_x [n,in_dim] (nullable) and parameter grads += from grad_y [n,out_dim]. */
+int nr_mlp_bwd(const nr_mlp_t* mlp, const float* x, const float* grad_y, int64_t n,
+               float* grad_x, const nr_mlp_grads_t* grads, nr_stream_t stream);
+
+/* NeuRADField.forward after the hash grid (fields/neurad_field.py:137-148), one launch:
+ *   h = mlp_geo(feats); sdf = h[0]; e = h[1:1+C]; sh = SH4((dir+1)/2) (no grad,
+ *   encodings.py:797-800 + fields/base_field.py:135-141 + utils/math.py:31-78);
+ *   feature = e + mlp_feature([e, sh]); alpha = sigmoid(-sdf*(|beta|+1e-4))
+ *   (model_components/utils.py:30-46).
+ * feats: element (i, k) at feats[i*feat_stride_n + (k/F)*feat_stride_l + k%F] (same convention as
+ * nr_hash_encode_fwd's `out`; F = feat_f).  directions [n_rays,3] per RAY, sample i belongs to
+ * ray i / n_samples.  Outputs feature [n,C], sdf [n], alpha [n]. */
+typedef struct nr_field {
+  nr_mlp_t geo;        /* in_dim = L*F, out_dim = 1 + C */
+  nr_mlp_t feat;       /* in_dim = C + 16, out_dim = C  */
+  const float* beta;   /* SigmoidDensity.beta, 1 float */
+} nr_field_t;
+
+typedef struct nr_field_grads {
+  nr_mlp_grads_t geo, feat;
+  float* beta;
+} nr_field_grads_t;
+
+int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
+                 int feat_f, const float* directions, int n_samples, int64_t n,
+                 float* feature, float* sdf, float* alpha, nr_stream_t stream);
+/* Backward: grad_feature [n,C], grad_alpha [n], grad_sdf [n] (nullable) ->
+ * grad_feats (same strides as feats, overwritten) and parameter grads +=. */
+int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
+                 int feat_f, const float* directions, int n_samples, int64_t n,
+                 const float* grad_feature, const float* grad_alpha, const float* grad_sdf,
+                 float* grad_feats, const nr_field_grads_t* grads, nr_stream_t stream);
+
+/* Degree-4 real spherical harmonics, 16 components: SHEncoding.forward torch path
+ * (encodings.py:797-805).  in [n,3] -> out [n,16].  (The caller applies (d+1)/2.) */
+int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Proposal field head  -- NeuRADProposalField.get_density after the grid
+ * (fields/neurad_field.py:211-212): density = trunc_exp(feats . w), w [in_dim] (Linear(L*F,1,
+ * bias=False)).  Backward uses exp(clamp(x,-15,15)) (field_components/activations.py:28-41).
+ * ---------------------------------------------------------------------------------------------- */
+int nr_prop_density_fwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
+                        const float* w, int in_dim, int64_t n, float* density, nr_stream_t stream);
+int nr_prop_density_bwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
+                        const float* w, int in_dim, int64_t n, const float* density,
+                        const float* grad_density, float* grad_feats, float* grad_w, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling  (model_components/ray_samplers.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* PowerSampler/SpacedSampler.generate_ray_samples (ray_samplers.py:98-132,838-852) with
+ * power_fn / inv_power_fn (utils/math.py:541-579).  nears, fars [n_rays]; t_rand [n_rays, S+1] or
+ * NULL (eval).  -> spacing [n_rays,S+1] (s-space edges), euclid [n_rays,S+1] (metres). */
+int nr_power_bins(const float* nears, const float* fars, const float* t_rand, int64_t n_rays, int n_samples,
+                  float lambda, float scaling, float* spacing, float* euclid, nr_stream_t stream);
+
+/* RaySamples.get_weights (cameras/rays.py:188-210): density [n_rays,S], euclid [n_rays,S+1] ->
+ * weights [n_rays,S] (wavefront scan). */
+int nr_weights_from_density_fwd(const float* density, const float* euclid, int64_t n_rays, int n_samples,
+                                float* weights, nr_stream_t stream);
+int nr_weights_from_density_bwd(const float* density, const float* euclid, const float* grad_weights,
+                                int64_t n_rays, int n_samples, float* grad_density, nr_stream_t stream);
+
+/* PDFSampler.generate_ray_samples, include_original=False, histogram_padding=0.01
+ * (ray_samplers.py:305-376): weights [n_rays,S] over spacing_in [n_rays,S+1] -> n_out+1 new edges.
+ * jitter [n_rays] in [0,1) (single_jitter, :325-326) or NULL (eval, :332-334).  nears/fars give
+ * the ray's spacing_to_euclidean_fn (:119-120).  Outputs are detached by construction. */
+int nr_pdf_resample(const float* weights, const float* spacing_in, const float* jitter,
+                    const float* nears, const float* fars, int64_t n_rays, int n_in, int n_out,
+                    float lambda, float scaling, float* spacing_out, float* euclid_out, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Compositing  -- replaces nerfacc.render_weight_from_alpha + accumulate_along_rays (batched
+ * branch; models/neuradar.py:1016, models/neurad.py:727-728) and the renderers
+ * (model_components/renderers.py:59-90,322-350) in the order of neuradar.py:504-517:
+ *   w_i = alpha_i prod_{j<i}(1-alpha_j); acc = sum w; w_last += 1-acc; features = sum w*feature;
+ *   depth = sum_{i<S-1} w_i*(start_i+end_i)/2.
+ * alpha [n_rays,S]; feature [n_rays,S,C]; euclid [n_rays,S+1].
+ * -> weights [n_rays,S] (after the sky fix-up), accumulation [n_rays], features [n_rays,C], depth [n_rays]
+ * ---------------------------------------------------------------------------------------------- */
+int nr_composite_fwd(const float* alpha, const float* feature, const float* euclid, int64_t n_rays,
+                     int n_samples, int n_channels, float* weights, float* accumulation, float* features,
+                     float* depth, nr_stream_t stream);
+/* grad_weights (nullable) is an extra upstream gradient on the returned weights (regularisers). */
+int nr_composite_bwd(const float* alpha, const float* feature, const float* euclid, const float* weights,
+                     const float* grad_features, const float* grad_depth, const float* grad_accumulation,
+                     const float* grad_weights, int64_t n_rays, int n_samples, int n_channels,
+                     float* grad_alpha, float* grad_feature, nr_stream_t stream);
+/* render_depth_simple alone (proposal depths, neuradar.py:527-528). */
+int nr_depth_from_weights(const float* weights, const float* euclid, int64_t n_rays, int n_samples,
+                          float* depth, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sensor ray generation (device-side; the reference runs these on CPU workers)
+ * ---------------------------------------------------------------------------------------------- */
+/* Cameras._generate_rays_from_coords, perspective branch, no lens distortion (cameras/cameras.py:
+ * 596-660,782-787,887-949) behind RayGenerator.forward (model_components/ray_generators.py:47-62).
+ * ray_indices [n,3] int64 (camera,row,col); c2w [n_cams,3,4]; fx,fy,cx,cy,cam_times [n_cams];
+ * velocities [n_cams,3], rs_offsets [n_cams,2], heights [n_cams] nullable together (rolling shutter).
+ * -> origins, directions [n,3]; pixel_area, times, directions_norm [n]. */
+int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
+                       const float* cx, const float* cy, const float* cam_times, const float* velocities,
+                       const float* rs_offsets, const float* heights, int64_t n,
+                       float* origins, float* directions, float* pixel_area, float* times,
+                       float* directions_norm, nr_stream_t stream);
+/* Lidars._generate_rays_from_points (cameras/lidars.py:356-417).  lidar_indices [n] int64;
+ * points [n,point_dim>=5]; l2w [n_lidars,3,4]; scan_times [n_lidars]; velocities [n_lidars,3] or NULL.
+ * -> ... did_return [n] uint8 (distance < 1e3). */
+int nr_gen_rays_lidar(const int64_t* lidar_indices, const float* points, int point_dim, const float* l2w,
+                      const float* scan_times, const float* velocities, int64_t n,
+                      float* origins, float* directions, float* pixel_area, float* times,
+                      float* directions_norm, uint8_t* did_return, nr_stream_t stream);
+/* Radars._generate_rays_from_fov (cameras/radars.py:268-358).  scan_indices [n_scans] int64;
+ * the FOV grid is n_az x n_el (azimuth-major) with az_i = (float)(min_az + i*d_az) evaluated in
+ * double like torch.arange.  r2w [n_radars,3,4]; scan_times [n_radars].
+ * -> rays [n_scans*n_az*n_el]: origins, directions [.,3]; pixel_area, times [.]; directions_spher [.,2]. */
+int nr_gen_rays_radar(const int64_t* scan_indices, int64_t n_scans, const float* r2w, const float* scan_times,
+                      float min_az, float d_az, int n_az, float min_el, float d_el, int n_el,
+                      float* origins, float* directions, float* pixel_area, float* times,
+                      float* directions_spher, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer: dense Adam/AdamW over a flat parameter buffer, one pass (param, grad, m, v), grad
+ * zeroed in the same pass.  Semantics of torch.optim.Adam(W) as configured in
+ * configs/method_configs.py:384-409 (eps=1e-15; weight_decay decoupled when `adamw`).
+ * `step` (1-based) sets the bias corrections; when `dev_hyper` (device float[3] = {lr, 1-beta1^t,
+ * sqrt(1-beta2^t)}) is non-NULL it overrides lr/step so that a captured hipGraph can be replayed
+ * while the schedule advances.  Pointers must be 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
+                 int step, float grad_scale, int zero_grad, const float* dev_hyper, nr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURADAR_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libneuradar_hip.so (C ABI in include/neuradar_hip.h).
+
+The HIP library IS the product path: there is no CPU / eager fallback.  If the shared object is
+missing this module raises at import of the first op (build it with `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C neuradar_amd/csrc`).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
+NR_MAX_LAYERS = 8
+NR_EINVAL = -1
+
+
+class NrMlp(Structure):
+    _fields_ = [("num_layers", c_int), ("in_dim", c_int), ("width", c_int), ("out_dim", c_int),
+                ("weight", c_void_p * NR_MAX_LAYERS), ("bias", c_void_p * NR_MAX_LAYERS)]
+
+
+class NrMlpGrads(Structure):
+    _fields_ = [("weight", c_void_p * NR_MAX_LAYERS), ("bias", c_void_p * NR_MAX_LAYERS)]
+
+
+class NrField(Structure):
+    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p)]
+
+
+class NrFieldGrads(Structure):
+    _fields_ = [("geo", NrMlpGrads), ("feat", NrMlpGrads), ("beta", c_void_p)]
+
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes (return type is int unless listed in _RESTYPES).  Mirrors include/neuradar_hip.h.
+PROTOTYPES = {
+    "nr_abi_version": [],
+    "nr_target_arch": [],
+    "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
+    "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
+    "nr_contract_gaussians": [P, P, P, P, L, I, F, P, P, P],
+    "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
+    "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
+    "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P],
+    "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P, POINTER(NrFieldGrads), P],
+    "nr_sh4_fwd": [P, L, P, P],
+    "nr_prop_density_fwd": [P, L, L, I, P, I, L, P, P],
+    "nr_prop_density_bwd": [P, L, L, I, P, I, L, P, P, P, P, P],
+    "nr_power_bins": [P, P, P, L, I, F, F, P, P, P],
+    "nr_weights_from_density_fwd": [P, P, L, I, P, P],
+    "nr_weights_from_density_bwd": [P, P, P, L, I, P, P],
+    "nr_pdf_resample": [P, P, P, P, P, L, I, I, F, F, P, P, P],
+    "nr_composite_fwd": [P, P, P, L, I, I, P, P, P, P, P],
+    "nr_composite_bwd": [P, P, P, P, P, P, P, P, L, I, I, P, P, P],
+    "nr_depth_from_weights": [P, P, L, I, P, P],
+    "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
+    "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
+    "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
+    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P],
+}
+_RESTYPES = {"nr_target_arch": c_char_p}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH) or _stale():
+        subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _stale() -> bool:
+    so = os.path.getmtime(LIB_PATH)
+    inc = os.path.join(os.path.dirname(CSRC), "..", "include", "neuradar_hip.h")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [inc]
+    return any(os.path.getmtime(s) > so for s in srcs if os.path.exists(s))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the only implementation of this path "
+                "(no CPU fallback). Build it with `make -C neuradar_amd/csrc`.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        if handle.nr_abi_version() != 1:
+            raise RuntimeError("libneuradar_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+class NeuradarHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == NR_EINVAL:
+        raise NeuradarHipError(f"{what}: invalid argument (NR_EINVAL)")
+    raise NeuradarHipError(f"{what}: HIP error {rc}")

@@ -1,0 +1,215 @@
+// Hash-grid kernels: frustum -> contracted Gaussian, multiresolution hash gather (fwd) and
+// scatter-add (bwd).  HBM/L2-bound integer+gather work: no MFMA here by design.
+//
+// Launch shape: blockIdx.y = level, so every wave gathers from ONE level's table region; with
+// `sample_major` the 64 lanes of a wave are 64 neighbouring RAYS at the same sample slot, which for
+// camera patches are centimetres apart -> the texture path merges most of a wave-instruction's
+// addresses into a few cache lines on all but the finest levels.
+#include "nr_common.h"
+
+namespace {
+
+template <int F>
+struct VecF;
+template <>
+struct VecF<1> { using type = float; };
+template <>
+struct VecF<2> { using type = float2; };
+template <>
+struct VecF<4> { using type = float4; };
+
+template <int F>
+__device__ __forceinline__ void load_entry(const float* p, float (&v)[F]) {
+  if constexpr (F == 1) {
+    v[0] = *p;
+  } else if constexpr (F == 2) {
+    float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else if constexpr (F == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) v[f] = p[f];
+  }
+}
+
+// sample index handled by thread i (identity, or ray-major storage walked sample-major)
+__device__ __forceinline__ int64_t sample_of_thread(int64_t i, int64_t n, int S) {
+  if (S <= 0) return i;
+  const int64_t B = n / S;
+  const int64_t b = i % B, s = i / B;
+  return b * S + s;
+}
+
+struct Corner {
+  int lo[3], hi[3];
+  float w[3];  // weight of the CEIL corner per axis (encodings.py:434,454-464)
+};
+
+__device__ __forceinline__ Corner make_corner(const float* x, int64_t idx, float scale) {
+  Corner c;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p = x[idx * 3 + a] * scale;
+    const float fl = floorf(p);
+    c.lo[a] = (int)fl;
+    c.hi[a] = (int)ceilf(p);
+    c.w[a] = p - fl;
+  }
+  return c;
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ table,
+                       const float* __restrict__ scalings, int log2T, float* __restrict__ out, int64_t sn, int64_t sl,
+                       int64_t n, int S) {
+  const int level = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t idx = sample_of_thread(i, n, S);
+  const float scale = scalings[level];
+  const Corner c = make_corner(x, idx, scale);
+  const uint32_t mask = (1u << log2T) - 1u;
+  const float* base = table + (((int64_t)level << log2T) * F);
+
+  // x-pairs for the four (y,z) selections, reduced x -> y -> z exactly like the reference
+  float acc_z[2][F];
+#pragma unroll
+  for (int zs = 0; zs < 2; ++zs) {  // zs = 0: ceil z, 1: floor z
+    const int iz = zs == 0 ? c.hi[2] : c.lo[2];
+    float acc_y[2][F];
+#pragma unroll
+    for (int ys = 0; ys < 2; ++ys) {
+      const int iy = ys == 0 ? c.hi[1] : c.lo[1];
+      float vh[F], vl[F];
+      load_entry<F>(base + (int64_t)nr_hash3(c.hi[0], iy, iz, mask) * F, vh);
+      load_entry<F>(base + (int64_t)nr_hash3(c.lo[0], iy, iz, mask) * F, vl);
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc_y[ys][f] = vh[f] * c.w[0] + vl[f] * (1.0f - c.w[0]);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc_z[zs][f] = acc_y[0][f] * c.w[1] + acc_y[1][f] * (1.0f - c.w[1]);
+  }
+  float r = 1.0f;
+  if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);  // neurad_encoding.py:314
+  float* o = out + idx * sn + (int64_t)level * sl;
+#pragma unroll
+  for (int f = 0; f < F; ++f) o[f] = (acc_z[0][f] * c.w[2] + acc_z[1][f] * (1.0f - c.w[2])) * r;
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings,
+                       int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl,
+                       float* __restrict__ gtable, int64_t n, int S) {
+  const int level = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t idx = sample_of_thread(i, n, S);
+  const float scale = scalings[level];
+  const Corner c = make_corner(x, idx, scale);
+  const uint32_t mask = (1u << log2T) - 1u;
+  float* base = gtable + (((int64_t)level << log2T) * F);
+  float r = 1.0f;
+  if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
+  float g[F];
+  const float* gi = gout + idx * sn + (int64_t)level * sl;
+#pragma unroll
+  for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+    const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
+    if (w == 0.0f) continue;  // e.g. exact-integer coordinates: ceil == floor carries weight 0
+    const uint32_t slot = nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask);
+    float* dst = base + (int64_t)slot * F;
+#pragma unroll
+    for (int f = 0; f < F; ++f) unsafeAtomicAdd(dst + f, g[f] * w);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+contract_gaussians_kernel(const float* __restrict__ origins, const float* __restrict__ directions,
+                          const float* __restrict__ pixel_area, const float* __restrict__ edges, int64_t n_rays,
+                          int S, float scale, float* __restrict__ x01, float* __restrict__ std01) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rays * S) return;
+  const int64_t b = i / S;
+  const int s = (int)(i - b * S);
+  const float e0 = edges[b * (S + 1) + s], e1 = edges[b * (S + 1) + s + 1];
+  // Frustums.get_fast_isotropic_gaussian, one multisample (cameras/rays.py:118-123)
+  const float half = (e1 - e0) / 2.0f;
+  const float t = e0 + 1.0f * half;
+  const float cross = pixel_area[b] * (t * t);
+  float sd = powf(cross * half, 1.0f / 3.0f);
+  float m[3];
+  float mag = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    m[a] = (origins[b * 3 + a] + directions[b * 3 + a] * t) / scale;  // spatial_distortions.py:133
+    mag = fmaxf(mag, fabsf(m[a]));
+  }
+  sd = sd / scale;
+  if (!(mag < 1.0f)) {  // spatial_distortions.py:107-112 (L-inf norm)
+    const float cm = fmaxf(mag, 1.0f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m[a] = (2.0f - (1.0f / cm)) * (m[a] / cm);
+    const float k = powf(2.0f * cm - 1.0f, 1.0f / 3.0f) / cm;
+    sd = sd * (k * k);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x01[i * 3 + a] = (m[a] + 2.0f) / 4.0f;  // :135
+  std01[i] = sd / 4.0f;                                               // :136
+}
+
+}  // namespace
+
+extern "C" int nr_hash_encode_fwd(const float* x, const float* std, const float* table, const float* scalings,
+                                  int L, int F, int log2T, float* out, int64_t sn, int64_t sl, int64_t n,
+                                  int sample_major, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !table || !scalings || !out || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
+  if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
+  dim3 grid((unsigned)nr_cdiv(n, 256), (unsigned)L), block(256);
+  switch (F) {
+    case 1: hipLaunchKernelGGL(hash_encode_fwd_kernel<1>, grid, block, 0, nr_s(stream), x, std, table, scalings, log2T, out, sn, sl, n, sample_major); break;
+    case 2: hipLaunchKernelGGL(hash_encode_fwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, table, scalings, log2T, out, sn, sl, n, sample_major); break;
+    case 4: hipLaunchKernelGGL(hash_encode_fwd_kernel<4>, grid, block, 0, nr_s(stream), x, std, table, scalings, log2T, out, sn, sl, n, sample_major); break;
+    case 8: hipLaunchKernelGGL(hash_encode_fwd_kernel<8>, grid, block, 0, nr_s(stream), x, std, table, scalings, log2T, out, sn, sl, n, sample_major); break;
+    default: return NR_EINVAL;
+  }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                  const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
+                                  int sample_major, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
+  if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
+  dim3 grid((unsigned)nr_cdiv(n, 256), (unsigned)L), block(256);
+  switch (F) {
+    case 1: hipLaunchKernelGGL(hash_encode_bwd_kernel<1>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    case 2: hipLaunchKernelGGL(hash_encode_bwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    case 4: hipLaunchKernelGGL(hash_encode_bwd_kernel<4>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    case 8: hipLaunchKernelGGL(hash_encode_bwd_kernel<8>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    default: return NR_EINVAL;
+  }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_contract_gaussians(const float* origins, const float* directions, const float* pixel_area,
+                                     const float* edges, int64_t n_rays, int S, float scale, float* x01, float* std01,
+                                     nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!origins || !directions || !pixel_area || !edges || !x01 || !std01 || S < 1 || n_rays < 0 || !(scale > 0)) return NR_EINVAL;
+  const int64_t n = n_rays * S;
+  hipLaunchKernelGGL(contract_gaussians_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), origins,
+                     directions, pixel_area, edges, n_rays, S, scale, x01, std01);
+  NR_LAUNCH_CHECK();
+  return 0;
+}

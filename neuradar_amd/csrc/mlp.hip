@@ -1,0 +1,456 @@
+// NeuRADField MLP stack on MFMA: mlp_geo -> (sdf, embedding) -> SH -> mlp_feature (+residual) ->
+// sigmoid density, forward and backward, one launch each (replaces 2x tcnn FullyFusedMLP + tcnn SH).
+// See mlp_tiles.h for the register/LDS layout.  Persistent 4-wave workgroups, one 32-sample tile per
+// wave per iteration; weights are loaded into LDS once per workgroup, weight gradients are summed in
+// LDS (ds_add_f32) over all tiles of the workgroup and flushed once with contiguous global atomics.
+#include "nr_common.h"
+#include "mlp_tiles.h"
+#include "sh4.h"
+
+using namespace nrmlp;
+
+namespace {
+
+constexpr int kC = 32;         // geo_feat_dim == nff_out_dim (fields/neurad_field.py:64,97)
+constexpr int kSH = 16;        // SHEncoding(levels=4)
+constexpr float kBetaMin = 1e-4f;  // model_components/utils.py:24
+
+template <int IN, int HID>
+struct FieldImage {
+  using G1 = Layer<IN, HID>;       // mlp_geo.layers[0]
+  using G2 = Layer<HID, kC>;       // mlp_geo.layers[1], embedding rows 1..C
+  using F1 = Layer<kC + kSH, HID>; // mlp_feature.layers[0]
+  using F2 = Layer<HID, HID>;
+  using F3 = Layer<HID, kC>;
+  static constexpr int SDF = HID + 1 + ((HID + 1) & 1);  // row 0 of mlp_geo.layers[1] + its bias (padded even)
+  // weight image offsets
+  static constexpr int oG1 = 0, oG2 = oG1 + G1::SIZE, oSdf = oG2 + G2::SIZE, oF1 = oSdf + SDF,
+                       oF2 = oF1 + F1::SIZE, oF3 = oF2 + F2::SIZE, W_TOTAL = oF3 + F3::SIZE;
+  // gradient image offsets
+  static constexpr int gG1 = 0, gG2 = gG1 + G1::G_SIZE, gSdf = gG2 + G2::G_SIZE, gF1 = gSdf + SDF,
+                       gF2 = gF1 + F1::G_SIZE, gF3 = gF2 + F2::G_SIZE, gBeta = gF3 + F3::G_SIZE,
+                       G_TOTAL = gBeta + 2;
+  static constexpr int HT = (HID + 31) / 32, IT = (IN + 31) / 32;
+};
+
+template <int IN, int HID>
+__device__ __forceinline__ void load_field_weights(float* lw, const nr_field_t& f) {
+  using I = FieldImage<IN, HID>;
+  load_layer<IN, HID>(lw + I::oG1, f.geo.weight[0], f.geo.bias[0], 0);
+  load_layer<HID, kC>(lw + I::oG2, f.geo.weight[1], f.geo.bias[1], 1);
+  for (int k = threadIdx.x; k < I::SDF; k += blockDim.x)
+    lw[I::oSdf + k] = k < HID ? f.geo.weight[1][k] : (k == HID ? f.geo.bias[1][0] : 0.0f);
+  load_layer<kC + kSH, HID>(lw + I::oF1, f.feat.weight[0], f.feat.bias[0], 0);
+  load_layer<HID, HID>(lw + I::oF2, f.feat.weight[1], f.feat.bias[1], 0);
+  load_layer<HID, kC>(lw + I::oF3, f.feat.weight[2], f.feat.bias[2], 0);
+  __syncthreads();
+}
+
+// load a [rows x 32 samples] block given per-sample element addressing elem(k) -> offset
+template <int ROWS, typename OffFn>
+__device__ __forceinline__ void load_rows(f32x16 (&t)[(ROWS + 31) / 32], const float* __restrict__ base, bool valid,
+                                          int h, OffFn off) {
+#pragma unroll
+  for (int kt = 0; kt < (ROWS + 31) / 32; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = kt * 32 + rowmap(r, 0) + 4 * h;
+      t[kt][r] = (valid && k < ROWS) ? base[off(k)] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ f32x16 sh_tile(const float* __restrict__ dirs, int64_t ray, int h) {
+  // SH of the [0,1]-mapped direction (fields/base_field.py:135-141 + encodings.py:797-800)
+  float sh[16];
+  nr_sh4((dirs[ray * 3 + 0] + 1.0f) / 2.0f, (dirs[ray * 3 + 1] + 1.0f) / 2.0f, (dirs[ray * 3 + 2] + 1.0f) / 2.0f, sh);
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = r < 8 ? (h ? sh[rowmap(r, 0) + 4] : sh[rowmap(r, 0)]) : 0.0f;
+  return t;
+}
+
+template <int HID>
+__device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], const float* wsdf, int h) {
+  float part = 0.0f;
+#pragma unroll
+  for (int t = 0; t < (HID + 31) / 32; ++t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = t * 32 + rowmap(s, 0) + 4 * h;
+      if (k < HID) part += wsdf[k] * h1[t][s];
+    }
+  return part + __shfl_xor(part, 32, NR_WAVE) + wsdf[HID];
+}
+
+template <int IN, int HID>
+__global__ void __launch_bounds__(256)
+field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
+                 const float* __restrict__ dirs, int S, int64_t n, float* __restrict__ feature,
+                 float* __restrict__ sdf_out, float* __restrict__ alpha_out) {
+  using I = FieldImage<IN, HID>;
+  __shared__ float lw[I::W_TOTAL];
+  load_field_weights<IN, HID>(lw, fld);
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const float beta = fabsf(fld.beta[0]) + kBetaMin;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    f32x16 x0[I::IT], h1[I::HT], e[1], cat[2], f1[I::HT], f2[I::HT], o[1];
+    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
+                  [&](int k) { return (int64_t)(k / F) * sl + (k % F); });
+    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
+    dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
+    const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
+    cat[0] = e[0];
+    cat[1] = sh_tile(dirs, valid ? smp / S : 0, h);
+    dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
+    dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
+    dense_fwd<HID, kC, false>(f2, o, lw + I::oF3, i, h);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // rows 8q+4h .. +3 are registers 4q..4q+3
+        float4 v = make_float4(e[0][4 * q] + o[0][4 * q], e[0][4 * q + 1] + o[0][4 * q + 1],
+                               e[0][4 * q + 2] + o[0][4 * q + 2], e[0][4 * q + 3] + o[0][4 * q + 3]);
+        *reinterpret_cast<float4*>(feature + smp * kC + 8 * q + 4 * h) = v;
+      }
+      if (h == 0) {
+        sdf_out[smp] = sdf;
+        alpha_out[smp] = 1.0f / (1.0f + expf(sdf * beta));  // sigmoid(-sdf*beta), utils.py:38
+      }
+    }
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f32x16 (&y)[(ROWS + 31) / 32]) {
+#pragma unroll
+  for (int t = 0; t < (ROWS + 31) / 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[t][r] = y[t][r] > 0.0f ? g[t][r] : 0.0f;
+}
+
+template <int IN, int HID>
+__global__ void __launch_bounds__(256)
+field_bwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
+                 const float* __restrict__ dirs, int S, int64_t n, const float* __restrict__ g_feature,
+                 const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ g_feats,
+                 nr_field_grads_t grads) {
+  using I = FieldImage<IN, HID>;
+  __shared__ float lw[I::W_TOTAL];
+  __shared__ float lg[I::G_TOTAL];
+  __shared__ float scr[4][2 * kScrTile + 32];
+  for (int k = threadIdx.x; k < I::G_TOTAL; k += blockDim.x) lg[k] = 0.0f;
+  load_field_weights<IN, HID>(lw, fld);  // ends with __syncthreads()
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  float* scrA = scr[wave];
+  float* scrB = scrA + kScrTile;
+  float* scrE = scrB + kScrTile;
+  const float beta_raw = fld.beta[0];
+  const float beta = fabsf(beta_raw) + kBetaMin;
+  float d_beta = 0.0f;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    // ---- recompute the forward activations (cheaper than storing ~1 KB/sample) ----
+    f32x16 x0[I::IT], h1[I::HT], e[1], cat[2], f1[I::HT], f2[I::HT];
+    auto foff = [&](int k) { return (int64_t)(k / F) * sl + (k % F); };
+    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
+    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
+    dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
+    const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
+    cat[0] = e[0];
+    cat[1] = sh_tile(dirs, valid ? smp / S : 0, h);
+    dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
+    dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
+    // ---- backward ----
+    f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2], d_h1[I::HT], d_x0[I::IT];
+    load_rows<kC>(d_o, g_feature + (valid ? smp * kC : 0), valid, h, [](int k) { return (int64_t)k; });
+    // mlp_feature.layers[2]: o = V3 f2 + b
+    dense_bwd_dw<HID, kC, false>(d_o, f2, lg + I::gF3, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dx<HID, kC>(d_o, d_f2, lw + I::oF3, i, h);
+    relu_mask<HID>(d_f2, f2);
+    // layers[1]
+    dense_bwd_dw<HID, HID, false>(d_f2, f1, lg + I::gF2, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dx<HID, HID>(d_f2, d_f1, lw + I::oF2, i, h);
+    relu_mask<HID>(d_f1, f1);
+    // layers[0]: input [e ; sh], only e carries gradient (SH is evaluated under no_grad)
+    dense_bwd_dw<kC + kSH, HID, false>(d_f1, cat, lg + I::gF1, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dx<kC + kSH, HID>(d_f1, d_cat, lw + I::oF1, i, h);
+    f32x16 d_e[1];
+    d_e[0] = d_o[0] + d_cat[0];  // residual: feature = e + mlp_feature([e, sh])
+    // alpha = sigmoid(-sdf * beta)
+    const float ga = valid ? g_alpha[smp] : 0.0f;
+    const float a = 1.0f / (1.0f + expf(sdf * beta));
+    const float dsig = ga * a * (1.0f - a);
+    float d_sdf = dsig * (-beta);
+    if (g_sdf != nullptr && valid) d_sdf += g_sdf[smp];
+    if (h == 0) d_beta += dsig * (-sdf) * (beta_raw >= 0.0f ? 1.0f : -1.0f);
+    // mlp_geo.layers[1]: rows 1..C -> e (MFMA), row 0 -> sdf (extra row)
+    dense_bwd_dw<HID, kC, true>(d_e, h1, lg + I::gG2, d_sdf, lg + I::gSdf, scrA, scrB, scrE, i, h);
+    dense_bwd_dx<HID, kC>(d_e, d_h1, lw + I::oG2, i, h);
+#pragma unroll
+    for (int t = 0; t < I::HT; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int k = t * 32 + rowmap(s, 0) + 4 * h;
+        if (k < HID) d_h1[t][s] += lw[I::oSdf + k] * d_sdf;
+      }
+    relu_mask<HID>(d_h1, h1);
+    // mlp_geo.layers[0]
+    dense_bwd_dw<IN, HID, false>(d_h1, x0, lg + I::gG1, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dx<IN, HID>(d_h1, d_x0, lw + I::oG1, i, h);
+    if (valid) {
+      float* gf = g_feats + smp * sn;
+#pragma unroll
+      for (int kt = 0; kt < I::IT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = kt * 32 + rowmap(r, 0) + 4 * h;
+          if (k < IN) gf[foff(k)] = d_x0[kt][r];
+        }
+    }
+  }
+  d_beta = nr_wave_sum(d_beta);
+  if (lane == 0) atomicAdd(&lg[I::gBeta], d_beta);
+  __syncthreads();
+  flush_layer_grads<IN, HID>(lg + I::gG1, grads.geo.weight[0], grads.geo.bias[0], 0);
+  flush_layer_grads<HID, kC>(lg + I::gG2, grads.geo.weight[1], grads.geo.bias[1], 1);
+  for (int k = threadIdx.x; k <= HID; k += blockDim.x) {
+    if (k < HID) unsafeAtomicAdd(grads.geo.weight[1] + k, lg[I::gSdf + k]);
+    else unsafeAtomicAdd(grads.geo.bias[1], lg[I::gSdf + HID]);
+  }
+  flush_layer_grads<kC + kSH, HID>(lg + I::gF1, grads.feat.weight[0], grads.feat.bias[0], 0);
+  flush_layer_grads<HID, HID>(lg + I::gF2, grads.feat.weight[1], grads.feat.bias[1], 0);
+  flush_layer_grads<HID, kC>(lg + I::gF3, grads.feat.weight[2], grads.feat.bias[2], 0);
+  if (threadIdx.x == 0 && grads.beta) unsafeAtomicAdd(grads.beta, lg[I::gBeta]);
+}
+
+// ---- generic MLP (drop-in for field_components/mlp.py:MLP, e.g. the lidar decoder 48->32->32->2) ----
+// Runs zero-padded on <KP, HP, MP> in {32,64}^3 with NL in {2,3} Linear layers.
+template <int KP, int HP, int MP, int NL>
+struct MlpImage {
+  using L0 = Layer<KP, HP>;
+  using L1 = Layer<HP, HP>;   // only when NL == 3
+  using L2 = Layer<HP, MP>;
+  static constexpr int o0 = 0, o1 = o0 + L0::SIZE, o2 = o1 + (NL == 3 ? L1::SIZE : 0), W_TOTAL = o2 + L2::SIZE;
+  static constexpr int g0 = 0, g1 = g0 + L0::G_SIZE, g2 = g1 + (NL == 3 ? L1::G_SIZE : 0), G_TOTAL = g2 + L2::G_SIZE;
+};
+
+template <int KP, int HP, int MP, int NL>
+__device__ __forceinline__ void load_mlp_weights(float* lw, const nr_mlp_t& m) {
+  using I = MlpImage<KP, HP, MP, NL>;
+  load_layer<KP, HP>(lw + I::o0, m.weight[0], m.bias[0], 0, m.in_dim, m.width);
+  if (NL == 3) load_layer<HP, HP>(lw + I::o1, m.weight[1], m.bias[1], 0, m.width, m.width);
+  load_layer<HP, MP>(lw + I::o2, m.weight[NL - 1], m.bias[NL - 1], 0, m.width, m.out_dim);
+  __syncthreads();
+}
+
+template <int KP, int HP, int MP, int NL>
+__global__ void __launch_bounds__(256)
+mlp_fwd_kernel(nr_mlp_t mlp, const float* __restrict__ x, int64_t n, float* __restrict__ y) {
+  using I = MlpImage<KP, HP, MP, NL>;
+  __shared__ float lw[I::W_TOTAL];
+  load_mlp_weights<KP, HP, MP, NL>(lw, mlp);
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int in_dim = mlp.in_dim, out_dim = mlp.out_dim;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    f32x16 x0[KP / 32], a1[HP / 32], a2[HP / 32], out[MP / 32];
+#pragma unroll
+    for (int kt = 0; kt < KP / 32; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kt * 32 + rowmap(r, 0) + 4 * h;
+        x0[kt][r] = (valid && k < in_dim) ? x[smp * in_dim + k] : 0.0f;
+      }
+    dense_fwd<KP, HP, true>(x0, a1, lw + I::o0, i, h);
+    if (NL == 3) {
+      dense_fwd<HP, HP, true>(a1, a2, lw + I::o1, i, h);
+      dense_fwd<HP, MP, false>(a2, out, lw + I::o2, i, h);
+    } else {
+      dense_fwd<HP, MP, false>(a1, out, lw + I::o2, i, h);
+    }
+    if (valid) {
+#pragma unroll
+      for (int mt = 0; mt < MP / 32; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mt * 32 + rowmap(r, 0) + 4 * h;
+          if (m < out_dim) y[smp * out_dim + m] = out[mt][r];
+        }
+    }
+  }
+}
+
+template <int KP, int HP, int MP, int NL>
+__global__ void __launch_bounds__(256)
+mlp_bwd_kernel(nr_mlp_t mlp, const float* __restrict__ x, const float* __restrict__ g_y, int64_t n,
+               float* __restrict__ g_x, nr_mlp_grads_t grads) {
+  using I = MlpImage<KP, HP, MP, NL>;
+  __shared__ float lw[I::W_TOTAL];
+  __shared__ float lg[I::G_TOTAL];
+  __shared__ float scr[4][2 * kScrTile + 32];
+  for (int k = threadIdx.x; k < I::G_TOTAL; k += blockDim.x) lg[k] = 0.0f;
+  load_mlp_weights<KP, HP, MP, NL>(lw, mlp);
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  float* scrA = scr[wave];
+  float* scrB = scrA + kScrTile;
+  float* scrE = scrB + kScrTile;
+  const int in_dim = mlp.in_dim, out_dim = mlp.out_dim;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    f32x16 x0[KP / 32], a1[HP / 32], a2[HP / 32], d_out[MP / 32], d_a2[HP / 32], d_a1[HP / 32], d_x0[KP / 32];
+#pragma unroll
+    for (int kt = 0; kt < KP / 32; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = kt * 32 + rowmap(r, 0) + 4 * h;
+        x0[kt][r] = (valid && k < in_dim) ? x[smp * in_dim + k] : 0.0f;
+      }
+#pragma unroll
+    for (int mt = 0; mt < MP / 32; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + rowmap(r, 0) + 4 * h;
+        d_out[mt][r] = (valid && m < out_dim) ? g_y[smp * out_dim + m] : 0.0f;
+      }
+    dense_fwd<KP, HP, true>(x0, a1, lw + I::o0, i, h);
+    if (NL == 3) {
+      dense_fwd<HP, HP, true>(a1, a2, lw + I::o1, i, h);
+      dense_bwd_dw<HP, MP, false>(d_out, a2, lg + I::g2, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+      dense_bwd_dx<HP, MP>(d_out, d_a2, lw + I::o2, i, h);
+      relu_mask<HP>(d_a2, a2);
+      dense_bwd_dw<HP, HP, false>(d_a2, a1, lg + I::g1, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+      dense_bwd_dx<HP, HP>(d_a2, d_a1, lw + I::o1, i, h);
+    } else {
+      dense_bwd_dw<HP, MP, false>(d_out, a1, lg + I::g2, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+      dense_bwd_dx<HP, MP>(d_out, d_a1, lw + I::o2, i, h);
+    }
+    relu_mask<HP>(d_a1, a1);
+    dense_bwd_dw<KP, HP, false>(d_a1, x0, lg + I::g0, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    if (g_x != nullptr) {
+      dense_bwd_dx<KP, HP>(d_a1, d_x0, lw + I::o0, i, h);
+      if (valid) {
+#pragma unroll
+        for (int kt = 0; kt < KP / 32; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + rowmap(r, 0) + 4 * h;
+            if (k < in_dim) g_x[smp * in_dim + k] = d_x0[kt][r];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  flush_layer_grads<KP, HP>(lg + I::g0, grads.weight[0], grads.bias[0], 0, mlp.in_dim, mlp.width);
+  if (NL == 3) flush_layer_grads<HP, HP>(lg + I::g1, grads.weight[1], grads.bias[1], 0, mlp.width, mlp.width);
+  flush_layer_grads<HP, MP>(lg + I::g2, grads.weight[NL - 1], grads.bias[NL - 1], 0, mlp.width, mlp.out_dim);
+}
+
+int check_mlp(const nr_mlp_t* m) {
+  if (!m || (m->num_layers != 2 && m->num_layers != 3)) return NR_EINVAL;
+  if (m->in_dim < 1 || m->in_dim > 64 || m->width < 1 || m->width > 64 || m->out_dim < 1 || m->out_dim > 64) return NR_EINVAL;
+  for (int l = 0; l < m->num_layers; ++l) if (!m->weight[l] || !m->bias[l]) return NR_EINVAL;
+  return 0;
+}
+
+#define NR_MLP_DISPATCH(KERNEL, ...)                                                                         \
+  do {                                                                                                       \
+    const int kp = mlp->in_dim > 32, hp = mlp->width > 32, mp = mlp->out_dim > 32, nl3 = mlp->num_layers == 3; \
+    const int key = kp | (hp << 1) | (mp << 2) | (nl3 << 3);                                                 \
+    switch (key) {                                                                                           \
+      case 0: hipLaunchKernelGGL((KERNEL<32, 32, 32, 2>), __VA_ARGS__); break;                              \
+      case 1: hipLaunchKernelGGL((KERNEL<64, 32, 32, 2>), __VA_ARGS__); break;                              \
+      case 2: hipLaunchKernelGGL((KERNEL<32, 64, 32, 2>), __VA_ARGS__); break;                              \
+      case 3: hipLaunchKernelGGL((KERNEL<64, 64, 32, 2>), __VA_ARGS__); break;                              \
+      case 4: hipLaunchKernelGGL((KERNEL<32, 32, 64, 2>), __VA_ARGS__); break;                              \
+      case 5: hipLaunchKernelGGL((KERNEL<64, 32, 64, 2>), __VA_ARGS__); break;                              \
+      case 6: hipLaunchKernelGGL((KERNEL<32, 64, 64, 2>), __VA_ARGS__); break;                              \
+      case 7: hipLaunchKernelGGL((KERNEL<64, 64, 64, 2>), __VA_ARGS__); break;                              \
+      case 8: hipLaunchKernelGGL((KERNEL<32, 32, 32, 3>), __VA_ARGS__); break;                              \
+      case 9: hipLaunchKernelGGL((KERNEL<64, 32, 32, 3>), __VA_ARGS__); break;                              \
+      case 10: hipLaunchKernelGGL((KERNEL<32, 64, 32, 3>), __VA_ARGS__); break;                             \
+      case 11: hipLaunchKernelGGL((KERNEL<64, 64, 32, 3>), __VA_ARGS__); break;                             \
+      case 12: hipLaunchKernelGGL((KERNEL<32, 32, 64, 3>), __VA_ARGS__); break;                             \
+      case 13: hipLaunchKernelGGL((KERNEL<64, 32, 64, 3>), __VA_ARGS__); break;                             \
+      case 14: hipLaunchKernelGGL((KERNEL<32, 64, 64, 3>), __VA_ARGS__); break;                             \
+      default: hipLaunchKernelGGL((KERNEL<64, 64, 64, 3>), __VA_ARGS__); break;                             \
+    }                                                                                                        \
+  } while (0)
+
+int check_field(const nr_field_t* f, int* hid) {
+  if (!f || !f->beta) return NR_EINVAL;
+  const nr_mlp_t &g = f->geo, &m = f->feat;
+  if (g.num_layers != 2 || m.num_layers != 3) return NR_EINVAL;
+  if (g.in_dim != 32 || g.out_dim != kC + 1 || m.in_dim != kC + kSH || m.out_dim != kC || g.width != m.width) return NR_EINVAL;
+  if (g.width != 32 && g.width != 64) return NR_EINVAL;
+  for (int l = 0; l < 2; ++l) if (!g.weight[l] || !g.bias[l]) return NR_EINVAL;
+  for (int l = 0; l < 3; ++l) if (!m.weight[l] || !m.bias[l]) return NR_EINVAL;
+  *hid = g.width;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
+                            const float* dirs, int S, int64_t n, float* feature, float* sdf, float* alpha,
+                            nr_stream_t stream) {
+  if (n == 0) return 0;
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 1 || F < 1 || n < 0) return NR_EINVAL;
+  const int64_t tiles = nr_cdiv(n, 32);
+  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
+  if (hid == 32)
+    hipLaunchKernelGGL((field_fwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, feature, sdf, alpha);
+  else
+    hipLaunchKernelGGL((field_fwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, feature, sdf, alpha);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
+                            const float* dirs, int S, int64_t n, const float* g_feature, const float* g_alpha,
+                            const float* g_sdf, float* g_feats, const nr_field_grads_t* grads, nr_stream_t stream) {
+  if (n == 0) return 0;
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || S < 1 || F < 1 || n < 0)
+    return NR_EINVAL;
+  for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
+  for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
+  const int64_t tiles = nr_cdiv(n, 32);
+  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  if (hid == 32)
+    hipLaunchKernelGGL((field_bwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, g_feats, *grads);
+  else
+    hipLaunchKernelGGL((field_bwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, g_feats, *grads);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_mlp_fwd(const nr_mlp_t* mlp, const float* x, int64_t n, float* y, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (check_mlp(mlp) != 0 || !x || !y || n < 0) return NR_EINVAL;
+  const int64_t tiles = nr_cdiv(n, 32);
+  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
+  NR_MLP_DISPATCH(mlp_fwd_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), *mlp, x, n, y);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_mlp_bwd(const nr_mlp_t* mlp, const float* x, const float* g_y, int64_t n, float* g_x,
+                          const nr_mlp_grads_t* grads, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (check_mlp(mlp) != 0 || !x || !g_y || !grads || n < 0) return NR_EINVAL;
+  for (int l = 0; l < mlp->num_layers; ++l) if (!grads->weight[l] || !grads->bias[l]) return NR_EINVAL;
+  const int64_t tiles = nr_cdiv(n, 32);
+  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  NR_MLP_DISPATCH(mlp_bwd_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), *mlp, x, g_y, n, g_x, *grads);
+  NR_LAUNCH_CHECK();
+  return 0;
+}

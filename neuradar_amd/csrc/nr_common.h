@@ -1,0 +1,114 @@
+// Shared device helpers for the NeuRadar gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/neuradar_hip.h"
+
+#define NR_WAVE 64
+
+#define NR_LAUNCH_CHECK()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+static inline hipStream_t nr_s(nr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t nr_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int64_t nr_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- spatial hash (field_components/encodings.py:406-421) -------------------------------------
+// The reference multiplies int32 corners by {1, 2654435761, 805459861} in int64, xors and takes
+// mod T.  T is a power of two, so the slot is the low log2(T) bits, which uint32 wrap-around
+// arithmetic reproduces exactly (also for negative corners, two's complement).
+__device__ __forceinline__ uint32_t nr_hash3(int ix, int iy, int iz, uint32_t mask) {
+  return (((uint32_t)ix * 1u) ^ ((uint32_t)iy * 2654435761u) ^ ((uint32_t)iz * 805459861u)) & mask;
+}
+
+// ---- ZipNeRF power transform (utils/math.py:541-579), finite-lambda branch ---------------------
+// torch.pow special-cases exponent -1 as a reciprocal; NeuRadar uses lambda = -1.
+__device__ __forceinline__ float nr_pow_lam(float base, float lam) {
+  return lam == -1.0f ? 1.0f / base : powf(base, lam);
+}
+__device__ __forceinline__ float nr_power_fn(float x, float lam) {
+  const float lam_1 = fabsf(lam - 1.0f);
+  return (lam_1 / lam) * (nr_pow_lam(x / lam_1 + 1.0f, lam) - 1.0f);
+}
+__device__ __forceinline__ float nr_inv_power_fn(float x, float lam) {
+  const float lam_1 = fabsf(lam - 1.0f);
+  const float b = fmaxf(x * lam / lam_1 + 1.0f, 1e-10f);
+  return (nr_pow_lam(b, 1.0f / lam) - 1.0f) * lam_1;
+}
+// spacing_to_euclidean_fn of SpacedSampler (model_components/ray_samplers.py:119-120) with
+// PowerSampler's spacing fns (:846-851)
+__device__ __forceinline__ float nr_spacing_to_euclid(float s, float s_near, float s_far, float lam, float scaling) {
+  return nr_inv_power_fn(s * s_far + (1.0f - s) * s_near, lam) / scaling;
+}
+
+// torch.linspace(start, end, steps)[idx] in fp32 (symmetric two-sided evaluation, like ATen)
+__device__ __forceinline__ float nr_linspace(float start, float end, int steps, int idx) {
+  if (steps == 1) return start;
+  const float step = (end - start) / (float)(steps - 1);
+  const int halfway = steps / 2;
+  return idx < halfway ? start + step * (float)idx : end - step * (float)(steps - idx - 1);
+}
+
+// torch.nan_to_num defaults: nan -> 0, +-inf -> +-FLT_MAX
+__device__ __forceinline__ float nr_nan_to_num(float v) {
+  if (isnan(v)) return 0.0f;
+  if (isinf(v)) return v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
+// ---- wave64 scans / reductions ----------------------------------------------------------------
+__device__ __forceinline__ int nr_lane() { return threadIdx.x & (NR_WAVE - 1); }
+
+__device__ __forceinline__ float nr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, NR_WAVE);
+  return v;
+}
+
+// inclusive prefix sum across the wave
+__device__ __forceinline__ float nr_wave_incl_sum(float v) {
+  const int lane = nr_lane();
+#pragma unroll
+  for (int o = 1; o < NR_WAVE; o <<= 1) {
+    float t = __shfl_up(v, o, NR_WAVE);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// inclusive suffix sum across the wave
+__device__ __forceinline__ float nr_wave_incl_suffix_sum(float v) {
+  const int lane = nr_lane();
+#pragma unroll
+  for (int o = 1; o < NR_WAVE; o <<= 1) {
+    float t = __shfl_down(v, o, NR_WAVE);
+    if (lane + o < NR_WAVE) v += t;
+  }
+  return v;
+}
+// exclusive prefix / suffix sums.  Shifted inclusive scans, NOT "inclusive - own": subtracting a
+// lane's own (possibly huge) value back out would cancel away the small prefix it sits on.
+__device__ __forceinline__ float nr_wave_excl_sum(float v) {
+  const float incl = nr_wave_incl_sum(v);
+  const float up = __shfl_up(incl, 1, NR_WAVE);
+  return nr_lane() == 0 ? 0.0f : up;
+}
+__device__ __forceinline__ float nr_wave_excl_suffix_sum(float v) {
+  const float incl = nr_wave_incl_suffix_sum(v);
+  const float dn = __shfl_down(incl, 1, NR_WAVE);
+  return nr_lane() == NR_WAVE - 1 ? 0.0f : dn;
+}
+// inclusive prefix product
+__device__ __forceinline__ float nr_wave_incl_prod(float v) {
+  const int lane = nr_lane();
+#pragma unroll
+  for (int o = 1; o < NR_WAVE; o <<= 1) {
+    float t = __shfl_up(v, o, NR_WAVE);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}

@@ -1,0 +1,185 @@
+// Sensor ray generation on the device (the reference runs these in CPU worker processes).
+// One thread per ray; tiny, bandwidth-trivial kernels whose job is to keep the batch on the GPU.
+#include "nr_common.h"
+
+namespace {
+
+constexpr float kEps = 1e-7f;            // camera_utils._EPS
+constexpr float kLidarHDiv = 3.0e-3f;    // lidars.py:41
+constexpr float kLidarVDiv = 1.5e-3f;    // lidars.py:42
+constexpr float kLidarValid = 1.0e3f;    // valid_lidar_distance_threshold
+
+// camera_utils.normalize_with_norm (camera_utils.py:596-610)
+__device__ __forceinline__ float normalize3(float (&v)[3]) {
+  const float norm = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), kEps);
+  v[0] /= norm; v[1] /= norm; v[2] /= norm;
+  return norm;
+}
+
+__global__ void __launch_bounds__(256)
+gen_rays_camera_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
+                       const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ cx,
+                       const float* __restrict__ cy, const float* __restrict__ cam_times,
+                       const float* __restrict__ velocities, const float* __restrict__ rs_offsets,
+                       const float* __restrict__ heights, int64_t n, float* __restrict__ origins,
+                       float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ times,
+                       float* __restrict__ directions_norm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t cam = ray_indices[i * 3 + 0];
+  const float y = (float)ray_indices[i * 3 + 1] + 0.5f;  // pixel centres (cameras.py:313)
+  const float x = (float)ray_indices[i * 3 + 2] + 0.5f;
+  const float fxv = fx[cam], fyv = fy[cam], cxv = cx[cam], cyv = cy[cam];
+  const float* pose = c2w + cam * 12;
+  // the pixel and its +1 neighbours in x and y (cameras.py:622-624), OpenCV -> OpenGL flip (:656),
+  // perspective branch z = -1 (:782-787), rotate (:892-894), normalise
+  float d[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float u = k == 1 ? (x - cxv + 1.0f) / fxv : (x - cxv) / fxv;
+    const float v = -(k == 2 ? (y - cyv + 1.0f) / fyv : (y - cyv) / fyv);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[k][r] = u * pose[r * 4 + 0] + v * pose[r * 4 + 1] + (-1.0f) * pose[r * 4 + 2];
+  }
+  const float norm0 = normalize3(d[0]);
+  normalize3(d[1]);
+  normalize3(d[2]);
+  float dx = 0.0f, dy = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    dx += (d[0][r] - d[1][r]) * (d[0][r] - d[1][r]);
+    dy += (d[0][r] - d[2][r]) * (d[0][r] - d[2][r]);
+  }
+  float o[3] = {pose[3], pose[7], pose[11]};
+  float t = cam_times[cam];
+  if (velocities != nullptr) {  // top-to-bottom rolling shutter (cameras.py:922-939)
+    const float off0 = rs_offsets[cam * 2], duration = rs_offsets[cam * 2 + 1] - off0;
+    const float dt = y / heights[cam] * duration + off0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o[r] = o[r] + velocities[cam * 3 + r] * dt;
+    t = t + dt;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    origins[i * 3 + r] = o[r];
+    directions[i * 3 + r] = d[0][r];
+  }
+  pixel_area[i] = sqrtf(dx) * sqrtf(dy);
+  times[i] = t;
+  directions_norm[i] = norm0;
+}
+
+__global__ void __launch_bounds__(256)
+gen_rays_lidar_kernel(const int64_t* __restrict__ lidar_indices, const float* __restrict__ points, int point_dim,
+                      const float* __restrict__ l2w, const float* __restrict__ scan_times,
+                      const float* __restrict__ velocities, int64_t n, float* __restrict__ origins,
+                      float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ times,
+                      float* __restrict__ directions_norm, uint8_t* __restrict__ did_return) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t li = lidar_indices[i];
+  const float* pose = l2w + li * 12;
+  const float* p = points + i * point_dim;
+  const float dt = p[4];
+  float v[3], o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float world = (p[0] * pose[r * 4 + 0] + p[1] * pose[r * 4 + 1] + p[2] * pose[r * 4 + 2]) + pose[r * 4 + 3];
+    o[r] = pose[r * 4 + 3];
+    if (velocities != nullptr) o[r] = o[r] + dt * velocities[li * 3 + r];  // lidars.py:378-380
+    v[r] = world - o[r];
+  }
+  const float dist = normalize3(v);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    origins[i * 3 + r] = o[r];
+    directions[i * 3 + r] = v[r];
+  }
+  pixel_area[i] = kLidarHDiv * kLidarVDiv;
+  times[i] = scan_times[li] + dt;
+  directions_norm[i] = dist;
+  did_return[i] = dist < kLidarValid ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+gen_rays_radar_kernel(const int64_t* __restrict__ scan_indices, int64_t n_scans, const float* __restrict__ r2w,
+                      const float* __restrict__ scan_times, float min_az, float d_az, int n_az, float min_el,
+                      float d_el, int n_el, float* __restrict__ origins, float* __restrict__ directions,
+                      float* __restrict__ pixel_area, float* __restrict__ times, float* __restrict__ spher) {
+  const int64_t per_scan = (int64_t)n_az * n_el;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_scans * per_scan) return;
+  const int64_t k = i / per_scan;
+  const int rem = (int)(i - k * per_scan);
+  const int ia = rem / n_el, ie = rem - ia * n_el;  // azimuth-major meshgrid (radars.py:293-296)
+  const int64_t scan = scan_indices[k];
+  // torch.arange evaluates start + i*step in double, then rounds to fp32
+  const float az = (float)((double)min_az + (double)ia * (double)d_az);
+  const float el = (float)((double)min_el + (double)ie * (double)d_el);
+  const float* pose = r2w + scan * 12;
+  const float l[3] = {cosf(el) * cosf(az), cosf(el) * sinf(az), sinf(el)};  // radars.py:313-316
+  float v[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // transform WITH translation, then subtract the origin again (radars.py:317-320)
+    const float world = (l[0] * pose[r * 4 + 0] + l[1] * pose[r * 4 + 1] + l[2] * pose[r * 4 + 2]) + pose[r * 4 + 3];
+    v[r] = world - pose[r * 4 + 3];
+    origins[i * 3 + r] = pose[r * 4 + 3];
+  }
+  normalize3(v);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) directions[i * 3 + r] = v[r];
+  pixel_area[i] = (d_az / 5.0f) * (d_el / 5.0f);  // radars.py:324-328
+  times[i] = scan_times[scan];
+  spher[i * 2 + 0] = az;
+  spher[i * 2 + 1] = el;
+}
+
+}  // namespace
+
+extern "C" int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
+                                  const float* cx, const float* cy, const float* cam_times, const float* velocities,
+                                  const float* rs_offsets, const float* heights, int64_t n, float* origins,
+                                  float* directions, float* pixel_area, float* times, float* directions_norm,
+                                  nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!ray_indices || !c2w || !fx || !fy || !cx || !cy || !cam_times || !origins || !directions || !pixel_area ||
+      !times || !directions_norm || n < 0)
+    return NR_EINVAL;
+  if ((velocities != nullptr) != (rs_offsets != nullptr) || (velocities != nullptr) != (heights != nullptr)) return NR_EINVAL;
+  hipLaunchKernelGGL(gen_rays_camera_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), ray_indices,
+                     c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, n, origins, directions,
+                     pixel_area, times, directions_norm);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_gen_rays_lidar(const int64_t* lidar_indices, const float* points, int point_dim, const float* l2w,
+                                 const float* scan_times, const float* velocities, int64_t n, float* origins,
+                                 float* directions, float* pixel_area, float* times, float* directions_norm,
+                                 uint8_t* did_return, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!lidar_indices || !points || point_dim < 5 || !l2w || !scan_times || !origins || !directions || !pixel_area ||
+      !times || !directions_norm || !did_return || n < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(gen_rays_lidar_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), lidar_indices,
+                     points, point_dim, l2w, scan_times, velocities, n, origins, directions, pixel_area, times,
+                     directions_norm, did_return);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_gen_rays_radar(const int64_t* scan_indices, int64_t n_scans, const float* r2w, const float* scan_times,
+                                 float min_az, float d_az, int n_az, float min_el, float d_el, int n_el, float* origins,
+                                 float* directions, float* pixel_area, float* times, float* spher, nr_stream_t stream) {
+  if (n_scans == 0) return 0;
+  if (!scan_indices || !r2w || !scan_times || !origins || !directions || !pixel_area || !times || !spher ||
+      n_az < 1 || n_el < 1 || n_scans < 0)
+    return NR_EINVAL;
+  const int64_t n = n_scans * n_az * n_el;
+  hipLaunchKernelGGL(gen_rays_radar_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), scan_indices,
+                     n_scans, r2w, scan_times, min_az, d_az, n_az, min_el, d_el, n_el, origins, directions, pixel_area,
+                     times, spher);
+  NR_LAUNCH_CHECK();
+  return 0;
+}

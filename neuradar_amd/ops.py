@@ -1,0 +1,326 @@
+"""torch.autograd wrappers over the C ABI (libneuradar_hip.so).
+
+Every function here launches hand-written gfx950 kernels on torch's current stream; tensors must live
+on a ROCm device.  torch is plumbing only (memory, streams, autograd bookkeeping).
+"""
+from ctypes import byref, c_void_p
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import NrField, NrFieldGrads, NrMlp, NrMlpGrads, check
+
+POWER_LAMBDA, POWER_SCALING = -1.0, 0.1  # models/neuradar.py:133-136
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: Tensor, what: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be a GPU tensor: neuradar_amd has no CPU path (the oracle is test-only)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ hash grid
+class _HashEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, std, table, scalings, log2_hashmap_size, level_major, sample_major):
+        x, table = _f32(x, "x"), _f32(table, "hash_table")
+        n, (L, F) = x.shape[0], (scalings.numel(), table.shape[1])
+        if level_major:  # [L, n, F] storage, returned as a [n, L*F]-shaped strided view
+            buf = torch.empty((L, n, F), device=x.device, dtype=torch.float32)
+            sn, sl = F, n * F
+        else:
+            buf = torch.empty((n, L * F), device=x.device, dtype=torch.float32)
+            sn, sl = L * F, F
+        check(_lib.lib().nr_hash_encode_fwd(_p(x), _p(std), _p(table), _p(scalings), L, F, log2_hashmap_size,
+                                            _p(buf), sn, sl, n, sample_major, _stream()), "nr_hash_encode_fwd")
+        ctx.save_for_backward(x, std if std is not None else x.new_empty(0), scalings)
+        ctx.meta = (table.shape, log2_hashmap_size, level_major, sample_major, std is not None, sn, sl)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        x, std, scalings = ctx.saved_tensors
+        shape, log2t, level_major, sample_major, has_std, sn, sl = ctx.meta
+        g = g.contiguous()
+        gtable = torch.zeros(shape, device=g.device, dtype=torch.float32)
+        check(_lib.lib().nr_hash_encode_bwd(_p(x), _p(std) if has_std else None, _p(scalings), scalings.numel(),
+                                            shape[1], log2t, _p(g), sn, sl, _p(gtable), x.shape[0], sample_major,
+                                            _stream()), "nr_hash_encode_bwd")
+        return None, None, gtable, None, None, None, None
+
+
+def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: int, std: Optional[Tensor] = None,
+                level_major: bool = False, sample_major: int = 0) -> Tensor:
+    """x [n,3] in [0,1] -> [n, L*F] (or the level-major buffer [L, n, F] when `level_major`)."""
+    return _HashEncode.apply(x, std, table, scalings, log2_hashmap_size, level_major, sample_major)
+
+
+def contract_gaussians(origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid: Tensor, scale: float
+                       ) -> Tuple[Tensor, Tensor]:
+    """Frustum samples -> contracted (x01 [B*S,3], std01 [B*S]).  No gradient (static scene)."""
+    B, S = euclid.shape[0], euclid.shape[1] - 1
+    x01 = torch.empty((B * S, 3), device=euclid.device, dtype=torch.float32)
+    std01 = torch.empty((B * S,), device=euclid.device, dtype=torch.float32)
+    check(_lib.lib().nr_contract_gaussians(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                           _p(_f32(pixel_area, "pixel_area")), _p(_f32(euclid, "euclid")), B, S,
+                                           float(scale), _p(x01), _p(std01), _stream()), "nr_contract_gaussians")
+    return x01, std01
+
+
+# ------------------------------------------------------------------------------------------------ MLPs
+def _mlp_struct(weights: Sequence[Tensor], biases: Sequence[Tensor]) -> NrMlp:
+    m = NrMlp()
+    m.num_layers = len(weights)
+    m.in_dim, m.out_dim = weights[0].shape[1], weights[-1].shape[0]
+    m.width = weights[0].shape[0] if len(weights) > 1 else weights[0].shape[0]
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        m.weight[i], m.bias[i] = w.data_ptr(), b.data_ptr()
+    return m
+
+
+def _mlp_grads_struct(gw: Sequence[Tensor], gb: Sequence[Tensor]) -> NrMlpGrads:
+    g = NrMlpGrads()
+    for i, (w, b) in enumerate(zip(gw, gb)):
+        g.weight[i], g.bias[i] = w.data_ptr(), b.data_ptr()
+    return g
+
+
+class _Mlp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_layers, *params):
+        x = _f32(x, "x")
+        ws = [_f32(p, "weight") for p in params[:n_layers]]
+        bs = [_f32(p, "bias") for p in params[n_layers:]]
+        m = _mlp_struct(ws, bs)
+        y = torch.empty((x.shape[0], m.out_dim), device=x.device, dtype=torch.float32)
+        check(_lib.lib().nr_mlp_fwd(byref(m), _p(x), x.shape[0], _p(y), _stream()), "nr_mlp_fwd")
+        ctx.save_for_backward(x, *ws, *bs)
+        ctx.n_layers = n_layers
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, *params = ctx.saved_tensors
+        nl = ctx.n_layers
+        ws, bs = params[:nl], params[nl:]
+        m = _mlp_struct(ws, bs)
+        gws, gbs = [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g = _mlp_grads_struct(gws, gbs)
+        check(_lib.lib().nr_mlp_bwd(byref(m), _p(x), _p(gy.contiguous()), x.shape[0], _p(gx), byref(g), _stream()),
+              "nr_mlp_bwd")
+        return (gx, None, *gws, *gbs)
+
+
+def mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> Tensor:
+    return _Mlp.apply(x, len(weights), *weights, *biases)
+
+
+class _Field(torch.autograd.Function):
+    """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
+
+    @staticmethod
+    def forward(ctx, feats, strides, feat_f, directions, n_samples, n, beta, n_geo, *params):
+        geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
+        rest = params[2 * n_geo:]
+        n_feat = len(rest) // 2
+        feat_w, feat_b = rest[:n_feat], rest[n_feat:]
+        fld = NrField()
+        fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
+        C = feat_w[-1].shape[0]
+        feature = torch.empty((n, C), device=feats.device, dtype=torch.float32)
+        sdf = torch.empty((n,), device=feats.device, dtype=torch.float32)
+        alpha = torch.empty((n,), device=feats.device, dtype=torch.float32)
+        sn, sl = strides
+        check(_lib.lib().nr_field_fwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, n,
+                                      _p(feature), _p(sdf), _p(alpha), _stream()), "nr_field_fwd")
+        ctx.save_for_backward(feats, directions, beta, *params)
+        ctx.meta = (strides, feat_f, n_samples, n, n_geo, n_feat)
+        return feature, sdf, alpha
+
+    @staticmethod
+    def backward(ctx, g_feature, g_sdf, g_alpha):
+        feats, directions, beta, *params = ctx.saved_tensors
+        (sn, sl), feat_f, n_samples, n, n_geo, n_feat = ctx.meta
+        geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
+        feat_w, feat_b = params[2 * n_geo:2 * n_geo + n_feat], params[2 * n_geo + n_feat:]
+        fld = NrField()
+        fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
+        grads = [torch.zeros_like(p) for p in params]
+        g_beta = torch.zeros_like(beta)
+        gs = NrFieldGrads()
+        gs.geo = _mlp_grads_struct(grads[:n_geo], grads[n_geo:2 * n_geo])
+        gs.feat = _mlp_grads_struct(grads[2 * n_geo:2 * n_geo + n_feat], grads[2 * n_geo + n_feat:])
+        gs.beta = g_beta.data_ptr()
+        g_feats = torch.empty_like(feats)
+        g_feature = torch.zeros((n, feat_w[-1].shape[0]), device=feats.device) if g_feature is None else g_feature.contiguous()
+        g_alpha = torch.zeros((n,), device=feats.device) if g_alpha is None else g_alpha.contiguous()
+        g_sdf = None if g_sdf is None else g_sdf.contiguous()
+        check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, n,
+                                      _p(g_feature), _p(g_alpha), _p(g_sdf), _p(g_feats), byref(gs), _stream()),
+              "nr_field_bwd")
+        return (g_feats, None, None, None, None, None, g_beta, None, *grads)
+
+
+def field_mlp(feats: Tensor, strides: Tuple[int, int], feat_f: int, directions: Tensor, n_samples: int, n: int,
+              geo: Tuple[List[Tensor], List[Tensor]], feat: Tuple[List[Tensor], List[Tensor]], beta: Tensor):
+    """NeuRADField after the grid (neurad_field.py:137-148).  feats is the raw buffer written by
+    hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]."""
+    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, n, beta, len(geo[0]),
+                        *geo[0], *geo[1], *feat[0], *feat[1])
+
+
+def sh4(dirs01: Tensor) -> Tensor:
+    d = _f32(dirs01, "directions").reshape(-1, 3)
+    out = torch.empty((d.shape[0], 16), device=d.device, dtype=torch.float32)
+    check(_lib.lib().nr_sh4_fwd(_p(d), d.shape[0], _p(out), _stream()), "nr_sh4_fwd")
+    return out.view(*dirs01.shape[:-1], 16)
+
+
+# ------------------------------------------------------------------------------------------------ proposal head
+class _PropDensity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, strides, feat_f, w, n):
+        sn, sl = strides
+        density = torch.empty((n,), device=feats.device, dtype=torch.float32)
+        wf = _f32(w, "decoder weight").reshape(-1)
+        check(_lib.lib().nr_prop_density_fwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, _p(density), _stream()),
+              "nr_prop_density_fwd")
+        ctx.save_for_backward(feats, wf, density)
+        ctx.meta = (strides, feat_f, n, w.shape)
+        return density
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, wf, density = ctx.saved_tensors
+        (sn, sl), feat_f, n, wshape = ctx.meta
+        g_feats = torch.empty_like(feats)
+        g_w = torch.zeros_like(wf)
+        check(_lib.lib().nr_prop_density_bwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, _p(density),
+                                             _p(g.contiguous()), _p(g_feats), _p(g_w), _stream()), "nr_prop_density_bwd")
+        return g_feats, None, None, g_w.view(wshape), None
+
+
+def prop_density(feats: Tensor, strides: Tuple[int, int], feat_f: int, w: Tensor, n: int) -> Tensor:
+    return _PropDensity.apply(feats, strides, feat_f, w, n)
+
+
+# ------------------------------------------------------------------------------------------------ sampling
+def power_bins(nears: Tensor, fars: Tensor, n_samples: int, t_rand: Optional[Tensor] = None,
+               lam: float = POWER_LAMBDA, scaling: float = POWER_SCALING) -> Tuple[Tensor, Tensor]:
+    nears, fars = _f32(nears, "nears").reshape(-1), _f32(fars, "fars").reshape(-1)
+    B = nears.shape[0]
+    spacing = torch.empty((B, n_samples + 1), device=nears.device, dtype=torch.float32)
+    euclid = torch.empty_like(spacing)
+    if t_rand is not None:
+        t_rand = _f32(t_rand, "t_rand")
+        assert t_rand.shape == (B, n_samples + 1)
+    check(_lib.lib().nr_power_bins(_p(nears), _p(fars), _p(t_rand), B, n_samples, lam, scaling, _p(spacing),
+                                   _p(euclid), _stream()), "nr_power_bins")
+    return spacing, euclid
+
+
+class _Weights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density, euclid):
+        density, euclid = _f32(density, "density"), _f32(euclid, "euclid")
+        B, S = density.shape
+        w = torch.empty_like(density)
+        check(_lib.lib().nr_weights_from_density_fwd(_p(density), _p(euclid), B, S, _p(w), _stream()),
+              "nr_weights_from_density_fwd")
+        ctx.save_for_backward(density, euclid)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        density, euclid = ctx.saved_tensors
+        B, S = density.shape
+        gd = torch.empty_like(density)
+        check(_lib.lib().nr_weights_from_density_bwd(_p(density), _p(euclid), _p(gw.contiguous()), B, S, _p(gd),
+                                                     _stream()), "nr_weights_from_density_bwd")
+        return gd, None
+
+
+def weights_from_density(density: Tensor, euclid: Tensor) -> Tensor:
+    """RaySamples.get_weights: density [B,S], euclid edges [B,S+1] -> weights [B,S]."""
+    return _Weights.apply(density, euclid)
+
+
+def pdf_resample(weights: Tensor, spacing_in: Tensor, nears: Tensor, fars: Tensor, n_out: int,
+                 jitter: Optional[Tensor] = None, lam: float = POWER_LAMBDA, scaling: float = POWER_SCALING
+                 ) -> Tuple[Tensor, Tensor]:
+    weights = _f32(weights.detach(), "weights")
+    B, S = weights.shape
+    sp = torch.empty((B, n_out + 1), device=weights.device, dtype=torch.float32)
+    eu = torch.empty_like(sp)
+    if jitter is not None:
+        jitter = _f32(jitter, "jitter").reshape(-1)
+    check(_lib.lib().nr_pdf_resample(_p(weights), _p(_f32(spacing_in, "spacing")), _p(jitter),
+                                     _p(_f32(nears, "nears").reshape(-1)), _p(_f32(fars, "fars").reshape(-1)), B, S,
+                                     n_out, lam, scaling, _p(sp), _p(eu), _stream()), "nr_pdf_resample")
+    return sp, eu
+
+
+# ------------------------------------------------------------------------------------------------ compositing
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha, feature, euclid):
+        alpha, feature, euclid = _f32(alpha, "alpha"), _f32(feature, "feature"), _f32(euclid, "euclid")
+        B, S = alpha.shape
+        C = feature.shape[-1]
+        w = torch.empty_like(alpha)
+        acc = torch.empty((B,), device=alpha.device, dtype=torch.float32)
+        feats = torch.empty((B, C), device=alpha.device, dtype=torch.float32)
+        depth = torch.empty((B,), device=alpha.device, dtype=torch.float32)
+        check(_lib.lib().nr_composite_fwd(_p(alpha), _p(feature), _p(euclid), B, S, C, _p(w), _p(acc), _p(feats),
+                                          _p(depth), _stream()), "nr_composite_fwd")
+        ctx.save_for_backward(alpha, feature, euclid, w)
+        return w, acc, feats, depth
+
+    @staticmethod
+    def backward(ctx, g_w, g_acc, g_feats, g_depth):
+        alpha, feature, euclid, w = ctx.saved_tensors
+        B, S = alpha.shape
+        C = feature.shape[-1]
+        g_alpha, g_feature = torch.empty_like(alpha), torch.empty_like(feature)
+        c = lambda t: None if t is None else t.contiguous()  # noqa: E731
+        check(_lib.lib().nr_composite_bwd(_p(alpha), _p(feature), _p(euclid), _p(w), _p(c(g_feats)), _p(c(g_depth)),
+                                          _p(c(g_acc)), _p(c(g_w)), B, S, C, _p(g_alpha), _p(g_feature), _stream()),
+              "nr_composite_bwd")
+        return g_alpha, g_feature, None
+
+
+def composite(alpha: Tensor, feature: Tensor, euclid: Tensor):
+    """alpha [B,S], feature [B,S,C], euclid [B,S+1] -> (weights [B,S] incl. sky fix-up,
+    accumulation [B], features [B,C], depth [B]).  models/neuradar.py:504-517."""
+    return _Composite.apply(alpha, feature, euclid)
+
+
+def depth_from_weights(weights: Tensor, euclid: Tensor) -> Tensor:
+    weights = _f32(weights.detach(), "weights")
+    B, S = weights.shape
+    depth = torch.empty((B,), device=weights.device, dtype=torch.float32)
+    check(_lib.lib().nr_depth_from_weights(_p(weights), _p(_f32(euclid, "euclid")), B, S, _p(depth), _stream()),
+          "nr_depth_from_weights")
+    return depth
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
+              betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,
+              grad_scale: float = 1.0, zero_grad: bool = True, dev_hyper: Optional[Tensor] = None) -> None:
+    check(_lib.lib().nr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0],
+                                  betas[1], eps, weight_decay, int(adamw), step, grad_scale, int(zero_grad),
+                                  _p(dev_hyper), _stream()), "nr_adam_step")

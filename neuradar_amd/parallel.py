@@ -1,0 +1,91 @@
+"""Data parallelism of the path: rays shard across ranks, parameters are replicated, one gradient
+all-reduce (mean) per step -- the behaviour of the reference's DDP wrap
+(pipelines/base_pipeline.py:305-307, scripts/train.py:110-164) over RCCL/xGMI.
+
+MI355X-first choices: >99 % of the gradient bytes are hash tables, so they get
+their own large flat buckets (one collective per table, no DDP bucketing/copy), all small parameters
+are packed into a single fused bucket, and unused parameters (proposal_fields[0]) are simply
+all-reduced as zeros instead of DDP's find_unused_parameters bitmap exchange.
+"""
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+SMALL_PARAM_NUMEL = 1 << 16
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend)
+    return rank, world, local_rank
+
+
+class GradAllReducer:
+    """Mean all-reduce of `.grad` over the world: big tensors in place, small ones via one flat bucket."""
+
+    def __init__(self, params: Iterable[nn.Parameter], group=None, table_dtype: Optional[torch.dtype] = None):
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.big = [p for p in self.params if p.numel() > SMALL_PARAM_NUMEL]
+        self.small = [p for p in self.params if p.numel() <= SMALL_PARAM_NUMEL]
+        self.table_dtype = table_dtype  # e.g. torch.bfloat16 halves the xGMI bytes of the table buckets
+        self._flat: Optional[torch.Tensor] = None
+
+    def bytes_per_step(self) -> int:
+        esz = 4 if self.table_dtype is None else torch.empty((), dtype=self.table_dtype).element_size()
+        return sum(p.numel() for p in self.big) * esz + sum(p.numel() for p in self.small) * 4
+
+    @torch.no_grad()
+    def all_reduce(self) -> None:
+        if self.world == 1:
+            return
+        works = []
+        for p in self.big:
+            g = p.grad
+            if self.table_dtype is not None:
+                low = g.to(self.table_dtype)
+                dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(low).div_(self.world)
+            else:
+                works.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), g))
+        if self.small:
+            if self._flat is None:
+                self._flat = torch.empty(sum(p.numel() for p in self.small), device=self.small[0].device,
+                                         dtype=torch.float32)
+            off = 0
+            for p in self.small:
+                n = p.numel()
+                self._flat[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=p.device))
+                off += n
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._flat.div_(self.world)
+            off = 0
+            for p in self.small:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                p.grad.copy_(self._flat[off:off + n].view_as(p))
+                off += n
+        for w, g in works:
+            w.wait()
+            g.div_(self.world)
+
+
+def broadcast_parameters(module: nn.Module, src: int = 0, group=None) -> None:
+    """DDP's initial parameter sync (rank 0's weights everywhere)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -1,0 +1,190 @@
+"""The hot loop as one module: `NeuRadarHotPath.get_nff_outputs` mirrors
+`NeuRadarModel.get_nff_outputs` (reference models/neuradar.py:495-548 with _get_ray_samples :570-586),
+and `TrainStep` is the step the benchmark times: forward + bench loss + backward + Adam, optionally
+captured into one hipGraph (the path is launch-bound at 4k-16k rays).
+
+What replaces the out-of-scope tail of the reference model (CNN / lidar / radar decoders, Hungarian
+radar loss): direct supervision of the path's own outputs with the reference's loss multipliers,
+plus the reference's two regularisers -- see DESIGN.md.
+"""
+import math
+import dataclasses
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import losses, ops
+from .field_heads import FieldHeadNames
+from .neurad_field import NeuRADField, NeuRADFieldConfig, NeuRADProposalField, NeuRADProposalFieldConfig
+from .ray_samplers import PowerSampler, ProposalNetworkSampler
+from .rays import RayBundle, RaySamples
+from .renderers import composite, render_depth_simple
+
+SKY_DISTANCE = 20000.0  # SamplingSettings.sky_distance, neuradar.py:137
+EPS = 1e-7
+
+
+@dataclass
+class HotPathConfig:
+    """The slice of NeuRadarModelConfig (neuradar.py:118-187) that parameterises the path."""
+
+    proposal_field_1: NeuRADProposalFieldConfig = dataclasses.field(default_factory=NeuRADProposalFieldConfig)
+    proposal_field_2: NeuRADProposalFieldConfig = dataclasses.field(default_factory=NeuRADProposalFieldConfig)
+    field: NeuRADFieldConfig = dataclasses.field(default_factory=NeuRADFieldConfig)
+    num_proposal_samples: Tuple[int, ...] = (128, 64)
+    num_nerf_samples: int = 32
+    power_lambda: float = -1.0
+    power_scaling: float = 0.1
+    single_jitter: bool = True
+    static_scale: float = 100.0
+    appearance_dim: int = 0  # 16 in the reference; the embedding lookup is a torch gather (neuradar.py:550-568)
+    duration: float = 20.0
+    num_sensors: int = 1
+    temporal_appearance_freq: float = 1.0
+    # loss multipliers (LossSettings, neuradar.py:80-115)
+    rgb_mult: float = 5.0
+    depth_mult: float = 0.01
+    interlevel_loss_mult: float = 0.001
+    distortion_loss_mult: float = 0.002
+
+
+class NeuRadarHotPath(nn.Module):
+    def __init__(self, config: HotPathConfig) -> None:
+        super().__init__()
+        self.config = config
+        c = config
+        self.field = c.field.setup(actors=None, static_scale=c.static_scale, implementation="hip")
+        self.proposal_fields = nn.ModuleList(
+            [pc.setup(actors=None, static_scale=c.static_scale, implementation="hip")
+             for pc in (c.proposal_field_1, c.proposal_field_2)])
+        # Reference quirk (neuradar.py:302): the density_fns list is built with a
+        # late-binding lambda, so BOTH proposal rounds evaluate proposal_fields[1]; proposal_fields[0]
+        # exists (state_dict, optimizer, all-reduce) but never runs.  Reproduced on purpose.
+        last = self.proposal_fields[-1]
+        self.density_fns = [lambda rs: last.get_density(rs)[0] for _ in self.proposal_fields]
+        self.sampler = ProposalNetworkSampler(
+            num_proposal_samples_per_ray=c.num_proposal_samples, num_nerf_samples_per_ray=c.num_nerf_samples,
+            num_proposal_network_iterations=len(c.num_proposal_samples), single_jitter=c.single_jitter,
+            initial_sampler=PowerSampler(lambda_=c.power_lambda, scaling=c.power_scaling), update_sched=lambda x: 0)
+        if c.appearance_dim > 0:
+            self._num_embeds_per_sensor = math.ceil(c.duration * c.temporal_appearance_freq)
+            self.appearance_embedding = nn.Embedding(c.num_sensors * self._num_embeds_per_sensor, c.appearance_dim)
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        groups: Dict[str, List[nn.Parameter]] = {"hashgrids": [], "fields": []}
+        for f in (self.field, *self.proposal_fields):
+            f.get_param_groups(groups)
+        if self.config.appearance_dim > 0:
+            groups["fields"] += list(self.appearance_embedding.parameters())
+        return groups
+
+    def _get_ray_samples(self, bundle: RayBundle, t_rand=None, jitters=(None, None)):
+        """neuradar.py:570-586."""
+        if bundle.fars is not None:
+            bundle.fars = bundle.fars.clamp_max(SKY_DISTANCE)
+        else:
+            bundle.fars = torch.full_like(bundle.pixel_area, SKY_DISTANCE)
+        if bundle.nears is None:
+            bundle.nears = torch.zeros_like(bundle.fars)
+        rs, prop_w, prop_rs = self.sampler(bundle, self.density_fns, pass_ray_samples=True, t_rand=t_rand,
+                                           jitters=jitters)
+        # "sky field": the last sample is stretched to sky_distance (:578-582)
+        dist_to_sky = SKY_DISTANCE - rs.euclid[:, -1]
+        euclid = torch.cat([rs.euclid[:, :-1], (rs.euclid[:, -1] + dist_to_sky)[:, None]], dim=-1)
+        spacing = torch.cat([rs.spacing[:, :-1], torch.full_like(rs.spacing[:, -1:], 1 - EPS)], dim=-1)
+        rs = RaySamples(rs.origins, rs.directions, rs.pixel_area, spacing, euclid, rs.nears, rs.fars, rs.times,
+                        rs.metadata, rs.camera_indices)
+        return rs, prop_rs, prop_w
+
+    def _get_appearance_embedding(self, bundle: RayBundle) -> Tensor:
+        """neuradar.py:550-568 (temporal appearance)."""
+        E = self._num_embeds_per_sensor
+        sensor_idx = bundle.metadata["sensor_idxs"]
+        time_idx = bundle.times / self.config.duration * E
+        before = time_idx.floor().clamp(0, E - 1)
+        after = (before + 1).clamp(0, E - 1)
+        ratio = time_idx - before
+        before, after = before + sensor_idx * E, after + sensor_idx * E
+        e0 = self.appearance_embedding(before.squeeze(-1).long())
+        e1 = self.appearance_embedding(after.squeeze(-1).long())
+        return e0 * (1 - ratio) + e1 * ratio
+
+    def get_nff_outputs(self, bundle: RayBundle, t_rand=None, jitters=(None, None)) -> Dict[str, Tensor]:
+        """neuradar.py:495-548.  `bundle.pixel_area` is expected to be already scaled
+        (sensors.scale_pixel_area = _scale_pixel_area)."""
+        rs, prop_rs, prop_w = self._get_ray_samples(bundle, t_rand, jitters)
+        outputs = self.field(rs)
+        weights, accumulation, features, depth = composite(outputs[FieldHeadNames.ALPHA],
+                                                           outputs[FieldHeadNames.FEATURE], rs)
+        if self.config.appearance_dim > 0:
+            features = torch.cat([features, self._get_appearance_embedding(bundle)], dim=-1)
+        out = {"features": features, "depth": depth, "accumulation": accumulation}
+        for i, (w, s) in enumerate(zip(prop_w, prop_rs)):
+            out[f"prop_depth_{i}"] = render_depth_simple(w, s)
+        # the sky sample is dropped from the lists the regularisers see (:515,534-535)
+        out["weights_list"] = prop_w + [weights[:, :-1]]
+        out["ray_samples_list"] = prop_rs + [rs.drop_last()]
+        out["weights"] = weights
+        out["field_outputs"] = outputs
+        out["ray_samples"] = rs
+        return out
+
+    forward = get_nff_outputs
+
+    def bench_loss(self, out: Dict[str, Tensor], target_features: Tensor, target_depth: Tensor) -> Tensor:
+        """rgb_mult*MSE(features) + depth_mult*L1(depth) + inter-level + distortion (neuradar.py:672-704
+        with the decoders replaced by direct supervision)."""
+        c = self.config
+        cs = [s.spacing for s in out["ray_samples_list"]]
+        ws = [w[..., 0] for w in out["weights_list"]]
+        loss = c.rgb_mult * torch.mean((out["features"][:, : target_features.shape[1]] - target_features) ** 2)
+        loss = loss + c.depth_mult * (out["depth"] - target_depth).abs().mean()
+        loss = loss + c.interlevel_loss_mult * losses.zipnerf_interlevel_loss(cs, ws)
+        loss = loss + c.distortion_loss_mult * losses.distortion_loss(cs[-1], ws[-1])
+        return loss
+
+
+class FlatAdam:
+    """Adam/AdamW over a list of parameters with the fused HIP kernel (one launch per tensor).
+
+    Hyper-parameters of configs/method_configs.py:384-409; the (lr, bias-correction) triple lives in a
+    device tensor updated by a few scalar ops so that a captured graph can be replayed."""
+
+    def __init__(self, params: List[nn.Parameter], lr: float, eps: float = 1e-15, weight_decay: float = 0.0,
+                 adamw: bool = False, betas=(0.9, 0.999), lr_final: Optional[float] = None, max_steps: int = 20001,
+                 warmup_steps: int = 500) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.eps, self.wd, self.adamw, self.betas = lr, eps, weight_decay, adamw, betas
+        self.lr_final, self.max_steps, self.warmup = lr_final, max_steps, warmup_steps
+        dev = self.params[0].device
+        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in self.params]
+        self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+
+    def _schedule(self, step: Tensor) -> Tensor:
+        """ExponentialDecayScheduler (engine/schedulers.py:112-143): cosine-ramp warm-up from
+        lr_pre_warmup = 1e-8, then log-linear decay to lr_final.  `step` is the 0-based scheduler step."""
+        lr_final = self.lr if self.lr_final is None else self.lr_final
+        t = torch.clamp((step - self.warmup) / max(self.max_steps - self.warmup, 1), 0, 1)
+        decayed = torch.exp(math.log(self.lr) * (1 - t) + math.log(lr_final) * t)
+        if self.warmup > 0:
+            pre = 1e-8
+            ramp = pre + (self.lr - pre) * torch.sin(0.5 * math.pi * torch.clamp(step / self.warmup, 0, 1))
+            return torch.where(step < self.warmup, ramp, decayed)
+        return decayed
+
+    @torch.no_grad()
+    def step(self) -> None:
+        b1, b2 = self.betas
+        self.hyper[0] = self._schedule(self.step_t)  # LambdaLR: lr of optimizer step k (1-based) is func(k-1)
+        self.step_t += 1
+        self.hyper[1] = 1 - b1**self.step_t
+        self.hyper[2] = torch.sqrt(1 - b2**self.step_t)
+        for p, (m, v) in zip(self.params, self.state):
+            ops.adam_step(p.data, p.grad, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw,
+                          zero_grad=True, dev_hyper=self.hyper)

@@ -1,0 +1,415 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated golden vectors and the
+CPU oracle on seeded inputs.  Tolerance: the north-star's 1e-4 relative (fp32), written per check;
+integer/index work (hash slots, did_return, scan ids) is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, load_golden, oracle_field_params, oracle_prop_params
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def dev(x):
+    return x.to(DEV) if isinstance(x, torch.Tensor) else x
+
+
+def cpu(x):
+    return x.detach().cpu()
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def make_field(g, prefix="", log2t_key="log2t", hidden=32, static=None):
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+
+    L = g[f"{prefix}scalings"].numel()
+    F = g[f"{prefix}table"].shape[1]
+    st = static or StaticSettings(hashgrid_dim=F, num_levels=L, log2_hashmap_size=int(g[log2t_key]))
+    fld = NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=st), geo_hidden_dim=hidden, nff_hidden_dim=hidden
+                            ).setup(actors=None, static_scale=100.0).to(DEV)
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(g[f"{prefix}table"])
+        fld.hashgrid.static_grid.scalings.copy_(g[f"{prefix}scalings"])
+        for i, l in enumerate(fld.mlp_geo.layers):
+            l.weight.copy_(g[f"{prefix}geo_w{i}"]); l.bias.copy_(g[f"{prefix}geo_b{i}"])
+        for i, l in enumerate(fld.mlp_feature.layers):
+            l.weight.copy_(g[f"{prefix}feat_w{i}"]); l.bias.copy_(g[f"{prefix}feat_b{i}"])
+        fld.sdf_to_density.beta.copy_(g[f"{prefix}beta"])
+    return fld
+
+
+def make_prop(g, prefix="prop_", log2t_key="prop_log2t"):
+    from neuradar_amd.neurad_field import NeuRADProposalFieldConfig
+
+    pc = NeuRADProposalFieldConfig()
+    pc.grid.static.log2_hashmap_size = int(g[log2t_key])
+    pf = pc.setup(actors=None, static_scale=100.0).to(DEV)
+    with torch.no_grad():
+        pf.hashgrid.static_grid.hash_table.copy_(g[f"{prefix}table"])
+        pf.hashgrid.static_grid.scalings.copy_(g[f"{prefix}scalings"])
+        pf.density_decoder.weight.copy_(g[f"{prefix}decoder"])
+    return pf
+
+
+def samples_from_edges(g, edges):
+    from neuradar_amd.rays import RaySamples
+
+    B = edges.shape[0]
+    return RaySamples(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(torch.zeros_like(edges)),
+                      dev(edges), dev(torch.zeros(B, 1)), dev(torch.full((B, 1), 1e6)))
+
+
+# ------------------------------------------------------------------------------------------------ a8
+@pytest.mark.parametrize("tag", ["l8f4", "l6f1", "l16f2", "l4f4"])
+@pytest.mark.parametrize("level_major", [False, True])
+def test_hash_encode_fwd_bwd_vs_reference_golden(tag, level_major):
+    from neuradar_amd import ops
+
+    g = load_golden("hash_encode")
+    x, table, sc = dev(g[f"{tag}_x"]), dev(g[f"{tag}_table"]).requires_grad_(True), dev(g[f"{tag}_scalings"])
+    n, L, F = x.shape[0], sc.numel(), table.shape[1]
+    sm = 60 if level_major else 0  # 300 = 5 "rays" x 60 samples: exercises the sample-major lane mapping
+    out = ops.hash_encode(x, table, sc, int(g[f"{tag}_log2t"]), level_major=level_major, sample_major=sm)
+    flat = out.permute(1, 0, 2).reshape(n, L * F) if level_major else out
+    assert_close(cpu(flat), g[f"{tag}_out"], rtol=1e-5, atol_scale=1e-6, what=tag)
+    gout = dev(g[f"{tag}_gout"])
+    gbuf = gout.view(n, L, F).permute(1, 0, 2).contiguous() if level_major else gout
+    (gt,) = torch.autograd.grad(out, table, gbuf)
+    assert_close(cpu(gt), g[f"{tag}_gtable"], rtol=1e-4, atol_scale=1e-5, what=tag + " grad")
+
+
+def test_hash_encode_module_is_dropin_and_linear_in_table():
+    """HashEncoding keeps the reference's surface (scalings buffer, hash_table parameter, out dim) and
+    the encoding is linear in the table (size-independent property, checked at a large n)."""
+    from neuradar_amd.encodings import HashEncoding
+
+    torch.manual_seed(0)
+    enc = HashEncoding(num_levels=8, min_res=32, max_res=8192, log2_hashmap_size=19, features_per_level=4).to(DEV)
+    assert enc.get_out_dim() == 32 and enc.scalings[-1].item() == 8191.0
+    assert enc.hash_table.shape == (8 * 2**19, 4) and isinstance(enc.hash_table, torch.nn.Parameter)
+    x = torch.rand(200_000, 3, device=DEV)
+    y1 = enc(x)
+    with torch.no_grad():
+        t0 = enc.hash_table.clone()
+        enc.hash_table.mul_(-2.5)
+    y2 = enc(x)
+    torch.testing.assert_close(y2, -2.5 * y1, rtol=1e-5, atol=1e-9)
+    with torch.no_grad():
+        enc.hash_table.copy_(torch.ones_like(t0))
+    y3 = enc(x)  # partition of unity: trilinear weights sum to one
+    torch.testing.assert_close(y3, torch.ones_like(y3), rtol=1e-5, atol=1e-6)
+    assert enc(torch.empty(0, 3, device=DEV)).shape == (0, 32)  # empty input
+
+
+# ------------------------------------------------------------------------------------------------ a6 a7 a9
+def test_contraction_and_rescaled_grid_features():
+    from neuradar_amd import ops
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+
+    g = load_golden("gaussian_contraction")
+    e = g["edges"]
+    x01, std01 = ops.contract_gaussians(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(e), 100.0)
+    B, S = e.shape[0], e.shape[1] - 1
+    assert_close(cpu(x01).view(B, S, 3), g["mean01"], rtol=1e-5, atol_scale=1e-6, what="mean01")
+    assert_close(cpu(std01).view(B, S, 1), g["std01"], rtol=2e-5, atol_scale=1e-6, what="std01")
+    x01a, std01a = ops.contract_gaussians(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(e), 10.0)
+    assert_close(cpu(x01a).view(B, S, 3), g["mean01_actor"], rtol=1e-5, atol_scale=1e-6)
+    assert_close(cpu(std01a).view(B, S, 1), g["std01_actor"], rtol=2e-5, atol_scale=1e-6)
+    hg = NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=int(g["log2t"]))).setup(
+        dynamic_actors=None, static_scale=100.0).to(DEV)
+    with torch.no_grad():
+        hg.static_grid.hash_table.copy_(g["table"])
+    feats, _ = hg(samples_from_edges(g, e))
+    assert_close(cpu(feats).view(B, S, -1), g["grid_features"], rtol=1e-4, atol_scale=1e-5, what="grid features")
+
+
+# ------------------------------------------------------------------------------------------------ a15 a11
+@pytest.mark.parametrize("tag,hidden", [("field_neurad", 32), ("field_l16f2w64", 64)])
+def test_field_fwd_bwd_vs_reference_golden(tag, hidden):
+    from neuradar_amd.field_heads import FieldHeadNames
+    from neuradar_amd.neurad_encoding import StaticSettings
+
+    g = load_golden(tag)
+    static = None
+    if hidden == 64:
+        static = StaticSettings(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024, log2_hashmap_size=int(g["log2t"]))
+    fld = make_field(g, hidden=hidden, static=static)
+    rs = samples_from_edges(g, g["edges"])
+    out = fld(rs)
+    assert_close(cpu(out[FieldHeadNames.FEATURE]), g["feature"], rtol=1e-4, atol_scale=1e-5, what="feature")
+    assert_close(cpu(out[FieldHeadNames.SDF]), g["sdf"], rtol=1e-4, atol_scale=1e-5, what="sdf")
+    assert_close(cpu(out[FieldHeadNames.ALPHA]), g["alpha"], rtol=1e-4, atol_scale=1e-5, what="alpha")
+    loss = (out[FieldHeadNames.FEATURE] * dev(g["g_feature"])).sum() + (out[FieldHeadNames.ALPHA] * dev(g["g_alpha"])).sum()
+    named = dict(fld.named_parameters())
+    keys = ["hashgrid.static_grid.hash_table"]
+    gold = ["grad_table"]
+    for i in range(2):
+        keys += [f"mlp_geo.layers.{i}.weight", f"mlp_geo.layers.{i}.bias"]; gold += [f"grad_geo_w{i}", f"grad_geo_b{i}"]
+    for i in range(3):
+        keys += [f"mlp_feature.layers.{i}.weight", f"mlp_feature.layers.{i}.bias"]; gold += [f"grad_feat_w{i}", f"grad_feat_b{i}"]
+    keys.append("sdf_to_density.beta"); gold.append("grad_beta")
+    grads = torch.autograd.grad(loss, [named[k] for k in keys])
+    for k, gk, gr in zip(keys, gold, grads):
+        assert_close(cpu(gr), g[gk], rtol=2e-4, atol_scale=2e-5, what="grad " + k)
+
+
+def test_proposal_density_fwd_bwd_vs_reference_golden():
+    g = load_golden("field_neurad")
+    pf = make_prop(g)
+    rs = samples_from_edges(g, g["edges"])
+    dens, _ = pf.get_density(rs)
+    assert_close(cpu(dens), g["prop_density"], rtol=1e-4, atol_scale=1e-5)
+    gt, gw = torch.autograd.grad((dens * dev(g["prop_g_density"])).sum(),
+                                 [pf.hashgrid.static_grid.hash_table, pf.density_decoder.weight])
+    assert_close(cpu(gt), g["prop_grad_table"], rtol=2e-4, atol_scale=2e-5)
+    assert_close(cpu(gw), g["prop_grad_decoder"], rtol=2e-4, atol_scale=2e-5)
+
+
+def test_sh_and_generic_mlp_vs_reference_golden_and_oracle_backward():
+    from neuradar_amd.encodings import SHEncoding
+    from neuradar_amd.mlp import MLP
+    from oracle import field as ofield
+
+    g = load_golden("sh_mlp")
+    assert_close(cpu(SHEncoding(levels=4)(dev(g["dirs"]))), g["sh_raw"], rtol=1e-5, atol_scale=1e-6)
+    m = MLP(in_dim=48, num_layers=3, layer_width=32, out_dim=2).to(DEV)  # lidar decoder shape (K7)
+    with torch.no_grad():
+        for i, l in enumerate(m.layers):
+            l.weight.copy_(g[f"mlp_w{i}"]); l.bias.copy_(g[f"mlp_b{i}"])
+    x = dev(g["mlp_x"]).requires_grad_(True)
+    y = m(x)
+    assert_close(cpu(y), g["mlp_y"], rtol=1e-4, atol_scale=1e-5)
+    # backward vs oracle autograd, ragged n (not a multiple of the 32-sample MFMA tile)
+    torch.manual_seed(3)
+    for (ind, width, outd, nl, n) in [(48, 32, 2, 3, 77), (32, 64, 33, 2, 301), (64, 64, 64, 3, 1000), (7, 16, 5, 2, 33)]:
+        m = MLP(in_dim=ind, num_layers=nl, layer_width=width, out_dim=outd).to(DEV)
+        x = torch.randn(n, ind, device=DEV, requires_grad=True)
+        gy = torch.randn(n, outd, device=DEV)
+        y = m(x)
+        params = list(m.parameters())
+        grads = torch.autograd.grad(y, [x] + params, gy)
+        xo = cpu(x).requires_grad_(True)
+        layers = [(cpu(l.weight).requires_grad_(True), cpu(l.bias).requires_grad_(True)) for l in m.layers]
+        yo = ofield.mlp(xo, layers)
+        assert_close(cpu(y), yo.detach(), rtol=1e-4, atol_scale=1e-5, what=f"mlp {ind}-{width}-{outd}")
+        flat = [xo] + [t for wb in layers for t in wb]
+        gos = torch.autograd.grad(yo, flat, cpu(gy))
+        got = [grads[0]] + [grads[1 + 2 * i + j] for i in range(nl) for j in range(2)]
+        for a, b in zip(got, gos):
+            assert_close(cpu(a), b, rtol=2e-4, atol_scale=2e-5, what=f"mlp grad {ind}-{width}-{outd}")
+
+
+# ------------------------------------------------------------------------------------------------ a5 a12 a13
+def test_sampler_kernels_vs_reference_golden():
+    from neuradar_amd import ops
+    from oracle import sampler as osampler
+
+    g = load_golden("sampler")
+    nears, fars = dev(g["nears"]), dev(g["fars"])
+    sp, eu = ops.power_bins(nears, fars, 128)
+    assert_close(cpu(sp), g["power_eval_spacing"], rtol=1e-6, atol_scale=1e-7)
+    assert_close(cpu(eu), g["power_eval_euclid"], rtol=1e-4, atol_scale=1e-6)
+    sp_t, eu_t = ops.power_bins(nears, fars, 128, dev(g["power_train_t_rand"]))
+    assert_close(cpu(sp_t), g["power_train_spacing"], rtol=1e-5, atol_scale=1e-6)
+    assert_close(cpu(eu_t), g["power_train_euclid"], rtol=1e-4, atol_scale=1e-6)
+    dens = dev(g["gw_density"]).requires_grad_(True)
+    w = ops.weights_from_density(dens, dev(g["power_train_euclid"]))
+    assert_close(cpu(w), g["gw_weights"], rtol=1e-4, atol_scale=1e-6)
+    # backward vs oracle autograd
+    gw = torch.randn_like(w)
+    (gd,) = torch.autograd.grad(w, dens, gw)
+    d_o = g["gw_density"].clone().requires_grad_(True)
+    e = g["power_train_euclid"]
+    w_o = osampler.weights_from_density(e[:, 1:] - e[:, :-1], d_o)
+    (gd_o,) = torch.autograd.grad(w_o, d_o, cpu(gw))
+    assert_close(cpu(gd), gd_o, rtol=2e-4, atol_scale=2e-5, what="weights bwd")
+    for S in (64, 32, 40):  # other widths incl. a ragged one
+        d2 = torch.rand(50, S, device=DEV).requires_grad_(True)
+        e2 = torch.cumsum(torch.rand(50, S + 1, device=DEV), -1)
+        w2 = ops.weights_from_density(d2, e2)
+        w2o = osampler.weights_from_density(cpu(e2[:, 1:] - e2[:, :-1]), cpu(d2).detach())
+        assert_close(cpu(w2), w2o, rtol=1e-4, atol_scale=1e-6, what=f"weights S={S}")
+    sp_e, eu_e = ops.pdf_resample(dev(g["gw_weights"]), dev(g["power_train_spacing"]), nears, fars, 64)
+    assert_close(cpu(sp_e), g["pdf_eval_spacing"], rtol=1e-4, atol_scale=1e-5)
+    assert_close(cpu(eu_e), g["pdf_eval_euclid"], rtol=1e-3, atol_scale=1e-5)  # euclid amplifies ds near s->1
+    sp_j, eu_j = ops.pdf_resample(dev(g["gw_weights"]), dev(g["power_train_spacing"]), nears, fars, 64,
+                                  dev(g["pdf_train_jitter"]))
+    assert_close(cpu(sp_j), g["pdf_train_spacing"], rtol=1e-4, atol_scale=1e-5)
+    assert_close(cpu(eu_j), g["pdf_train_euclid"], rtol=1e-3, atol_scale=1e-5)
+    assert bool((sp_j[:, 1:] >= sp_j[:, :-1]).all())  # sortedness of the resampled edges
+
+
+# ------------------------------------------------------------------------------------------------ a16-a18
+def test_composite_fwd_bwd_vs_oracle():
+    from neuradar_amd import ops
+    from oracle import render as orender
+
+    torch.manual_seed(5)
+    for (B, S, C) in [(37, 32, 32), (8, 7, 48), (5, 64, 3)]:
+        alpha = torch.rand(B, S, device=DEV) ** 3
+        alpha[0] = 0.0
+        alpha[1, 3] = 1.0  # full occlusion mid-ray: exercises the division-free backward
+        alpha.requires_grad_(True)
+        feat = torch.randn(B, S, C, device=DEV, requires_grad=True)
+        eu = torch.cumsum(torch.rand(B, S + 1, device=DEV) * 3, -1)
+        w, acc, fo, d = ops.composite(alpha, feat, eu)
+        a_o, f_o = cpu(alpha).requires_grad_(True), cpu(feat).requires_grad_(True)
+        ref = orender.composite(a_o[..., None], f_o, cpu(eu)[:, :-1], cpu(eu)[:, 1:])
+        assert_close(cpu(w), ref["weights"].detach(), rtol=1e-4, atol_scale=1e-6, what="weights")
+        assert_close(cpu(acc), ref["accumulation"][:, 0].detach(), rtol=1e-4, atol_scale=1e-6)
+        assert_close(cpu(fo), ref["features"].detach(), rtol=1e-4, atol_scale=1e-5)
+        assert_close(cpu(d), ref["depth"][:, 0].detach(), rtol=1e-4, atol_scale=1e-5)
+        gw, ga, gf, gd = torch.randn_like(w), torch.randn_like(acc), torch.randn_like(fo), torch.randn_like(d)
+        gw[:, -1] = 0
+        loss = (w * gw).sum() + (acc * ga).sum() + (fo * gf).sum() + (d * gd).sum()
+        g_alpha, g_feat = torch.autograd.grad(loss, [alpha, feat])
+        loss_o = ((ref["weights"] * cpu(gw)).sum() + (ref["accumulation"][:, 0] * cpu(ga)).sum()
+                  + (ref["features"] * cpu(gf)).sum() + (ref["depth"][:, 0] * cpu(gd)).sum())
+        go_alpha, go_feat = torch.autograd.grad(loss_o, [a_o, f_o])
+        assert_close(cpu(g_feat), go_feat, rtol=1e-4, atol_scale=1e-5, what="g_feature")
+        mask = cpu(alpha) < 1.0  # torch's cumprod backward is itself ill-defined exactly at alpha == 1
+        assert_close(cpu(g_alpha)[mask], go_alpha[mask], rtol=2e-4, atol_scale=2e-5, what="g_alpha")
+    # size-independent property at full size: weights are a partition of unity after the sky fix-up
+    alpha = torch.rand(16384, 32, device=DEV)
+    w, acc, fo, _ = ops.composite(alpha, torch.ones(16384, 32, 32, device=DEV), torch.zeros(16384, 33, device=DEV))
+    torch.testing.assert_close(w.sum(-1), torch.ones(16384, device=DEV), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fo, torch.ones_like(fo), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ a4 a14 end to end
+def build_hot_path(g):
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
+
+    cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=int(g["main_log2t"])))))
+    cfg.proposal_field_1.grid.static.log2_hashmap_size = int(g["prop_log2t"])
+    cfg.proposal_field_2.grid.static.log2_hashmap_size = int(g["prop_log2t"])
+    model = NeuRadarHotPath(cfg).to(DEV)
+    src = make_field(g, prefix="main_", log2t_key="main_log2t")
+    model.field.load_state_dict(src.state_dict())
+    model.proposal_fields[1].load_state_dict(make_prop(g, prefix="prop1_", log2t_key="prop_log2t").state_dict())
+    return model
+
+
+def test_pipeline_end_to_end_vs_reference_golden():
+    from neuradar_amd.rays import RayBundle
+
+    g = load_golden("pipeline")
+    model = build_hot_path(g).train()
+    bundle = RayBundle(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), fars=dev(g["fars"]))
+    out = model.get_nff_outputs(bundle, t_rand=dev(g["t_rand"]), jitters=(dev(g["jitter1"]), dev(g["jitter2"])))
+    rsl = out["ray_samples_list"]
+    for i in (0, 1):
+        assert_close(cpu(rsl[i].spacing), g[f"prop_spacing_{i}"], rtol=1e-4, atol_scale=1e-5, what=f"prop spacing {i}")
+        assert_close(cpu(rsl[i].euclid), g[f"prop_euclid_{i}"], rtol=1e-3, atol_scale=1e-5, what=f"prop euclid {i}")
+        assert_close(cpu(out["weights_list"][i][..., 0]), g[f"prop_weights_{i}"], rtol=1e-3, atol_scale=1e-4)
+        assert_close(cpu(out[f"prop_depth_{i}"]), g[f"prop_depth_{i}"], rtol=1e-3, atol_scale=1e-4)
+    assert_close(cpu(out["ray_samples"].spacing), g["final_spacing"], rtol=1e-4, atol_scale=1e-5, what="final spacing")
+    assert_close(cpu(out["ray_samples"].euclid), g["final_euclid"], rtol=1e-3, atol_scale=1e-5, what="final euclid")
+    # north-star bar: rendered features / depth within 1e-4 relative (of the tensor's scale)
+    assert_close(cpu(out["weights"][..., 0]), g["weights"], rtol=1e-4, atol_scale=1e-4, what="weights")
+    assert_close(cpu(out["accumulation"]), g["accumulation"], rtol=1e-4, atol_scale=1e-4, what="accumulation")
+    assert_close(cpu(out["features"]), g["features"], rtol=1e-4, atol_scale=1e-4, what="features")
+    assert_close(cpu(out["depth"]), g["depth"], rtol=1e-4, atol_scale=1e-4, what="depth")
+    loss = model.bench_loss(out, dev(g["target_features"]), dev(g["target_depth"]))
+    assert_close(cpu(loss), g["loss"], rtol=1e-4, atol_scale=1e-5, what="loss")
+    names = {
+        "main_hashgrid_static_grid_hash_table": model.field.hashgrid.static_grid.hash_table,
+        "main_sdf_to_density_beta": model.field.sdf_to_density.beta,
+        "prop1_hashgrid_static_grid_hash_table": model.proposal_fields[1].hashgrid.static_grid.hash_table,
+        "prop1_density_decoder_weight": model.proposal_fields[1].density_decoder.weight,
+    }
+    for i, l in enumerate(model.field.mlp_geo.layers):
+        names[f"main_mlp_geo_layers_{i}_weight"], names[f"main_mlp_geo_layers_{i}_bias"] = l.weight, l.bias
+    for i, l in enumerate(model.field.mlp_feature.layers):
+        names[f"main_mlp_feature_layers_{i}_weight"], names[f"main_mlp_feature_layers_{i}_bias"] = l.weight, l.bias
+    # the reference quirk: proposal_fields[0] never runs, so it must have no gradient
+    p0 = model.proposal_fields[0].hashgrid.static_grid.hash_table
+    grads = torch.autograd.grad(loss, list(names.values()) + [p0], allow_unused=True)
+    assert grads[-1] is None
+    for (n, _), gr in zip(names.items(), grads):
+        assert_close(cpu(gr), g["grad_" + n], rtol=1e-3, atol_scale=1e-4, what="grad " + n)
+
+
+def test_regularisers_product_vs_reference_golden():
+    from neuradar_amd import losses
+
+    g = load_golden("losses")
+    ws = [dev(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
+    cs = [dev(g[f"c{i}"]) for i in range(3)]
+    inter = losses.zipnerf_interlevel_loss(cs, ws)
+    dist = losses.distortion_loss(cs[-1], ws[-1])
+    assert_close(cpu(inter), g["interlevel"], rtol=1e-4, atol_scale=1e-6)
+    assert_close(cpu(dist), g["distortion"], rtol=1e-4, atol_scale=1e-6)
+    gi = torch.autograd.grad(inter, ws[:2])
+    assert_close(cpu(gi[0]), g["g_inter_w0"], rtol=1e-3, atol_scale=1e-5)
+    assert_close(cpu(gi[1]), g["g_inter_w1"], rtol=1e-3, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ a1 a2 a3
+def test_raygen_vs_reference_golden():
+    from neuradar_amd.sensors import Cameras, Lidars, Radars
+
+    g = load_golden("raygen")
+    cams = Cameras(dev(g["cam_c2w"]), dev(g["cam_fx"]), dev(g["cam_fy"]), dev(g["cam_cx"]), dev(g["cam_cy"]),
+                   dev(g["cam_heights"]), dev(g["cam_times_in"]), dev(g["cam_vel"]), dev(g["cam_rs_offsets"]))
+    b = cams.generate_rays(dev(g["cam_ray_indices"]))
+    assert_close(cpu(b.origins), g["cam_origins"], rtol=1e-5, atol_scale=1e-6, what="cam origins")
+    assert_close(cpu(b.directions), g["cam_directions"], rtol=1e-5, atol_scale=1e-6, what="cam directions")
+    assert_close(cpu(b.pixel_area), g["cam_pixel_area"], rtol=1e-3, atol_scale=1e-4, what="cam pixel_area")
+    assert_close(cpu(b.times), g["cam_times"], rtol=1e-6, atol_scale=1e-7, what="cam times")
+    assert_close(cpu(b.metadata["directions_norm"]), g["cam_directions_norm"], rtol=1e-5, atol_scale=1e-6)
+    cams2 = Cameras(dev(g["cam_c2w"]), dev(g["cam_fx"]), dev(g["cam_fy"]), dev(g["cam_cx"]), dev(g["cam_cy"]),
+                    dev(g["cam_heights"]), dev(g["cam_times_in"]))
+    b2 = cams2.generate_rays(dev(g["cam_ray_indices"]))
+    assert_close(cpu(b2.origins), g["cam_nors_origins"], rtol=1e-6, atol_scale=1e-7)
+    assert_close(cpu(b2.times), g["cam_nors_times"], rtol=1e-6, atol_scale=1e-7)
+
+    lid = Lidars(dev(g["lid_l2w"]), dev(g["lid_times_in"]), dev(g["lid_vel"]))
+    lb = lid.generate_rays(dev(g["lid_indices"]), dev(g["lid_points"]))
+    assert_close(cpu(lb.origins), g["lid_origins"], rtol=1e-5, atol_scale=1e-6, what="lidar origins")
+    assert_close(cpu(lb.directions), g["lid_directions"], rtol=1e-4, atol_scale=2e-5, what="lidar directions")
+    assert_close(cpu(lb.metadata["directions_norm"]), g["lid_directions_norm"], rtol=1e-5, atol_scale=1e-6)
+    assert_close(cpu(lb.times), g["lid_times"], rtol=1e-6, atol_scale=1e-7)
+    assert_close(cpu(lb.pixel_area), g["lid_pixel_area"], rtol=1e-6, atol_scale=1e-7)
+    assert torch.equal(cpu(lb.metadata["did_return"]), g["lid_did_return"])
+
+    rad = Radars(dev(g["rad_r2w"]), dev(g["rad_times_in"]), 0.015, 0.015, -0.80, 0.80, -0.08, 0.4)
+    assert rad.grid_shape() == (107, 33)  # ZOD: 3 531 rays per scan
+    rb = rad.generate_rays(dev(g["rad_scans"]))
+    assert_close(cpu(rb.metadata["directions_spher"]), g["rad_directions_spher"], rtol=1e-6, atol_scale=1e-7, what="az/el grid")
+    assert torch.equal(cpu(rb.origins), g["rad_origins"])
+    # (R d + t) - t cancellation noise of the reference is ~eps*|t| = 5e-6 absolute on a unit vector
+    assert_close(cpu(rb.directions), g["rad_directions"], rtol=1e-4, atol_scale=2e-5, what="radar directions")
+    assert_close(cpu(rb.pixel_area), g["rad_pixel_area"], rtol=1e-6, atol_scale=1e-7)
+    assert torch.equal(cpu(rb.times).reshape(-1), g["rad_times"].reshape(-1))
+    assert torch.equal(cpu(rb.camera_indices[:, 0]), g["rad_scan_of_ray"])
+    vod = Radars(dev(g["rad_r2w"]), dev(g["rad_times_in"]), 0.02, 0.02, -1.0, 1.0, -0.39, 0.49)
+    assert vod.grid_shape()[0] * vod.grid_shape()[1] == 4545
+    vb = vod.generate_rays(torch.tensor([1], device=DEV))
+    assert_close(cpu(vb.metadata["directions_spher"]), g["rad_vod_directions_spher"], rtol=1e-6, atol_scale=1e-7)
+    assert_close(cpu(vb.directions), g["rad_vod_directions"], rtol=1e-4, atol_scale=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_fused_adam_matches_torch_optim():
+    from neuradar_amd import ops
+
+    torch.manual_seed(1)
+    for adamw, wd in ((False, 0.0), (True, 1e-2), (False, 1e-3)):
+        p = torch.randn(100_003, device=DEV)
+        ref = torch.nn.Parameter(p.clone())
+        opt = (torch.optim.AdamW if adamw else torch.optim.Adam)([ref], lr=1e-2, eps=1e-15, weight_decay=wd)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in range(1, 6):
+            g = torch.randn_like(p) * (step % 2)  # includes an all-zero gradient step (dense Adam still moves)
+            ref.grad = g.clone()
+            opt.step()
+            gbuf = g.clone()
+            ops.adam_step(p, gbuf, m, v, 1e-2, step, eps=1e-15, weight_decay=wd, adamw=adamw)
+            assert float(gbuf.abs().max()) == 0.0  # grad zeroed in the same pass
+        torch.testing.assert_close(p, ref.data, rtol=1e-5, atol=1e-7)
