@@ -5,6 +5,8 @@
 // `sample_major` the 64 lanes of a wave are 64 neighbouring RAYS at the same sample slot, which for
 // camera patches are centimetres apart -> the texture path merges most of a wave-instruction's
 // addresses into a few cache lines on all but the finest levels.
+#include <limits.h>
+
 #include "nr_common.h"
 
 namespace {
@@ -99,6 +101,15 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
   for (int f = 0; f < F; ++f) o[f] = (acc_z[0][f] * c.w[2] + acc_z[1][f] * (1.0f - c.w[2])) * r;
 }
 
+// Backward scatter-add.  Memory-side float atomics are the scarce resource here (about 20 G
+// requests/s chip-wide, far less when many lanes hit one address -- and coherent camera rays do exactly
+// that), so contributions are summed on chip first:
+//   1. lanes l and l^32 (the same pixel column of two adjacent patch rows under the sample-major
+//      mapping) that fall in the same grid cell are folded into one lane;
+//   2. a segmented wave scan sums every run of consecutive lanes that share a cell (a cell fixes all
+//      eight corner slots), and only the run's last lane issues the 8*F atomics.
+// Incoherent rays (lidar points, radar grids) simply form runs of length one: the cost is a fixed
+// ~(9 + 8F) shuffles per scan step and no loss against plain atomics.
 template <int F>
 __global__ void __launch_bounds__(256)
 hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings,
@@ -106,27 +117,88 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
                        float* __restrict__ gtable, int64_t n, int S) {
   const int level = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t idx = sample_of_thread(i, n, S);
+  const bool valid = i < n;  // no early exit: every lane takes part in the wave scans
+  const int lane = nr_lane();
   const float scale = scalings[level];
-  const Corner c = make_corner(x, idx, scale);
   const uint32_t mask = (1u << log2T) - 1u;
   float* base = gtable + (((int64_t)level << log2T) * F);
-  float r = 1.0f;
-  if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
-  float g[F];
-  const float* gi = gout + idx * sn + (int64_t)level * sl;
+
+  Corner c;
+  float v[8][F];
+  if (valid) {
+    const int64_t idx = sample_of_thread(i, n, S);
+    c = make_corner(x, idx, scale);
+    float r = 1.0f;
+    if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
+    const float* gi = gout + idx * sn + (int64_t)level * sl;
+    float g[F];
 #pragma unroll
-  for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
+    for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
 #pragma unroll
-  for (int corner = 0; corner < 8; ++corner) {
-    const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
-    const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
-    if (w == 0.0f) continue;  // e.g. exact-integer coordinates: ceil == floor carries weight 0
-    const uint32_t slot = nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask);
-    float* dst = base + (int64_t)slot * F;
+    for (int corner = 0; corner < 8; ++corner) {
+      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+      const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
 #pragma unroll
-    for (int f = 0; f < F; ++f) unsafeAtomicAdd(dst + f, g[f] * w);
+      for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { c.lo[a] = INT_MIN + lane; c.hi[a] = INT_MIN + lane; c.w[a] = 0.0f; }
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
+  }
+  // a lane's cell is (lo, hi) per axis: hi == lo exactly on grid planes, so both are compared
+  auto same_cell = [&](int lx, int ly, int lz, int ux, int uy, int uz) {
+    return lx == c.lo[0] && ly == c.lo[1] && lz == c.lo[2] && ux == c.hi[0] && uy == c.hi[1] && uz == c.hi[2];
+  };
+  // 1. fold the upper half-wave onto the lower one where the cells agree
+  {
+    const bool same = same_cell(__shfl_xor(c.lo[0], 32, NR_WAVE), __shfl_xor(c.lo[1], 32, NR_WAVE),
+                                __shfl_xor(c.lo[2], 32, NR_WAVE), __shfl_xor(c.hi[0], 32, NR_WAVE),
+                                __shfl_xor(c.hi[1], 32, NR_WAVE), __shfl_xor(c.hi[2], 32, NR_WAVE));
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float o = __shfl_xor(v[corner][f], 32, NR_WAVE);
+        if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
+      }
+  }
+  // 2. segmented inclusive scan over runs of equal cells
+  const bool head = lane == 0 || !same_cell(__shfl_up(c.lo[0], 1, NR_WAVE), __shfl_up(c.lo[1], 1, NR_WAVE),
+                                            __shfl_up(c.lo[2], 1, NR_WAVE), __shfl_up(c.hi[0], 1, NR_WAVE),
+                                            __shfl_up(c.hi[1], 1, NR_WAVE), __shfl_up(c.hi[2], 1, NR_WAVE));
+  int flag = head ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < NR_WAVE; d <<= 1) {
+    const int fprev = __shfl_up(flag, d, NR_WAVE);
+    const bool take = lane >= d && !flag;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float t = __shfl_up(v[corner][f], d, NR_WAVE);
+        if (take) v[corner][f] += t;
+      }
+    if (take) flag = fprev;
+  }
+  const int next_head = __shfl_down(head ? 1 : 0, 1, NR_WAVE);
+  const bool tail = lane == NR_WAVE - 1 || next_head;
+  if (tail) {
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+      bool nz = false;
+#pragma unroll
+      for (int f = 0; f < F; ++f) nz |= v[corner][f] != 0.0f;
+      if (!nz) continue;  // zero-weight corners (exact grid planes), folded or padding lanes
+      const uint32_t slot = nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask);
+      float* dst = base + (int64_t)slot * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) unsafeAtomicAdd(dst + f, v[corner][f]);
+    }
   }
 }
 
