@@ -103,101 +103,154 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 
 // Backward scatter-add.  Memory-side float atomics are the scarce resource here (about 20 G
 // requests/s chip-wide, far less when many lanes hit one address -- and coherent camera rays do exactly
-// that), so contributions are summed on chip first:
+// that: a 131k-sample batch touches only 10^1..10^4 distinct cells per level), so contributions are
+// summed on chip first, keyed by grid CELL (a cell fixes all eight corner slots):
 //   1. lanes l and l^32 (the same pixel column of two adjacent patch rows under the sample-major
-//      mapping) that fall in the same grid cell are folded into one lane;
-//   2. a segmented wave scan sums every run of consecutive lanes that share a cell (a cell fixes all
-//      eight corner slots), and only the run's last lane issues the 8*F atomics.
-// Incoherent rays (lidar points, radar grids) simply form runs of length one: the cost is a fixed
-// ~(9 + 8F) shuffles per scan step and no loss against plain atomics.
+//      mapping) that fall in the same cell are folded into one lane;
+//   2. a segmented wave scan sums every run of consecutive lanes that share a cell;
+//   3. the run's last lane adds its 8*F partial sums into the workgroup's LDS hash table
+//      (open addressing, 64-bit cell key, ds_cmpst + ds_add_f32); a workgroup is persistent over
+//      kChunk samples of ONE level, so cells shared by thousands of samples cost one table entry;
+//   4. at the end every occupied entry is flushed with 8*F global atomics.
+// Table overflow (fine levels, incoherent lidar/radar rays) falls back to direct global atomics, so
+// the worst case is the plain-atomic kernel plus a fixed scan cost.
+constexpr int kBwdChunk = 4096;            // samples per workgroup (of one level)
+constexpr int kBwdValFloats = 16384;       // 64 KiB of accumulators: capacity = 16384 / (8 F) cells
+constexpr unsigned long long kEmptyKey = ~0ull;
+
+__device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
+  return ((unsigned long long)(uint32_t)lo[0] & 0x1FFFFFull) | (((unsigned long long)(uint32_t)lo[1] & 0x1FFFFFull) << 21) |
+         (((unsigned long long)(uint32_t)lo[2] & 0x1FFFFFull) << 42);
+}
+
 template <int F>
 __global__ void __launch_bounds__(256)
 hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings,
                        int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl,
                        float* __restrict__ gtable, int64_t n, int S) {
+  constexpr int CAP = kBwdValFloats / (8 * F);
+  __shared__ unsigned long long s_key[CAP];
+  __shared__ float s_val[CAP * 8 * F];
   const int level = blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;  // no early exit: every lane takes part in the wave scans
   const int lane = nr_lane();
   const float scale = scalings[level];
   const uint32_t mask = (1u << log2T) - 1u;
   float* base = gtable + (((int64_t)level << log2T) * F);
+  for (int k = threadIdx.x; k < CAP; k += blockDim.x) s_key[k] = kEmptyKey;
+  for (int k = threadIdx.x; k < CAP * 8 * F; k += blockDim.x) s_val[k] = 0.0f;
+  __syncthreads();
 
-  Corner c;
-  float v[8][F];
-  if (valid) {
-    const int64_t idx = sample_of_thread(i, n, S);
-    c = make_corner(x, idx, scale);
-    float r = 1.0f;
-    if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
-    const float* gi = gout + idx * sn + (int64_t)level * sl;
-    float g[F];
+  const int64_t chunk0 = (int64_t)blockIdx.x * kBwdChunk;
+  for (int64_t i = chunk0 + threadIdx.x; i < chunk0 + kBwdChunk; i += blockDim.x) {  // block-uniform trip count
+    const bool valid = i < n;  // no early exit: every lane takes part in the wave scans
+    int lo[3];
+    float v[8][F];
+    if (valid) {
+      const int64_t idx = sample_of_thread(i, n, S);
+      const Corner c = make_corner(x, idx, scale);
+      float r = 1.0f;
+      if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
+      const float* gi = gout + idx * sn + (int64_t)level * sl;
+      float g[F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
+      for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
-      const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
+      for (int a = 0; a < 3; ++a) lo[a] = c.lo[a];
 #pragma unroll
-      for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
+      for (int corner = 0; corner < 8; ++corner) {
+        const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+        // on an exact grid plane ceil == floor and the "ceil" weight is 0: that corner's value is 0
+        // whichever slot it is credited to, so a cell is identified by its floor corner alone
+        const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) lo[a] = INT_MIN + lane;
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
     }
-  } else {
+    auto same_cell = [&](int lx, int ly, int lz) { return lx == lo[0] && ly == lo[1] && lz == lo[2]; };
+    // 1. fold the upper half-wave onto the lower one where the cells agree
+    {
+      const bool same = same_cell(__shfl_xor(lo[0], 32, NR_WAVE), __shfl_xor(lo[1], 32, NR_WAVE), __shfl_xor(lo[2], 32, NR_WAVE));
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { c.lo[a] = INT_MIN + lane; c.hi[a] = INT_MIN + lane; c.w[a] = 0.0f; }
+      for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner)
+        for (int f = 0; f < F; ++f) {
+          const float o = __shfl_xor(v[corner][f], 32, NR_WAVE);
+          if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
+        }
+    }
+    // 2. segmented inclusive scan over runs of equal cells
+    const bool head = lane == 0 || !same_cell(__shfl_up(lo[0], 1, NR_WAVE), __shfl_up(lo[1], 1, NR_WAVE), __shfl_up(lo[2], 1, NR_WAVE));
+    int flag = head ? 1 : 0;
 #pragma unroll
-      for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
-  }
-  // a lane's cell is (lo, hi) per axis: hi == lo exactly on grid planes, so both are compared
-  auto same_cell = [&](int lx, int ly, int lz, int ux, int uy, int uz) {
-    return lx == c.lo[0] && ly == c.lo[1] && lz == c.lo[2] && ux == c.hi[0] && uy == c.hi[1] && uz == c.hi[2];
-  };
-  // 1. fold the upper half-wave onto the lower one where the cells agree
-  {
-    const bool same = same_cell(__shfl_xor(c.lo[0], 32, NR_WAVE), __shfl_xor(c.lo[1], 32, NR_WAVE),
-                                __shfl_xor(c.lo[2], 32, NR_WAVE), __shfl_xor(c.hi[0], 32, NR_WAVE),
-                                __shfl_xor(c.hi[1], 32, NR_WAVE), __shfl_xor(c.hi[2], 32, NR_WAVE));
+    for (int d = 1; d < NR_WAVE; d <<= 1) {
+      const int fprev = __shfl_up(flag, d, NR_WAVE);
+      const bool take = lane >= d && !flag;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner)
+      for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float o = __shfl_xor(v[corner][f], 32, NR_WAVE);
-        if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
-      }
-  }
-  // 2. segmented inclusive scan over runs of equal cells
-  const bool head = lane == 0 || !same_cell(__shfl_up(c.lo[0], 1, NR_WAVE), __shfl_up(c.lo[1], 1, NR_WAVE),
-                                            __shfl_up(c.lo[2], 1, NR_WAVE), __shfl_up(c.hi[0], 1, NR_WAVE),
-                                            __shfl_up(c.hi[1], 1, NR_WAVE), __shfl_up(c.hi[2], 1, NR_WAVE));
-  int flag = head ? 1 : 0;
-#pragma unroll
-  for (int d = 1; d < NR_WAVE; d <<= 1) {
-    const int fprev = __shfl_up(flag, d, NR_WAVE);
-    const bool take = lane >= d && !flag;
+        for (int f = 0; f < F; ++f) {
+          const float t = __shfl_up(v[corner][f], d, NR_WAVE);
+          if (take) v[corner][f] += t;
+        }
+      if (take) flag = fprev;
+    }
+    const int next_head = __shfl_down(head ? 1 : 0, 1, NR_WAVE);
+    bool nz = false;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float t = __shfl_up(v[corner][f], d, NR_WAVE);
-        if (take) v[corner][f] += t;
-      }
-    if (take) flag = fprev;
-  }
-  const int next_head = __shfl_down(head ? 1 : 0, 1, NR_WAVE);
-  const bool tail = lane == NR_WAVE - 1 || next_head;
-  if (tail) {
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
-      bool nz = false;
 #pragma unroll
       for (int f = 0; f < F; ++f) nz |= v[corner][f] != 0.0f;
-      if (!nz) continue;  // zero-weight corners (exact grid planes), folded or padding lanes
-      const uint32_t slot = nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask);
-      float* dst = base + (int64_t)slot * F;
+    if ((lane == NR_WAVE - 1 || next_head) && nz) {
+      // 3. run total -> LDS table (linear probing, 4 tries), else straight to memory
+      const unsigned long long key = pack_cell(lo);
+      uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
+      bool done = false;
+#pragma unroll 1
+      for (int probe = 0; probe < 4 && !done; ++probe) {
+        const unsigned long long old = atomicCAS(&s_key[slot], kEmptyKey, key);
+        if (old == kEmptyKey || old == key) {
 #pragma unroll
-      for (int f = 0; f < F; ++f) unsafeAtomicAdd(dst + f, v[corner][f]);
+          for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+              if (v[corner][f] != 0.0f) atomicAdd(&s_val[(slot * 8 + corner) * F + f], v[corner][f]);
+          done = true;
+        }
+        slot = (slot + 1) & (CAP - 1);
+      }
+      if (!done) {
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+          const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+            if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // 4. flush: one (entry, corner) pair per thread
+  for (int k = threadIdx.x; k < CAP * 8; k += blockDim.x) {
+    const int slot = k >> 3, corner = k & 7;
+    const unsigned long long key = s_key[slot];
+    if (key == kEmptyKey) continue;
+    // sign-extend the 21-bit fields back (coordinates are >= 0 for inputs in [0,1], kept general)
+    const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
+    const int cy = ((int)((uint32_t)((key >> 21) & 0x1FFFFF) << 11)) >> 11;
+    const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
+    const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const float t = s_val[k * F + f];
+      if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
     }
   }
 }
@@ -262,7 +315,7 @@ extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float*
   if (n == 0) return 0;
   if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
-  dim3 grid((unsigned)nr_cdiv(n, 256), (unsigned)L), block(256);
+  dim3 grid((unsigned)nr_cdiv(n, kBwdChunk), (unsigned)L), block(256);
   switch (F) {
     case 1: hipLaunchKernelGGL(hash_encode_bwd_kernel<1>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
     case 2: hipLaunchKernelGGL(hash_encode_bwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;

@@ -3,6 +3,8 @@
 // See mlp_tiles.h for the register/LDS layout.  Persistent 4-wave workgroups, one 32-sample tile per
 // wave per iteration; weights are loaded into LDS once per workgroup, weight gradients are summed in
 // LDS (ds_add_f32) over all tiles of the workgroup and flushed once with contiguous global atomics.
+#include <stdlib.h>
+
 #include "nr_common.h"
 #include "mlp_tiles.h"
 #include "sh4.h"
@@ -424,7 +426,11 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
-  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+  }
   if (hid == 32)
     hipLaunchKernelGGL((field_bwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, g_feats, *grads);
   else

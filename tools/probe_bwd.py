@@ -1,0 +1,57 @@
+"""GPU probe: per-level cost of the scatter kernel and grid-size sensitivity of nr_field_bwd on the
+bench workload's real sample positions.  Development tool (not part of tests/bench)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from neuradar_amd import ops  # noqa: E402
+from neuradar_amd.sensors import scale_pixel_area  # noqa: E402
+
+wl_name = sys.argv[1] if len(sys.argv) > 1 else "cam4096_l16f2_w64"
+wl = bench.WORKLOADS[wl_name]
+dev = torch.device("cuda")
+model = bench.build_model(wl, dev)
+scene = bench.SyntheticScene(dev, 1000)
+torch.manual_seed(1)
+with torch.no_grad():
+    bundle = scene.cameras.generate_rays(scene.sample_ray_indices(wl["rays"]))
+    scale_pixel_area(bundle)
+    out = model.get_nff_outputs(bundle)
+lib, p, st = ops._lib.lib(), ops._p, ops._stream
+for tag, fld, rs in [("prop_s128", model.proposal_fields[1], out["ray_samples_list"][0]),
+                     ("prop_s64", model.proposal_fields[1], out["ray_samples_list"][1]),
+                     ("main_s32", model.field, out["ray_samples"])]:
+    g = fld.hashgrid.static_grid
+    B, S = rs.shape
+    n, L, F = B * S, g.num_levels, g.features_per_level
+    x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, fld.hashgrid.static_scale)
+    T = 2 ** g.log2_hashmap_size
+    gtab = torch.zeros_like(g.hash_table)
+    for l in range(L):
+        gb = torch.randn((1, n, F), device=dev)
+        sc = g.scalings[l:l + 1].contiguous()
+        gt = gtab[l * T:(l + 1) * T]
+        for sm in (S, 0):
+            fn = lambda: lib.nr_hash_encode_bwd(p(x01), p(std01), p(sc), 1, F, g.log2_hashmap_size, p(gb), F, n * F, p(gt), n, sm, st())  # noqa: E731
+            t = bench.time_kernel(fn, 10)
+            print(f"{tag} level {l:2d} scale {float(sc[0]):7.0f} sample_major={sm:3d}: {t * 1e6:8.1f} us")
+# field bwd vs grid size
+rs = out["ray_samples"]
+B, S = rs.shape
+n = B * S
+fld = model.field
+buf, strides = fld.hashgrid.encode_samples(rs)
+gw, gb_ = fld.mlp_geo.weights()
+fw, fb = fld.mlp_feature.weights()
+for blocks in (32, 64, 128, 256, 512):
+    os.environ["NR_FIELD_BWD_BLOCKS"] = str(blocks)
+    feats = buf.detach().clone().requires_grad_(True)
+    f, sdf, a = ops.field_mlp(feats, strides, g.features_per_level if False else fld.hashgrid.static_grid.features_per_level,
+                              rs.directions, S, n, (gw, gb_), (fw, fb), fld.sdf_to_density.beta)
+    gf, ga = torch.randn_like(f), torch.randn_like(a)
+    fn = lambda: torch.autograd.grad([f, a], [feats], [gf, ga], retain_graph=True)  # noqa: E731
+    t = bench.time_kernel(fn, 10)
+    print(f"field_bwd blocks={blocks}: {t * 1e6:8.1f} us (incl. autograd glue)")
