@@ -1,0 +1,65 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of the path (rank bootstrap, parameter
+broadcast, bucketed gradient mean all-reduce incl. the unused-parameter case) -- the N>1 path that
+runs over RCCL on the GPU box."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, bf16):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from neuradar_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
+
+    r, w, _ = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # deliberately different init per rank
+    table = torch.nn.Parameter(torch.randn(1 << 17, 2))       # "hash table": its own bucket
+    unused = torch.nn.Parameter(torch.randn(1 << 17, 1))      # proposal_fields[0]: never gets a gradient
+    small = [torch.nn.Parameter(torch.randn(33, 32)), torch.nn.Parameter(torch.randn(33))]
+    mod = torch.nn.ParameterList([table, unused, *small])
+    broadcast_parameters(mod)
+    ref = [p.detach().clone() for p in mod]
+    gathered = [torch.empty_like(ref[0]) for _ in range(world)]
+    dist.all_gather(gathered, ref[0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered), "broadcast did not synchronise the replicas"
+
+    table.grad = torch.full_like(table, float(rank + 1))
+    unused.grad = torch.zeros_like(unused)
+    small[0].grad = torch.full_like(small[0], 10.0 * (rank + 1))
+    small[1].grad = None  # e.g. a bias that did not take part
+    red = GradAllReducer(list(mod), table_dtype=torch.bfloat16 if bf16 else None)
+    assert red.bytes_per_step() == (table.numel() + unused.numel()) * (2 if bf16 else 4) + (33 * 32 + 33) * 4
+    red.all_reduce()
+    mean = sum(range(1, world + 1)) / world
+    assert torch.allclose(table.grad, torch.full_like(table, mean), rtol=1e-2 if bf16 else 1e-6)
+    assert float(unused.grad.abs().max()) == 0.0
+    assert torch.allclose(small[0].grad, torch.full_like(small[0], 10.0 * mean))
+    assert small[1].grad is not None and float(small[1].grad.abs().max()) == 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(bf16):
+    mp.spawn(_worker, args=(2, _free_port(), bf16), nprocs=2, join=True)
+
+
+def test_two_rank_grad_allreduce_fp32():
+    _run(False)
+
+
+def test_two_rank_grad_allreduce_bf16_tables():
+    _run(True)
