@@ -96,19 +96,36 @@ class SyntheticScene:
         return idx.reshape(-1, 3)
 
 
-def make_step(model, scene, opts, reducer, targets, n_rays):
-    """Returns (fwd_bwd, optim) closures; together they are one training step."""
+def make_step(model, scene, opts, reducer, targets, n_rays, fused=True):
+    """Returns (fwd_bwd, optim) closures; together they are one training step.
+
+    fused=True: the autograd-free FusedTrainStep (the same kernels, chained by hand over preallocated
+    buffers); fused=False: the modular torch.autograd path through the drop-in modules."""
     from neuradar_amd.sensors import scale_pixel_area
 
     tgt_f, tgt_d = targets
+    if fused:
+        from neuradar_amd.fused_step import FusedTrainStep
 
-    def fwd_bwd():
-        bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
-        scale_pixel_area(bundle)
-        out = model.get_nff_outputs(bundle)
-        loss = model.bench_loss(out, tgt_f, tgt_d)
-        loss.backward()
-        return loss.detach()
+        stepper = FusedTrainStep(model, n_rays)
+        S0 = model.config.num_proposal_samples[0]
+        dev = tgt_f.device
+
+        def fwd_bwd():
+            bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
+            area = bundle.pixel_area[:, 0] * 9.0  # _scale_pixel_area: camera rays x rgb_upsample_factor^2
+            t_rand = torch.rand((n_rays, S0 + 1), device=dev)  # PowerSampler: per-edge jitter (ray_samplers.py:111)
+            jit = torch.rand((2, n_rays), device=dev)           # PDFSampler: one jitter per ray and round (:326)
+            return stepper.forward_backward(bundle.origins, bundle.directions, area, bundle.fars[:, 0], tgt_f,
+                                            tgt_d[:, 0], t_rand, jit[0], jit[1])
+    else:
+        def fwd_bwd():
+            bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
+            scale_pixel_area(bundle)
+            out = model.get_nff_outputs(bundle)
+            loss = model.bench_loss(out, tgt_f, tgt_d)
+            loss.backward()
+            return loss.detach()
 
     def optim():
         reducer.all_reduce()
@@ -209,6 +226,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cam4096_l16f2_w64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--autograd", action="store_true", help="time the modular torch.autograd path instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=1024)
@@ -234,15 +252,16 @@ def main():
     broadcast_parameters(model)
     groups = model.get_param_groups()
     # configs/method_configs.py:384-409: hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
-    opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, lr_final=1e-3, max_steps=20001, warmup_steps=500),
+    unused = list(model.proposal_fields[0].parameters())  # never evaluated (reference quirk) -> never stepped
+    opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, lr_final=1e-3, max_steps=20001, warmup_steps=500, skip=unused),
             FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3,
-                     max_steps=20001, warmup_steps=500)]
-    reducer = GradAllReducer([p for grp in groups.values() for p in grp],
+                     max_steps=20001, warmup_steps=500, skip=unused)]
+    reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None)
     scene = SyntheticScene(device, seed=1000 + rank)  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
-    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays)
+    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd)
 
     use_graph = not args.no_graph
     graphs = []
@@ -332,7 +351,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
-                       "graph": bool(use_graph), "parallelism": f"dp{world}",
+                       "graph": bool(use_graph), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": reducer.bytes_per_step() if world > 1 else 0},
             "roofline": roof, "cpu_baseline": cpu,
         }

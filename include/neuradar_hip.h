@@ -162,10 +162,13 @@ int nr_weights_from_density_bwd(const float* density, const float* euclid, const
 /* PDFSampler.generate_ray_samples, include_original=False, histogram_padding=0.01
  * (ray_samplers.py:305-376): weights [n_rays,S] over spacing_in [n_rays,S+1] -> n_out+1 new edges.
  * jitter [n_rays] in [0,1) (single_jitter, :325-326) or NULL (eval, :332-334).  nears/fars give
- * the ray's spacing_to_euclidean_fn (:119-120).  Outputs are detached by construction. */
+ * the ray's spacing_to_euclidean_fn (:119-120).  Outputs are detached by construction.
+ * sky_distance > 0 additionally applies the "sky field" stretch of models/neuradar.py:578-582 to the
+ * LAST edge (euclid += sky_distance - euclid, spacing := 1 - 1e-7); pass 0 for plain PDF sampling. */
 int nr_pdf_resample(const float* weights, const float* spacing_in, const float* jitter,
                     const float* nears, const float* fars, int64_t n_rays, int n_in, int n_out,
-                    float lambda, float scaling, float* spacing_out, float* euclid_out, nr_stream_t stream);
+                    float lambda, float scaling, float sky_distance, float* spacing_out, float* euclid_out,
+                    nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Compositing  -- replaces nerfacc.render_weight_from_alpha + accumulate_along_rays (batched
@@ -216,6 +219,30 @@ int nr_gen_rays_radar(const int64_t* scan_indices, int64_t n_scans, const float*
                       float min_az, float d_az, int n_az, float min_el, float d_el, int n_el,
                       float* origins, float* directions, float* pixel_area, float* times,
                       float* directions_spher, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss tail of a training step.  Each entry adds its (already weighted)
+ * loss value to loss[0] and writes the gradient w.r.t. the tensors it consumes, so no autograd graph
+ * is needed between compositing and the backward kernels.
+ * ---------------------------------------------------------------------------------------------- */
+/* rgb_mult*mean((features[:, :C] - target_f)^2) + depth_mult*mean(|depth - target_d|): the stand-in
+ * for the reference's decoders + image/lidar losses (models/neuradar.py:672-704).
+ * features rows have stride feat_stride >= C.  -> g_features (same stride, first C columns), g_depth. */
+int nr_supervision_loss(const float* features, int feat_stride, const float* target_f, int n_channels,
+                        const float* depth, const float* target_d, int64_t n_rays, float rgb_mult,
+                        float depth_mult, float* g_features, float* g_depth, float* loss, nr_stream_t stream);
+/* distortion_loss (model_components/losses.py:137-157) of the final level: c [n_rays,c_stride]
+ * s-space edges, w [n_rays,w_stride] weights, first n_used samples (sky sample dropped,
+ * neuradar.py:515,534).  mult * mean over rays.  -> g_w [n_rays,w_stride] (overwritten). */
+int nr_distortion_loss(const float* c, int c_stride, const float* w, int w_stride, int n_used, int64_t n_rays,
+                       float mult, float* g_w, float* loss, nr_stream_t stream);
+/* zipnerf_interlevel_loss (losses.py:626-705) for one proposal level: the final level (c, w, first
+ * n_used <= 31 samples, detached) is blurred with a box of half-width `pulse`, integrated and
+ * resampled at the proposal edges cp [n_rays,Sp+1]; loss = mult * mean_rays sum_j
+ * relu(target_j - wp_j)^2 / (wp_j + 1e-5).  -> g_wp [n_rays,Sp] (overwritten). */
+int nr_interlevel_loss(const float* c, int c_stride, const float* w, int w_stride, int n_used, const float* cp,
+                       const float* wp, int n_prop_samples, int64_t n_rays, float pulse, float mult, float* g_wp,
+                       float* loss, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: dense Adam/AdamW over a flat parameter buffer, one pass (param, grad, m, v), grad

@@ -1,0 +1,222 @@
+// Loss tail of the training step as three kernels: direct supervision of the
+// rendered features/depth, mip-NeRF-360 distortion and the ZipNeRF anti-aliased inter-level loss
+// (reference model_components/losses.py:137-156,626-705).  Each kernel produces the loss value AND
+// the gradient w.r.t. the weights it consumes in one pass (the inter-level target is detached in the
+// reference, so its gradient is elementwise in the proposal weights).  One wavefront per ray.
+#include "nr_common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__global__ void __launch_bounds__(256)
+supervision_loss_kernel(const float* __restrict__ features, int feat_stride, const float* __restrict__ target_f, int C,
+                        const float* __restrict__ depth, const float* __restrict__ target_d, int64_t n_rays,
+                        float rgb_mult, float depth_mult, float* __restrict__ g_features, float* __restrict__ g_depth,
+                        float* __restrict__ loss) {
+  // rgb_mult * mean((f - t)^2) + depth_mult * mean(|d - t|)
+  const int64_t total = n_rays * C;
+  float acc = 0.0f;
+  const float kf = rgb_mult / (float)total, kd = depth_mult / (float)n_rays;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    const float diff = features[b * feat_stride + c] - target_f[i];
+    acc += kf * diff * diff;
+    g_features[b * feat_stride + c] = 2.0f * kf * diff;
+    if (c == 0) {
+      const float dd = depth[b] - target_d[b];
+      acc += kd * fabsf(dd);
+      g_depth[b] = dd > 0.0f ? kd : (dd < 0.0f ? -kd : 0.0f);
+    }
+  }
+  acc = nr_wave_sum(acc);
+  if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss, acc);
+}
+
+// losses.py:137-157.  c [n_rays, c_stride] s-space edges, w [n_rays, w_stride]; the first n_used
+// samples take part (the sky sample is dropped, neuradar.py:515,534).  g_w [n_rays, w_stride] is
+// overwritten (entries >= n_used get 0).
+__global__ void __launch_bounds__(256)
+distortion_loss_kernel(const float* __restrict__ c, int c_stride, const float* __restrict__ w, int w_stride, int n_used,
+                       int64_t n_rays, float mult, float* __restrict__ g_w, float* __restrict__ loss) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  const bool on = lane < n_used;
+  const float c0 = on ? c[ray * c_stride + lane] : 0.0f, c1 = on ? c[ray * c_stride + lane + 1] : 0.0f;
+  const float wi = on ? w[ray * w_stride + lane] : 0.0f;
+  const float mid = (c1 + c0) / 2.0f;
+  float inner = 0.0f;
+  for (int j = 0; j < n_used; ++j) inner += __shfl(wi, j, NR_WAVE) * fabsf(mid - __shfl(mid, j, NR_WAVE));
+  const float k = mult / (float)n_rays;
+  float l = wi * inner + wi * wi * (c1 - c0) / 3.0f;
+  l = nr_wave_sum(on ? l : 0.0f);
+  if (lane < w_stride) g_w[ray * w_stride + lane] = on ? k * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
+  if (lane == 0) unsafeAtomicAdd(loss, k * l);
+}
+
+// losses.py:626-705 for ONE proposal level.  Final level: c [.., n_used+1 edges], w [.., n_used]
+// (detached); proposal level: cp [n_rays, Sp+1], wp [n_rays, Sp].  n_used <= 31 so that the 2*(n_used+1)
+// blur knots fit one wavefront.  Outputs g_wp [n_rays, Sp] (overwritten) and loss +=.
+constexpr int kMaxKnots = 66;
+constexpr int kMaxProp = 256;
+
+__global__ void __launch_bounds__(256)
+interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* __restrict__ w, int w_stride, int n_used,
+                       const float* __restrict__ cp, const float* __restrict__ wp, int Sp, int64_t n_rays, float pulse,
+                       float mult, float* __restrict__ g_wp, float* __restrict__ loss) {
+  __shared__ float s_knot[kWavesPerBlock][kMaxKnots];   // c_  : [0, sorted knots, 1]
+  __shared__ float s_val[kWavesPerBlock][kMaxKnots];    // w_  : blurred density at the knots
+  __shared__ float s_cdf[kWavesPerBlock][kMaxKnots];    // cdf : integral of the piecewise-linear density
+  __shared__ float s_q[kWavesPerBlock][kMaxProp + 1];   // cdf interpolated at the proposal edges
+  const int wave = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  float* knot = s_knot[wave];
+  float* val = s_val[wave];
+  float* cdf = s_cdf[wave];
+  float* q = s_q[wave];
+  const int E = n_used + 1;  // edges of the final level
+  const int K = 2 * E;       // blur knots
+  // ---- final-level histogram, remaining mass on the last kept sample (:663-664) ----
+  const float wi = lane < n_used ? w[ray * w_stride + lane] : 0.0f;
+  const float acc = nr_wave_sum(wi);
+  const float ci = lane < E ? c[ray * c_stride + lane] : 0.0f;
+  const float c_next = __shfl_down(ci, 1, NR_WAVE);
+  float dens = 0.0f;  // w_norm (:666)
+  if (lane < n_used) dens = (lane == n_used - 1 ? wi + (1.0f - acc) : wi) / (c_next - ci);
+  // ---- box blur (:626-635): knots c-r (lanes 0..E-1) and c+r (lanes E..2E-1), merged by rank ----
+  const int src = lane < E ? lane : lane - E;                 // which edge this lane's knot comes from
+  const float edge = __shfl(ci, src, NR_WAVE);
+  const float mine = lane < E ? edge - pulse : edge + pulse;
+  const float d_prev = __shfl_up(dens, 1, NR_WAVE);
+  const float jump_e = ((lane < n_used ? dens : 0.0f) - (lane >= 1 && lane <= n_used ? d_prev : 0.0f)) / (2.0f * pulse);
+  const float jump = __shfl(jump_e, src, NR_WAVE) * (lane < E ? 1.0f : -1.0f);  // slope change at this knot
+  // rank in the merged order: own index + number of knots of the OTHER list that sort before it.
+  // The edges go through LDS for the search: lanes leave the loop at different times, and a shuffle
+  // cannot read a lane that has already dropped out of the loop.
+  if (lane < E) q[lane] = ci;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int other = 0;
+  if (lane < K) {
+    int lo = 0, hi = E;
+    while (lo < hi) {  // the other list is sorted ascending: c[k] -+ pulse
+      const int m = (lo + hi) >> 1;
+      const float o = q[m] + (lane < E ? pulse : -pulse);
+      const bool before = lane < E ? (o < mine) : (o <= mine);
+      if (before) lo = m + 1; else hi = m;
+    }
+    other = lo;
+  }
+  const int rank = src + other;
+  if (lane < K) {
+    knot[1 + rank] = mine;
+    val[1 + rank] = jump;  // temporarily: slope jump at this knot
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // sorted order: lane j holds knot j (j < K)
+  const float xj = lane < K ? knot[1 + lane] : 0.0f;
+  const float sj = lane < K ? val[1 + lane] : 0.0f;
+  const float x_next = __shfl_down(xj, 1, NR_WAVE);
+  // y2 is defined on the first K-1 sorted knots (:632); slope after knot j = cumsum(y2)[j]
+  const float slope = nr_wave_incl_sum(lane < K - 1 ? sj : 0.0f);
+  const float seg = lane < K - 1 ? (x_next - xj) * slope : 0.0f;
+  float yr = fmaxf(nr_wave_incl_sum(seg), 0.0f);        // value at knot j+1 (:633)
+  float y_at = __shfl_up(yr, 1, NR_WAVE);               // value at knot j
+  if (lane == 0) y_at = 0.0f;
+  const float y_next = lane < K - 1 ? yr : 0.0f;        // value at knot j+1 (only used for j < K-1)
+  const float area = lane < K - 1 ? 0.5f * (y_next + y_at) * (x_next - xj) : 0.0f;  // :685
+  const float cdf_incl = nr_wave_incl_sum(area);        // cdf at knot j+1
+  float cdf_at = __shfl_up(cdf_incl, 1, NR_WAVE);
+  if (lane == 0) cdf_at = 0.0f;
+  if (lane < K) {
+    val[1 + lane] = y_at;
+    cdf[1 + lane] = cdf_at;
+  }
+  if (lane == 0) {  // padding (:688-691)
+    knot[0] = 0.0f; val[0] = 0.0f; cdf[0] = 0.0f;
+    knot[K + 1] = 1.0f; val[K + 1] = 0.0f; cdf[K + 1] = 1.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- query the piecewise-quadratic cdf at the proposal edges (:638-651) ----
+  const int NK = K + 2;
+  for (int j = lane; j <= Sp; j += NR_WAVE) {
+    const float x = cp[ray * (Sp + 1) + j];
+    int lo = 0, hi = NK;  // searchsorted(left): first index with knot >= x
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (knot[m] < x) lo = m + 1; else hi = m;
+    }
+    const int left = max(lo - 1, 0), right = min(lo, NK - 1);
+    const float x0 = knot[left], x1 = knot[right], v0 = val[left], v1 = val[right], f0 = cdf[left];
+    float t = (x - x0) / (x1 - x0);
+    t = isnan(t) ? 0.0f : nr_nan_to_num(t);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    q[j] = f0 + (x - x0) * (v0 + v1 * t + v0 * (1.0f - t)) * 0.5f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- loss and its gradient w.r.t. the proposal weights (:700-704) ----
+  const float k = mult / (float)n_rays;
+  float l = 0.0f;
+  for (int j = lane; j < Sp; j += NR_WAVE) {
+    const float target = q[j + 1] - q[j];
+    const float p = wp[ray * Sp + j];
+    const float ex = fmaxf(target - p, 0.0f), den = p + 1e-5f;
+    l += ex * ex / den;
+    g_wp[ray * Sp + j] = k * (-2.0f * ex / den - ex * ex / (den * den));
+  }
+  l = nr_wave_sum(l);
+  if (lane == 0) unsafeAtomicAdd(loss, k * l);
+}
+
+}  // namespace
+
+extern "C" int nr_supervision_loss(const float* features, int feat_stride, const float* target_f, int C,
+                                   const float* depth, const float* target_d, int64_t n_rays, float rgb_mult,
+                                   float depth_mult, float* g_features, float* g_depth, float* loss,
+                                   nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!features || !target_f || !depth || !target_d || !g_features || !g_depth || !loss || C < 1 || feat_stride < C || n_rays < 0)
+    return NR_EINVAL;
+  const int64_t want = nr_cdiv(n_rays * C, 256);
+  hipLaunchKernelGGL(supervision_loss_kernel, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, nr_s(stream),
+                     features, feat_stride, target_f, C, depth, target_d, n_rays, rgb_mult, depth_mult, g_features,
+                     g_depth, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_distortion_loss(const float* c, int c_stride, const float* w, int w_stride, int n_used, int64_t n_rays,
+                                  float mult, float* g_w, float* loss, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!c || !w || !g_w || !loss || n_used < 1 || n_used > NR_WAVE || w_stride < n_used || w_stride > NR_WAVE ||
+      c_stride < n_used + 1 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(distortion_loss_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
+                     c, c_stride, w, w_stride, n_used, n_rays, mult, g_w, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_interlevel_loss(const float* c, int c_stride, const float* w, int w_stride, int n_used, const float* cp,
+                                  const float* wp, int Sp, int64_t n_rays, float pulse, float mult, float* g_wp,
+                                  float* loss, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!c || !w || !cp || !wp || !g_wp || !loss || n_used < 1 || n_used > 31 || w_stride < n_used ||
+      c_stride < n_used + 1 || Sp < 1 || Sp > kMaxProp || !(pulse > 0.0f) || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(interlevel_loss_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
+                     c, c_stride, w, w_stride, n_used, cp, wp, Sp, n_rays, pulse, mult, g_wp, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}

@@ -102,8 +102,8 @@ template <int ITEMS>
 __global__ void __launch_bounds__(256)
 pdf_resample_kernel(const float* __restrict__ weights, const float* __restrict__ spacing_in,
                     const float* __restrict__ jitter, const float* __restrict__ nears, const float* __restrict__ fars,
-                    int64_t n_rays, int S, int S_out, float lam, float scaling, float* __restrict__ spacing_out,
-                    float* __restrict__ euclid_out) {
+                    int64_t n_rays, int S, int S_out, float lam, float scaling, float sky_distance,
+                    float* __restrict__ spacing_out, float* __restrict__ euclid_out) {
   __shared__ float s_cdf[kWavesPerBlock][64 * ITEMS + 1];
   __shared__ float s_bins[kWavesPerBlock][64 * ITEMS + 1];
   const int wave = threadIdx.x >> 6;
@@ -162,8 +162,14 @@ pdf_resample_kernel(const float* __restrict__ weights, const float* __restrict__
     t = isnan(t) ? 0.0f : nr_nan_to_num(t);  // nan_to_num(., 0)
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     const float nb = b0 + t * (b1 - b0);
-    spacing_out[ray * num_bins + j] = nb;
-    euclid_out[ray * num_bins + j] = nr_spacing_to_euclid(nb, s_near, s_far, lam, scaling);
+    float eu = nr_spacing_to_euclid(nb, s_near, s_far, lam, scaling);
+    float sp = nb;
+    if (sky_distance > 0.0f && j == S_out) {  // "sky field" (models/neuradar.py:578-582)
+      eu = eu + (sky_distance - eu);
+      sp = 1.0f - 1e-7f;
+    }
+    spacing_out[ray * num_bins + j] = sp;
+    euclid_out[ray * num_bins + j] = eu;
   }
 }
 
@@ -213,13 +219,13 @@ extern "C" int nr_weights_from_density_bwd(const float* density, const float* eu
 
 extern "C" int nr_pdf_resample(const float* weights, const float* spacing_in, const float* jitter, const float* nears,
                                const float* fars, int64_t n_rays, int S, int S_out, float lam, float scaling,
-                               float* spacing_out, float* euclid_out, nr_stream_t stream) {
+                               float sky_distance, float* spacing_out, float* euclid_out, nr_stream_t stream) {
   if (n_rays == 0) return 0;
   if (!weights || !spacing_in || !nears || !fars || !spacing_out || !euclid_out || S < 1 || S > kMaxS || S_out < 1 ||
       n_rays < 0 || lam == 0.0f || lam == 1.0f)
     return NR_EINVAL;
   dim3 grid((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), block(256);
-#define CALL(I) hipLaunchKernelGGL(pdf_resample_kernel<I>, grid, block, 0, nr_s(stream), weights, spacing_in, jitter, nears, fars, n_rays, S, S_out, lam, scaling, spacing_out, euclid_out)
+#define CALL(I) hipLaunchKernelGGL(pdf_resample_kernel<I>, grid, block, 0, nr_s(stream), weights, spacing_in, jitter, nears, fars, n_rays, S, S_out, lam, scaling, sky_distance, spacing_out, euclid_out)
   NR_DISPATCH_ITEMS(S, CALL);
 #undef CALL
   NR_LAUNCH_CHECK();

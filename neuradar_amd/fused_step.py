@@ -1,0 +1,174 @@
+"""Autograd-free training step of the hot path: the same kernels as `NeuRadarHotPath`, launched
+back-to-back through the C ABI over buffers allocated once, forward and hand-chained backward, then
+the fused Adam.  ~45 launches per step (vs ~370 with torch autograd + torch loss glue), all on one
+stream -> replayable as a single hipGraph.
+
+Sequence = models/neuradar.py:495-548 (get_nff_outputs, training branch) + the bench loss
+ + backward + optimizer.  Checked against the autograd path and the oracle in
+tests/test_gpu_parity.py::test_fused_step_matches_autograd_path.
+"""
+from ctypes import byref, c_void_p
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib, losses, ops
+from ._lib import NrField, NrFieldGrads, check
+from .step import SKY_DISTANCE, NeuRadarHotPath
+
+
+def flatten_parameters(params: List[nn.Parameter]) -> Dict[str, Tensor]:
+    """Re-home `params` (and their .grad) as views of one flat buffer each, so the optimizer and the
+    gradient all-reduce touch them with ONE launch.  Parameter objects, names and shapes are unchanged
+    (state_dict round-trips as before)."""
+    dev, n = params[0].device, sum(p.numel() for p in params)
+    n_pad = (n + 3) // 4 * 4
+    flat = torch.zeros(n_pad, device=dev, dtype=torch.float32)
+    flat_grad = torch.zeros_like(flat)
+    off = 0
+    for p in params:
+        k = p.numel()
+        flat[off:off + k].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + k].view_as(p)
+        p.grad = flat_grad[off:off + k].view_as(p)
+        off += k
+    return {"param": flat, "grad": flat_grad}
+
+
+class FusedTrainStep:
+    def __init__(self, model: NeuRadarHotPath, n_rays: int) -> None:
+        c = model.config
+        assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
+        assert len(c.num_proposal_samples) == 2
+        self.model, self.cfg, self.B = model, c, n_rays
+        self.lib = _lib.lib()
+        dev = next(model.parameters()).device
+        self.dev = dev
+        B = n_rays
+        self.S = (*c.num_proposal_samples, c.num_nerf_samples)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.prop = model.proposal_fields[-1]  # both rounds use proposal_fields[1] (neuradar.py:302 quirk)
+        self.pgrid, self.mgrid = self.prop.hashgrid.static_grid, model.field.hashgrid.static_grid
+        self.nears = torch.zeros(B, **f32)
+        self.fars = torch.empty(B, **f32)
+        self.sp, self.eu, self.x01, self.std, self.feats, self.g_feats = [], [], [], [], [], []
+        for lvl, S in enumerate(self.S):
+            grid = self.pgrid if lvl < 2 else self.mgrid
+            self.sp.append(torch.empty(B, S + 1, **f32))
+            self.eu.append(torch.empty(B, S + 1, **f32))
+            self.x01.append(torch.empty(B * S, 3, **f32))
+            self.std.append(torch.empty(B * S, **f32))
+            self.feats.append(torch.empty(grid.num_levels, B * S, grid.features_per_level, **f32))
+            self.g_feats.append(torch.empty_like(self.feats[-1]))
+        self.dens = [torch.empty(B, S, **f32) for S in self.S[:2]]
+        self.g_dens = [torch.empty(B, S, **f32) for S in self.S[:2]]
+        self.w = [torch.empty(B, S, **f32) for S in self.S]       # proposal weights x2, final weights
+        self.g_w = [torch.empty(B, S, **f32) for S in self.S]
+        self.prop_depth = [torch.empty(B, **f32) for _ in range(2)]
+        Sm, C = self.S[2], c.field.nff_out_dim
+        self.C = C
+        self.feature = torch.empty(B * Sm, C, **f32)
+        self.sdf = torch.empty(B * Sm, **f32)
+        self.alpha = torch.empty(B * Sm, **f32)
+        self.acc = torch.empty(B, **f32)
+        self.features = torch.empty(B, C, **f32)
+        self.depth = torch.empty(B, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.g_features = torch.zeros(B, C, **f32)
+        self.g_depth = torch.empty(B, **f32)
+        self.g_alpha = torch.empty(B * Sm, **f32)
+        self.g_feature = torch.empty(B * Sm, C, **f32)
+        for p in model.parameters():
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self._structs()
+
+    def _structs(self) -> None:
+        """(Re)build the ctypes views of the parameters -- call again if parameters were re-homed."""
+        fld = self.model.field
+        gw, gb = fld.mlp_geo.weights()
+        fw, fb = fld.mlp_feature.weights()
+        self.field_struct = NrField()
+        self.field_struct.geo, self.field_struct.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
+        self.field_struct.beta = fld.sdf_to_density.beta.data_ptr()
+        self.field_grads = NrFieldGrads()
+        self.field_grads.geo = ops._mlp_grads_struct([w.grad for w in gw], [b.grad for b in gb])
+        self.field_grads.feat = ops._mlp_grads_struct([w.grad for w in fw], [b.grad for b in fb])
+        self.field_grads.beta = fld.sdf_to_density.beta.grad.data_ptr()
+
+    # -------------------------------------------------------------------------------------------
+    def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
+                         target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
+                         jitter2: Tensor) -> Tensor:
+        """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
+        targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns loss [1]."""
+        lib, p, c, B = self.lib, ops._p, self.cfg, self.B
+        st = ops._stream()
+        lam, scal = c.power_lambda, c.power_scaling
+        o, d, area = p(origins), p(directions), p(pixel_area)
+        torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=self.fars)  # neuradar.py:573
+        nears, far = p(self.nears), p(self.fars)
+        scale = self.model.field.hashgrid.static_scale
+        check(lib.nr_power_bins(nears, far, p(t_rand), B, self.S[0], lam, scal, p(self.sp[0]), p(self.eu[0]), st), "power_bins")
+        jit = (jitter1, jitter2)
+        pg, w_dec = self.pgrid, self.prop.density_decoder.weight
+        for lvl in range(2):
+            S, n = self.S[lvl], B * self.S[lvl]
+            check(lib.nr_contract_gaussians(o, d, area, p(self.eu[lvl]), B, S, scale, p(self.x01[lvl]), p(self.std[lvl]), st), "contract")
+            check(lib.nr_hash_encode_fwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels,
+                                         pg.features_per_level, pg.log2_hashmap_size, p(self.feats[lvl]),
+                                         pg.features_per_level, n * pg.features_per_level, n, S, st), "hash_fwd")
+            check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
+                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, p(self.dens[lvl]), st), "prop_density")
+            check(lib.nr_weights_from_density_fwd(p(self.dens[lvl]), p(self.eu[lvl]), B, S, p(self.w[lvl]), st), "weights")
+            check(lib.nr_depth_from_weights(p(self.w[lvl]), p(self.eu[lvl]), B, S, p(self.prop_depth[lvl]), st), "prop depth")
+            check(lib.nr_pdf_resample(p(self.w[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, B, S, self.S[lvl + 1], lam, scal,
+                                      SKY_DISTANCE if lvl == 1 else 0.0, p(self.sp[lvl + 1]), p(self.eu[lvl + 1]), st), "pdf_resample")
+        mg, Sm = self.mgrid, self.S[2]
+        n = B * Sm
+        F = mg.features_per_level
+        check(lib.nr_contract_gaussians(o, d, area, p(self.eu[2]), B, Sm, scale, p(self.x01[2]), p(self.std[2]), st), "contract")
+        check(lib.nr_hash_encode_fwd(p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
+                                     mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, Sm, st), "hash_fwd")
+        check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, n, p(self.feature), p(self.sdf),
+                               p(self.alpha), st), "field_fwd")
+        check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
+                                   p(self.features), p(self.depth), st), "composite_fwd")
+        # ---- loss tail: value + gradients w.r.t. features, depth and the three weight tensors ----
+        self.loss.zero_()
+        check(lib.nr_supervision_loss(p(self.features), self.C, p(target_features), target_features.shape[1], p(self.depth),
+                                      p(target_depth), B, c.rgb_mult, c.depth_mult, p(self.g_features), p(self.g_depth),
+                                      p(self.loss), st), "supervision_loss")
+        check(lib.nr_distortion_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, B, c.distortion_loss_mult, p(self.g_w[2]),
+                                     p(self.loss), st), "distortion_loss")
+        for lvl in range(2):
+            check(lib.nr_interlevel_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]), p(self.w[lvl]),
+                                         self.S[lvl], B, losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_w[lvl]),
+                                         p(self.loss), st), "interlevel_loss")
+        # ---- backward ----
+        check(lib.nr_composite_bwd(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.w[2]), p(self.g_features),
+                                   p(self.g_depth), None, p(self.g_w[2]), B, Sm, self.C, p(self.g_alpha), p(self.g_feature), st),
+              "composite_bwd")
+        check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, n, p(self.g_feature),
+                               p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), st), "field_bwd")
+        check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
+                                     p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
+        Fp = pg.features_per_level
+        for lvl in (1, 0):
+            S, n = self.S[lvl], B * self.S[lvl]
+            check(lib.nr_weights_from_density_bwd(p(self.dens[lvl]), p(self.eu[lvl]), p(self.g_w[lvl]), B, S, p(self.g_dens[lvl]), st),
+                  "weights_bwd")
+            check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, n * Fp, Fp, p(w_dec), w_dec.numel(), n, p(self.dens[lvl]),
+                                          p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), st), "prop_density_bwd")
+            check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
+                                         pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, n * Fp, p(pg.hash_table.grad), n, S, st),
+                  "hash_bwd")
+        return self.loss
+
+    def outputs(self) -> Dict[str, Tensor]:
+        """Views of the last step's rendered outputs (get_nff_outputs keys)."""
+        return {"features": self.features, "depth": self.depth[:, None], "accumulation": self.acc[:, None],
+                "weights": self.w[2], "prop_weights_0": self.w[0], "prop_weights_1": self.w[1],
+                "prop_depth_0": self.prop_depth[0][:, None], "prop_depth_1": self.prop_depth[1][:, None],
+                "final_spacing": self.sp[2], "final_euclid": self.eu[2]}

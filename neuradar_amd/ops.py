@@ -259,8 +259,8 @@ def weights_from_density(density: Tensor, euclid: Tensor) -> Tensor:
 
 
 def pdf_resample(weights: Tensor, spacing_in: Tensor, nears: Tensor, fars: Tensor, n_out: int,
-                 jitter: Optional[Tensor] = None, lam: float = POWER_LAMBDA, scaling: float = POWER_SCALING
-                 ) -> Tuple[Tensor, Tensor]:
+                 jitter: Optional[Tensor] = None, lam: float = POWER_LAMBDA, scaling: float = POWER_SCALING,
+                 sky_distance: float = 0.0) -> Tuple[Tensor, Tensor]:
     weights = _f32(weights.detach(), "weights")
     B, S = weights.shape
     sp = torch.empty((B, n_out + 1), device=weights.device, dtype=torch.float32)
@@ -269,7 +269,7 @@ def pdf_resample(weights: Tensor, spacing_in: Tensor, nears: Tensor, fars: Tenso
         jitter = _f32(jitter, "jitter").reshape(-1)
     check(_lib.lib().nr_pdf_resample(_p(weights), _p(_f32(spacing_in, "spacing")), _p(jitter),
                                      _p(_f32(nears, "nears").reshape(-1)), _p(_f32(fars, "fars").reshape(-1)), B, S,
-                                     n_out, lam, scaling, _p(sp), _p(eu), _stream()), "nr_pdf_resample")
+                                     n_out, lam, scaling, sky_distance, _p(sp), _p(eu), _stream()), "nr_pdf_resample")
     return sp, eu
 
 
@@ -324,3 +324,37 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     check(_lib.lib().nr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0],
                                   betas[1], eps, weight_decay, int(adamw), step, grad_scale, int(zero_grad),
                                   _p(dev_hyper), _stream()), "nr_adam_step")
+
+
+# ------------------------------------------------------------------------------------------------ loss tail
+def supervision_loss(features: Tensor, target_f: Tensor, depth: Tensor, target_d: Tensor, rgb_mult: float,
+                     depth_mult: float, loss: Tensor, g_features: Optional[Tensor] = None,
+                     g_depth: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """loss[0] += rgb_mult*MSE(features[:, :C], target_f) + depth_mult*L1(depth, target_d); returns the
+    gradients (g_features zero beyond the first C columns)."""
+    B, C = target_f.shape
+    g_features = torch.zeros_like(features) if g_features is None else g_features
+    g_depth = torch.empty_like(depth) if g_depth is None else g_depth
+    check(_lib.lib().nr_supervision_loss(_p(features), features.shape[1], _p(target_f), C, _p(depth), _p(target_d), B,
+                                         rgb_mult, depth_mult, _p(g_features), _p(g_depth), _p(loss), _stream()),
+          "nr_supervision_loss")
+    return g_features, g_depth
+
+
+def distortion_loss(spacing: Tensor, weights: Tensor, n_used: int, mult: float, loss: Tensor,
+                    g_w: Optional[Tensor] = None) -> Tensor:
+    """loss[0] += mult*distortion(spacing[:, :n_used+1], weights[:, :n_used]); returns d loss / d weights."""
+    g_w = torch.empty_like(weights) if g_w is None else g_w
+    check(_lib.lib().nr_distortion_loss(_p(spacing), spacing.shape[1], _p(weights), weights.shape[1], n_used,
+                                        weights.shape[0], mult, _p(g_w), _p(loss), _stream()), "nr_distortion_loss")
+    return g_w
+
+
+def interlevel_loss(spacing: Tensor, weights: Tensor, n_used: int, prop_spacing: Tensor, prop_weights: Tensor,
+                    pulse: float, mult: float, loss: Tensor, g_wp: Optional[Tensor] = None) -> Tensor:
+    """loss[0] += mult * zipnerf inter-level loss of one proposal level; returns d loss / d prop_weights."""
+    g_wp = torch.empty_like(prop_weights) if g_wp is None else g_wp
+    check(_lib.lib().nr_interlevel_loss(_p(spacing), spacing.shape[1], _p(weights), weights.shape[1], n_used,
+                                        _p(prop_spacing), _p(prop_weights), prop_weights.shape[1], weights.shape[0],
+                                        pulse, mult, _p(g_wp), _p(loss), _stream()), "nr_interlevel_loss")
+    return g_wp

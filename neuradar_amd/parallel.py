@@ -31,17 +31,34 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     return rank, world, local_rank
 
 
+class _GradHolder:
+    """Adapter: a bare gradient buffer seen as an object with .grad / .numel()."""
+
+    def __init__(self, grad: torch.Tensor):
+        self.grad = grad
+
+    def numel(self) -> int:
+        return self.grad.numel()
+
+
 class GradAllReducer:
     """Mean all-reduce of `.grad` over the world: big tensors in place, small ones via one flat bucket."""
 
-    def __init__(self, params: Iterable[nn.Parameter], group=None, table_dtype: Optional[torch.dtype] = None):
-        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+    def __init__(self, params: Optional[Iterable[nn.Parameter]], group=None, table_dtype: Optional[torch.dtype] = None,
+                 buffers: Optional[List[torch.Tensor]] = None):
+        """`params`: parameters whose .grad is reduced; or `buffers`: ready-made flat gradient buffers
+        (FlatAdam.grad_buffers(): one per hash table + one holding every small parameter)."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.table_dtype = table_dtype
+        self._flat: Optional[torch.Tensor] = None
+        if buffers is not None:
+            self.params = [_GradHolder(b) for b in buffers]
+            self.big, self.small = self.params, []
+            return
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         self.big = [p for p in self.params if p.numel() > SMALL_PARAM_NUMEL]
         self.small = [p for p in self.params if p.numel() <= SMALL_PARAM_NUMEL]
-        self.table_dtype = table_dtype  # e.g. torch.bfloat16 halves the xGMI bytes of the table buckets
-        self._flat: Optional[torch.Tensor] = None
 
     def bytes_per_step(self) -> int:
         esz = 4 if self.table_dtype is None else torch.empty((), dtype=self.table_dtype).element_size()

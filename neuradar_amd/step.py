@@ -147,24 +147,41 @@ class NeuRadarHotPath(nn.Module):
 
 
 class FlatAdam:
-    """Adam/AdamW over a list of parameters with the fused HIP kernel (one launch per tensor).
+    """Adam/AdamW with the fused HIP kernel.  Small parameters are re-homed into ONE flat buffer
+    (views keep names/shapes), so a step is one launch for all of them plus one per hash table.
 
     Hyper-parameters of configs/method_configs.py:384-409; the (lr, bias-correction) triple lives in a
-    device tensor updated by a few scalar ops so that a captured graph can be replayed."""
+    device tensor updated by a few scalar ops so that a captured graph can be replayed.  Parameters in
+    `skip` never receive a gradient (proposal_fields[0], see NeuRadarHotPath) and are left untouched,
+    like torch.optim skips parameters whose .grad is None."""
+
+    BIG = 1 << 16
 
     def __init__(self, params: List[nn.Parameter], lr: float, eps: float = 1e-15, weight_decay: float = 0.0,
                  adamw: bool = False, betas=(0.9, 0.999), lr_final: Optional[float] = None, max_steps: int = 20001,
-                 warmup_steps: int = 500) -> None:
-        self.params = [p for p in params if p.requires_grad]
+                 warmup_steps: int = 500, skip: Optional[List[nn.Parameter]] = None, flatten: bool = True) -> None:
+        skip_ids = {id(p) for p in (skip or [])}
+        self.params = [p for p in params if p.requires_grad and id(p) not in skip_ids]
         self.lr, self.eps, self.wd, self.adamw, self.betas = lr, eps, weight_decay, adamw, betas
         self.lr_final, self.max_steps, self.warmup = lr_final, max_steps, warmup_steps
         dev = self.params[0].device
-        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in self.params]
-        self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
-        self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
+        small = [p for p in self.params if p.numel() <= self.BIG] if flatten else []
+        big = [p for p in self.params if p.numel() > self.BIG or not flatten]
+        self.buffers = [(p.data, p.grad) for p in big]  # (param, grad) flat views stepped by one launch each
+        if small:
+            from .fused_step import flatten_parameters
+
+            flat = flatten_parameters(small)
+            self.buffers.append((flat["param"], flat["grad"]))
+        self.state = [(torch.zeros_like(b), torch.zeros_like(b)) for b, _ in self.buffers]
+        self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
+
+    def grad_buffers(self) -> List[Tensor]:
+        return [g for _, g in self.buffers]
 
     def _schedule(self, step: Tensor) -> Tensor:
         """ExponentialDecayScheduler (engine/schedulers.py:112-143): cosine-ramp warm-up from
@@ -185,6 +202,6 @@ class FlatAdam:
         self.step_t += 1
         self.hyper[1] = 1 - b1**self.step_t
         self.hyper[2] = torch.sqrt(1 - b2**self.step_t)
-        for p, (m, v) in zip(self.params, self.state):
-            ops.adam_step(p.data, p.grad, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw,
+        for (p, g), (m, v) in zip(self.buffers, self.state):
+            ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw,
                           zero_grad=True, dev_hyper=self.hyper)
