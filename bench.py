@@ -111,13 +111,18 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True):
         S0 = model.config.num_proposal_samples[0]
         dev = tgt_f.device
 
+        n_p = n_rays // (scene.PATCH * scene.PATCH)
+        n_t, n_u = n_rays * (S0 + 1), 3 * n_p
+        fars = torch.full((n_rays,), 1e6, device=dev)  # cameras.py:948
+
         def fwd_bwd():
-            bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
-            area = bundle.pixel_area[:, 0] * 9.0  # _scale_pixel_area: camera rays x rgb_upsample_factor^2
-            t_rand = torch.rand((n_rays, S0 + 1), device=dev)  # PowerSampler: per-edge jitter (ray_samplers.py:111)
-            jit = torch.rand((2, n_rays), device=dev)           # PDFSampler: one jitter per ray and round (:326)
-            return stepper.forward_backward(bundle.origins, bundle.directions, area, bundle.fars[:, 0], tgt_f,
-                                            tgt_d[:, 0], t_rand, jit[0], jit[1])
+            # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
+            # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly
+            r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
+            bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
+                                                          scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
+            return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], fars, tgt_f, tgt_d[:, 0],
+                                            r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays])
     else:
         def fwd_bwd():
             bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))

@@ -27,6 +27,7 @@ extern "C" {
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
 #define NR_ABI_VERSION 1
+#define NR_LOSS_SLOTS 64   /* loss kernels add into loss[0..63]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
 
@@ -222,7 +223,7 @@ int nr_gen_rays_radar(const int64_t* scan_indices, int64_t n_scans, const float*
 
 /* ------------------------------------------------------------------------------------------------
  * Loss tail of a training step.  Each entry adds its (already weighted)
- * loss value to loss[0] and writes the gradient w.r.t. the tensors it consumes, so no autograd graph
+ * loss value into the NR_LOSS_SLOTS partial sums loss[0..63] (their sum is the loss) and writes the gradient w.r.t. the tensors it consumes, so no autograd graph
  * is needed between compositing and the backward kernels.
  * ---------------------------------------------------------------------------------------------- */
 /* rgb_mult*mean((features[:, :C] - target_f)^2) + depth_mult*mean(|depth - target_d|): the stand-in
@@ -255,6 +256,27 @@ int nr_interlevel_loss(const float* c, int c_stride, const float* w, int w_strid
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
                  int step, float grad_scale, int zero_grad, const float* dev_hyper, nr_stream_t stream);
+
+/* Advance the optimizer step counter step_t[0] (device float, 0-based scheduler step) and refresh
+ * dev_hyper = {lr(step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))} with the reference's
+ * ExponentialDecayScheduler (engine/schedulers.py:112-143: cosine ramp from 1e-8 over `warmup` steps,
+ * then log-linear decay lr -> lr_final until max_steps).  One launch, graph-replayable. */
+int nr_adam_hyper(float* step_t, float* dev_hyper, float lr, float lr_final, int warmup, int max_steps,
+                  float beta1, float beta2, nr_stream_t stream);
+
+/* On-device batch assembly for camera patches (the reference samples patches
+ * in data/pixel_samplers.py and generates rays on CPU workers): u [n_patches,3] uniform [0,1) ->
+ * patch (camera, y0, x0) = (floor(u0*n_cams), floor(u1*(H-span)), floor(u2*(W-span))), span =
+ * patch*stride; ray k of patch p is pixel (y0 + stride*(k / patch), x0 + stride*(k % patch)).
+ * Rays are generated exactly as nr_gen_rays_camera; pixel_area is multiplied by area_scale
+ * (_scale_pixel_area, models/neuradar.py:996-1008).  ray_indices [n,3] int64 (nullable) receives the
+ * (camera,row,col) triples.  n = n_patches*patch*patch. */
+int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, int height, int width, int patch,
+                               int stride, float area_scale, const float* c2w, const float* fx, const float* fy,
+                               const float* cx, const float* cy, const float* cam_times, const float* velocities,
+                               const float* rs_offsets, const float* heights, float* origins, float* directions,
+                               float* pixel_area, float* times, float* directions_norm, int64_t* ray_indices,
+                               nr_stream_t stream);
 
 #ifdef __cplusplus
 }

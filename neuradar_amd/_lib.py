@@ -13,6 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
+NR_LOSS_SLOTS = 64
 
 
 class NrMlp(Structure):
@@ -62,6 +63,8 @@ PROTOTYPES = {
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
+    "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
+    "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p}
 

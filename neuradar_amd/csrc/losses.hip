@@ -8,6 +8,9 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+// loss values are summed into NR_LOSS_SLOTS partial sums (slot = block index mod slots): thousands of
+// atomics on ONE address serialise at the memory side (~15 ns each), spread over 64 they do not.
+__device__ __forceinline__ float* loss_slot(float* loss) { return loss + (blockIdx.x & (NR_LOSS_SLOTS - 1)); }
 
 __global__ void __launch_bounds__(256)
 supervision_loss_kernel(const float* __restrict__ features, int feat_stride, const float* __restrict__ target_f, int C,
@@ -31,7 +34,7 @@ supervision_loss_kernel(const float* __restrict__ features, int feat_stride, con
     }
   }
   acc = nr_wave_sum(acc);
-  if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss, acc);
+  if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss_slot(loss), acc);
 }
 
 // losses.py:137-157.  c [n_rays, c_stride] s-space edges, w [n_rays, w_stride]; the first n_used
@@ -53,7 +56,7 @@ distortion_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   float l = wi * inner + wi * wi * (c1 - c0) / 3.0f;
   l = nr_wave_sum(on ? l : 0.0f);
   if (lane < w_stride) g_w[ray * w_stride + lane] = on ? k * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
-  if (lane == 0) unsafeAtomicAdd(loss, k * l);
+  if (lane == 0) unsafeAtomicAdd(loss_slot(loss), k * l);
 }
 
 // losses.py:626-705 for ONE proposal level.  Final level: c [.., n_used+1 edges], w [.., n_used]
@@ -176,7 +179,7 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     g_wp[ray * Sp + j] = k * (-2.0f * ex / den - ex * ex / (den * den));
   }
   l = nr_wave_sum(l);
-  if (lane == 0) unsafeAtomicAdd(loss, k * l);
+  if (lane == 0) unsafeAtomicAdd(loss_slot(loss), k * l);
 }
 
 }  // namespace

@@ -95,7 +95,41 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
     upd(param[i], grad[i], m[i], v[i]);
 }
 
+// One-thread kernel: advances the optimizer step counter and refreshes {lr, 1-beta1^t, sqrt(1-beta2^t)}
+// (ExponentialDecayScheduler, engine/schedulers.py:112-143; LambdaLR applies func(k-1) to step k).
+__global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict__ hyper, float lr, float lr_final,
+                                  int warmup, int max_steps, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double step = (double)step_t[0];
+  double cur;
+  if (step < (double)warmup) {
+    const double pre = 1e-8;
+    double r = step / (double)warmup;
+    r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+    cur = pre + ((double)lr - pre) * sin(0.5 * 3.14159265358979323846 * r);
+  } else {
+    const int span = max_steps - warmup > 1 ? max_steps - warmup : 1;
+    double t = (step - (double)warmup) / (double)span;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    cur = exp(log((double)lr) * (1.0 - t) + log((double)lr_final) * t);
+  }
+  const double k = step + 1.0;
+  step_t[0] = (float)k;
+  hyper[0] = (float)cur;
+  hyper[1] = (float)(1.0 - pow((double)beta1, k));
+  hyper[2] = (float)sqrt(1.0 - pow((double)beta2, k));
+}
+
 }  // namespace
+
+extern "C" int nr_adam_hyper(float* step_t, float* hyper, float lr, float lr_final, int warmup, int max_steps,
+                             float beta1, float beta2, nr_stream_t stream) {
+  if (!step_t || !hyper || !(lr > 0.0f) || !(lr_final > 0.0f) || warmup < 0 || max_steps < 1) return NR_EINVAL;
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, nr_s(stream), step_t, hyper, lr, lr_final, warmup, max_steps,
+                     beta1, beta2);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_prop_density_fwd(const float* feats, int64_t sn, int64_t sl, int F, const float* w, int in_dim,
                                    int64_t n, float* density, nr_stream_t stream) {

@@ -16,19 +16,16 @@ __device__ __forceinline__ float normalize3(float (&v)[3]) {
   return norm;
 }
 
-__global__ void __launch_bounds__(256)
-gen_rays_camera_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
-                       const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ cx,
-                       const float* __restrict__ cy, const float* __restrict__ cam_times,
-                       const float* __restrict__ velocities, const float* __restrict__ rs_offsets,
-                       const float* __restrict__ heights, int64_t n, float* __restrict__ origins,
-                       float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ times,
-                       float* __restrict__ directions_norm) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t cam = ray_indices[i * 3 + 0];
-  const float y = (float)ray_indices[i * 3 + 1] + 0.5f;  // pixel centres (cameras.py:313)
-  const float x = (float)ray_indices[i * 3 + 2] + 0.5f;
+__device__ __forceinline__ void camera_ray(int64_t i, int64_t cam, int64_t row, int64_t col, const float* __restrict__ c2w,
+                                           const float* __restrict__ fx, const float* __restrict__ fy,
+                                           const float* __restrict__ cx, const float* __restrict__ cy,
+                                           const float* __restrict__ cam_times, const float* __restrict__ velocities,
+                                           const float* __restrict__ rs_offsets, const float* __restrict__ heights,
+                                           float area_scale, float* __restrict__ origins, float* __restrict__ directions,
+                                           float* __restrict__ pixel_area, float* __restrict__ times,
+                                           float* __restrict__ directions_norm) {
+  const float y = (float)row + 0.5f;  // pixel centres (cameras.py:313)
+  const float x = (float)col + 0.5f;
   const float fxv = fx[cam], fyv = fy[cam], cxv = cx[cam], cyv = cy[cam];
   const float* pose = c2w + cam * 12;
   // the pixel and its +1 neighbours in x and y (cameras.py:622-624), OpenCV -> OpenGL flip (:656),
@@ -64,9 +61,49 @@ gen_rays_camera_kernel(const int64_t* __restrict__ ray_indices, const float* __r
     origins[i * 3 + r] = o[r];
     directions[i * 3 + r] = d[0][r];
   }
-  pixel_area[i] = sqrtf(dx) * sqrtf(dy);
+  pixel_area[i] = (sqrtf(dx) * sqrtf(dy)) * area_scale;
   times[i] = t;
-  directions_norm[i] = norm0;
+  if (directions_norm != nullptr) directions_norm[i] = norm0;
+}
+
+__global__ void __launch_bounds__(256)
+gen_rays_camera_kernel(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w,
+                       const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ cx,
+                       const float* __restrict__ cy, const float* __restrict__ cam_times,
+                       const float* __restrict__ velocities, const float* __restrict__ rs_offsets,
+                       const float* __restrict__ heights, int64_t n, float* __restrict__ origins,
+                       float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ times,
+                       float* __restrict__ directions_norm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  camera_ray(i, ray_indices[i * 3 + 0], ray_indices[i * 3 + 1], ray_indices[i * 3 + 2], c2w, fx, fy, cx, cy, cam_times,
+             velocities, rs_offsets, heights, 1.0f, origins, directions, pixel_area, times, directions_norm);
+}
+
+__global__ void __launch_bounds__(256)
+gen_rays_camera_patches_kernel(const float* __restrict__ u, int64_t n_patches, int n_cams, int H, int W, int patch, int stride,
+                               float area_scale, const float* __restrict__ c2w, const float* __restrict__ fx,
+                               const float* __restrict__ fy, const float* __restrict__ cx, const float* __restrict__ cy,
+                               const float* __restrict__ cam_times, const float* __restrict__ velocities,
+                               const float* __restrict__ rs_offsets, const float* __restrict__ heights,
+                               float* __restrict__ origins, float* __restrict__ directions, float* __restrict__ pixel_area,
+                               float* __restrict__ times, float* __restrict__ directions_norm,
+                               int64_t* __restrict__ ray_indices) {
+  const int per = patch * patch;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_patches * per) return;
+  const int64_t p = i / per;
+  const int k = (int)(i - p * per);
+  const int span = patch * stride;
+  const int64_t cam = min((int64_t)(u[p * 3 + 0] * (float)n_cams), (int64_t)n_cams - 1);
+  const int64_t y0 = min((int64_t)(u[p * 3 + 1] * (float)(H - span)), (int64_t)(H - span - 1));
+  const int64_t x0 = min((int64_t)(u[p * 3 + 2] * (float)(W - span)), (int64_t)(W - span - 1));
+  const int64_t row = y0 + (int64_t)stride * (k / patch), col = x0 + (int64_t)stride * (k % patch);
+  if (ray_indices != nullptr) {
+    ray_indices[i * 3 + 0] = cam; ray_indices[i * 3 + 1] = row; ray_indices[i * 3 + 2] = col;
+  }
+  camera_ray(i, cam, row, col, c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, area_scale, origins,
+             directions, pixel_area, times, directions_norm);
 }
 
 __global__ void __launch_bounds__(256)
@@ -150,6 +187,25 @@ extern "C" int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, 
   hipLaunchKernelGGL(gen_rays_camera_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), ray_indices,
                      c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, n, origins, directions,
                      pixel_area, times, directions_norm);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, int H, int W, int patch, int stride,
+                                          float area_scale, const float* c2w, const float* fx, const float* fy,
+                                          const float* cx, const float* cy, const float* cam_times, const float* velocities,
+                                          const float* rs_offsets, const float* heights, float* origins, float* directions,
+                                          float* pixel_area, float* times, float* directions_norm, int64_t* ray_indices,
+                                          nr_stream_t stream) {
+  if (n_patches == 0) return 0;
+  if (!u || !c2w || !fx || !fy || !cx || !cy || !cam_times || !origins || !directions || !pixel_area || !times ||
+      n_patches < 0 || n_cams < 1 || patch < 1 || stride < 1 || H <= patch * stride || W <= patch * stride)
+    return NR_EINVAL;
+  if ((velocities != nullptr) != (rs_offsets != nullptr) || (velocities != nullptr) != (heights != nullptr)) return NR_EINVAL;
+  const int64_t n = n_patches * patch * patch;
+  hipLaunchKernelGGL(gen_rays_camera_patches_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), u, n_patches,
+                     n_cams, H, W, patch, stride, area_scale, c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights,
+                     origins, directions, pixel_area, times, directions_norm, ray_indices);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -74,7 +74,7 @@ class FusedTrainStep:
         self.acc = torch.empty(B, **f32)
         self.features = torch.empty(B, C, **f32)
         self.depth = torch.empty(B, **f32)
-        self.loss = torch.zeros(1, **f32)
+        self.loss = torch.zeros(_lib.NR_LOSS_SLOTS, **f32)  # partial sums; loss value = self.loss.sum()
         self.g_features = torch.zeros(B, C, **f32)
         self.g_depth = torch.empty(B, **f32)
         self.g_alpha = torch.empty(B * Sm, **f32)
@@ -102,7 +102,8 @@ class FusedTrainStep:
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
                          jitter2: Tensor) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
-        targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns loss [1]."""
+        targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
+        NR_LOSS_SLOTS partial sums (call .sum() when the value is needed)."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
         lam, scal = c.power_lambda, c.power_scaling

@@ -52,6 +52,26 @@ class Cameras:
                          times=t[:, None], metadata={"directions_norm": norm[:, None]})
 
 
+    def generate_patch_rays(self, u: Tensor, patch: int, stride: int, height: int, width: int,
+                            area_scale: float = 1.0, return_indices: bool = False):
+        """On-device batch assembly: u [n_patches,3] uniform -> rays of random
+        patch x patch blocks at pixel stride `stride`, one kernel.  Returns (RayBundle, ray_indices|None)."""
+        n_p, dev = u.shape[0], u.device
+        n = n_p * patch * patch
+        o, d = _new(n, 3, device=dev), _new(n, 3, device=dev)
+        area, t = _new(n, device=dev), _new(n, device=dev)
+        idx = _new(n, 3, device=dev, dtype=torch.int64) if return_indices else None
+        rs = self.velocities is not None and self.rolling_shutter_offsets is not None
+        p = ops._p
+        check(_lib.lib().nr_gen_rays_camera_patches(
+            p(u), n_p, self.fx.shape[0], height, width, patch,
+            stride, area_scale, p(self.camera_to_worlds), p(self.fx), p(self.fy), p(self.cx), p(self.cy), p(self.times),
+            p(self.velocities) if rs else None, p(self.rolling_shutter_offsets) if rs else None,
+            p(self.height) if rs else None, p(o), p(d), p(area), p(t), None, p(idx), ops._stream()),
+            "nr_gen_rays_camera_patches")
+        return RayBundle(o, d, area[:, None], fars=torch.full((n, 1), FAR, device=dev), times=t[:, None]), idx
+
+
 @dataclass
 class Lidars:
     lidar_to_worlds: Tensor  # [N,3,4]

@@ -177,7 +177,7 @@ class FlatAdam:
             flat = flatten_parameters(small)
             self.buffers.append((flat["param"], flat["grad"]))
         self.state = [(torch.zeros_like(b), torch.zeros_like(b)) for b, _ in self.buffers]
-        self.step_t = torch.zeros((), device=dev, dtype=torch.float32)
+        self.step_t = torch.zeros(1, device=dev, dtype=torch.float32)
         self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
 
     def grad_buffers(self) -> List[Tensor]:
@@ -197,11 +197,10 @@ class FlatAdam:
 
     @torch.no_grad()
     def step(self) -> None:
-        b1, b2 = self.betas
-        self.hyper[0] = self._schedule(self.step_t)  # LambdaLR: lr of optimizer step k (1-based) is func(k-1)
-        self.step_t += 1
-        self.hyper[1] = 1 - b1**self.step_t
-        self.hyper[2] = torch.sqrt(1 - b2**self.step_t)
+        # one tiny kernel: lr(step) [LambdaLR: step k uses func(k-1)], bias corrections, step += 1
+        ops.check(ops._lib.lib().nr_adam_hyper(ops._p(self.step_t), ops._p(self.hyper), self.lr,
+                                               self.lr if self.lr_final is None else self.lr_final, self.warmup,
+                                               self.max_steps, self.betas[0], self.betas[1], ops._stream()), "nr_adam_hyper")
         for (p, g), (m, v) in zip(self.buffers, self.state):
             ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw,
                           zero_grad=True, dev_hyper=self.hyper)

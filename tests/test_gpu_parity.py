@@ -426,9 +426,9 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
     B = c2.shape[0]
     c_full = torch.cat([c2, torch.ones(B, 1, device=DEV)], 1).contiguous()
     w_full = torch.cat([w2, torch.full((B, 1), 0.123, device=DEV)], 1).contiguous()
-    loss = torch.zeros(1, device=DEV)
+    loss = torch.zeros(64, device=DEV)  # NR_LOSS_SLOTS partial sums
     gd = ops.distortion_loss(c_full, w_full, 31, 1.0, loss)
-    assert_close(cpu(loss)[0], g["distortion"], rtol=1e-4, atol_scale=1e-6, what="distortion")
+    assert_close(cpu(loss).sum(), g["distortion"], rtol=1e-4, atol_scale=1e-6, what="distortion")
     assert_close(cpu(gd[:, :31]), g["g_dist_w2"], rtol=1e-4, atol_scale=1e-5, what="distortion grad")
     assert float(gd[:, 31].abs().max()) == 0.0
     total = 0.0
@@ -441,7 +441,7 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
         assert_close(cpu(gi), g[f"g_inter_w{i}"], rtol=3e-2 if i else 1e-3, atol_scale=1e-4, what=f"interlevel grad {i}")
         close = torch.isclose(cpu(gi), g[f"g_inter_w{i}"], rtol=1e-3, atol=1e-4 * float(g[f"g_inter_w{i}"].abs().max()))
         assert close.float().mean() > 0.995
-        total += float(loss)
+        total += float(loss.sum())
     assert abs(total - float(g["interlevel"])) <= 1e-4 * abs(float(g["interlevel"]))
     # supervision loss vs plain torch
     torch.manual_seed(0)
@@ -452,7 +452,7 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
     fr, dr = f.clone().requires_grad_(True), d.clone().requires_grad_(True)
     ref = 5.0 * torch.mean((fr[:, :32] - tf) ** 2) + 0.01 * (dr - td).abs().mean()
     gfr, gdr = torch.autograd.grad(ref, [fr, dr])
-    torch.testing.assert_close(loss[0], ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss.sum(), ref.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(gf, gfr, rtol=1e-5, atol=1e-8)
     torch.testing.assert_close(gdp, gdr, rtol=1e-5, atol=1e-8)
 
@@ -483,7 +483,7 @@ def test_fused_step_matches_autograd_path():
     assert_close(cpu(fo["accumulation"]), g["accumulation"], rtol=1e-4, atol_scale=1e-4, what="accumulation")
     assert_close(cpu(fo["final_euclid"]), g["final_euclid"], rtol=1e-3, atol_scale=1e-5, what="final euclid")
     assert_close(cpu(fo["prop_depth_0"]), g["prop_depth_0"], rtol=1e-3, atol_scale=1e-4)
-    assert_close(cpu(floss)[0], g["loss"], rtol=1e-4, atol_scale=1e-5, what="loss")
+    assert_close(cpu(floss).sum(), g["loss"], rtol=1e-4, atol_scale=1e-5, what="loss")
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     for n, p, rg in zip(names, params, ref_grads):
         if rg is None:
@@ -520,3 +520,43 @@ def test_flat_adam_flattening_keeps_parameters_and_matches_torch():
         torch.testing.assert_close(p.data, r.data, rtol=1e-5, atol=1e-7)
         assert float(p.grad.abs().max()) == 0.0
     assert set(dict(lin.named_parameters())) == {"0.weight", "0.bias", "1.weight", "1.bias"}
+
+
+def test_patch_ray_assembly_matches_index_path_and_adam_hyper_schedule():
+    """f-1: the one-kernel patch sampler + ray generator equals generate_rays on the indices it
+    reports; nr_adam_hyper reproduces the reference LR schedule and bias corrections."""
+    import math
+
+    import numpy as np
+
+    from neuradar_amd import ops
+    from neuradar_amd.sensors import Cameras
+
+    g = load_golden("raygen")
+    cams = Cameras(dev(g["cam_c2w"]), dev(g["cam_fx"]), dev(g["cam_fy"]), dev(g["cam_cx"]), dev(g["cam_cy"]),
+                   dev(g["cam_heights"]), dev(g["cam_times_in"]), dev(g["cam_vel"]), dev(g["cam_rs_offsets"]))
+    torch.manual_seed(0)
+    u = torch.rand(7, 3, device=DEV)
+    u[0] = 0.0
+    u[1] = 0.999999
+    b, idx = cams.generate_patch_rays(u, 32, 3, 1080, 1920, area_scale=9.0, return_indices=True)
+    assert idx.shape == (7 * 1024, 3)
+    assert int(idx[:, 0].max()) < 5 and int(idx[:, 1].max()) < 1080 and int(idx[:, 2].max()) < 1920 and int(idx.min()) >= 0
+    p0 = idx[:1024].view(32, 32, 3)
+    assert torch.equal(p0[:, :, 1], (p0[0, 0, 1] + 3 * torch.arange(32, device=DEV))[:, None].expand(32, 32))
+    assert torch.equal(p0[:, :, 2], (p0[0, 0, 2] + 3 * torch.arange(32, device=DEV))[None, :].expand(32, 32))
+    ref = cams.generate_rays(idx)
+    assert torch.equal(b.origins, ref.origins) and torch.equal(b.directions, ref.directions)
+    torch.testing.assert_close(b.pixel_area, ref.pixel_area * 9.0, rtol=1e-6, atol=0)
+    assert torch.equal(b.times, ref.times)
+
+    step_t, hyper = torch.zeros(1, device=DEV), torch.zeros(3, device=DEV)
+    for k in range(1, 4):
+        ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, ops._stream()), "hyper")
+        lr = 1e-8 + (1e-2 - 1e-8) * np.sin(0.5 * np.pi * (k - 1) / 500)
+        want = torch.tensor([lr, 1 - 0.9**k, math.sqrt(1 - 0.999**k)])
+        torch.testing.assert_close(cpu(hyper), want.float(), rtol=1e-5, atol=1e-12)
+    step_t.fill_(10000.0)
+    ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, ops._stream()), "hyper")
+    t = (10000 - 500) / (20001 - 500)
+    assert abs(float(hyper[0]) - math.exp(math.log(1e-2) * (1 - t) + math.log(1e-3) * t)) < 1e-8
