@@ -123,11 +123,13 @@ int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t feat_strid
                  int feat_f, const float* directions, int n_samples, int64_t n,
                  float* feature, float* sdf, float* alpha, nr_stream_t stream);
 /* Backward: grad_feature [n,C], grad_alpha [n], grad_sdf [n] (nullable) ->
- * grad_feats (same strides as feats, overwritten) and parameter grads +=. */
+ * grad_feats (same strides as feats, overwritten) and parameter grads +=.
+ * workspace: n*(C+1) floats of caller-owned scratch (the two launches of the backward hand d_e and
+ * d_sdf through it; the library allocates nothing). */
 int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
                  int feat_f, const float* directions, int n_samples, int64_t n,
                  const float* grad_feature, const float* grad_alpha, const float* grad_sdf,
-                 float* grad_feats, const nr_field_grads_t* grads, nr_stream_t stream);
+                 float* grad_feats, const nr_field_grads_t* grads, float* workspace, nr_stream_t stream);
 
 /* Degree-4 real spherical harmonics, 16 components: SHEncoding.forward torch path
  * (encodings.py:797-805).  in [n,3] -> out [n,16].  (The caller applies (d+1)/2.) */

@@ -45,7 +45,7 @@ PROTOTYPES = {
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
     "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P],
-    "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P, POINTER(NrFieldGrads), P],
+    "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
     "nr_sh4_fwd": [P, L, P, P],
     "nr_prop_density_fwd": [P, L, L, I, P, I, L, P, P],
     "nr_prop_density_bwd": [P, L, L, I, P, I, L, P, P, P, P, P],

@@ -84,8 +84,15 @@ __device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], co
   return part + __shfl_xor(part, 32, NR_WAVE) + wsdf[HID];
 }
 
+#ifndef NR_MLP_FWD_WAVES
+#define NR_MLP_FWD_WAVES 1
+#endif
+#ifndef NR_MLP_BWD_WAVES
+#define NR_MLP_BWD_WAVES 1
+#endif
+
 template <int IN, int HID>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NR_MLP_FWD_WAVES)
 field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                  const float* __restrict__ dirs, int S, int64_t n, float* __restrict__ feature,
                  float* __restrict__ sdf_out, float* __restrict__ alpha_out) {
@@ -132,56 +139,65 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f
     for (int r = 0; r < 16; ++r) g[t][r] = y[t][r] > 0.0f ? g[t][r] : 0.0f;
 }
 
+// Backward is split into two launches so that each keeps its weight-gradient accumulators AND its
+// activations in registers (one kernel for all five layers needs > 512 registers per lane at width 64):
+//   A (feature half): recompute geo fwd -> e, sdf; feat fwd; backward through mlp_feature and the
+//     sigmoid; writes d_e [n,C] and d_sdf [n] to the workspace; accumulates dV1..dV3, d_beta.
+//   B (geometry half): recompute h1; backward through mlp_geo from the workspace; accumulates dW1, dW2
+//     (the sdf row via per-lane partial products); writes grad_feats.
+constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
+
 template <int IN, int HID>
-__global__ void __launch_bounds__(256)
-field_bwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
-                 const float* __restrict__ dirs, int S, int64_t n, const float* __restrict__ g_feature,
-                 const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ g_feats,
-                 nr_field_grads_t grads) {
+__global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
+field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
+                      const float* __restrict__ dirs, int S, int64_t n, const float* __restrict__ g_feature,
+                      const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ ws,
+                      nr_field_grads_t grads) {
   using I = FieldImage<IN, HID>;
+  constexpr int kScrPerWave = kBwdScrTiles * kScrTile;
+  constexpr int kImg = I::F1::G_SIZE + I::F2::G_SIZE + I::F3::G_SIZE + 2;
+  constexpr int kScrTotal = 4 * kScrPerWave > kImg ? 4 * kScrPerWave : kImg;
+  constexpr int oF1 = 0, oF2 = oF1 + I::F1::G_SIZE, oF3 = oF2 + I::F2::G_SIZE, oBeta = oF3 + I::F3::G_SIZE;
   __shared__ float lw[I::W_TOTAL];
-  __shared__ float lg[I::G_TOTAL];
-  __shared__ float scr[4][2 * kScrTile + 32];
-  for (int k = threadIdx.x; k < I::G_TOTAL; k += blockDim.x) lg[k] = 0.0f;
+  __shared__ float scr_all[kScrTotal];  // per-wave staging; reused as the block's gradient image at the end
   load_field_weights<IN, HID>(lw, fld);  // ends with __syncthreads()
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-  float* scrA = scr[wave];
-  float* scrB = scrA + kScrTile;
-  float* scrE = scrB + kScrTile;
+  float* scr = scr_all + wave * kScrPerWave;
   const float beta_raw = fld.beta[0];
   const float beta = fabsf(beta_raw) + kBetaMin;
-  float d_beta = 0.0f;
+  f32x16 aF1[I::HT][2], aF2[I::HT][I::HT], aF3[1][I::HT];
+  float bF1[I::HT], bF2[I::HT], bF3[1], d_beta = 0.0f;
+#pragma unroll
+  for (int t = 0; t < I::HT; ++t) { zero_tiles(aF1[t]); zero_tiles(aF2[t]); bF1[t] = bF2[t] = 0.0f; }
+  zero_tiles(aF3[0]);
+  bF3[0] = 0.0f;
   const int64_t tiles = nr_cdiv_dev(n, 32);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
-    // ---- recompute the forward activations (cheaper than storing ~1 KB/sample) ----
-    f32x16 x0[I::IT], h1[I::HT], e[1], cat[2], f1[I::HT], f2[I::HT];
-    auto foff = [&](int k) { return (int64_t)(k / F) * sl + (k % F); };
-    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
-    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
-    dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
-    const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
-    cat[0] = e[0];
+    f32x16 cat[2], f1[I::HT], f2[I::HT];
+    float sdf;
+    {
+      f32x16 x0[I::IT], h1[I::HT], e[1];
+      load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, [&](int k) { return (int64_t)(k / F) * sl + (k % F); });
+      dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
+      dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
+      sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
+      cat[0] = e[0];
+    }
     cat[1] = sh_tile(dirs, valid ? smp / S : 0, h);
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
-    // ---- backward ----
-    f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2], d_h1[I::HT], d_x0[I::IT];
+    f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2];
     load_rows<kC>(d_o, g_feature + (valid ? smp * kC : 0), valid, h, [](int k) { return (int64_t)k; });
-    // mlp_feature.layers[2]: o = V3 f2 + b
-    dense_bwd_dw<HID, kC, false>(d_o, f2, lg + I::gF3, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dw_reg<HID, kC>(d_o, f2, aF3, bF3, scr, i, h);          // layers[2]: o = V3 f2 + b
     dense_bwd_dx<HID, kC>(d_o, d_f2, lw + I::oF3, i, h);
     relu_mask<HID>(d_f2, f2);
-    // layers[1]
-    dense_bwd_dw<HID, HID, false>(d_f2, f1, lg + I::gF2, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dw_reg<HID, HID>(d_f2, f1, aF2, bF2, scr, i, h);        // layers[1]
     dense_bwd_dx<HID, HID>(d_f2, d_f1, lw + I::oF2, i, h);
     relu_mask<HID>(d_f1, f1);
-    // layers[0]: input [e ; sh], only e carries gradient (SH is evaluated under no_grad)
-    dense_bwd_dw<kC + kSH, HID, false>(d_f1, cat, lg + I::gF1, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dw_reg<kC + kSH, HID>(d_f1, cat, aF1, bF1, scr, i, h);  // layers[0]: input [e ; sh]
     dense_bwd_dx<kC + kSH, HID>(d_f1, d_cat, lw + I::oF1, i, h);
-    f32x16 d_e[1];
-    d_e[0] = d_o[0] + d_cat[0];  // residual: feature = e + mlp_feature([e, sh])
     // alpha = sigmoid(-sdf * beta)
     const float ga = valid ? g_alpha[smp] : 0.0f;
     const float a = 1.0f / (1.0f + expf(sdf * beta));
@@ -189,19 +205,80 @@ field_bwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     float d_sdf = dsig * (-beta);
     if (g_sdf != nullptr && valid) d_sdf += g_sdf[smp];
     if (h == 0) d_beta += dsig * (-sdf) * (beta_raw >= 0.0f ? 1.0f : -1.0f);
-    // mlp_geo.layers[1]: rows 1..C -> e (MFMA), row 0 -> sdf (extra row)
-    dense_bwd_dw<HID, kC, true>(d_e, h1, lg + I::gG2, d_sdf, lg + I::gSdf, scrA, scrB, scrE, i, h);
+    if (valid) {  // d_e = d_o + d_cat[0] (residual; SH carries no gradient) and d_sdf -> workspace
+      float* w = ws + smp * (kC + 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[rowmap(r, 0) + 4 * h] = d_o[0][r] + d_cat[0][r];
+      if (h == 0) w[kC] = d_sdf;
+    }
+  }
+  d_beta = nr_wave_sum(d_beta);
+  float* img = scr_all;
+  __syncthreads();  // every wave is done with its staging scratch
+  for (int w = 0; w < 4; ++w) {  // wave 0 assigns, waves 1..3 add: plain LDS stores, no atomics
+    if (wave == w) {
+      const bool first = w == 0;
+      merge_dw<kC + kSH, HID>(aF1, bF1, img + oF1, first, i, h);
+      merge_dw<HID, HID>(aF2, bF2, img + oF2, first, i, h);
+      merge_dw<HID, kC>(aF3, bF3, img + oF3, first, i, h);
+      if (lane == 0) img[oBeta] = first ? d_beta : img[oBeta] + d_beta;
+    }
+    __syncthreads();
+  }
+  flush_layer_grads<kC + kSH, HID>(img + oF1, grads.feat.weight[0], grads.feat.bias[0], 0);
+  flush_layer_grads<HID, HID>(img + oF2, grads.feat.weight[1], grads.feat.bias[1], 0);
+  flush_layer_grads<HID, kC>(img + oF3, grads.feat.weight[2], grads.feat.bias[2], 0);
+  if (threadIdx.x == 0 && grads.beta) unsafeAtomicAdd(grads.beta, img[oBeta]);
+}
+
+template <int IN, int HID>
+__global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
+field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F, int64_t n,
+                     const float* __restrict__ ws, float* __restrict__ g_feats, nr_field_grads_t grads) {
+  using I = FieldImage<IN, HID>;
+  constexpr int kScrPerWave = kBwdScrTiles * kScrTile;
+  constexpr int kImg = I::G1::G_SIZE + I::G2::G_SIZE + I::SDF;
+  constexpr int kScrTotal = 4 * kScrPerWave > kImg ? 4 * kScrPerWave : kImg;
+  constexpr int oG1 = 0, oG2 = oG1 + I::G1::G_SIZE, oSdf = oG2 + I::G2::G_SIZE;
+  __shared__ float lw[I::oF1];  // only the geometry MLP's weights
+  __shared__ float scr_all[kScrTotal];
+  load_layer<IN, HID>(lw + I::oG1, fld.geo.weight[0], fld.geo.bias[0], 0);
+  load_layer<HID, kC>(lw + I::oG2, fld.geo.weight[1], fld.geo.bias[1], 1);
+  for (int k = threadIdx.x; k < I::SDF; k += blockDim.x)
+    lw[I::oSdf + k] = k < HID ? fld.geo.weight[1][k] : (k == HID ? fld.geo.bias[1][0] : 0.0f);
+  __syncthreads();
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  float* scr = scr_all + wave * kScrPerWave;
+  f32x16 aG1[I::HT][I::IT], aG2[1][I::HT], aSdf[I::HT];
+  float bG1[I::HT], bG2[1], bSdf = 0.0f;
+#pragma unroll
+  for (int t = 0; t < I::HT; ++t) { zero_tiles(aG1[t]); bG1[t] = 0.0f; }
+  zero_tiles(aG2[0]); zero_tiles(aSdf);
+  bG2[0] = 0.0f;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    f32x16 x0[I::IT], h1[I::HT], d_e[1], d_h1[I::HT], d_x0[I::IT];
+    auto foff = [&](int k) { return (int64_t)(k / F) * sl + (k % F); };
+    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
+    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
+    load_rows<kC>(d_e, ws + (valid ? smp * (kC + 1) : 0), valid, h, [](int k) { return (int64_t)k; });
+    const float d_sdf = valid ? ws[smp * (kC + 1) + kC] : 0.0f;
+    if (h == 0) bSdf += d_sdf;
+    // mlp_geo.layers[1]: rows 1..C -> e (MFMA), row 0 -> sdf (per-lane partial products, reduced at the end)
+    dense_bwd_dw_reg<HID, kC>(d_e, h1, aG2, bG2, scr, i, h);
     dense_bwd_dx<HID, kC>(d_e, d_h1, lw + I::oG2, i, h);
 #pragma unroll
     for (int t = 0; t < I::HT; ++t)
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int k = t * 32 + rowmap(s, 0) + 4 * h;
+        aSdf[t][s] += d_sdf * h1[t][s];
         if (k < HID) d_h1[t][s] += lw[I::oSdf + k] * d_sdf;
       }
     relu_mask<HID>(d_h1, h1);
-    // mlp_geo.layers[0]
-    dense_bwd_dw<IN, HID, false>(d_h1, x0, lg + I::gG1, 0.0f, nullptr, scrA, scrB, scrE, i, h);
+    dense_bwd_dw_reg<IN, HID>(d_h1, x0, aG1, bG1, scr, i, h);  // mlp_geo.layers[0]
     dense_bwd_dx<IN, HID>(d_h1, d_x0, lw + I::oG1, i, h);
     if (valid) {
       float* gf = g_feats + smp * sn;
@@ -214,19 +291,43 @@ field_bwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
         }
     }
   }
-  d_beta = nr_wave_sum(d_beta);
-  if (lane == 0) atomicAdd(&lg[I::gBeta], d_beta);
+  // sdf row: sum the per-lane partials over the 32 sample lanes of each half
+#pragma unroll
+  for (int t = 0; t < I::HT; ++t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float v = aSdf[t][s];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, NR_WAVE);
+      aSdf[t][s] = v;
+    }
+  bSdf = nr_wave_sum(bSdf);
+  float* img = scr_all;
   __syncthreads();
-  flush_layer_grads<IN, HID>(lg + I::gG1, grads.geo.weight[0], grads.geo.bias[0], 0);
-  flush_layer_grads<HID, kC>(lg + I::gG2, grads.geo.weight[1], grads.geo.bias[1], 1);
-  for (int k = threadIdx.x; k <= HID; k += blockDim.x) {
-    if (k < HID) unsafeAtomicAdd(grads.geo.weight[1] + k, lg[I::gSdf + k]);
-    else unsafeAtomicAdd(grads.geo.bias[1], lg[I::gSdf + HID]);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      const bool first = w == 0;
+      merge_dw<IN, HID>(aG1, bG1, img + oG1, first, i, h);
+      merge_dw<HID, kC>(aG2, bG2, img + oG2, first, i, h);
+      if (i == 0) {
+#pragma unroll
+        for (int t = 0; t < I::HT; ++t)
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const int k = t * 32 + rowmap(s, 0) + 4 * h;
+            if (k < HID) img[oSdf + k] = first ? aSdf[t][s] : img[oSdf + k] + aSdf[t][s];
+          }
+        if (h == 0) img[oSdf + HID] = first ? bSdf : img[oSdf + HID] + bSdf;
+      }
+    }
+    __syncthreads();
   }
-  flush_layer_grads<kC + kSH, HID>(lg + I::gF1, grads.feat.weight[0], grads.feat.bias[0], 0);
-  flush_layer_grads<HID, HID>(lg + I::gF2, grads.feat.weight[1], grads.feat.bias[1], 0);
-  flush_layer_grads<HID, kC>(lg + I::gF3, grads.feat.weight[2], grads.feat.bias[2], 0);
-  if (threadIdx.x == 0 && grads.beta) unsafeAtomicAdd(grads.beta, lg[I::gBeta]);
+  flush_layer_grads<IN, HID>(img + oG1, grads.geo.weight[0], grads.geo.bias[0], 0);
+  flush_layer_grads<HID, kC>(img + oG2, grads.geo.weight[1], grads.geo.bias[1], 1);
+  for (int k = threadIdx.x; k <= HID; k += blockDim.x) {
+    if (k < HID) unsafeAtomicAdd(grads.geo.weight[1] + k, img[oSdf + k]);
+    else unsafeAtomicAdd(grads.geo.bias[1], img[oSdf + HID]);
+  }
 }
 
 // ---- generic MLP (drop-in for field_components/mlp.py:MLP, e.g. the lidar decoder 48->32->32->2) ----
@@ -407,7 +508,11 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
   int hid = 0;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 1 || F < 1 || n < 0) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
-  const unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
+  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
+  if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+  }
   if (hid == 32)
     hipLaunchKernelGGL((field_fwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, feature, sdf, alpha);
   else
@@ -418,10 +523,12 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
 
 extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
                             const float* dirs, int S, int64_t n, const float* g_feature, const float* g_alpha,
-                            const float* g_sdf, float* g_feats, const nr_field_grads_t* grads, nr_stream_t stream) {
+                            const float* g_sdf, float* g_feats, const nr_field_grads_t* grads, float* workspace,
+                            nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
-  if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || S < 1 || F < 1 || n < 0)
+  if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
+      S < 1 || F < 1 || n < 0)
     return NR_EINVAL;
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
@@ -431,10 +538,13 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     const int v = atoi(e);
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
-  if (hid == 32)
-    hipLaunchKernelGGL((field_bwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, g_feats, *grads);
-  else
-    hipLaunchKernelGGL((field_bwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, g_feats, *grads);
+  if (hid == 32) {
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, workspace, *grads);
+    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
+  } else {
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, workspace, *grads);
+    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
+  }
   NR_LAUNCH_CHECK();
   return 0;
 }

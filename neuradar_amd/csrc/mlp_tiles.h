@@ -14,6 +14,14 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Keeps hipcc from hoisting every LDS weight read of a fully unrolled layer to the top of the kernel
+// (which costs 500+ registers and spills): reads stay within one 16-MFMA group of their use.
+#ifndef NR_MLP_NO_SCHED_FENCE
+#define NR_MLP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NR_MLP_SCHED_FENCE() ((void)0)
+#endif
+
 namespace nrmlp {
 
 __host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -90,6 +98,7 @@ __device__ __forceinline__ void dense_fwd(const f32x16 (&x)[(K + 31) / 32], f32x
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         if (s < ns) acc = mfma(wrow[kt * 32 + rowmap(s, 0)], x[kt][s], acc);
+      NR_MLP_SCHED_FENCE();
     }
     if (RELU) {
 #pragma unroll
@@ -116,6 +125,7 @@ __device__ __forceinline__ void dense_bwd_dx(const f32x16 (&dz)[(M + 31) / 32], 
 #pragma unroll
       for (int s = 0; s < 16; ++s)
         if (s < ns) acc = mfma(wcol[rowmap(s, 0) * L::LDW], dz[mt][s], acc);
+      NR_MLP_SCHED_FENCE();
     }
     dx[kt] = acc;
   }
@@ -143,6 +153,9 @@ __device__ __forceinline__ void dense_bwd_dw(const f32x16 (&dz)[(M + 31) / 32], 
                                              float* lg, float extra, float* lg_extra, float* scrA, float* scrB,
                                              float* scrE, int i, int h) {
   using L = Layer<K, M>;
+#ifdef NR_ABLATE_DW
+  return;
+#endif
   if (EXTRA) {
     if (h == 0) scrE[i] = extra;
   }
@@ -170,7 +183,13 @@ __device__ __forceinline__ void dense_bwd_dw(const f32x16 (&dz)[(M + 31) / 32], 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + rowmap(r, 0) + 4 * h;
+#if defined(NR_ABLATE_DSADD)
+        if (m < M && k < K && acc[r] == 123.456f) lg[m * K + k] = acc[r];
+#elif defined(NR_ABLATE_PLAINRMW)
+        if (m < M && k < K) lg[m * K + k] += acc[r];
+#else
         if (m < M && k < K) atomicAdd(&lg[m * K + k], acc[r]);
+#endif
       }
       if (kt == 0 && mt * 32 + i < M) atomicAdd(&lg[M * K + mt * 32 + i], rowsum);
     }
@@ -194,6 +213,69 @@ __device__ __forceinline__ void dense_bwd_dw(const f32x16 (&dz)[(M + 31) / 32], 
     }
   }
   wave_lds_fence();
+}
+
+// Register-accumulating variant: acc[mt][kt] (MFMA C/D tiles of dW) and rowsum[mt] (bias-gradient
+// partials) persist in registers across all tiles of a wave -- LDS float atomics (ds_add_f32) turned
+// out to cost more than the MFMAs themselves.  All KT input tiles and MT gradient tiles of the layer
+// are staged once (scr: (KT+MT) * kScrTile floats), one fence, then MT*KT*16 MFMAs.
+template <int K, int M>
+__device__ __forceinline__ void dense_bwd_dw_reg(const f32x16 (&dz)[(M + 31) / 32], const f32x16 (&x)[(K + 31) / 32],
+                                                 f32x16 (&acc)[(M + 31) / 32][(K + 31) / 32],
+                                                 float (&rowsum)[(M + 31) / 32], float* scr, int i, int h) {
+  using L = Layer<K, M>;
+  wave_lds_fence();  // the previous layer's transposed reads are done before the scratch is overwritten
+#pragma unroll
+  for (int kt = 0; kt < L::KT; ++kt) stage_tile(scr + kt * kScrTile, x[kt], i, h);
+#pragma unroll
+  for (int mt = 0; mt < L::MT; ++mt) stage_tile(scr + (L::KT + mt) * kScrTile, dz[mt], i, h);
+  wave_lds_fence();
+#pragma unroll
+  for (int mt = 0; mt < L::MT; ++mt) {
+    const float* A = scr + (L::KT + mt) * kScrTile + i * kScrLd + h;
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      a[s] = A[2 * s];
+      rowsum[mt] += a[s];
+    }
+#pragma unroll
+    for (int kt = 0; kt < L::KT; ++kt) {
+      const float* B = scr + kt * kScrTile + i * kScrLd + h;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc[mt][kt] = mfma(a[s], B[2 * s], acc[mt][kt]);
+      NR_MLP_SCHED_FENCE();
+    }
+  }
+}
+
+// Merge one wave's register accumulators into the block's gradient image `img` ([M][K] then [M]),
+// plain stores: the caller serialises the waves (first wave assigns, later waves add).
+template <int K, int M>
+__device__ __forceinline__ void merge_dw(const f32x16 (&acc)[(M + 31) / 32][(K + 31) / 32],
+                                         const float (&rowsum)[(M + 31) / 32], float* img, bool first, int i, int h) {
+  using L = Layer<K, M>;
+#pragma unroll
+  for (int mt = 0; mt < L::MT; ++mt) {
+#pragma unroll
+    for (int kt = 0; kt < L::KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + rowmap(r, 0) + 4 * h, k = kt * 32 + i;
+        if (m < M && k < K) img[m * K + k] = first ? acc[mt][kt][r] : img[m * K + k] + acc[mt][kt][r];
+      }
+    const float rs = rowsum[mt] + __shfl_xor(rowsum[mt], 32, 64);  // lane halves hold even / odd samples
+    const int m = mt * 32 + i;
+    if (h == 0 && m < M) img[M * K + m] = first ? rs : img[M * K + m] + rs;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[n][r] = 0.0f;
 }
 
 }  // namespace nrmlp

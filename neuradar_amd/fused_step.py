@@ -79,6 +79,7 @@ class FusedTrainStep:
         self.g_depth = torch.empty(B, **f32)
         self.g_alpha = torch.empty(B * Sm, **f32)
         self.g_feature = torch.empty(B * Sm, C, **f32)
+        self.field_ws = torch.empty(B * Sm * (C + 1), **f32)  # nr_field_bwd workspace
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -152,7 +153,7 @@ class FusedTrainStep:
                                    p(self.g_depth), None, p(self.g_w[2]), B, Sm, self.C, p(self.g_alpha), p(self.g_feature), st),
               "composite_bwd")
         check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, n, p(self.g_feature),
-                               p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), st), "field_bwd")
+                               p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
         check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
                                      p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
         Fp = pg.features_per_level

@@ -1,0 +1,33 @@
+"""GPU probe: time nr_field_fwd / nr_field_bwd alone on the bench workload (development tool)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from neuradar_amd import ops  # noqa: E402
+from neuradar_amd.fused_step import FusedTrainStep  # noqa: E402
+
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cam4096_l16f2_w64"]
+dev = torch.device("cuda")
+model = bench.build_model(wl, dev)
+B = wl["rays"]
+st = FusedTrainStep(model, B)
+n = B * 32
+F = st.mgrid.features_per_level
+torch.manual_seed(0)
+st.feats[2].normal_()
+d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+st.g_feature.normal_()
+st.g_alpha.normal_()
+from ctypes import byref  # noqa: E402
+lib, p, s = st.lib, ops._p, ops._stream
+for fb in os.environ.get("FWD_BLOCKS", "256,512").split(","):
+    os.environ["NR_FIELD_FWD_BLOCKS"] = fb
+    t = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, n, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
+    print(f"field_fwd blocks={fb}: {t * 1e6:7.1f} us")
+for bb in os.environ.get("BWD_BLOCKS", "128,256").split(","):
+    os.environ["NR_FIELD_BWD_BLOCKS"] = bb
+    t = bench.time_kernel(lambda: lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, n, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s()), 20)
+    print(f"field_bwd blocks={bb}: {t * 1e6:7.1f} us")
