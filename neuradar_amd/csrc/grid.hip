@@ -108,14 +108,15 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 //   1. lanes l and l^32 (the same pixel column of two adjacent patch rows under the sample-major
 //      mapping) that fall in the same cell are folded into one lane;
 //   2. a segmented wave scan sums every run of consecutive lanes that share a cell;
-//   3. the run's last lane adds its 8*F partial sums into the workgroup's LDS hash table
-//      (open addressing, 64-bit cell key, ds_cmpst + ds_add_f32); a workgroup is persistent over
-//      kChunk samples of ONE level, so cells shared by thousands of samples cost one table entry;
-//   4. at the end every occupied entry is flushed with 8*F global atomics.
+//   3. the run's last lane adds its 8*F partial sums into its WAVE's private LDS hash table.  LDS
+//      atomics (ds_add_f32 / ds_cmpst) measured an order of magnitude slower than plain LDS traffic,
+//      so the table uses none: a wave owns its table exclusively, slots are claimed by
+//      write-then-read-back, and lanes that target the same slot take turns through an owner word;
+//   4. after kBwdChunk samples every occupied entry is flushed with 8*F global atomics.
 // Table overflow (fine levels, incoherent lidar/radar rays) falls back to direct global atomics, so
 // the worst case is the plain-atomic kernel plus a fixed scan cost.
-constexpr int kBwdChunk = 4096;            // samples per workgroup (of one level)
-constexpr int kBwdValFloats = 16384;       // 64 KiB of accumulators: capacity = 16384 / (8 F) cells
+constexpr int kBwdChunk = 1024;            // samples per WAVE (of one level)
+constexpr int kBwdValFloats = 2048;        // 8 KiB of accumulators per wave: capacity = 2048 / (8 F) cells
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 __device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
@@ -123,25 +124,37 @@ __device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
          (((unsigned long long)(uint32_t)lo[2] & 0x1FFFFFull) << 42);
 }
 
+__device__ __forceinline__ void wave_fence() {
+  // LDS operations of one wave execute in order; this only pins the compiler's ordering
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int F>
 __global__ void __launch_bounds__(256)
 hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings,
                        int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl,
                        float* __restrict__ gtable, int64_t n, int S) {
-  constexpr int CAP = kBwdValFloats / (8 * F);
-  __shared__ unsigned long long s_key[CAP];
-  __shared__ float s_val[CAP * 8 * F];
+  constexpr int NV = 8 * F;                   // accumulators per cell
+  constexpr int CAP = kBwdValFloats / NV;     // cells per wave table
+  __shared__ unsigned long long s_key[4][CAP];
+  __shared__ float s_val[4][CAP * NV];
+  __shared__ int s_owner[4][CAP];
   const int level = blockIdx.y;
-  const int lane = nr_lane();
+  const int lane = nr_lane(), wave = threadIdx.x >> 6;
+  unsigned long long* keys = s_key[wave];
+  float* vals = s_val[wave];
+  int* owner = s_owner[wave];
   const float scale = scalings[level];
   const uint32_t mask = (1u << log2T) - 1u;
   float* base = gtable + (((int64_t)level << log2T) * F);
-  for (int k = threadIdx.x; k < CAP; k += blockDim.x) s_key[k] = kEmptyKey;
-  for (int k = threadIdx.x; k < CAP * 8 * F; k += blockDim.x) s_val[k] = 0.0f;
-  __syncthreads();
+  for (int k = lane; k < CAP; k += NR_WAVE) keys[k] = kEmptyKey;
+  for (int k = lane; k < CAP * NV; k += NR_WAVE) vals[k] = 0.0f;
+  wave_fence();
 
-  const int64_t chunk0 = (int64_t)blockIdx.x * kBwdChunk;
-  for (int64_t i = chunk0 + threadIdx.x; i < chunk0 + kBwdChunk; i += blockDim.x) {  // block-uniform trip count
+  const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * kBwdChunk;
+  for (int64_t i = chunk0 + lane; i < chunk0 + kBwdChunk; i += NR_WAVE) {  // wave-uniform trip count
     const bool valid = i < n;  // no early exit: every lane takes part in the wave scans
     int lo[3];
     float v[8][F];
@@ -207,40 +220,52 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
       for (int f = 0; f < F; ++f) nz |= v[corner][f] != 0.0f;
-    if ((lane == NR_WAVE - 1 || next_head) && nz) {
-      // 3. run total -> LDS table (linear probing, 4 tries), else straight to memory
-      const unsigned long long key = pack_cell(lo);
-      uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
-      bool done = false;
+    const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
+    // 3a. find or claim the cell's slot in the wave's table: write-then-read-back, 4 linear probes
+    const unsigned long long key = pack_cell(lo);
+    uint32_t s0 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
+    int slot = -1;
 #pragma unroll 1
-      for (int probe = 0; probe < 4 && !done; ++probe) {
-        const unsigned long long old = atomicCAS(&s_key[slot], kEmptyKey, key);
-        if (old == kEmptyKey || old == key) {
-#pragma unroll
-          for (int corner = 0; corner < 8; ++corner)
-#pragma unroll
-            for (int f = 0; f < F; ++f)
-              if (v[corner][f] != 0.0f) atomicAdd(&s_val[(slot * 8 + corner) * F + f], v[corner][f]);
-          done = true;
-        }
-        slot = (slot + 1) & (CAP - 1);
+    for (int probe = 0; probe < 4; ++probe) {
+      const bool searching = want && slot < 0;
+      if (!__any(searching)) break;
+      if (searching && keys[s0] == kEmptyKey) keys[s0] = key;  // several lanes may race: one value sticks
+      wave_fence();
+      if (searching) {
+        if (keys[s0] == key) slot = (int)s0; else s0 = (s0 + 1) & (CAP - 1);
       }
-      if (!done) {
+      wave_fence();
+    }
+    // 3b. lanes sharing a slot take turns (owner word), everyone else adds concurrently: plain RMW
+    bool pending = slot >= 0;
+#pragma unroll 1
+    while (__any(pending)) {
+      if (pending) owner[slot] = lane;
+      wave_fence();
+      if (pending && owner[slot] == lane) {
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-          const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
+        for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-          for (int f = 0; f < F; ++f)
-            if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
-        }
+          for (int f = 0; f < F; ++f) vals[slot * NV + corner * F + f] += v[corner][f];
+        pending = false;
+      }
+      wave_fence();
+    }
+    if (want && slot < 0) {  // table full around this hash: straight to memory
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+          if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
       }
     }
   }
-  __syncthreads();
-  // 4. flush: one (entry, corner) pair per thread
-  for (int k = threadIdx.x; k < CAP * 8; k += blockDim.x) {
+  wave_fence();
+  // 4. flush: one (entry, corner) pair per lane
+  for (int k = lane; k < CAP * 8; k += NR_WAVE) {
     const int slot = k >> 3, corner = k & 7;
-    const unsigned long long key = s_key[slot];
+    const unsigned long long key = keys[slot];
     if (key == kEmptyKey) continue;
     // sign-extend the 21-bit fields back (coordinates are >= 0 for inputs in [0,1], kept general)
     const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
@@ -249,7 +274,7 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      const float t = s_val[k * F + f];
+      const float t = vals[k * F + f];
       if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
     }
   }
@@ -315,7 +340,7 @@ extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float*
   if (n == 0) return 0;
   if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
-  dim3 grid((unsigned)nr_cdiv(n, kBwdChunk), (unsigned)L), block(256);
+  dim3 grid((unsigned)nr_cdiv(n, 4 * kBwdChunk), (unsigned)L), block(256);
   switch (F) {
     case 1: hipLaunchKernelGGL(hash_encode_bwd_kernel<1>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
     case 2: hipLaunchKernelGGL(hash_encode_bwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
