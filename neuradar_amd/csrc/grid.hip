@@ -7,6 +7,8 @@
 // addresses into a few cache lines on all but the finest levels.
 #include <limits.h>
 
+#include <type_traits>
+
 #include "nr_common.h"
 
 namespace {
@@ -115,8 +117,14 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 //   4. after kBwdChunk samples every occupied entry is flushed with 8*F global atomics.
 // Table overflow (fine levels, incoherent lidar/radar rays) falls back to direct global atomics, so
 // the worst case is the plain-atomic kernel plus a fixed scan cost.
-constexpr int kBwdChunk = 1024;            // samples per WAVE (of one level)
-constexpr int kBwdValFloats = 2048;        // 8 KiB of accumulators per wave: capacity = 2048 / (8 F) cells
+#ifndef NR_BWD_CHUNK
+#define NR_BWD_CHUNK 1024
+#endif
+#ifndef NR_BWD_VALS
+#define NR_BWD_VALS 2048
+#endif
+constexpr int kBwdChunk = NR_BWD_CHUNK;    // samples per WAVE (of one level)
+constexpr int kBwdValFloats = NR_BWD_VALS; // floats of accumulators per wave: capacity = NR_BWD_VALS / (8 F) cells
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 __device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
@@ -187,34 +195,45 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
         for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
     }
     auto same_cell = [&](int lx, int ly, int lz) { return lx == lo[0] && ly == lo[1] && lz == lo[2]; };
-    // 1. fold the upper half-wave onto the lower one where the cells agree
+    // 1. fold the upper half-wave onto the lower one where the cells agree (v_permlane32_swap)
     {
-      const bool same = same_cell(__shfl_xor(lo[0], 32, NR_WAVE), __shfl_xor(lo[1], 32, NR_WAVE), __shfl_xor(lo[2], 32, NR_WAVE));
+      const bool same = same_cell(nr_xor32_i(lo[0]), nr_xor32_i(lo[1]), nr_xor32_i(lo[2]));
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          const float o = __shfl_xor(v[corner][f], 32, NR_WAVE);
+          const float o = nr_xor32_f(v[corner][f]);
           if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
         }
     }
-    // 2. segmented inclusive scan over runs of equal cells
-    const bool head = lane == 0 || !same_cell(__shfl_up(lo[0], 1, NR_WAVE), __shfl_up(lo[1], 1, NR_WAVE), __shfl_up(lo[2], 1, NR_WAVE));
+    // 2. segmented inclusive scan over runs of equal cells, all in DPP: Hillis-Steele inside each row
+    //    of 16 lanes (row_shr 1,2,4,8), then the carry of lane 15/31/47 into rows 1,2,3 in turn.
+    //    `flag` = "a run head lies inside the range this lane has covered so far".
+    const bool head = lane == 0 || !same_cell(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[0]),
+                                              nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]),
+                                              nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[2]));
     int flag = head ? 1 : 0;
-#pragma unroll
-    for (int d = 1; d < NR_WAVE; d <<= 1) {
-      const int fprev = __shfl_up(flag, d, NR_WAVE);
-      const bool take = lane >= d && !flag;
+    auto scan_step = [&](auto ctrl, auto rowmask) {
+      constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
+      const int fprev = nr_dpp_i<C, R>(0, flag);  // lanes without a source read (0, 0): no change
+      const bool take = !flag;
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-          const float t = __shfl_up(v[corner][f], d, NR_WAVE);
+          const float t = nr_dpp_f<C, R>(0.0f, v[corner][f]);
           if (take) v[corner][f] += t;
         }
       if (take) flag = fprev;
-    }
-    const int next_head = __shfl_down(head ? 1 : 0, 1, NR_WAVE);
+    };
+    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
+    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+    const int next_head = nr_dpp_i<NR_DPP_WAVE_SHL1, 0xF>(1, head ? 1 : 0);
     bool nz = false;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)

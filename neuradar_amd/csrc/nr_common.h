@@ -61,6 +61,27 @@ __device__ __forceinline__ float nr_nan_to_num(float v) {
   return v;
 }
 
+// ---- DPP / permlane cross-lane moves (VALU only; ds_bpermute-based __shfl_* goes through the LDS
+// crossbar and measured ~16 cycles per wave-instruction per CU, which made the scatter shuffle-bound) --
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int nr_dpp_i(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xF, false);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float nr_dpp_f(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xF, false));
+}
+constexpr int NR_DPP_ROW_SHR = 0x110;   // + n: lane i <- lane i-n inside its row of 16
+constexpr int NR_DPP_WAVE_SHL1 = 0x130; // lane i <- lane i+1 (whole wave)
+constexpr int NR_DPP_WAVE_SHR1 = 0x138; // lane i <- lane i-1 (whole wave)
+constexpr int NR_DPP_ROW_BCAST15 = 0x142;  // lane 15 of row r -> every lane of row r+1
+// value of lane (l ^ 32): v_permlane32_swap exchanges the upper half of one register with the lower half of another
+__device__ __forceinline__ int nr_xor32_i(int x) {
+  auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+}
+__device__ __forceinline__ float nr_xor32_f(float x) { return __int_as_float(nr_xor32_i(__float_as_int(x))); }
+
 // ---- wave64 scans / reductions ----------------------------------------------------------------
 __device__ __forceinline__ int nr_lane() { return threadIdx.x & (NR_WAVE - 1); }
 
