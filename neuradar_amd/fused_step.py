@@ -37,8 +37,10 @@ def flatten_parameters(params: List[nn.Parameter]) -> Dict[str, Tensor]:
 
 
 class FusedTrainStep:
-    def __init__(self, model: NeuRadarHotPath, n_rays: int) -> None:
+    def __init__(self, model: NeuRadarHotPath, n_rays: int, overlap: bool = True) -> None:
         c = model.config
+        self.overlap = overlap
+        self._streams = None
         assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
@@ -84,6 +86,11 @@ class FusedTrainStep:
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._structs()
+
+    def _side_streams(self):
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+        return self._streams
 
     def _structs(self) -> None:
         """(Re)build the ctypes views of the parameters -- call again if parameters were re-homed."""
@@ -137,18 +144,35 @@ class FusedTrainStep:
                                p(self.alpha), st), "field_fwd")
         check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
                                    p(self.features), p(self.depth), st), "composite_fwd")
-        # ---- loss tail: value + gradients w.r.t. features, depth and the three weight tensors ----
+        # ---- loss tail + backward.  After compositing the step forks into three independent chains
+        #      (main field / proposal round 1 / proposal round 0) that only meet again in the optimizer;
+        #      each runs on its own stream so the mostly latency-bound kernels overlap. ----
         self.loss.zero_()
+        main = torch.cuda.current_stream()
+        side = self._side_streams() if self.overlap else [main, main]
+        for s_ in side:
+            if s_ is not main:
+                s_.wait_stream(main)
+        Fp = pg.features_per_level
+        for lvl, stream in zip((1, 0), side):
+            with torch.cuda.stream(stream):
+                sp_ = ops._stream()
+                S, nl = self.S[lvl], B * self.S[lvl]
+                check(lib.nr_interlevel_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]), p(self.w[lvl]),
+                                             S, B, losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_w[lvl]),
+                                             p(self.loss), sp_), "interlevel_loss")
+                check(lib.nr_weights_from_density_bwd(p(self.dens[lvl]), p(self.eu[lvl]), p(self.g_w[lvl]), B, S,
+                                                      p(self.g_dens[lvl]), sp_), "weights_bwd")
+                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, p(self.dens[lvl]),
+                                              p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
+                check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
+                                             pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, S,
+                                             sp_), "hash_bwd")
         check(lib.nr_supervision_loss(p(self.features), self.C, p(target_features), target_features.shape[1], p(self.depth),
                                       p(target_depth), B, c.rgb_mult, c.depth_mult, p(self.g_features), p(self.g_depth),
                                       p(self.loss), st), "supervision_loss")
         check(lib.nr_distortion_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, B, c.distortion_loss_mult, p(self.g_w[2]),
                                      p(self.loss), st), "distortion_loss")
-        for lvl in range(2):
-            check(lib.nr_interlevel_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]), p(self.w[lvl]),
-                                         self.S[lvl], B, losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_w[lvl]),
-                                         p(self.loss), st), "interlevel_loss")
-        # ---- backward ----
         check(lib.nr_composite_bwd(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.w[2]), p(self.g_features),
                                    p(self.g_depth), None, p(self.g_w[2]), B, Sm, self.C, p(self.g_alpha), p(self.g_feature), st),
               "composite_bwd")
@@ -156,16 +180,9 @@ class FusedTrainStep:
                                p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
         check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
                                      p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
-        Fp = pg.features_per_level
-        for lvl in (1, 0):
-            S, n = self.S[lvl], B * self.S[lvl]
-            check(lib.nr_weights_from_density_bwd(p(self.dens[lvl]), p(self.eu[lvl]), p(self.g_w[lvl]), B, S, p(self.g_dens[lvl]), st),
-                  "weights_bwd")
-            check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, n * Fp, Fp, p(w_dec), w_dec.numel(), n, p(self.dens[lvl]),
-                                          p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), st), "prop_density_bwd")
-            check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
-                                         pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, n * Fp, p(pg.hash_table.grad), n, S, st),
-                  "hash_bwd")
+        for s_ in side:
+            if s_ is not main:
+                main.wait_stream(s_)
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:
