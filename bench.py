@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads of the CPU baseline (intra-op scaling of "
                     "the oracle saturates well below the host's core count)")
     ap.add_argument("--bf16-allreduce", action="store_true", help="all-reduce the table gradients in bf16")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' + "
+                    "--single-device lets the multi-rank code path be exercised on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (functional testing only)")
     args = ap.parse_args()
 
     from neuradar_amd import _lib
@@ -245,7 +248,9 @@ def main():
     from neuradar_amd.step import FlatAdam
 
     _lib.lib()  # fail loudly if the HIP extension is missing
-    rank, world, local_rank = init_distributed()
+    rank, world, local_rank = init_distributed(args.dist_backend)
+    if args.single_device:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     device = torch.device("cuda", local_rank)

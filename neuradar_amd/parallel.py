@@ -27,6 +27,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(min(local_rank, torch.cuda.device_count() - 1))
         dist.init_process_group(backend=backend)
     return rank, world, local_rank
 
