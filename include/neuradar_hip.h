@@ -67,6 +67,14 @@ int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings,
                        const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                        float* grad_table, int64_t n, int sample_major, nr_stream_t stream);
 
+/* grad_x [n,3] = d(sum out*grad_out)/dx (overwritten).  Only needed where positions depend on
+ * parameters: samples inside dynamic-actor boxes, whose box-frame coordinates follow the learnable
+ * trajectories (require_actor_grad, field_components/neurad_encoding.py:83,176). */
+int nr_hash_encode_bwd_input(const float* x, const float* std, const float* table, const float* scalings,
+                             int num_levels, int features_per_level, int log2_hashmap_size,
+                             const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
+                             float* grad_x, int64_t n, nr_stream_t stream);
+
 /* Frustums.get_fast_isotropic_gaussian(1) (cameras/rays.py:109-124) followed by
  * ScaledSceneContraction(order=inf, scale) on the GaussiansStd
  * (field_components/spatial_distortions.py:103-113,126-136):
@@ -107,7 +115,9 @@ int nr_mlp_bwd(const nr_mlp_t* mlp, const float* x, const float* grad_y, int64_t
  *   (model_components/utils.py:30-46).
  * feats: element (i, k) at feats[i*feat_stride_n + (k/F)*feat_stride_l + k%F] (same convention as
  * nr_hash_encode_fwd's `out`; F = feat_f).  directions [n_rays,3] per RAY, sample i belongs to
- * ray i / n_samples.  Outputs feature [n,C], sdf [n], alpha [n]. */
+ * ray i / n_samples; n_samples == 0 means directions are per SAMPLE [n,3] (dynamic actors rotate the
+ * view direction of the samples inside their boxes, neurad_encoding.py:210-215).
+ * Outputs feature [n,C], sdf [n], alpha [n]. */
 typedef struct nr_field {
   nr_mlp_t geo;        /* in_dim = L*F, out_dim = 1 + C */
   nr_mlp_t feat;       /* in_dim = C + 16, out_dim = C  */

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "nr_target_arch": [],
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
+    "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
     "nr_contract_gaussians": [P, P, P, P, L, I, F, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],

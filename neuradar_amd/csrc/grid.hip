@@ -299,6 +299,52 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
   }
 }
 
+// Gradient w.r.t. the input positions (needed only where positions depend on parameters: samples
+// inside dynamic-actor boxes, whose box-frame coordinates depend on the learnable trajectories;
+// field_components/neurad_encoding.py:176,205-207).  d out / d x_a = scale_l * d interp / d w_a:
+// floor/ceil are piecewise constant, the interpolation weight w = p - floor(p) has slope 1.
+template <int F>
+__global__ void __launch_bounds__(256)
+hash_encode_bwd_input_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ table,
+                             const float* __restrict__ scalings, int L, int log2T, const float* __restrict__ gout,
+                             int64_t sn, int64_t sl, float* __restrict__ gx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mask = (1u << log2T) - 1u;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int level = 0; level < L; ++level) {
+    const float scale = scalings[level];
+    const Corner c = make_corner(x, i, scale);
+    const float* base = table + (((int64_t)level << log2T) * F);
+    float r = scale;
+    if (std != nullptr) r = scale / fmaxf(scale * 2.0f * std[i], 1.0f);
+    float g[F];
+    const float* gi = gout + i * sn + (int64_t)level * sl;
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = gi[f];
+    // t[corner] = <table[corner], g>
+    float t[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+      float v[F];
+      load_entry<F>(base + (int64_t)nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask) * F, v);
+      float d = 0.0f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) d += v[f] * g[f];
+      t[corner] = d;
+    }
+    const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+    // corner index bits: 1 = x hi, 2 = y hi, 4 = z hi
+    const float dx = ((t[7] - t[6]) * wy + (t[5] - t[4]) * (1.0f - wy)) * wz + ((t[3] - t[2]) * wy + (t[1] - t[0]) * (1.0f - wy)) * (1.0f - wz);
+    const float dy = ((t[7] - t[5]) * wx + (t[6] - t[4]) * (1.0f - wx)) * wz + ((t[3] - t[1]) * wx + (t[2] - t[0]) * (1.0f - wx)) * (1.0f - wz);
+    const float dz = ((t[7] - t[3]) * wx + (t[6] - t[2]) * (1.0f - wx)) * wy + ((t[5] - t[1]) * wx + (t[4] - t[0]) * (1.0f - wx)) * (1.0f - wy);
+    acc[0] += dx * r; acc[1] += dy * r; acc[2] += dz * r;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gx[i * 3 + a] = acc[a];
+}
+
 __global__ void __launch_bounds__(256)
 contract_gaussians_kernel(const float* __restrict__ origins, const float* __restrict__ directions,
                           const float* __restrict__ pixel_area, const float* __restrict__ edges, int64_t n_rays,
@@ -365,6 +411,23 @@ extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float*
     case 2: hipLaunchKernelGGL(hash_encode_bwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
     case 4: hipLaunchKernelGGL(hash_encode_bwd_kernel<4>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
     case 8: hipLaunchKernelGGL(hash_encode_bwd_kernel<8>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    default: return NR_EINVAL;
+  }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_hash_encode_bwd_input(const float* x, const float* std, const float* table, const float* scalings, int L,
+                                        int F, int log2T, const float* gout, int64_t sn, int64_t sl, float* gx, int64_t n,
+                                        nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !table || !scalings || !gout || !gx || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
+  dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
+  switch (F) {
+    case 1: hipLaunchKernelGGL(hash_encode_bwd_input_kernel<1>, grid, block, 0, nr_s(stream), x, std, table, scalings, L, log2T, gout, sn, sl, gx, n); break;
+    case 2: hipLaunchKernelGGL(hash_encode_bwd_input_kernel<2>, grid, block, 0, nr_s(stream), x, std, table, scalings, L, log2T, gout, sn, sl, gx, n); break;
+    case 4: hipLaunchKernelGGL(hash_encode_bwd_input_kernel<4>, grid, block, 0, nr_s(stream), x, std, table, scalings, L, log2T, gout, sn, sl, gx, n); break;
+    case 8: hipLaunchKernelGGL(hash_encode_bwd_input_kernel<8>, grid, block, 0, nr_s(stream), x, std, table, scalings, L, log2T, gout, sn, sl, gx, n); break;
     default: return NR_EINVAL;
   }
   NR_LAUNCH_CHECK();

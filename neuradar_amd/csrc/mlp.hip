@@ -112,7 +112,7 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
     const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
     cat[0] = e[0];
-    cat[1] = sh_tile(dirs, valid ? smp / S : 0, h);
+    cat[1] = sh_tile(dirs, valid ? (S > 0 ? smp / S : smp) : 0, h);
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     dense_fwd<HID, kC, false>(f2, o, lw + I::oF3, i, h);
@@ -185,7 +185,7 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
       sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
       cat[0] = e[0];
     }
-    cat[1] = sh_tile(dirs, valid ? smp / S : 0, h);
+    cat[1] = sh_tile(dirs, valid ? (S > 0 ? smp / S : smp) : 0, h);
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2];
@@ -506,7 +506,7 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
                             nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
-  if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 1 || F < 1 || n < 0) return NR_EINVAL;
+  if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 0 || F < 1 || n < 0) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
   if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
@@ -528,7 +528,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   if (n == 0) return 0;
   int hid = 0;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
-      S < 1 || F < 1 || n < 0)
+      S < 0 || F < 1 || n < 0)
     return NR_EINVAL;
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;

@@ -69,12 +69,15 @@ class NeuRADField(nn.Module):
         param_groups["fields"] += list(self.mlp_geo.parameters()) + list(self.mlp_feature.parameters())
         param_groups["fields"] += list(self.sdf_to_density.parameters())
 
-    def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[FieldHeadNames, Tensor]:
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False, flip: Optional[Tensor] = None
+                ) -> Dict[FieldHeadNames, Tensor]:
         B, S = ray_samples.shape
-        buf, strides = self.hashgrid.encode_samples(ray_samples)
+        buf, strides, dirs = self.hashgrid.encode_samples(ray_samples, directions=True, flip=flip)
+        # per-ray directions, or per-sample ones (n_samples = 0) when dynamic actors rotated some of them
         feature, sdf, alpha = ops.field_mlp(buf, strides, self.hashgrid.static_grid.features_per_level,
-                                            ray_samples.directions, S, B * S, self.mlp_geo.weights(),
-                                            self.mlp_feature.weights(), self.sdf_to_density.beta)
+                                            ray_samples.directions if dirs is None else dirs, S if dirs is None else 0,
+                                            B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
+                                            self.sdf_to_density.beta)
         return {FieldHeadNames.FEATURE: feature.view(B, S, -1), FieldHeadNames.SDF: sdf.view(B, S, 1),
                 FieldHeadNames.ALPHA: alpha.view(B, S, 1)}
 
@@ -108,7 +111,7 @@ class NeuRADProposalField(nn.Module):
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         B, S = ray_samples.shape
-        buf, strides = self.hashgrid.encode_samples(ray_samples)
+        buf, strides, _ = self.hashgrid.encode_samples(ray_samples)
         density = ops.prop_density(buf, strides, self.hashgrid.static_grid.features_per_level,
                                    self.density_decoder.weight, B * S)
         return density.view(B, S, 1), None

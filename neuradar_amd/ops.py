@@ -45,20 +45,26 @@ class _HashEncode(torch.autograd.Function):
             sn, sl = L * F, F
         check(_lib.lib().nr_hash_encode_fwd(_p(x), _p(std), _p(table), _p(scalings), L, F, log2_hashmap_size,
                                             _p(buf), sn, sl, n, sample_major, _stream()), "nr_hash_encode_fwd")
-        ctx.save_for_backward(x, std if std is not None else x.new_empty(0), scalings)
+        ctx.save_for_backward(x, std if std is not None else x.new_empty(0), scalings, table)
         ctx.meta = (table.shape, log2_hashmap_size, level_major, sample_major, std is not None, sn, sl)
         return buf
 
     @staticmethod
     def backward(ctx, g):
-        x, std, scalings = ctx.saved_tensors
+        x, std, scalings, table = ctx.saved_tensors
         shape, log2t, level_major, sample_major, has_std, sn, sl = ctx.meta
         g = g.contiguous()
         gtable = torch.zeros(shape, device=g.device, dtype=torch.float32)
         check(_lib.lib().nr_hash_encode_bwd(_p(x), _p(std) if has_std else None, _p(scalings), scalings.numel(),
                                             shape[1], log2t, _p(g), sn, sl, _p(gtable), x.shape[0], sample_major,
                                             _stream()), "nr_hash_encode_bwd")
-        return None, None, gtable, None, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:  # positions that depend on parameters (dynamic-actor trajectories)
+            gx = torch.empty_like(x)
+            check(_lib.lib().nr_hash_encode_bwd_input(_p(x), _p(std) if has_std else None, _p(table), _p(scalings),
+                                                      scalings.numel(), shape[1], log2t, _p(g), sn, sl, _p(gx), x.shape[0],
+                                                      _stream()), "nr_hash_encode_bwd_input")
+        return gx, None, gtable, None, None, None, None
 
 
 def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: int, std: Optional[Tensor] = None,

@@ -453,7 +453,92 @@ def golden_raygen():
     save("raygen", **out)
 
 
+def golden_actors():
+    """a10: dynamic actors -- 2 boxes on a toy trajectory, rays that cross them; NeuRADField (one 3-D grid
+    per actor, the torch path) in eval mode and in train mode with the per-ray flip reproduced;
+    gradients incl. the trajectory parameters; NeuRADProposalField density."""
+    from nerfstudio.cameras.camera_utils import matrix_to_rotation_6d  # noqa: F401
+
+    def pose(x, y, yaw):
+        c, s = np.cos(yaw), np.sin(yaw)
+        m = torch.eye(4)
+        m[:3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        m[:3, 3] = torch.tensor([x, y, 0.8])
+        return m
+
+    ts = torch.tensor([0.0, 1.0, 2.0])
+    trajs = [
+        {"poses": torch.stack([pose(8.0 + 3 * t, 1.0, 0.1 * t) for t in ts.tolist()]), "timestamps": ts.clone(),
+         "dims": torch.tensor([2.0, 4.6, 1.6]), "symmetric": True, "deformable": False},
+        {"poses": torch.stack([pose(14.0, -3.0, 1.2) for _ in ts.tolist()[:2]]), "timestamps": ts[:2].clone(),
+         "dims": torch.tensor([1.9, 4.2, 1.5]), "symmetric": True, "deformable": False},
+    ]
+    torch.manual_seed(17)
+    actors = DynamicActorsConfig().setup(trajectories=trajs)
+    grid_cfg = NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=12),
+                                        actor=ActorSettings(flip_prob=0.25, log2_hashmap_size=10))
+    fld = NeuRADFieldConfig(grid=grid_cfg).setup(actors=actors, static_scale=STATIC_SCALE, implementation="torch")
+    pcfg = NeuRADProposalFieldConfig()
+    pcfg.grid.static.log2_hashmap_size = 12
+    pcfg.grid.actor.log2_hashmap_size = 10
+    prop = pcfg.setup(actors=actors, static_scale=STATIC_SCALE, implementation="torch")
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.mul_(300.0)
+        for gr in fld.hashgrid.actor_grids:
+            gr.hash_table.mul_(400.0)
+        prop.hashgrid.static_grid.hash_table.mul_(2000.0)
+        for gr in prop.hashgrid.actor_grids:
+            gr.hash_table.mul_(2500.0)
+        prop.density_decoder.weight.mul_(2.0)
+    g = torch.Generator().manual_seed(91)
+    B, S = 48, 24
+    o = torch.cat([torch.randn(B, 2, generator=g) * 0.5, torch.full((B, 1), 1.2)], -1)
+    tgt = torch.stack([8.0 + 8 * torch.rand(B, generator=g), -4.0 + 6 * torch.rand(B, generator=g), 0.3 + torch.rand(B, generator=g)], -1)
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    area = torch.full((B, 1), 2e-6)
+    times = torch.rand(B, 1, generator=g) * 2.2
+    edges = torch.linspace(0.5, 26.0, S + 1)[None, :].repeat(B, 1) + 0.3 * torch.rand(B, 1, generator=g)
+    bundle = RayBundle(origins=o, directions=d, pixel_area=area, nears=torch.zeros(B, 1), fars=torch.full((B, 1), 1e6),
+                       times=times, metadata={})
+    rs = bundle.get_ray_samples(bin_starts=edges[:, :-1, None], bin_ends=edges[:, 1:, None])
+    out = {}
+    fld.eval(); prop.eval()
+    ev = fld(rs)
+    out.update(eval_feature=ev[FieldHeadNames.FEATURE], eval_sdf=ev[FieldHeadNames.SDF], eval_alpha=ev[FieldHeadNames.ALPHA],
+               eval_prop_density=prop.get_density(rs)[0])
+    # how many samples fell inside actors (sanity of the fixture)
+    with torch.no_grad():
+        gs = rs.frustums.get_fast_isotropic_gaussian(1)
+        (ri, si, ai), _, _ = fld.hashgrid._split_static_vs_actors(gs, rs.times, rs.frustums.directions)
+    out.update(actor_ray_idx=ri, actor_sample_idx=si, actor_actor_idx=ai)
+    fld.train(); prop.train()
+    torch.manual_seed(5)
+    tr = fld(rs)
+    torch.manual_seed(5)
+    flip = torch.bernoulli(torch.full((B,), 0.25)) * -2 + 1
+    feat, alpha = tr[FieldHeadNames.FEATURE], tr[FieldHeadNames.ALPHA]
+    g_feat, g_alpha = torch.randn(feat.shape, generator=g), torch.randn(alpha.shape, generator=g)
+    named = dict(fld.named_parameters())
+    keys = ["hashgrid.static_grid.hash_table", "hashgrid.actor_grids.0.hash_table", "hashgrid.actor_grids.1.hash_table",
+            "hashgrid.actors.actor_positions", "hashgrid.actors.actor_rotations_6d", "mlp_geo.layers.0.weight"]
+    grads = torch.autograd.grad((feat * g_feat).sum() + (alpha * g_alpha).sum(), [named[k] for k in keys])
+    out.update(train_feature=feat, train_sdf=tr[FieldHeadNames.SDF], train_alpha=alpha, flip=flip, g_feature=g_feat, g_alpha=g_alpha)
+    for k, gr in zip(keys, grads):
+        out["grad_" + k.replace(".", "_")] = gr
+    a = fld.hashgrid.actors
+    out.update(origins=o, directions=d, pixel_area=area, times=times, edges=edges, actor_positions=a.actor_positions,
+               actor_rotations_6d=a.actor_rotations_6d, actor_timestamps=a.unique_timestamps, actor_present=a.actor_present_at_time,
+               actor_sizes=a.actor_sizes, actor_padding=a.actor_padding, log2t=12, actor_log2t=10, prop_log2t=12)
+    out.update(_field_param_dict("", fld))
+    out.update({f"actor{i}_table": gr.hash_table for i, gr in enumerate(fld.hashgrid.actor_grids)})
+    out["actor_scalings"] = fld.hashgrid.actor_grids[0].scalings
+    out.update(_field_param_dict("prop_", prop))
+    out.update({f"prop_actor{i}_table": gr.hash_table for i, gr in enumerate(prop.hashgrid.actor_grids)})
+    out["prop_actor_scalings"] = prop.hashgrid.actor_grids[0].scalings
+    save("actors", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "sh_mlp", "sampler", "pipeline", "losses", "raygen"]
+    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors"]
     for w in which:
         globals()["golden_" + w]()

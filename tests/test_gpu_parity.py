@@ -560,3 +560,66 @@ def test_patch_ray_assembly_matches_index_path_and_adam_hyper_schedule():
     ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, ops._stream()), "hyper")
     t = (10000 - 500) / (20001 - 500)
     assert abs(float(hyper[0]) - math.exp(math.log(1e-2) * (1 - t) + math.log(1e-3) * t)) < 1e-8
+
+
+# ------------------------------------------------------------------------------------------------ a10 dynamic actors
+def test_dynamic_actors_vs_reference_golden():
+    """Culling, world->box transform, per-ray flip, one 3-D grid per actor, overwrite of the static
+    features, per-sample view directions, trajectory gradients (through nr_hash_encode_bwd_input)."""
+    from neuradar_amd.dynamic_actors import DynamicActors
+    from neuradar_amd.field_heads import FieldHeadNames
+    from neuradar_amd.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig, NeuRADProposalFieldConfig
+    from neuradar_amd.rays import RaySamples
+
+    g = load_golden("actors")
+    actors = DynamicActors.from_state(g["actor_positions"], g["actor_rotations_6d"], g["actor_timestamps"],
+                                      g["actor_present"], g["actor_sizes"]).to(DEV)
+    grid_cfg = NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=int(g["log2t"])),
+                                        actor=ActorSettings(flip_prob=0.25, log2_hashmap_size=int(g["actor_log2t"])))
+    fld = NeuRADFieldConfig(grid=grid_cfg).setup(actors=actors, static_scale=100.0).to(DEV)
+    pcfg = NeuRADProposalFieldConfig()
+    pcfg.grid.static.log2_hashmap_size = int(g["prop_log2t"])
+    pcfg.grid.actor.log2_hashmap_size = int(g["actor_log2t"])
+    prop = pcfg.setup(actors=actors, static_scale=100.0).to(DEV)
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(g["table"])
+        for i, gr in enumerate(fld.hashgrid.actor_grids):
+            gr.hash_table.copy_(g[f"actor{i}_table"])
+        for i, l in enumerate(fld.mlp_geo.layers):
+            l.weight.copy_(g[f"geo_w{i}"]); l.bias.copy_(g[f"geo_b{i}"])
+        for i, l in enumerate(fld.mlp_feature.layers):
+            l.weight.copy_(g[f"feat_w{i}"]); l.bias.copy_(g[f"feat_b{i}"])
+        fld.sdf_to_density.beta.copy_(g["beta"])
+        prop.hashgrid.static_grid.hash_table.copy_(g["prop_table"])
+        for i, gr in enumerate(prop.hashgrid.actor_grids):
+            gr.hash_table.copy_(g[f"prop_actor{i}_table"])
+        prop.density_decoder.weight.copy_(g["prop_decoder"])
+    e = g["edges"]
+    B = e.shape[0]
+    rs = RaySamples(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(torch.zeros_like(e)), dev(e),
+                    dev(torch.zeros(B, 1)), dev(torch.full((B, 1), 1e6)), times=dev(g["times"]))
+    fld.eval(); prop.eval()
+    out = fld(rs)
+    assert_close(cpu(out[FieldHeadNames.FEATURE]), g["eval_feature"], rtol=1e-4, atol_scale=1e-5, what="eval feature")
+    assert_close(cpu(out[FieldHeadNames.ALPHA]), g["eval_alpha"], rtol=1e-4, atol_scale=1e-5, what="eval alpha")
+    assert_close(cpu(prop.get_density(rs)[0]), g["eval_prop_density"], rtol=1e-4, atol_scale=1e-5, what="eval prop density")
+    found = fld.hashgrid._get_actor_indices(
+        dev(g["origins"])[:, None, :] + dev(g["directions"])[:, None, :] * ((dev(e)[:, :-1] + dev(e)[:, 1:]) / 2)[..., None],
+        *(lambda b2w, valid: (b2w, valid, __import__("neuradar_amd.dynamic_actors", fromlist=["x"]).pose_inverse(b2w)))(
+            *actors.get_boxes2world(dev(g["times"])[:, 0])))
+    assert torch.equal(cpu(found[0]), g["actor_ray_idx"]) and torch.equal(cpu(found[1]), g["actor_sample_idx"])
+    assert torch.equal(cpu(found[2]), g["actor_actor_idx"])
+    fld.train()
+    out = fld(rs, flip=dev(g["flip"]))
+    assert_close(cpu(out[FieldHeadNames.FEATURE]), g["train_feature"], rtol=1e-4, atol_scale=1e-5, what="train feature")
+    assert_close(cpu(out[FieldHeadNames.ALPHA]), g["train_alpha"], rtol=1e-4, atol_scale=1e-5, what="train alpha")
+    loss = (out[FieldHeadNames.FEATURE] * dev(g["g_feature"])).sum() + (out[FieldHeadNames.ALPHA] * dev(g["g_alpha"])).sum()
+    wrt = {"hashgrid_static_grid_hash_table": fld.hashgrid.static_grid.hash_table,
+           "hashgrid_actor_grids_0_hash_table": fld.hashgrid.actor_grids[0].hash_table,
+           "hashgrid_actor_grids_1_hash_table": fld.hashgrid.actor_grids[1].hash_table,
+           "hashgrid_actors_actor_positions": actors.actor_positions,
+           "hashgrid_actors_actor_rotations_6d": actors.actor_rotations_6d,
+           "mlp_geo_layers_0_weight": fld.mlp_geo.layers[0].weight}
+    for (k, _), gr in zip(wrt.items(), torch.autograd.grad(loss, list(wrt.values()))):
+        assert_close(cpu(gr), g["grad_" + k], rtol=1e-3, atol_scale=1e-4, what="grad " + k)

@@ -191,3 +191,48 @@ def test_raygen_camera_lidar_radar():
         assert_close(r["directions"], g[f"rad_{tag}_directions"], rtol=1e-5, atol_scale=1e-6)
         assert_close(r["directions_spher"], g[f"rad_{tag}_directions_spher"], rtol=1e-6, atol_scale=1e-7)
         assert_close(r["pixel_area"], g[f"rad_{tag}_pixel_area"], rtol=1e-6, atol_scale=1e-7)
+
+
+def _actor_setup(g, requires_grad=False):
+    from oracle import actors as oactors
+    from oracle.field import GridParams
+
+    state = oactors.ActorState(t(g["actor_positions"], requires_grad), t(g["actor_rotations_6d"], requires_grad),
+                               g["actor_timestamps"], g["actor_present"], g["actor_sizes"], g["actor_padding"])
+    fp = oracle_field_params(g, requires_grad=requires_grad)
+    fp.actor_grids = [GridParams(t(g[f"actor{i}_table"], requires_grad), g["actor_scalings"], int(g["actor_log2t"])) for i in range(2)]
+    pp = oracle_prop_params(g, requires_grad=requires_grad)
+    pp.actor_grids = [GridParams(g[f"prop_actor{i}_table"], g["prop_actor_scalings"], int(g["actor_log2t"])) for i in range(2)]
+    return state, fp, pp
+
+
+def test_dynamic_actors_eval_and_train_with_trajectory_grads():
+    """a10: culling, world->box transform, per-ray flip, per-actor grids, pose gradients."""
+    from oracle import actors as oactors
+
+    g = load_golden("actors")
+    e = g["edges"]
+    args = (g["origins"], g["directions"], e[:, :-1], e[:, 1:], g["pixel_area"])
+    state, fp, pp = _actor_setup(g)
+    mean, _ = field.isotropic_gaussian(*args)
+    b2w, valid = oactors.boxes2world(state, g["times"][:, 0])
+    ri, si, ai = oactors.actor_indices(mean, b2w, valid, oactors.pose_inverse(b2w), state.bounds())
+    assert torch.equal(ri, g["actor_ray_idx"]) and torch.equal(si, g["actor_sample_idx"]) and torch.equal(ai, g["actor_actor_idx"])
+    ctx = {"state": state, "times": g["times"][:, 0], "flip": None}
+    feat, sdf, alpha = field.field_forward(fp, *args, actor_ctx=ctx)
+    assert_close(feat, g["eval_feature"], rtol=1e-5, atol_scale=1e-6, what="eval feature")
+    assert_close(alpha, g["eval_alpha"], rtol=1e-5, atol_scale=1e-6, what="eval alpha")
+    dens = field.proposal_density(pp, *args, actor_ctx={**ctx, "require_grad": False})
+    assert_close(dens, g["eval_prop_density"], rtol=1e-5, atol_scale=1e-6, what="eval prop density")
+    # training: per-ray flip + gradients incl. the trajectory parameters
+    state, fp, pp = _actor_setup(g, requires_grad=True)
+    ctx = {"state": state, "times": g["times"][:, 0], "flip": g["flip"]}
+    feat, sdf, alpha = field.field_forward(fp, *args, actor_ctx=ctx)
+    assert_close(feat, g["train_feature"], rtol=1e-5, atol_scale=1e-6, what="train feature")
+    assert_close(alpha, g["train_alpha"], rtol=1e-5, atol_scale=1e-6, what="train alpha")
+    loss = (feat * g["g_feature"]).sum() + (alpha * g["g_alpha"]).sum()
+    wrt = [fp.grid.table, fp.actor_grids[0].table, fp.actor_grids[1].table, state.positions, state.rotations_6d, fp.geo[0][0]]
+    keys = ["hashgrid_static_grid_hash_table", "hashgrid_actor_grids_0_hash_table", "hashgrid_actor_grids_1_hash_table",
+            "hashgrid_actors_actor_positions", "hashgrid_actors_actor_rotations_6d", "mlp_geo_layers_0_weight"]
+    for k, gr in zip(keys, torch.autograd.grad(loss, wrt)):
+        assert_close(gr, g["grad_" + k], rtol=1e-4, atol_scale=1e-5, what="grad " + k)
