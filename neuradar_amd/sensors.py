@@ -166,5 +166,7 @@ def merge_bundles(*bundles: RayBundle) -> RayBundle:
             parts.append(v if v is not None else torch.full((len(b), width), fill, dtype=dtype, device=dev))
         meta[key] = torch.cat(parts, dim=0)
     assert meta["is_lidar"].shape[0] == n_tot
-    return RayBundle(cat("origins"), cat("directions"), cat("pixel_area"), camera_indices=cat("camera_indices"),
+    cam_idx = torch.cat([b.camera_indices.reshape(len(b), -1)[:, :1] if b.camera_indices is not None
+                         else torch.zeros((len(b), 1), dtype=torch.int64, device=dev) for b in bundles], dim=0)
+    return RayBundle(cat("origins"), cat("directions"), cat("pixel_area"), camera_indices=cam_idx,
                      fars=cat("fars"), times=cat("times"), metadata=meta)

@@ -98,6 +98,18 @@ class NeuRadarHotPath(nn.Module):
                         rs.metadata, rs.camera_indices)
         return rs, prop_rs, prop_w
 
+    def _compute_is_close_to_lidar(self, rs: RaySamples, carving_epsilon: float = 0.1,
+                                   non_return_lidar_distance: float = 150.0) -> Tensor:
+        """neuradar.py:971-994: per-sample mask [B,S,1], False on non-lidar rays.  Branch-free
+        (no nonzero / host sync): lidar rays with a return are "close" within carving_epsilon of the
+        measured range, non-returns everywhere below non_return_lidar_distance."""
+        md = rs.metadata
+        mid = (rs.euclid[:, :-1] + rs.euclid[:, 1:])[..., None] * 0.5
+        close_to_hit = (md["directions_norm"][:, None, :] - mid).abs() < carving_epsilon
+        did_return = md["did_return"][:, None, :] if "did_return" in md else torch.ones_like(close_to_hit)
+        in_range = mid < non_return_lidar_distance
+        return md["is_lidar"][:, None, :] & ((did_return & close_to_hit) | ((~did_return) & in_range))
+
     def _get_appearance_embedding(self, bundle: RayBundle) -> Tensor:
         """neuradar.py:550-568 (temporal appearance)."""
         E = self._num_embeds_per_sensor
@@ -121,8 +133,19 @@ class NeuRadarHotPath(nn.Module):
         if self.config.appearance_dim > 0:
             features = torch.cat([features, self._get_appearance_embedding(bundle)], dim=-1)
         out = {"features": features, "depth": depth, "accumulation": accumulation}
+        lidar = self.training and "is_lidar" in bundle.metadata
+        if lidar:  # neuradar.py:584-585
+            for s in (rs, *prop_rs):
+                s.metadata = dict(s.metadata, is_close_to_lidar=self._compute_is_close_to_lidar(s))
         for i, (w, s) in enumerate(zip(prop_w, prop_rs)):
             out[f"prop_depth_{i}"] = render_depth_simple(w, s)
+            if lidar:  # :529-531
+                mask = (~s.metadata["is_close_to_lidar"]) & s.metadata["is_lidar"][:, None, :]
+                out[f"prop_weights_loss_{i}"] = ((w * mask) ** 2).sum()
+        if lidar:  # :537-541: weights of lidar samples away from the measured return (carving loss input)
+            md = rs.metadata
+            m = ((~md["is_close_to_lidar"][:, :-1]) & md["is_lidar"][:, None, :]).squeeze(-1)
+            out["non_nearby_weights"] = weights[:, :-1][m]
         # the sky sample is dropped from the lists the regularisers see (:515,534-535)
         out["weights_list"] = prop_w + [weights[:, :-1]]
         out["ray_samples_list"] = prop_rs + [rs.drop_last()]

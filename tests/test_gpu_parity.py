@@ -623,3 +623,68 @@ def test_dynamic_actors_vs_reference_golden():
            "mlp_geo_layers_0_weight": fld.mlp_geo.layers[0].weight}
     for (k, _), gr in zip(wrt.items(), torch.autograd.grad(loss, list(wrt.values()))):
         assert_close(cpu(gr), g["grad_" + k], rtol=1e-3, atol_scale=1e-4, what="grad " + k)
+
+
+# ------------------------------------------------------------------------------------------------ mixed sensors, a19, a20
+def test_mixed_sensor_batch_with_appearance_and_lidar_masks_vs_oracle():
+    """configs[2]-style batch: camera patch + lidar points + one ZOD radar scan generated on the device,
+    pixel-area scaling (a4), appearance embedding (a19), is_close_to_lidar / carving side outputs (a20);
+    everything compared with the CPU oracle on the same rays and jitter."""
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.sensors import Cameras, Lidars, Radars, merge_bundles, scale_pixel_area
+    from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
+    from oracle import field as of, pipeline as op, raygen as orr
+
+    g = load_golden("raygen")
+    torch.manual_seed(0)
+    cams = Cameras(dev(g["cam_c2w"]), dev(g["cam_fx"]), dev(g["cam_fy"]), dev(g["cam_cx"]), dev(g["cam_cy"]),
+                   dev(g["cam_heights"]), dev(g["cam_times_in"]), dev(g["cam_vel"]), dev(g["cam_rs_offsets"]))
+    cam_b, _ = cams.generate_patch_rays(torch.rand(1, 3, device=DEV), 8, 3, 1080, 1920)
+    lid_b = Lidars(dev(g["lid_l2w"]), dev(g["lid_times_in"]), dev(g["lid_vel"])).generate_rays(dev(g["lid_indices"]), dev(g["lid_points"]))
+    rad = Radars(dev(g["rad_r2w"]), dev(g["rad_times_in"]), 0.0625, 0.0625, -0.5, 0.5, -0.5, 0.5)
+    rad_b = rad.generate_rays(torch.tensor([1], device=DEV))
+    bundle = merge_bundles(cam_b, lid_b, rad_b)
+    n_cam, n_lid, n_rad = len(cam_b), len(lid_b), len(rad_b)
+    assert n_rad == 256 and len(bundle) == n_cam + n_lid + n_rad
+    scale_pixel_area(bundle)
+    assert torch.equal(bundle.pixel_area[:n_cam], cam_b.pixel_area * 9) and torch.equal(bundle.pixel_area[n_cam:n_cam + n_lid], lid_b.pixel_area)
+    B = len(bundle)
+    bundle.times = bundle.times.clamp(0, 19.9)
+    bundle.metadata["sensor_idxs"] = torch.cat([torch.zeros(n_cam, 1), torch.ones(n_lid, 1), torch.full((n_rad, 1), 2.0)]).long().to(DEV)
+    cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=12))),
+                        appearance_dim=16, duration=20.0, num_sensors=3)
+    cfg.proposal_field_1.grid.static.log2_hashmap_size = 11
+    cfg.proposal_field_2.grid.static.log2_hashmap_size = 11
+    model = NeuRadarHotPath(cfg).to(DEV).train()
+    with torch.no_grad():
+        model.field.hashgrid.static_grid.hash_table.mul_(300.0)
+        model.proposal_fields[1].hashgrid.static_grid.hash_table.mul_(2000.0)
+    t_rand, j1, j2 = torch.rand(B, 129, device=DEV), torch.rand(B, 1, device=DEV), torch.rand(B, 1, device=DEV)
+    o, d, area, fars, times = (cpu(x).clone() for x in (bundle.origins, bundle.directions, bundle.pixel_area, bundle.fars, bundle.times))
+    out = model.get_nff_outputs(bundle, t_rand=t_rand, jitters=(j1, j2))
+
+    def grid(m):
+        gg = m.hashgrid.static_grid
+        return of.GridParams(cpu(gg.hash_table), cpu(gg.scalings), gg.log2_hashmap_size)
+
+    fp = of.FieldParams(grid(model.field), [(cpu(l.weight), cpu(l.bias)) for l in model.field.mlp_geo.layers],
+                        [(cpu(l.weight), cpu(l.bias)) for l in model.field.mlp_feature.layers],
+                        cpu(model.field.sdf_to_density.beta), 100.0)
+    pf = model.proposal_fields[1]
+    pp = of.ProposalParams(grid(pf), cpu(pf.density_decoder.weight), 100.0)
+    md = {k: cpu(v) for k, v in bundle.metadata.items()}
+    ref = op.nff_outputs(fp, [pp, pp], {"origins": o, "directions": d, "pixel_area": area, "fars": fars, "times": times,
+                                        "sensor_idx": md["sensor_idxs"], "is_lidar": md["is_lidar"],
+                                        "directions_norm": md["directions_norm"], "did_return": md["did_return"]},
+                         cpu(t_rand), (cpu(j1), cpu(j2)),
+                         appearance={"table": cpu(model.appearance_embedding.weight), "duration": 20.0, "embeds_per_sensor": 20})
+    assert out["features"].shape == (B, 48)
+    assert_close(cpu(out["features"]), ref["features"].detach(), rtol=1e-4, atol_scale=1e-4, what="features+appearance")
+    assert_close(cpu(out["depth"]), ref["depth"].detach(), rtol=1e-4, atol_scale=1e-4, what="depth")
+    for i in (0, 1):
+        assert_close(cpu(out[f"prop_weights_loss_{i}"]), ref[f"prop_weights_loss_{i}"].detach(), rtol=1e-3, atol_scale=1e-4,
+                     what=f"prop_weights_loss_{i}")
+    # radar sanity on the rendered depths of the radar rays (256-ray scan): finite and inside the sky range
+    rd = out["depth"][n_cam + n_lid:]
+    assert bool(torch.isfinite(rd).all()) and float(rd.max()) < 20000.0
