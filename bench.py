@@ -96,7 +96,7 @@ class SyntheticScene:
         return idx.reshape(-1, 3)
 
 
-def make_step(model, scene, opts, reducer, targets, n_rays, fused=True):
+def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=False):
     """Returns (fwd_bwd, optim) closures; together they are one training step.
 
     fused=True: the autograd-free FusedTrainStep (the same kernels, chained by hand over preallocated
@@ -122,7 +122,8 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True):
             bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
                                                           scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
             return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], fars, tgt_f, tgt_d[:, 0],
-                                            r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays])
+                                            r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
+                                            optimizers=opts if fuse_optimizer else None)
     else:
         def fwd_bwd():
             bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
@@ -133,6 +134,8 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True):
             return loss.detach()
 
     def optim():
+        if fused and fuse_optimizer:
+            return  # already stepped inside forward_backward (single process: no all-reduce in between)
         reducer.all_reduce()
         for o in opts:
             o.step()
@@ -271,7 +274,9 @@ def main():
     scene = SyntheticScene(device, seed=1000 + rank)  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
-    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd)
+    fuse_opt = world == 1 and not args.autograd  # optimizer kernels inside the step graph, stream-placed
+    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd,
+                               fuse_optimizer=fuse_opt)
 
     use_graph = not args.no_graph
     graphs = []
@@ -296,7 +301,7 @@ def main():
 
     if use_graph:
         g_opt = None
-        if world == 1:
+        if world == 1 and not fuse_opt:
             try:
                 g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_opt):
@@ -310,7 +315,7 @@ def main():
             graphs[0].replay()
             if g_opt is not None:
                 g_opt.replay()
-            else:
+            elif not fuse_opt:
                 optim()
     else:
         def step():

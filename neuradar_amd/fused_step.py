@@ -108,12 +108,20 @@ class FusedTrainStep:
     # -------------------------------------------------------------------------------------------
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
-                         jitter2: Tensor) -> Tensor:
+                         jitter2: Tensor, optimizers=None) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
-        NR_LOSS_SLOTS partial sums (call .sum() when the value is needed)."""
+        NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
+
+        optimizers = (table_opt, field_opt) (FlatAdam) fuses the optimizer into the step (single-process
+        training only -- with several ranks the gradient all-reduce has to come first): the proposal
+        table is stepped on its side stream as soon as both proposal chains are done, overlapping the
+        main field's backward."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
+        if optimizers is not None:
+            for o_ in optimizers:
+                o_.advance()
         lam, scal = c.power_lambda, c.power_scaling
         o, d, area = p(origins), p(directions), p(pixel_area)
         torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=self.fars)  # neuradar.py:573
@@ -180,9 +188,19 @@ class FusedTrainStep:
                                p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
         check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
                                      p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
+        if optimizers is not None:
+            table_opt, field_opt = optimizers
+            if side[0] is not main:  # proposal chains done -> step the proposal table beside the main backward
+                side[0].wait_stream(side[1])
+            with torch.cuda.stream(side[0]):
+                table_opt.step_buffer(table_opt.buffer_of(pg.hash_table))
+            table_opt.step_buffer(table_opt.buffer_of(mg.hash_table))
         for s_ in side:
             if s_ is not main:
                 main.wait_stream(s_)
+        if optimizers is not None:
+            for i in range(len(field_opt.buffers)):  # small parameters: need field_bwd and both prop_density_bwd
+                field_opt.step_buffer(i)
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:

@@ -219,11 +219,29 @@ class FlatAdam:
         return decayed
 
     @torch.no_grad()
-    def step(self) -> None:
-        # one tiny kernel: lr(step) [LambdaLR: step k uses func(k-1)], bias corrections, step += 1
+    def advance(self) -> None:
+        """One tiny kernel: lr(step) [LambdaLR: step k uses func(k-1)], bias corrections, step += 1."""
         ops.check(ops._lib.lib().nr_adam_hyper(ops._p(self.step_t), ops._p(self.hyper), self.lr,
                                                self.lr if self.lr_final is None else self.lr_final, self.warmup,
                                                self.max_steps, self.betas[0], self.betas[1], ops._stream()), "nr_adam_hyper")
-        for (p, g), (m, v) in zip(self.buffers, self.state):
-            ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw,
-                          zero_grad=True, dev_hyper=self.hyper)
+
+    @torch.no_grad()
+    def step_buffer(self, i: int) -> None:
+        """Adam on buffer i (after `advance()`), on the current stream."""
+        (p, g), (m, v) = self.buffers[i], self.state[i]
+        ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, zero_grad=True,
+                      dev_hyper=self.hyper)
+
+    def buffer_of(self, param: nn.Parameter) -> int:
+        """Index of the buffer that holds `param` (its own for tables, the flat one for small parameters)."""
+        ptr = param.data_ptr()
+        for i, (p, _) in enumerate(self.buffers):
+            if p.data_ptr() <= ptr < p.data_ptr() + p.numel() * 4:
+                return i
+        raise KeyError("parameter is not managed by this optimizer")
+
+    @torch.no_grad()
+    def step(self) -> None:
+        self.advance()
+        for i in range(len(self.buffers)):
+            self.step_buffer(i)
