@@ -168,7 +168,14 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     float v[8][F];
     if (valid) {
       const int64_t idx = sample_of_thread(i, n, S);
-      const Corner c = make_corner(x, idx, scale);
+      float cw[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {  // floor corner + interpolation weight (ceil is not needed here)
+        const float p = x[idx * 3 + a] * scale;
+        const float fl = floorf(p);
+        lo[a] = (int)fl;
+        cw[a] = p - fl;
+      }
       float r = 1.0f;
       if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
       const float* gi = gout + idx * sn + (int64_t)level * sl;
@@ -176,13 +183,11 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 #pragma unroll
       for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) lo[a] = c.lo[a];
-#pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
         const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
         // on an exact grid plane ceil == floor and the "ceil" weight is 0: that corner's value is 0
         // whichever slot it is credited to, so a cell is identified by its floor corner alone
-        const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
+        const float w = (hx ? cw[0] : 1.0f - cw[0]) * (hy ? cw[1] : 1.0f - cw[1]) * (hz ? cw[2] : 1.0f - cw[2]);
 #pragma unroll
         for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
       }
@@ -196,6 +201,7 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     }
     auto same_cell = [&](int lx, int ly, int lz) { return lx == lo[0] && ly == lo[1] && lz == lo[2]; };
     // 1. fold the upper half-wave onto the lower one where the cells agree (v_permlane32_swap)
+#ifndef NR_BWD_NO_FOLD
     {
       const bool same = same_cell(nr_xor32_i(lo[0]), nr_xor32_i(lo[1]), nr_xor32_i(lo[2]));
 #pragma unroll
@@ -206,6 +212,7 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
           if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
         }
     }
+#endif
     // 2. segmented inclusive scan over runs of equal cells, all in DPP: Hillis-Steele inside each row
     //    of 16 lanes (row_shr 1,2,4,8), then the carry of lane 15/31/47 into rows 1,2,3 in turn.
     //    `flag` = "a run head lies inside the range this lane has covered so far".
@@ -215,16 +222,14 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     int flag = head ? 1 : 0;
     auto scan_step = [&](auto ctrl, auto rowmask) {
       constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-      const int fprev = nr_dpp_i<C, R>(0, flag);  // lanes without a source read (0, 0): no change
-      const bool take = !flag;
+      // lanes without a source read (0, 0): no change.  v += t * (flag ? 0 : 1) folds into one
+      // v_fmac_f32_dpp per value, flag |= flag_src into one v_or_b32_dpp.
+      const float take = flag ? 0.0f : 1.0f;
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const float t = nr_dpp_f<C, R>(0.0f, v[corner][f]);
-          if (take) v[corner][f] += t;
-        }
-      if (take) flag = fprev;
+        for (int f = 0; f < F; ++f) v[corner][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, v[corner][f]), take, v[corner][f]);
+      flag |= nr_dpp_i<C, R>(0, flag);
     };
     scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
     scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
@@ -234,11 +239,12 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
     scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
     const int next_head = nr_dpp_i<NR_DPP_WAVE_SHL1, 0xF>(1, head ? 1 : 0);
-    bool nz = false;
+    float mag = 0.0f;
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-      for (int f = 0; f < F; ++f) nz |= v[corner][f] != 0.0f;
+      for (int f = 0; f < F; ++f) mag += fabsf(v[corner][f]);
+    const bool nz = mag != 0.0f;  // also false for NaN-free all-zero runs (padding, folded lanes, zero-weight planes)
     const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
     // 3a. find or claim the cell's slot in the wave's table: write-then-read-back, 4 linear probes
     const unsigned long long key = pack_cell(lo);
