@@ -108,7 +108,7 @@ class FusedTrainStep:
     # -------------------------------------------------------------------------------------------
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
-                         jitter2: Tensor, optimizers=None) -> Tensor:
+                         jitter2: Tensor, optimizers=None, reducer=None) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
@@ -116,7 +116,12 @@ class FusedTrainStep:
         optimizers = (table_opt, field_opt) (FlatAdam) fuses the optimizer into the step (single-process
         training only -- with several ranks the gradient all-reduce has to come first): the proposal
         table is stepped on its side stream as soon as both proposal chains are done, overlapping the
-        main field's backward."""
+        main field's backward.
+
+        reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The SUM
+        all-reduce of the proposal table's gradient is issued as soon as both proposal chains finish and
+        runs over RCCL/xGMI underneath the main field's backward; the main table and the small-parameter
+        bucket follow; Adam applies 1/world (DDP's mean)."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
         if optimizers is not None:
@@ -190,17 +195,29 @@ class FusedTrainStep:
                                      p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
         if optimizers is not None:
             table_opt, field_opt = optimizers
-            if side[0] is not main:  # proposal chains done -> step the proposal table beside the main backward
+            scale = 1.0 if reducer is None else 1.0 / reducer.world
+            i_prop, i_main = table_opt.buffer_of(pg.hash_table), table_opt.buffer_of(mg.hash_table)
+            if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main backward
                 side[0].wait_stream(side[1])
             with torch.cuda.stream(side[0]):
-                table_opt.step_buffer(table_opt.buffer_of(pg.hash_table))
-            table_opt.step_buffer(table_opt.buffer_of(mg.hash_table))
+                if reducer is not None:
+                    reducer.start(table_opt.buffers[i_prop][1])
+                    reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
+                table_opt.step_buffer(i_prop, scale)
+            if reducer is not None:
+                reducer.start(table_opt.buffers[i_main][1])
+                reducer.wait_all()
+            table_opt.step_buffer(i_main, scale)
         for s_ in side:
             if s_ is not main:
                 main.wait_stream(s_)
         if optimizers is not None:
-            for i in range(len(field_opt.buffers)):  # small parameters: need field_bwd and both prop_density_bwd
-                field_opt.step_buffer(i)
+            if reducer is not None:  # small parameters: need field_bwd and both prop_density_bwd
+                for _, g_ in field_opt.buffers:
+                    reducer.start(g_)
+                reducer.wait_all()
+            for i in range(len(field_opt.buffers)):
+                field_opt.step_buffer(i, scale)
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:

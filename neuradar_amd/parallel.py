@@ -62,6 +62,27 @@ class GradAllReducer:
         self.big = [p for p in self.params if p.numel() > SMALL_PARAM_NUMEL]
         self.small = [p for p in self.params if p.numel() <= SMALL_PARAM_NUMEL]
 
+    # ---- fine-grained interface used by FusedTrainStep: issue early, overlap, wait late -------------
+    def start(self, grad: torch.Tensor) -> None:
+        """Asynchronous SUM all-reduce of one gradient buffer, ordered after the current stream's work."""
+        if self.world == 1:
+            return
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        if self.table_dtype is not None and grad.numel() > SMALL_PARAM_NUMEL:
+            low = grad.to(self.table_dtype)
+            self._pending.append((dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True), grad, low))
+        else:
+            self._pending.append((dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), grad, None))
+
+    def wait_all(self) -> None:
+        """Make the current stream wait for every collective issued with start()."""
+        for work, grad, low in getattr(self, "_pending", []):
+            work.wait()
+            if low is not None:
+                grad.copy_(low)
+        self._pending = []
+
     def bytes_per_step(self) -> int:
         esz = 4 if self.table_dtype is None else torch.empty((), dtype=self.table_dtype).element_size()
         return sum(p.numel() for p in self.big) * esz + sum(p.numel() for p in self.small) * 4

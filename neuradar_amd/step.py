@@ -226,11 +226,12 @@ class FlatAdam:
                                                self.max_steps, self.betas[0], self.betas[1], ops._stream()), "nr_adam_hyper")
 
     @torch.no_grad()
-    def step_buffer(self, i: int) -> None:
-        """Adam on buffer i (after `advance()`), on the current stream."""
+    def step_buffer(self, i: int, grad_scale: float = 1.0) -> None:
+        """Adam on buffer i (after `advance()`), on the current stream.  grad_scale = 1/world turns the
+        SUM all-reduce of the data-parallel ranks into DDP's mean without a separate pass."""
         (p, g), (m, v) = self.buffers[i], self.state[i]
-        ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, zero_grad=True,
-                      dev_hyper=self.hyper)
+        ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
+                      zero_grad=True, dev_hyper=self.hyper)
 
     def buffer_of(self, param: nn.Parameter) -> int:
         """Index of the buffer that holds `param` (its own for tables, the flat one for small parameters)."""

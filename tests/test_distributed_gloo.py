@@ -49,6 +49,15 @@ def _worker(rank, world, port, bf16):
     assert float(unused.grad.abs().max()) == 0.0
     assert torch.allclose(small[0].grad, torch.full_like(small[0], 10.0 * mean))
     assert small[1].grad is not None and float(small[1].grad.abs().max()) == 0.0
+    # fine-grained interface of the fused step: issue early (start), wait late (wait_all)
+    bufs = [torch.full((1 << 17,), float(rank + 1)), torch.full((100,), 2.0 * (rank + 1))]
+    red2 = GradAllReducer(None, buffers=bufs, table_dtype=torch.bfloat16 if bf16 else None)
+    for b in bufs:
+        red2.start(b)
+    red2.wait_all()
+    total = float(sum(range(1, world + 1)))
+    assert torch.allclose(bufs[0], torch.full_like(bufs[0], total), rtol=1e-2 if bf16 else 1e-6)
+    assert torch.allclose(bufs[1], torch.full_like(bufs[1], 2.0 * total))
     dist.barrier()
     dist.destroy_process_group()
 
