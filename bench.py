@@ -190,6 +190,22 @@ def roofline_probe(model, scene, n_rays):
     return rows
 
 
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_hash_kernels_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB ->
+    bytes, FETCH_SIZE as reported -- see the file for the gfx950 caveats).  None when no profile of this
+    workload/kernel is committed: bench.py does not run the profiler itself."""
+    path = os.path.join(ROOT, "profiles", "r01_hash_kernels_pmc.json")
+    if workload != "cam4096_l16f2_w64" or not os.path.exists(path):
+        return None
+    tag = kernel[kernel.index("[") + 1:-1]
+    kind = "bwd" if "bwd" in kernel else "fwd"
+    for name, c in json.load(open(path))["kernels"].items():
+        if kind in name and tag in name:
+            return int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def cpu_baseline(wl, n_rays_sample, threads):
     """The CPU oracle (port of the reference's torch path) on a bounded sample of the same workload:
     fwd + bwd of the bench loss, median of 3 after 1 warm-up."""
@@ -362,7 +378,7 @@ def main():
         dom = max(rows, key=lambda r: r["seconds"])
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom["kernel"]),
                 "avg_us": round(dom["seconds"] * 1e6, 2), "bytes_per_launch": dom["bytes"],
                 "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
                                       "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows]}
