@@ -207,14 +207,18 @@ int nr_depth_from_weights(const float* weights, const float* euclid, int64_t n_r
 /* ------------------------------------------------------------------------------------------------
  * Sensor ray generation (device-side; the reference runs these on CPU workers)
  * ---------------------------------------------------------------------------------------------- */
-/* Cameras._generate_rays_from_coords, perspective branch, no lens distortion (cameras/cameras.py:
- * 596-660,782-787,887-949) behind RayGenerator.forward (model_components/ray_generators.py:47-62).
+/* Cameras._generate_rays_from_coords (cameras/cameras.py:596-660,782-804,887-949) behind
+ * RayGenerator.forward (model_components/ray_generators.py:47-62).
  * ray_indices [n,3] int64 (camera,row,col); c2w [n_cams,3,4]; fx,fy,cx,cy,cam_times [n_cams];
- * velocities [n_cams,3], rs_offsets [n_cams,2], heights [n_cams] nullable together (rolling shutter).
+ * velocities [n_cams,3], rs_offsets [n_cams,2], heights [n_cams] nullable together (rolling shutter);
+ * distortion [n_cams,6] = [k1,k2,k3,k4,p1,p2] or NULL: iterative undistortion
+ * (cameras/camera_utils.py:655-758); camera_type [n_cams] int32 or NULL: 0 = PERSPECTIVE (:782-787),
+ * 1 = FISHEYE (:789-804, the ZOD camera model).
  * -> origins, directions [n,3]; pixel_area, times, directions_norm [n]. */
 int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
                        const float* cx, const float* cy, const float* cam_times, const float* velocities,
-                       const float* rs_offsets, const float* heights, int64_t n,
+                       const float* rs_offsets, const float* heights, const float* distortion,
+                       const int* camera_type, int64_t n,
                        float* origins, float* directions, float* pixel_area, float* times,
                        float* directions_norm, nr_stream_t stream);
 /* Lidars._generate_rays_from_points (cameras/lidars.py:356-417).  lidar_indices [n] int64;
@@ -286,7 +290,8 @@ int nr_adam_hyper(float* step_t, float* dev_hyper, float lr, float lr_final, int
 int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, int height, int width, int patch,
                                int stride, float area_scale, const float* c2w, const float* fx, const float* fy,
                                const float* cx, const float* cy, const float* cam_times, const float* velocities,
-                               const float* rs_offsets, const float* heights, float* origins, float* directions,
+                               const float* rs_offsets, const float* heights, const float* distortion,
+                               const int* camera_type, float* origins, float* directions,
                                float* pixel_area, float* times, float* directions_norm, int64_t* ray_indices,
                                nr_stream_t stream);
 

@@ -57,7 +57,7 @@ PROTOTYPES = {
     "nr_composite_fwd": [P, P, P, L, I, I, P, P, P, P, P],
     "nr_composite_bwd": [P, P, P, P, P, P, P, P, L, I, I, P, P, P],
     "nr_depth_from_weights": [P, P, L, I, P, P],
-    "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
+    "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
     "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
     "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P],
@@ -65,7 +65,7 @@ PROTOTYPES = {
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
-    "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p}
 

@@ -16,11 +16,38 @@ __device__ __forceinline__ float normalize3(float (&v)[3]) {
   return norm;
 }
 
+// radial_and_tangential_undistort (cameras/camera_utils.py:655-758): 10 Newton steps on the OpenCV
+// model [k1,k2,k3,k4,p1,p2], step suppressed where |det J| <= 1e-3.
+__device__ __forceinline__ void undistort(float& u, float& v, const float* __restrict__ k) {
+  const float xd = u, yd = v;
+  float x = xd, y = yd;
+#pragma unroll 1
+  for (int it = 0; it < 10; ++it) {
+    const float r = x * x + y * y;
+    const float d = 1.0f + r * (k[0] + r * (k[1] + r * (k[2] + r * k[3])));
+    const float fx = d * x + 2.0f * k[4] * x * y + k[5] * (r + 2.0f * x * x) - xd;
+    const float fy = d * y + 2.0f * k[5] * x * y + k[4] * (r + 2.0f * y * y) - yd;
+    const float d_r = k[0] + r * (2.0f * k[1] + r * (3.0f * k[2] + r * 4.0f * k[3]));
+    const float d_x = 2.0f * x * d_r, d_y = 2.0f * y * d_r;
+    const float fx_x = d + d_x * x + 2.0f * k[4] * y + 6.0f * k[5] * x;
+    const float fx_y = d_y * x + 2.0f * k[4] * x + 2.0f * k[5] * y;
+    const float fy_x = d_x * y + 2.0f * k[5] * y + 2.0f * k[4] * x;
+    const float fy_y = d + d_y * y + 2.0f * k[5] * x + 6.0f * k[4] * y;
+    const float den = fy_x * fx_y - fx_x * fy_y;
+    const bool ok = fabsf(den) > 1e-3f;
+    x = x + (ok ? (fx * fy_y - fy * fx_y) / den : 0.0f);
+    y = y + (ok ? (fy * fx_x - fx * fy_x) / den : 0.0f);
+  }
+  u = x;
+  v = y;
+}
+
 __device__ __forceinline__ void camera_ray(int64_t i, int64_t cam, int64_t row, int64_t col, const float* __restrict__ c2w,
                                            const float* __restrict__ fx, const float* __restrict__ fy,
                                            const float* __restrict__ cx, const float* __restrict__ cy,
                                            const float* __restrict__ cam_times, const float* __restrict__ velocities,
                                            const float* __restrict__ rs_offsets, const float* __restrict__ heights,
+                                           const float* __restrict__ distortion, const int* __restrict__ camera_type,
                                            float area_scale, float* __restrict__ origins, float* __restrict__ directions,
                                            float* __restrict__ pixel_area, float* __restrict__ times,
                                            float* __restrict__ directions_norm) {
@@ -28,15 +55,26 @@ __device__ __forceinline__ void camera_ray(int64_t i, int64_t cam, int64_t row, 
   const float x = (float)col + 0.5f;
   const float fxv = fx[cam], fyv = fy[cam], cxv = cx[cam], cyv = cy[cam];
   const float* pose = c2w + cam * 12;
-  // the pixel and its +1 neighbours in x and y (cameras.py:622-624), OpenCV -> OpenGL flip (:656),
-  // perspective branch z = -1 (:782-787), rotate (:892-894), normalise
+  // the pixel and its +1 neighbours in x and y (cameras.py:622-624), lens undistortion (:636-653),
+  // OpenCV -> OpenGL flip (:656), perspective z = -1 (:782-787) or fisheye (:789-804), rotate (:892-894)
+  const bool fisheye = camera_type != nullptr && camera_type[cam] == 1;
   float d[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float u = k == 1 ? (x - cxv + 1.0f) / fxv : (x - cxv) / fxv;
-    const float v = -(k == 2 ? (y - cyv + 1.0f) / fyv : (y - cyv) / fyv);
+    float u = k == 1 ? (x - cxv + 1.0f) / fxv : (x - cxv) / fxv;
+    float v = k == 2 ? (y - cyv + 1.0f) / fyv : (y - cyv) / fyv;
+    if (distortion != nullptr) undistort(u, v, distortion + cam * 6);
+    v = -v;
+    float w = -1.0f;
+    if (fisheye) {
+      const float theta = fminf(fmaxf(sqrtf(u * u + v * v), 0.0f), 3.14159265358979323846f);
+      const float st = sinf(theta);
+      u = u * st / theta;
+      v = v * st / theta;
+      w = -cosf(theta);
+    }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) d[k][r] = u * pose[r * 4 + 0] + v * pose[r * 4 + 1] + (-1.0f) * pose[r * 4 + 2];
+    for (int r = 0; r < 3; ++r) d[k][r] = u * pose[r * 4 + 0] + v * pose[r * 4 + 1] + w * pose[r * 4 + 2];
   }
   const float norm0 = normalize3(d[0]);
   normalize3(d[1]);
@@ -71,13 +109,15 @@ gen_rays_camera_kernel(const int64_t* __restrict__ ray_indices, const float* __r
                        const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ cx,
                        const float* __restrict__ cy, const float* __restrict__ cam_times,
                        const float* __restrict__ velocities, const float* __restrict__ rs_offsets,
-                       const float* __restrict__ heights, int64_t n, float* __restrict__ origins,
+                       const float* __restrict__ heights, const float* __restrict__ distortion,
+                       const int* __restrict__ camera_type, int64_t n, float* __restrict__ origins,
                        float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ times,
                        float* __restrict__ directions_norm) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   camera_ray(i, ray_indices[i * 3 + 0], ray_indices[i * 3 + 1], ray_indices[i * 3 + 2], c2w, fx, fy, cx, cy, cam_times,
-             velocities, rs_offsets, heights, 1.0f, origins, directions, pixel_area, times, directions_norm);
+             velocities, rs_offsets, heights, distortion, camera_type, 1.0f, origins, directions, pixel_area, times,
+             directions_norm);
 }
 
 __global__ void __launch_bounds__(256)
@@ -86,6 +126,7 @@ gen_rays_camera_patches_kernel(const float* __restrict__ u, int64_t n_patches, i
                                const float* __restrict__ fy, const float* __restrict__ cx, const float* __restrict__ cy,
                                const float* __restrict__ cam_times, const float* __restrict__ velocities,
                                const float* __restrict__ rs_offsets, const float* __restrict__ heights,
+                               const float* __restrict__ distortion, const int* __restrict__ camera_type,
                                float* __restrict__ origins, float* __restrict__ directions, float* __restrict__ pixel_area,
                                float* __restrict__ times, float* __restrict__ directions_norm,
                                int64_t* __restrict__ ray_indices) {
@@ -102,8 +143,8 @@ gen_rays_camera_patches_kernel(const float* __restrict__ u, int64_t n_patches, i
   if (ray_indices != nullptr) {
     ray_indices[i * 3 + 0] = cam; ray_indices[i * 3 + 1] = row; ray_indices[i * 3 + 2] = col;
   }
-  camera_ray(i, cam, row, col, c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, area_scale, origins,
-             directions, pixel_area, times, directions_norm);
+  camera_ray(i, cam, row, col, c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, distortion, camera_type,
+             area_scale, origins, directions, pixel_area, times, directions_norm);
 }
 
 __global__ void __launch_bounds__(256)
@@ -176,17 +217,17 @@ gen_rays_radar_kernel(const int64_t* __restrict__ scan_indices, int64_t n_scans,
 
 extern "C" int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
                                   const float* cx, const float* cy, const float* cam_times, const float* velocities,
-                                  const float* rs_offsets, const float* heights, int64_t n, float* origins,
-                                  float* directions, float* pixel_area, float* times, float* directions_norm,
-                                  nr_stream_t stream) {
+                                  const float* rs_offsets, const float* heights, const float* distortion,
+                                  const int* camera_type, int64_t n, float* origins, float* directions,
+                                  float* pixel_area, float* times, float* directions_norm, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!ray_indices || !c2w || !fx || !fy || !cx || !cy || !cam_times || !origins || !directions || !pixel_area ||
       !times || !directions_norm || n < 0)
     return NR_EINVAL;
   if ((velocities != nullptr) != (rs_offsets != nullptr) || (velocities != nullptr) != (heights != nullptr)) return NR_EINVAL;
   hipLaunchKernelGGL(gen_rays_camera_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), ray_indices,
-                     c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, n, origins, directions,
-                     pixel_area, times, directions_norm);
+                     c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights, distortion, camera_type, n, origins,
+                     directions, pixel_area, times, directions_norm);
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -194,9 +235,9 @@ extern "C" int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, 
 extern "C" int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, int H, int W, int patch, int stride,
                                           float area_scale, const float* c2w, const float* fx, const float* fy,
                                           const float* cx, const float* cy, const float* cam_times, const float* velocities,
-                                          const float* rs_offsets, const float* heights, float* origins, float* directions,
-                                          float* pixel_area, float* times, float* directions_norm, int64_t* ray_indices,
-                                          nr_stream_t stream) {
+                                          const float* rs_offsets, const float* heights, const float* distortion,
+                                          const int* camera_type, float* origins, float* directions, float* pixel_area,
+                                          float* times, float* directions_norm, int64_t* ray_indices, nr_stream_t stream) {
   if (n_patches == 0) return 0;
   if (!u || !c2w || !fx || !fy || !cx || !cy || !cam_times || !origins || !directions || !pixel_area || !times ||
       n_patches < 0 || n_cams < 1 || patch < 1 || stride < 1 || H <= patch * stride || W <= patch * stride)
@@ -205,7 +246,7 @@ extern "C" int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int
   const int64_t n = n_patches * patch * patch;
   hipLaunchKernelGGL(gen_rays_camera_patches_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), u, n_patches,
                      n_cams, H, W, patch, stride, area_scale, c2w, fx, fy, cx, cy, cam_times, velocities, rs_offsets, heights,
-                     origins, directions, pixel_area, times, directions_norm, ray_indices);
+                     distortion, camera_type, origins, directions, pixel_area, times, directions_norm, ray_indices);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,8 @@ class Cameras:
     times: Tensor  # [C]
     velocities: Optional[Tensor] = None  # [C,3]  (metadata["velocities"], ad_dataparser.py:398-403)
     rolling_shutter_offsets: Optional[Tensor] = None  # [C,2]
+    distortion_params: Optional[Tensor] = None  # [C,6] k1,k2,k3,k4,p1,p2 (cameras.py:100)
+    camera_type: Optional[Tensor] = None  # [C] int32: 0 PERSPECTIVE, 1 FISHEYE (ZOD: zod_dataparser.py:261)
 
     def generate_rays(self, ray_indices: Tensor) -> RayBundle:
         """RayGenerator.forward: ray_indices [n,3] int64 (camera,row,col) -> RayBundle."""
@@ -46,8 +48,8 @@ class Cameras:
         check(_lib.lib().nr_gen_rays_camera(
             p(ray_indices.contiguous()), p(self.camera_to_worlds.contiguous()), p(self.fx), p(self.fy), p(self.cx),
             p(self.cy), p(self.times), p(self.velocities) if rs else None,
-            p(self.rolling_shutter_offsets) if rs else None, p(self.height) if rs else None, n, p(o), p(d), p(area),
-            p(t), p(norm), ops._stream()), "nr_gen_rays_camera")
+            p(self.rolling_shutter_offsets) if rs else None, p(self.height) if rs else None, p(self.distortion_params),
+            p(self.camera_type), n, p(o), p(d), p(area), p(t), p(norm), ops._stream()), "nr_gen_rays_camera")
         return RayBundle(o, d, area[:, None], camera_indices=ray_indices[:, :1], fars=torch.full((n, 1), FAR, device=dev),
                          times=t[:, None], metadata={"directions_norm": norm[:, None]})
 
@@ -67,7 +69,8 @@ class Cameras:
             p(u), n_p, self.fx.shape[0], height, width, patch,
             stride, area_scale, p(self.camera_to_worlds), p(self.fx), p(self.fy), p(self.cx), p(self.cy), p(self.times),
             p(self.velocities) if rs else None, p(self.rolling_shutter_offsets) if rs else None,
-            p(self.height) if rs else None, p(o), p(d), p(area), p(t), None, p(idx), ops._stream()),
+            p(self.height) if rs else None, p(self.distortion_params), p(self.camera_type), p(o), p(d), p(area), p(t), None,
+            p(idx), ops._stream()),
             "nr_gen_rays_camera_patches")
         return RayBundle(o, d, area[:, None], fars=torch.full((n, 1), FAR, device=dev), times=t[:, None]), idx
 

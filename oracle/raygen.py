@@ -23,9 +23,36 @@ def normalize_with_norm(x):
     return x / norm, norm
 
 
-def camera_rays(ray_indices, c2w, fx, fy, cx, cy, cam_times, velocities=None, rs_offsets=None, heights=None):
-    """Perspective pinhole rays.  RayGenerator.forward (ray_generators.py:47-62) ->
-    Cameras._generate_rays_from_coords (cameras.py:596-949), no lens distortion.
+def undistort(coords, distortion_params, eps: float = 1e-3, max_iterations: int = 10):
+    """radial_and_tangential_undistort: 10 Newton steps on the OpenCV model [k1,k2,k3,k4,p1,p2].
+    camera_utils.py:655-758.  coords [...,2], distortion_params broadcastable [...,6]."""
+    k1, k2, k3, k4, p1, p2 = (distortion_params[..., i] for i in range(6))
+    xd, yd = coords[..., 0], coords[..., 1]
+    x, y = xd, yd
+    for _ in range(max_iterations):
+        r = x * x + y * y
+        d = 1.0 + r * (k1 + r * (k2 + r * (k3 + r * k4)))
+        fx = d * x + 2 * p1 * x * y + p2 * (r + 2 * x * x) - xd
+        fy = d * y + 2 * p2 * x * y + p1 * (r + 2 * y * y) - yd
+        d_r = k1 + r * (2.0 * k2 + r * (3.0 * k3 + r * 4.0 * k4))
+        d_x, d_y = 2.0 * x * d_r, 2.0 * y * d_r
+        fx_x = d + d_x * x + 2.0 * p1 * y + 6.0 * p2 * x
+        fx_y = d_y * x + 2.0 * p1 * x + 2.0 * p2 * y
+        fy_x = d_x * y + 2.0 * p2 * y + 2.0 * p1 * x
+        fy_y = d + d_y * y + 2.0 * p2 * x + 6.0 * p1 * y
+        den = fy_x * fx_y - fx_x * fy_y
+        ok = torch.abs(den) > eps
+        x = x + torch.where(ok, (fx * fy_y - fy * fx_y) / den, torch.zeros_like(den))
+        y = y + torch.where(ok, (fy * fx_x - fx * fy_x) / den, torch.zeros_like(den))
+    return torch.stack([x, y], dim=-1)
+
+
+def camera_rays(ray_indices, c2w, fx, fy, cx, cy, cam_times, velocities=None, rs_offsets=None, heights=None,
+                distortion=None, fisheye=None):
+    """Pinhole / fisheye rays.  RayGenerator.forward (ray_generators.py:47-62) ->
+    Cameras._generate_rays_from_coords (cameras.py:596-949).  distortion [C,6] (optional) applies the
+    iterative undistortion (:636-653); fisheye [C] bool selects the FISHEYE branch (:789-804, ZOD's
+    camera model) instead of PERSPECTIVE (:782-787).
 
     ray_indices [B,3] int64 (camera, row, col); c2w [C,3,4]; fx,fy,cx,cy [C]; cam_times [C];
     velocities [C,3] + rs_offsets [C,2] + heights [C] enable the top-to-bottom rolling shutter
@@ -40,8 +67,15 @@ def camera_rays(ray_indices, c2w, fx, fy, cx, cy, cam_times, velocities=None, rs
     coord_dx = torch.stack([(x - cx + 1) / fx, (y - cy) / fy], -1)
     coord_dy = torch.stack([(x - cx) / fx, (y - cy + 1) / fy], -1)
     stack = torch.stack([coord, coord_dx, coord_dy], dim=0)  # [3,B,2]
+    if distortion is not None:
+        stack = undistort(stack, distortion[c][None])
     stack = stack * torch.tensor([1.0, -1.0], dtype=stack.dtype)  # OpenCV -> OpenGL (cameras.py:656)
     dirs = torch.cat([stack, -torch.ones_like(stack[..., :1])], dim=-1)  # perspective branch :782-787
+    if fisheye is not None:
+        theta = torch.clip(torch.sqrt(torch.sum(stack**2, dim=-1)), 0.0, torch.pi)
+        fish = torch.stack([stack[..., 0] * torch.sin(theta) / theta, stack[..., 1] * torch.sin(theta) / theta,
+                            -torch.cos(theta)], dim=-1)
+        dirs = torch.where(fisheye[c][None, :, None], fish, dirs)
     rot = c2w[c][:, :3, :3]  # [B,3,3]
     dirs = torch.sum(dirs[..., None, :] * rot, dim=-1)  # cameras.py:892-894
     dirs, norms = normalize_with_norm(dirs)

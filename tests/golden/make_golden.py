@@ -409,6 +409,18 @@ def golden_raygen():
                         camera_type=CameraType.PERSPECTIVE, times=cam_times)
     cb2 = RayGenerator(cams_nors)(ridx)
     out.update(cam_nors_origins=cb2.origins, cam_nors_times=cb2.times)
+    # ZOD-style cameras: FISHEYE model with radial distortion [k1..k4, 0, 0] (zod_dataparser.py:236-261)
+    dist = torch.cat([torch.tensor([[0.08, -0.02, 0.004, -0.0005]]).repeat(C, 1) * (1 + 0.1 * torch.randn(C, 4, generator=g)),
+                      torch.zeros(C, 2)], -1)
+    dist[1, 4:] = torch.tensor([1e-3, -2e-3])  # one camera with tangential terms as well
+    cams_fe = Cameras(camera_to_worlds=c2w, fx=fx, fy=fy, cx=cx, cy=cy, width=W, height=H, distortion_params=dist,
+                      camera_type=CameraType.FISHEYE, times=cam_times)
+    cb3 = RayGenerator(cams_fe)(ridx)
+    cams_pd = Cameras(camera_to_worlds=c2w, fx=fx, fy=fy, cx=cx, cy=cy, width=W, height=H, distortion_params=dist,
+                      camera_type=CameraType.PERSPECTIVE, times=cam_times)
+    cb4 = RayGenerator(cams_pd)(ridx)
+    out.update(cam_dist=dist, cam_fe_directions=cb3.directions, cam_fe_pixel_area=cb3.pixel_area,
+               cam_pd_directions=cb4.directions, cam_pd_pixel_area=cb4.pixel_area)
 
     # --- lidar
     NL = 4

@@ -369,6 +369,15 @@ def test_raygen_vs_reference_golden():
     assert_close(cpu(b2.origins), g["cam_nors_origins"], rtol=1e-6, atol_scale=1e-7)
     assert_close(cpu(b2.times), g["cam_nors_times"], rtol=1e-6, atol_scale=1e-7)
 
+    # lens undistortion + fisheye (the ZOD camera model), and undistorted pinhole
+    for ctype, key in ((1, "fe"), (0, "pd")):
+        cams3 = Cameras(dev(g["cam_c2w"]), dev(g["cam_fx"]), dev(g["cam_fy"]), dev(g["cam_cx"]), dev(g["cam_cy"]),
+                        dev(g["cam_heights"]), dev(g["cam_times_in"]), distortion_params=dev(g["cam_dist"]),
+                        camera_type=torch.full((5,), ctype, dtype=torch.int32, device=DEV))
+        b3 = cams3.generate_rays(dev(g["cam_ray_indices"]))
+        assert_close(cpu(b3.directions), g[f"cam_{key}_directions"], rtol=1e-5, atol_scale=2e-6, what=f"{key} directions")
+        assert_close(cpu(b3.pixel_area), g[f"cam_{key}_pixel_area"], rtol=2e-3, atol_scale=1e-4, what=f"{key} pixel_area")
+
     lid = Lidars(dev(g["lid_l2w"]), dev(g["lid_times_in"]), dev(g["lid_vel"]))
     lb = lid.generate_rays(dev(g["lid_indices"]), dev(g["lid_points"]))
     assert_close(cpu(lb.origins), g["lid_origins"], rtol=1e-5, atol_scale=1e-6, what="lidar origins")

@@ -174,6 +174,12 @@ def test_raygen_camera_lidar_radar():
                               g["cam_times_in"])
     assert_close(cam2["origins"], g["cam_nors_origins"], rtol=1e-6, atol_scale=1e-7)
     assert_close(cam2["times"], g["cam_nors_times"], rtol=1e-6, atol_scale=1e-7)
+    cam_args = (g["cam_ray_indices"], g["cam_c2w"], g["cam_fx"], g["cam_fy"], g["cam_cx"], g["cam_cy"], g["cam_times_in"])
+    fe = raygen.camera_rays(*cam_args, distortion=g["cam_dist"], fisheye=torch.ones(5, dtype=torch.bool))  # ZOD model
+    assert_close(fe["directions"], g["cam_fe_directions"], rtol=1e-6, atol_scale=1e-7, what="fisheye directions")
+    assert_close(fe["pixel_area"], g["cam_fe_pixel_area"], rtol=1e-5, atol_scale=1e-7, what="fisheye pixel_area")
+    pd = raygen.camera_rays(*cam_args, distortion=g["cam_dist"])
+    assert_close(pd["directions"], g["cam_pd_directions"], rtol=1e-6, atol_scale=1e-7, what="undistorted pinhole directions")
     lid = raygen.lidar_rays(g["lid_indices"], g["lid_points"], g["lid_l2w"], g["lid_times_in"], g["lid_vel"])
     for k in ("origins", "directions", "pixel_area", "times", "fars", "directions_norm"):
         assert_close(lid[k], g["lid_" + k], rtol=1e-5, atol_scale=1e-6, what="lidar " + k)
