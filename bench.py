@@ -175,15 +175,17 @@ def roofline_probe(model, scene, n_rays):
         g = fld.hashgrid.static_grid
         B, S = rs.shape
         n, L, F = B * S, g.num_levels, g.features_per_level
-        x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, fld.hashgrid.static_scale)
+        # rows in the step's own order: sample-major (row s*B+b), walked identically
+        x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, fld.hashgrid.static_scale,
+                                            sample_major_rows=True)
         buf = torch.empty((L, n, F), device=x01.device)
         gbuf = torch.randn_like(buf)
         gtab = torch.zeros_like(g.hash_table)
         lib, p, st = ops._lib.lib(), ops._p, ops._stream
         fwd = lambda: lib.nr_hash_encode_fwd(p(x01), p(std01), p(g.hash_table), p(g.scalings), L, F,  # noqa: E731
-                                             g.log2_hashmap_size, p(buf), F, n * F, n, S, st())
+                                             g.log2_hashmap_size, p(buf), F, n * F, n, 0, st())
         bwd = lambda: lib.nr_hash_encode_bwd(p(x01), p(std01), p(g.scalings), L, F, g.log2_hashmap_size,  # noqa: E731
-                                             p(gbuf), F, n * F, p(gtab), n, S, st())
+                                             p(gbuf), F, n * F, p(gtab), n, 0, st())
         bytes_fwd = n * L * 8 * F * 4
         rows.append(dict(kernel=f"hash_encode_fwd[{tag}]", seconds=time_kernel(fwd), bytes=bytes_fwd))
         rows.append(dict(kernel=f"hash_encode_bwd[{tag}]", seconds=time_kernel(bwd), bytes=2 * bytes_fwd))

@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 1
+#define NR_ABI_VERSION 2
 #define NR_LOSS_SLOTS 64   /* loss kernels add into loss[0..63]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
@@ -79,10 +79,15 @@ int nr_hash_encode_bwd_input(const float* x, const float* std, const float* tabl
  * ScaledSceneContraction(order=inf, scale) on the GaussiansStd
  * (field_components/spatial_distortions.py:103-113,126-136):
  *   origins, directions [n_rays,3]; pixel_area [n_rays]; edges [n_rays, n_samples+1] (metres)
- *   -> x01 [n_rays*n_samples, 3] in [0,1], std01 [n_rays*n_samples]. */
+ *   -> x01 [n_rays*n_samples, 3] in [0,1], std01 [n_rays*n_samples].
+ * Row order of the outputs: sample_major_rows = 0: row b*S+s (the reference's [B,S] flattening);
+ * 1: row s*B+b.  The second form is what the fused step feeds the hash grid and the MLP kernels
+ * (rows_sample_major below): 64 consecutive rows are then 64 neighbouring rays at one sample slot,
+ * which makes every per-sample load coalesced and the touched grid cells coherent.  Per-ray arrays
+ * (densities, alphas, weights, rendered features) always stay in the reference's [B,S] order. */
 int nr_contract_gaussians(const float* origins, const float* directions, const float* pixel_area,
                           const float* edges, int64_t n_rays, int n_samples, float scale,
-                          float* x01, float* std01, nr_stream_t stream);
+                          int sample_major_rows, float* x01, float* std01, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small MLPs on MFMA  -- replaces tcnn.Network{FullyFusedMLP} (field_components/mlp.py:109-113,
@@ -117,7 +122,9 @@ int nr_mlp_bwd(const nr_mlp_t* mlp, const float* x, const float* grad_y, int64_t
  * nr_hash_encode_fwd's `out`; F = feat_f).  directions [n_rays,3] per RAY, sample i belongs to
  * ray i / n_samples; n_samples == 0 means directions are per SAMPLE [n,3] (dynamic actors rotate the
  * view direction of the samples inside their boxes, neurad_encoding.py:210-215).
- * Outputs feature [n,C], sdf [n], alpha [n]. */
+ * Outputs feature [n,C], sdf [n], alpha [n].
+ * rows_sample_major = 1 (needs n_samples > 0): row j of feats / grad_feats is sample (b = j % B,
+ * s = j / B), B = n / n_samples; outputs and their gradients stay at row b*n_samples + s. */
 typedef struct nr_field {
   nr_mlp_t geo;        /* in_dim = L*F, out_dim = 1 + C */
   nr_mlp_t feat;       /* in_dim = C + 16, out_dim = C  */
@@ -130,14 +137,14 @@ typedef struct nr_field_grads {
 } nr_field_grads_t;
 
 int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
-                 int feat_f, const float* directions, int n_samples, int64_t n,
+                 int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,
                  float* feature, float* sdf, float* alpha, nr_stream_t stream);
 /* Backward: grad_feature [n,C], grad_alpha [n], grad_sdf [n] (nullable) ->
  * grad_feats (same strides as feats, overwritten) and parameter grads +=.
  * workspace: n*(C+1) floats of caller-owned scratch (the two launches of the backward hand d_e and
  * d_sdf through it; the library allocates nothing). */
 int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
-                 int feat_f, const float* directions, int n_samples, int64_t n,
+                 int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,
                  const float* grad_feature, const float* grad_alpha, const float* grad_sdf,
                  float* grad_feats, const nr_field_grads_t* grads, float* workspace, nr_stream_t stream);
 
@@ -149,12 +156,16 @@ int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t stream);
  * Proposal field head  -- NeuRADProposalField.get_density after the grid
  * (fields/neurad_field.py:211-212): density = trunc_exp(feats . w), w [in_dim] (Linear(L*F,1,
  * bias=False)).  Backward uses exp(clamp(x,-15,15)) (field_components/activations.py:28-41).
+ * rows_sample_major = 1 (needs n_samples): feats / grad_feats rows are s*B+b, density and
+ * grad_density stay [B,S] (see nr_contract_gaussians).
  * ---------------------------------------------------------------------------------------------- */
 int nr_prop_density_fwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
-                        const float* w, int in_dim, int64_t n, float* density, nr_stream_t stream);
+                        const float* w, int in_dim, int64_t n, int n_samples, int rows_sample_major,
+                        float* density, nr_stream_t stream);
 int nr_prop_density_bwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
-                        const float* w, int in_dim, int64_t n, const float* density,
-                        const float* grad_density, float* grad_feats, float* grad_w, nr_stream_t stream);
+                        const float* w, int in_dim, int64_t n, int n_samples, int rows_sample_major,
+                        const float* density, const float* grad_density, float* grad_feats, float* grad_w,
+                        nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampling  (model_components/ray_samplers.py)

@@ -42,14 +42,14 @@ PROTOTYPES = {
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
-    "nr_contract_gaussians": [P, P, P, P, L, I, F, P, P, P],
+    "nr_contract_gaussians": [P, P, P, P, L, I, F, I, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
-    "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P],
-    "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
+    "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P],
+    "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
     "nr_sh4_fwd": [P, L, P, P],
-    "nr_prop_density_fwd": [P, L, L, I, P, I, L, P, P],
-    "nr_prop_density_bwd": [P, L, L, I, P, I, L, P, P, P, P, P],
+    "nr_prop_density_fwd": [P, L, L, I, P, I, L, I, I, P, P],
+    "nr_prop_density_bwd": [P, L, L, I, P, I, L, I, I, P, P, P, P, P],
     "nr_power_bins": [P, P, P, L, I, F, F, P, P, P],
     "nr_weights_from_density_fwd": [P, P, L, I, P, P],
     "nr_weights_from_density_bwd": [P, P, P, L, I, P, P],
@@ -98,7 +98,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 1:
+        if handle.nr_abi_version() != 2:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -114,11 +114,17 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 //      atomics (ds_add_f32 / ds_cmpst) measured an order of magnitude slower than plain LDS traffic,
 //      so the table uses none: a wave owns its table exclusively, slots are claimed by
 //      write-then-read-back, and lanes that target the same slot take turns through an owner word;
-//   4. after kBwdChunk samples every occupied entry is flushed with 8*F global atomics.
-// Table overflow (fine levels, incoherent lidar/radar rays) falls back to direct global atomics, so
-// the worst case is the plain-atomic kernel plus a fixed scan cost.
+//   4. when the table is three quarters full, and after kBwdChunk samples, every occupied entry is
+//      flushed with 8*F global atomics.  A contribution that finds no slot in four probes goes straight
+//      to memory (incoherent lidar/radar rays: the worst case is the plain-atomic kernel plus a fixed
+//      scan cost).
+// The wave's inputs for iteration i+1 are requested before iteration i is processed (the loop holds no
+// global atomics on its common path, so the loads stay in flight across it), and the sample-major
+// index is advanced incrementally instead of divided out per sample.  PMC (profiles/): the kernel
+// is bound by the memory-side atomic rate on the proposal grids and by per-wave latency on the
+// coarse levels of the main grid.
 #ifndef NR_BWD_CHUNK
-#define NR_BWD_CHUNK 1024
+#define NR_BWD_CHUNK 512
 #endif
 #ifndef NR_BWD_VALS
 #define NR_BWD_VALS 2048
@@ -139,16 +145,42 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int F, int CAP>
+__device__ __forceinline__ void flush_table(unsigned long long* keys, float* vals, float* base, uint32_t mask, int lane,
+                                            bool reset) {
+#pragma unroll 1
+  for (int k = lane; k < CAP * 8; k += NR_WAVE) {
+    const int slot = k >> 3, corner = k & 7;
+    const unsigned long long key = keys[slot];
+    if (key == kEmptyKey) continue;
+    const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
+    const int cy = ((int)((uint32_t)((key >> 21) & 0x1FFFFF) << 11)) >> 11;
+    const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
+    const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const float t = vals[k * F + f];
+      if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
+      if (reset) vals[k * F + f] = 0.0f;
+    }
+  }
+  if (reset) {
+    wave_fence();
+    for (int k = lane; k < CAP; k += NR_WAVE) keys[k] = kEmptyKey;
+    wave_fence();
+  }
+}
+
 template <int F>
 __global__ void __launch_bounds__(256)
-hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings,
-                       int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl,
-                       float* __restrict__ gtable, int64_t n, int S) {
+hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int log2T,
+           const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int S) {
   constexpr int NV = 8 * F;                   // accumulators per cell
   constexpr int CAP = kBwdValFloats / NV;     // cells per wave table
-  __shared__ unsigned long long s_key[4][CAP];
-  __shared__ float s_val[4][CAP * NV];
-  __shared__ int s_owner[4][CAP];
+  constexpr int W = 4, CHUNK = kBwdChunk;
+  __shared__ unsigned long long s_key[W][CAP];
+  __shared__ float s_val[W][CAP * NV];
+  __shared__ int s_owner[W][CAP];
   const int level = blockIdx.y;
   const int lane = nr_lane(), wave = threadIdx.x >> 6;
   unsigned long long* keys = s_key[wave];
@@ -161,32 +193,76 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
   for (int k = lane; k < CAP * NV; k += NR_WAVE) vals[k] = 0.0f;
   wave_fence();
 
-  const int64_t chunk0 = ((int64_t)blockIdx.x * 4 + wave) * kBwdChunk;
-  for (int64_t i = chunk0 + lane; i < chunk0 + kBwdChunk; i += NR_WAVE) {  // wave-uniform trip count
-    const bool valid = i < n;  // no early exit: every lane takes part in the wave scans
+  const int64_t chunk0 = ((int64_t)blockIdx.x * W + wave) * CHUNK;
+  if (chunk0 >= n) return;
+  // storage index of this lane's sample, advanced incrementally: thread i = s * B + b reads sample b * S + s
+  const int64_t B = S > 0 ? n / S : 0;
+  int64_t idx;
+  int64_t rb = 0;  // ray index of the lane's current sample (sample-major walk only)
+  if (S > 0) {
+    const int64_t i = chunk0 + lane;
+    rb = i % B;
+    idx = rb * S + i / B;
+  } else {
+    idx = chunk0 + lane;
+  }
+  const float* gl = gout + (int64_t)level * sl;
+  float nx[3] = {0.0f, 0.0f, 0.0f}, nstd = 0.0f, ng[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) ng[f] = 0.0f;
+  auto fetch = [&](int64_t i) {
+    if (i < n) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) nx[a] = x[idx * 3 + a];
+      if (std != nullptr) nstd = std[idx];
+#pragma unroll
+      for (int f = 0; f < F; ++f) ng[f] = gl[idx * sn + f];
+    }
+  };
+  auto advance = [&]() {
+    if (S > 0) {
+      rb += NR_WAVE;
+      idx += (int64_t)NR_WAVE * S;
+      while (rb >= B) {  // wrapped past the last ray: next sample slot
+        rb -= B;
+        idx -= B * S - 1;
+      }
+    } else {
+      idx += NR_WAVE;
+    }
+  };
+  fetch(chunk0 + lane);
+  int fill = 0;
+#pragma unroll 1
+  for (int64_t i = chunk0 + lane; i < chunk0 + CHUNK; i += NR_WAVE) {
+    const bool valid = i < n;
+    float cx[3], cstd, cg[F];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cx[a] = nx[a];
+    cstd = nstd;
+#pragma unroll
+    for (int f = 0; f < F; ++f) cg[f] = ng[f];
+    advance();
+    if (i + NR_WAVE < chunk0 + CHUNK) fetch(i + NR_WAVE);
     int lo[3];
     float v[8][F];
     if (valid) {
-      const int64_t idx = sample_of_thread(i, n, S);
       float cw[3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {  // floor corner + interpolation weight (ceil is not needed here)
-        const float p = x[idx * 3 + a] * scale;
+      for (int a = 0; a < 3; ++a) {
+        const float p = cx[a] * scale;
         const float fl = floorf(p);
         lo[a] = (int)fl;
         cw[a] = p - fl;
       }
       float r = 1.0f;
-      if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);
-      const float* gi = gout + idx * sn + (int64_t)level * sl;
+      if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * cstd, 1.0f);
       float g[F];
 #pragma unroll
-      for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
+      for (int f = 0; f < F; ++f) g[f] = cg[f] * r;
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner) {
         const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
-        // on an exact grid plane ceil == floor and the "ceil" weight is 0: that corner's value is 0
-        // whichever slot it is credited to, so a cell is identified by its floor corner alone
         const float w = (hx ? cw[0] : 1.0f - cw[0]) * (hy ? cw[1] : 1.0f - cw[1]) * (hz ? cw[2] : 1.0f - cw[2]);
 #pragma unroll
         for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
@@ -200,8 +276,6 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
         for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
     }
     auto same_cell = [&](int lx, int ly, int lz) { return lx == lo[0] && ly == lo[1] && lz == lo[2]; };
-    // 1. fold the upper half-wave onto the lower one where the cells agree (v_permlane32_swap)
-#ifndef NR_BWD_NO_FOLD
     {
       const bool same = same_cell(nr_xor32_i(lo[0]), nr_xor32_i(lo[1]), nr_xor32_i(lo[2]));
 #pragma unroll
@@ -212,18 +286,12 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
           if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
         }
     }
-#endif
-    // 2. segmented inclusive scan over runs of equal cells, all in DPP: Hillis-Steele inside each row
-    //    of 16 lanes (row_shr 1,2,4,8), then the carry of lane 15/31/47 into rows 1,2,3 in turn.
-    //    `flag` = "a run head lies inside the range this lane has covered so far".
     const bool head = lane == 0 || !same_cell(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[0]),
                                               nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]),
                                               nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[2]));
     int flag = head ? 1 : 0;
     auto scan_step = [&](auto ctrl, auto rowmask) {
       constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-      // lanes without a source read (0, 0): no change.  v += t * (flag ? 0 : 1) folds into one
-      // v_fmac_f32_dpp per value, flag |= flag_src into one v_or_b32_dpp.
       const float take = flag ? 0.0f : 1.0f;
 #pragma unroll
       for (int corner = 0; corner < 8; ++corner)
@@ -244,23 +312,25 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
       for (int f = 0; f < F; ++f) mag += fabsf(v[corner][f]);
-    const bool nz = mag != 0.0f;  // also false for NaN-free all-zero runs (padding, folded lanes, zero-weight planes)
+    const bool nz = mag != 0.0f;
     const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
-    // 3a. find or claim the cell's slot in the wave's table: write-then-read-back, 4 linear probes
     const unsigned long long key = pack_cell(lo);
     uint32_t s0 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
     int slot = -1;
+    bool fresh = false;
 #pragma unroll 1
     for (int probe = 0; probe < 4; ++probe) {
       const bool searching = want && slot < 0;
       if (!__any(searching)) break;
-      if (searching && keys[s0] == kEmptyKey) keys[s0] = key;  // several lanes may race: one value sticks
+      const bool was_empty = searching && keys[s0] == kEmptyKey;
+      if (was_empty) keys[s0] = key;
       wave_fence();
       if (searching) {
-        if (keys[s0] == key) slot = (int)s0; else s0 = (s0 + 1) & (CAP - 1);
+        if (keys[s0] == key) { slot = (int)s0; fresh = was_empty; } else s0 = (s0 + 1) & (CAP - 1);
       }
       wave_fence();
     }
+    fill += __popcll(__ballot(fresh));  // upper bound: lanes of one new cell may each count it
     // 3b. lanes sharing a slot take turns (owner word), everyone else adds concurrently: plain RMW
     bool pending = slot >= 0;
 #pragma unroll 1
@@ -276,33 +346,26 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
       }
       wave_fence();
     }
-    if (want && slot < 0) {  // table full around this hash: straight to memory
+    const bool spill = want && slot < 0;
+    if (__any(spill)) {
+      if (spill) {
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner) {
-        const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
+        for (int corner = 0; corner < 8; ++corner) {
+          const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
 #pragma unroll
-        for (int f = 0; f < F; ++f)
-          if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
+          for (int f = 0; f < F; ++f)
+            if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
+        }
       }
+      fill = CAP;  // crowded around some hash: make room
+    }
+    if (fill >= CAP * 3 / 4 && i + NR_WAVE < chunk0 + CHUNK) {
+      flush_table<F, CAP>(keys, vals, base, mask, lane, true);
+      fill = 0;
     }
   }
   wave_fence();
-  // 4. flush: one (entry, corner) pair per lane
-  for (int k = lane; k < CAP * 8; k += NR_WAVE) {
-    const int slot = k >> 3, corner = k & 7;
-    const unsigned long long key = keys[slot];
-    if (key == kEmptyKey) continue;
-    // sign-extend the 21-bit fields back (coordinates are >= 0 for inputs in [0,1], kept general)
-    const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
-    const int cy = ((int)((uint32_t)((key >> 21) & 0x1FFFFF) << 11)) >> 11;
-    const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
-    const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      const float t = vals[k * F + f];
-      if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
-    }
-  }
+  flush_table<F, CAP>(keys, vals, base, mask, lane, false);
 }
 
 // Gradient w.r.t. the input positions (needed only where positions depend on parameters: samples
@@ -354,11 +417,18 @@ hash_encode_bwd_input_kernel(const float* __restrict__ x, const float* __restric
 __global__ void __launch_bounds__(256)
 contract_gaussians_kernel(const float* __restrict__ origins, const float* __restrict__ directions,
                           const float* __restrict__ pixel_area, const float* __restrict__ edges, int64_t n_rays,
-                          int S, float scale, float* __restrict__ x01, float* __restrict__ std01) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                          int S, float scale, int sample_major, float* __restrict__ x01, float* __restrict__ std01) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output row
   if (i >= n_rays * S) return;
-  const int64_t b = i / S;
-  const int s = (int)(i - b * S);
+  int64_t b;
+  int s;
+  if (sample_major) {
+    s = (int)(i / n_rays);
+    b = i - (int64_t)s * n_rays;
+  } else {
+    b = i / S;
+    s = (int)(i - b * S);
+  }
   const float e0 = edges[b * (S + 1) + s], e1 = edges[b * (S + 1) + s + 1];
   // Frustums.get_fast_isotropic_gaussian, one multisample (cameras/rays.py:118-123)
   const float half = (e1 - e0) / 2.0f;
@@ -441,13 +511,13 @@ extern "C" int nr_hash_encode_bwd_input(const float* x, const float* std, const 
 }
 
 extern "C" int nr_contract_gaussians(const float* origins, const float* directions, const float* pixel_area,
-                                     const float* edges, int64_t n_rays, int S, float scale, float* x01, float* std01,
-                                     nr_stream_t stream) {
+                                     const float* edges, int64_t n_rays, int S, float scale, int sample_major, float* x01,
+                                     float* std01, nr_stream_t stream) {
   if (n_rays == 0) return 0;
   if (!origins || !directions || !pixel_area || !edges || !x01 || !std01 || S < 1 || n_rays < 0 || !(scale > 0)) return NR_EINVAL;
   const int64_t n = n_rays * S;
   hipLaunchKernelGGL(contract_gaussians_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), origins,
-                     directions, pixel_area, edges, n_rays, S, scale, x01, std01);
+                     directions, pixel_area, edges, n_rays, S, scale, sample_major, x01, std01);
   NR_LAUNCH_CHECK();
   return 0;
 }

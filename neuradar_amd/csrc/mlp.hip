@@ -94,7 +94,7 @@ __device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], co
 template <int IN, int HID>
 __global__ void __launch_bounds__(256, NR_MLP_FWD_WAVES)
 field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
-                 const float* __restrict__ dirs, int S, int64_t n, float* __restrict__ feature,
+                 const float* __restrict__ dirs, int S, int rows_sm, int64_t n, float* __restrict__ feature,
                  float* __restrict__ sdf_out, float* __restrict__ alpha_out) {
   using I = FieldImage<IN, HID>;
   __shared__ float lw[I::W_TOTAL];
@@ -112,7 +112,8 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
     const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
     cat[0] = e[0];
-    cat[1] = sh_tile(dirs, valid ? (S > 0 ? smp / S : smp) : 0, h);
+    const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
+    cat[1] = sh_tile(dirs, rm.ray, h);
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     dense_fwd<HID, kC, false>(f2, o, lw + I::oF3, i, h);
@@ -121,11 +122,11 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
       for (int q = 0; q < 4; ++q) {  // rows 8q+4h .. +3 are registers 4q..4q+3
         float4 v = make_float4(e[0][4 * q] + o[0][4 * q], e[0][4 * q + 1] + o[0][4 * q + 1],
                                e[0][4 * q + 2] + o[0][4 * q + 2], e[0][4 * q + 3] + o[0][4 * q + 3]);
-        *reinterpret_cast<float4*>(feature + smp * kC + 8 * q + 4 * h) = v;
+        *reinterpret_cast<float4*>(feature + rm.out * kC + 8 * q + 4 * h) = v;
       }
       if (h == 0) {
-        sdf_out[smp] = sdf;
-        alpha_out[smp] = 1.0f / (1.0f + expf(sdf * beta));  // sigmoid(-sdf*beta), utils.py:38
+        sdf_out[rm.out] = sdf;
+        alpha_out[rm.out] = 1.0f / (1.0f + expf(sdf * beta));  // sigmoid(-sdf*beta), utils.py:38
       }
     }
   }
@@ -150,7 +151,7 @@ constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
 template <int IN, int HID>
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
-                      const float* __restrict__ dirs, int S, int64_t n, const float* __restrict__ g_feature,
+                      const float* __restrict__ dirs, int S, int rows_sm, int64_t n, const float* __restrict__ g_feature,
                       const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ ws,
                       nr_field_grads_t grads) {
   using I = FieldImage<IN, HID>;
@@ -185,11 +186,12 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
       sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
       cat[0] = e[0];
     }
-    cat[1] = sh_tile(dirs, valid ? (S > 0 ? smp / S : smp) : 0, h);
+    const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
+    cat[1] = sh_tile(dirs, rm.ray, h);
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2];
-    load_rows<kC>(d_o, g_feature + (valid ? smp * kC : 0), valid, h, [](int k) { return (int64_t)k; });
+    load_rows<kC>(d_o, g_feature + rm.out * kC, valid, h, [](int k) { return (int64_t)k; });
     dense_bwd_dw_reg<HID, kC>(d_o, f2, aF3, bF3, scr, i, h);          // layers[2]: o = V3 f2 + b
     dense_bwd_dx<HID, kC>(d_o, d_f2, lw + I::oF3, i, h);
     relu_mask<HID>(d_f2, f2);
@@ -199,11 +201,11 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
     dense_bwd_dw_reg<kC + kSH, HID>(d_f1, cat, aF1, bF1, scr, i, h);  // layers[0]: input [e ; sh]
     dense_bwd_dx<kC + kSH, HID>(d_f1, d_cat, lw + I::oF1, i, h);
     // alpha = sigmoid(-sdf * beta)
-    const float ga = valid ? g_alpha[smp] : 0.0f;
+    const float ga = valid ? g_alpha[rm.out] : 0.0f;
     const float a = 1.0f / (1.0f + expf(sdf * beta));
     const float dsig = ga * a * (1.0f - a);
     float d_sdf = dsig * (-beta);
-    if (g_sdf != nullptr && valid) d_sdf += g_sdf[smp];
+    if (g_sdf != nullptr && valid) d_sdf += g_sdf[rm.out];
     if (h == 0) d_beta += dsig * (-sdf) * (beta_raw >= 0.0f ? 1.0f : -1.0f);
     if (valid) {  // d_e = d_o + d_cat[0] (residual; SH carries no gradient) and d_sdf -> workspace
       float* w = ws + smp * (kC + 1);
@@ -502,11 +504,12 @@ int check_field(const nr_field_t* f, int* hid) {
 }  // namespace
 
 extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
-                            const float* dirs, int S, int64_t n, float* feature, float* sdf, float* alpha,
-                            nr_stream_t stream) {
+                            const float* dirs, int S, int rows_sample_major, int64_t n, float* feature, float* sdf,
+                            float* alpha, nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 0 || F < 1 || n < 0) return NR_EINVAL;
+  if (rows_sample_major && (S < 1 || n % S != 0)) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
   if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
@@ -514,22 +517,23 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
   if (hid == 32)
-    hipLaunchKernelGGL((field_fwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, feature, sdf, alpha);
+    hipLaunchKernelGGL((field_fwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha);
   else
-    hipLaunchKernelGGL((field_fwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, feature, sdf, alpha);
+    hipLaunchKernelGGL((field_fwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha);
   NR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
-                            const float* dirs, int S, int64_t n, const float* g_feature, const float* g_alpha,
-                            const float* g_sdf, float* g_feats, const nr_field_grads_t* grads, float* workspace,
-                            nr_stream_t stream) {
+                            const float* dirs, int S, int rows_sample_major, int64_t n, const float* g_feature,
+                            const float* g_alpha, const float* g_sdf, float* g_feats, const nr_field_grads_t* grads,
+                            float* workspace, nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
       S < 0 || F < 1 || n < 0)
     return NR_EINVAL;
+  if (rows_sample_major && (S < 1 || n % S != 0)) return NR_EINVAL;
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
@@ -539,10 +543,10 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
   if (hid == 32) {
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, workspace, *grads);
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, *grads);
     hipLaunchKernelGGL((field_bwd_geo_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
   } else {
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, n, g_feature, g_alpha, g_sdf, workspace, *grads);
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, *grads);
     hipLaunchKernelGGL((field_bwd_geo_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
   }
   NR_LAUNCH_CHECK();

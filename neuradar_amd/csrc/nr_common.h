@@ -26,6 +26,29 @@ __device__ __forceinline__ uint32_t nr_hash3(int ix, int iy, int iz, uint32_t ma
   return (((uint32_t)ix * 1u) ^ ((uint32_t)iy * 2654435761u) ^ ((uint32_t)iz * 805459861u)) & mask;
 }
 
+// ---- per-sample row order ------------------------------------------------------------------------
+// The fused step keeps the per-sample arrays that only the hash grid and the MLPs touch (positions,
+// per-level features and their gradients) in SAMPLE-major order, row j = s * B + b, so that a wave's
+// 64 rows are 64 neighbouring rays at one sample slot: coalesced loads AND coherent grid cells.
+// Per-ray scans (weights, resampling, compositing) keep the ray-major order b * S + s; this maps a
+// sample-major row to it.
+struct NrRowMap {
+  int64_t ray, out;  // ray index, ray-major sample index
+};
+__device__ __forceinline__ NrRowMap nr_row_map(int64_t j, int64_t n, int S, bool sample_major) {
+  NrRowMap m;
+  if (S <= 0) {
+    m.ray = j; m.out = j;
+  } else if (!sample_major) {
+    m.ray = j / S; m.out = j;
+  } else {
+    const int64_t B = n / S, s = j / B;
+    m.ray = j - s * B;
+    m.out = m.ray * S + s;
+  }
+  return m;
+}
+
 // ---- ZipNeRF power transform (utils/math.py:541-579), finite-lambda branch ---------------------
 // torch.pow special-cases exponent -1 as a reciprocal; NeuRadar uses lambda = -1.
 __device__ __forceinline__ float nr_pow_lam(float base, float lam) {

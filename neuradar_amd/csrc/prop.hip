@@ -10,18 +10,18 @@ __device__ __forceinline__ float feat_at(const float* feats, int64_t i, int k, i
 
 __global__ void __launch_bounds__(256)
 prop_density_fwd_kernel(const float* __restrict__ feats, int64_t sn, int64_t sl, int F, const float* __restrict__ w,
-                        int in_dim, int64_t n, float* __restrict__ density) {
+                        int in_dim, int64_t n, int S, int rows_sample_major, float* __restrict__ density) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float x = 0.0f;
   for (int k = 0; k < in_dim; ++k) x += feat_at(feats, i, k, sn, sl, F) * w[k];
-  density[i] = expf(x);  // trunc_exp forward (activations.py:33-35)
+  density[nr_row_map(i, n, S, rows_sample_major).out] = expf(x);  // trunc_exp forward (activations.py:33-35)
 }
 
 __global__ void __launch_bounds__(256)
 prop_density_bwd_kernel(const float* __restrict__ feats, int64_t sn, int64_t sl, int F, const float* __restrict__ w,
-                        int in_dim, int64_t n, const float* __restrict__ g_density, float* __restrict__ g_feats,
-                        float* __restrict__ g_w) {
+                        int in_dim, int64_t n, int S, int rows_sample_major, const float* __restrict__ g_density,
+                        float* __restrict__ g_feats, float* __restrict__ g_w) {
   __shared__ float s_gw[64];
   if (threadIdx.x < 64) s_gw[threadIdx.x] = 0.0f;
   __syncthreads();
@@ -32,7 +32,7 @@ prop_density_bwd_kernel(const float* __restrict__ feats, int64_t sn, int64_t sl,
     float x = 0.0f;
     if (valid)
       for (int k = 0; k < in_dim; ++k) x += feat_at(feats, i, k, sn, sl, F) * w[k];
-    const float g = valid ? g_density[i] * expf(fminf(fmaxf(x, -15.0f), 15.0f)) : 0.0f;  // activations.py:38-41
+    const float g = valid ? g_density[nr_row_map(i, n, S, rows_sample_major).out] * expf(fminf(fmaxf(x, -15.0f), 15.0f)) : 0.0f;  // activations.py:38-41
     for (int k = 0; k < in_dim; ++k) {
       const float f = valid ? feat_at(feats, i, k, sn, sl, F) : 0.0f;
       if (valid) g_feats[i * sn + (int64_t)(k / F) * sl + (k % F)] = g * w[k];
@@ -148,24 +148,27 @@ extern "C" int nr_adam_hyper(float* step_t, float* hyper, float lr, float lr_fin
 }
 
 extern "C" int nr_prop_density_fwd(const float* feats, int64_t sn, int64_t sl, int F, const float* w, int in_dim,
-                                   int64_t n, float* density, nr_stream_t stream) {
+                                   int64_t n, int n_samples, int rows_sample_major, float* density,
+                                   nr_stream_t stream) {
   if (n == 0) return 0;
   if (!feats || !w || !density || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
+  if (rows_sample_major && (n_samples < 1 || n % n_samples != 0)) return NR_EINVAL;
   hipLaunchKernelGGL(prop_density_fwd_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), feats, sn,
-                     sl, F, w, in_dim, n, density);
+                     sl, F, w, in_dim, n, n_samples, rows_sample_major, density);
   NR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int nr_prop_density_bwd(const float* feats, int64_t sn, int64_t sl, int F, const float* w, int in_dim,
-                                   int64_t n, const float* density, const float* g_density, float* g_feats, float* g_w,
-                                   nr_stream_t stream) {
+                                   int64_t n, int n_samples, int rows_sample_major, const float* density,
+                                   const float* g_density, float* g_feats, float* g_w, nr_stream_t stream) {
   (void)density;  // the clamped backward needs the pre-activation, which is recomputed from feats
   if (n == 0) return 0;
   if (!feats || !w || !g_density || !g_feats || !g_w || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
+  if (rows_sample_major && (n_samples < 1 || n % n_samples != 0)) return NR_EINVAL;
   const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < 2048 ? nr_cdiv(n, 256) : 2048);
   hipLaunchKernelGGL(prop_density_bwd_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n,
-                     g_density, g_feats, g_w);
+                     n_samples, rows_sample_major, g_density, g_feats, g_w);
   NR_LAUNCH_CHECK();
   return 0;
 }

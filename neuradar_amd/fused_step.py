@@ -137,12 +137,14 @@ class FusedTrainStep:
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
             S, n = self.S[lvl], B * self.S[lvl]
-            check(lib.nr_contract_gaussians(o, d, area, p(self.eu[lvl]), B, S, scale, p(self.x01[lvl]), p(self.std[lvl]), st), "contract")
+            # per-sample rows (positions, grid features, their gradients) are kept SAMPLE-major, row s*B+b
+            # (include/neuradar_hip.h, nr_contract_gaussians); per-ray arrays stay [B,S]
+            check(lib.nr_contract_gaussians(o, d, area, p(self.eu[lvl]), B, S, scale, 1, p(self.x01[lvl]), p(self.std[lvl]), st), "contract")
             check(lib.nr_hash_encode_fwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels,
                                          pg.features_per_level, pg.log2_hashmap_size, p(self.feats[lvl]),
-                                         pg.features_per_level, n * pg.features_per_level, n, S, st), "hash_fwd")
+                                         pg.features_per_level, n * pg.features_per_level, n, 0, st), "hash_fwd")
             check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
-                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, p(self.dens[lvl]), st), "prop_density")
+                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, S, 1, p(self.dens[lvl]), st), "prop_density")
             check(lib.nr_weights_from_density_fwd(p(self.dens[lvl]), p(self.eu[lvl]), B, S, p(self.w[lvl]), st), "weights")
             check(lib.nr_depth_from_weights(p(self.w[lvl]), p(self.eu[lvl]), B, S, p(self.prop_depth[lvl]), st), "prop depth")
             check(lib.nr_pdf_resample(p(self.w[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, B, S, self.S[lvl + 1], lam, scal,
@@ -150,10 +152,10 @@ class FusedTrainStep:
         mg, Sm = self.mgrid, self.S[2]
         n = B * Sm
         F = mg.features_per_level
-        check(lib.nr_contract_gaussians(o, d, area, p(self.eu[2]), B, Sm, scale, p(self.x01[2]), p(self.std[2]), st), "contract")
+        check(lib.nr_contract_gaussians(o, d, area, p(self.eu[2]), B, Sm, scale, 1, p(self.x01[2]), p(self.std[2]), st), "contract")
         check(lib.nr_hash_encode_fwd(p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
-                                     mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, Sm, st), "hash_fwd")
-        check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, n, p(self.feature), p(self.sdf),
+                                     mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
+        check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.feature), p(self.sdf),
                                p(self.alpha), st), "field_fwd")
         check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
                                    p(self.features), p(self.depth), st), "composite_fwd")
@@ -176,10 +178,10 @@ class FusedTrainStep:
                                              p(self.loss), sp_), "interlevel_loss")
                 check(lib.nr_weights_from_density_bwd(p(self.dens[lvl]), p(self.eu[lvl]), p(self.g_w[lvl]), B, S,
                                                       p(self.g_dens[lvl]), sp_), "weights_bwd")
-                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, p(self.dens[lvl]),
+                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, 1, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
                 check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
-                                             pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, S,
+                                             pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0,
                                              sp_), "hash_bwd")
         check(lib.nr_supervision_loss(p(self.features), self.C, p(target_features), target_features.shape[1], p(self.depth),
                                       p(target_depth), B, c.rgb_mult, c.depth_mult, p(self.g_features), p(self.g_depth),
@@ -189,10 +191,10 @@ class FusedTrainStep:
         check(lib.nr_composite_bwd(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.w[2]), p(self.g_features),
                                    p(self.g_depth), None, p(self.g_w[2]), B, Sm, self.C, p(self.g_alpha), p(self.g_feature), st),
               "composite_bwd")
-        check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, n, p(self.g_feature),
+        check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature),
                                p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
         check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
-                                     p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, Sm, st), "hash_bwd")
+                                     p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, 0, st), "hash_bwd")
         if optimizers is not None:
             table_opt, field_opt = optimizers
             scale = 1.0 if reducer is None else 1.0 / reducer.world

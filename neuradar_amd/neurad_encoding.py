@@ -79,30 +79,32 @@ class NeuRADHashEncoding(nn.Module):
         param_groups["hashgrids"] += list(self.static_grid.parameters()) + list(self.actor_grids.parameters())
 
     def encode_samples(self, ray_samples, level_major: bool = True, sample_major: bool = True,
-                       directions: bool = False, flip: Optional[Tensor] = None):
+                       directions: bool = False, flip: Optional[Tensor] = None, rows_sample_major: bool = False):
         """Fast path used by the fields: frustum samples -> raw feature buffer + (stride_n, stride_l)
-        (+ per-sample directions [B*S,3] when actors changed them, else None).
+        (+ per-sample directions [B*S,3] when actors changed them, else None) + whether the buffer's rows
+        are sample-major (row s*B+b; granted on request when no actor grid has to be written over it).
 
         = get_fast_isotropic_gaussian(1) (cameras/rays.py:109-124) -> static_contraction
         (neurad_encoding.py:169) -> static_grid -> _rescale_grid_features (:277-280,309-316) -> actor
         features written over the static ones (:175-187)."""
         g = self.static_grid
         B, S = ray_samples.shape
+        rows_sm = rows_sample_major and self.n_actors == 0
         x01, std01 = ops.contract_gaussians(ray_samples.origins, ray_samples.directions, ray_samples.pixel_area,
-                                            ray_samples.euclid, self.static_scale)
+                                            ray_samples.euclid, self.static_scale, sample_major_rows=rows_sm)
         buf = ops.hash_encode(x01, g.hash_table, g.scalings, g.log2_hashmap_size, std=std01,
-                              level_major=level_major, sample_major=S if sample_major else 0)
+                              level_major=level_major, sample_major=S if (sample_major and not rows_sm) else 0)
         F_, n = g.features_per_level, B * S
         strides = (F_, n * F_) if level_major else (g.get_out_dim(), F_)
         dirs = None
         if self.n_actors > 0:
             dirs = self._overwrite_actor_features(buf, level_major, ray_samples, directions, flip)
-        return buf, strides, dirs
+        return buf, strides, dirs, rows_sm
 
     def forward(self, ray_samples, times: Optional[Tensor] = None, directions: Optional[Tensor] = None
                 ) -> Tuple[Tensor, Optional[Tensor]]:
         """Reference-shaped result: features [B*S, L*F] (torch layout) and the directions."""
-        buf, _, dirs = self.encode_samples(ray_samples, level_major=False, directions=directions is not None)
+        buf, _, dirs, _ = self.encode_samples(ray_samples, level_major=False, directions=directions is not None)
         return buf, (dirs if dirs is not None else directions)
 
     # ------------------------------------------------------------------------------------------ actors

@@ -72,12 +72,13 @@ class NeuRADField(nn.Module):
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False, flip: Optional[Tensor] = None
                 ) -> Dict[FieldHeadNames, Tensor]:
         B, S = ray_samples.shape
-        buf, strides, dirs = self.hashgrid.encode_samples(ray_samples, directions=True, flip=flip)
+        buf, strides, dirs, rows_sm = self.hashgrid.encode_samples(ray_samples, directions=True, flip=flip,
+                                                                   rows_sample_major=True)
         # per-ray directions, or per-sample ones (n_samples = 0) when dynamic actors rotated some of them
         feature, sdf, alpha = ops.field_mlp(buf, strides, self.hashgrid.static_grid.features_per_level,
                                             ray_samples.directions if dirs is None else dirs, S if dirs is None else 0,
                                             B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
-                                            self.sdf_to_density.beta)
+                                            self.sdf_to_density.beta, rows_sample_major=rows_sm)
         return {FieldHeadNames.FEATURE: feature.view(B, S, -1), FieldHeadNames.SDF: sdf.view(B, S, 1),
                 FieldHeadNames.ALPHA: alpha.view(B, S, 1)}
 
@@ -111,9 +112,9 @@ class NeuRADProposalField(nn.Module):
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         B, S = ray_samples.shape
-        buf, strides, _ = self.hashgrid.encode_samples(ray_samples)
+        buf, strides, _, rows_sm = self.hashgrid.encode_samples(ray_samples, rows_sample_major=True)
         density = ops.prop_density(buf, strides, self.hashgrid.static_grid.features_per_level,
-                                   self.density_decoder.weight, B * S)
+                                   self.density_decoder.weight, B * S, n_samples=S, rows_sample_major=rows_sm)
         return density.view(B, S, 1), None
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> dict:

@@ -73,15 +73,17 @@ def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
     return _HashEncode.apply(x, std, table, scalings, log2_hashmap_size, level_major, sample_major)
 
 
-def contract_gaussians(origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid: Tensor, scale: float
-                       ) -> Tuple[Tensor, Tensor]:
-    """Frustum samples -> contracted (x01 [B*S,3], std01 [B*S]).  No gradient (static scene)."""
+def contract_gaussians(origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid: Tensor, scale: float,
+                       sample_major_rows: bool = False) -> Tuple[Tensor, Tensor]:
+    """Frustum samples -> contracted (x01 [B*S,3], std01 [B*S]).  No gradient (static scene).
+    sample_major_rows: row s*B+b instead of b*S+s (include/neuradar_hip.h, nr_contract_gaussians)."""
     B, S = euclid.shape[0], euclid.shape[1] - 1
     x01 = torch.empty((B * S, 3), device=euclid.device, dtype=torch.float32)
     std01 = torch.empty((B * S,), device=euclid.device, dtype=torch.float32)
     check(_lib.lib().nr_contract_gaussians(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
                                            _p(_f32(pixel_area, "pixel_area")), _p(_f32(euclid, "euclid")), B, S,
-                                           float(scale), _p(x01), _p(std01), _stream()), "nr_contract_gaussians")
+                                           float(scale), int(sample_major_rows), _p(x01), _p(std01), _stream()),
+          "nr_contract_gaussians")
     return x01, std01
 
 
@@ -138,7 +140,7 @@ class _Field(torch.autograd.Function):
     """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
 
     @staticmethod
-    def forward(ctx, feats, strides, feat_f, directions, n_samples, n, beta, n_geo, *params):
+    def forward(ctx, feats, strides, feat_f, directions, n_samples, rows_sm, n, beta, n_geo, *params):
         geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
         rest = params[2 * n_geo:]
         n_feat = len(rest) // 2
@@ -150,16 +152,16 @@ class _Field(torch.autograd.Function):
         sdf = torch.empty((n,), device=feats.device, dtype=torch.float32)
         alpha = torch.empty((n,), device=feats.device, dtype=torch.float32)
         sn, sl = strides
-        check(_lib.lib().nr_field_fwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, n,
+        check(_lib.lib().nr_field_fwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(feature), _p(sdf), _p(alpha), _stream()), "nr_field_fwd")
         ctx.save_for_backward(feats, directions, beta, *params)
-        ctx.meta = (strides, feat_f, n_samples, n, n_geo, n_feat)
+        ctx.meta = (strides, feat_f, n_samples, rows_sm, n, n_geo, n_feat)
         return feature, sdf, alpha
 
     @staticmethod
     def backward(ctx, g_feature, g_sdf, g_alpha):
         feats, directions, beta, *params = ctx.saved_tensors
-        (sn, sl), feat_f, n_samples, n, n_geo, n_feat = ctx.meta
+        (sn, sl), feat_f, n_samples, rows_sm, n, n_geo, n_feat = ctx.meta
         geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
         feat_w, feat_b = params[2 * n_geo:2 * n_geo + n_feat], params[2 * n_geo + n_feat:]
         fld = NrField()
@@ -175,17 +177,19 @@ class _Field(torch.autograd.Function):
         g_alpha = torch.zeros((n,), device=feats.device) if g_alpha is None else g_alpha.contiguous()
         g_sdf = None if g_sdf is None else g_sdf.contiguous()
         ws = torch.empty(n * (feat_w[-1].shape[0] + 1), device=feats.device, dtype=torch.float32)
-        check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, n,
+        check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(g_feature), _p(g_alpha), _p(g_sdf), _p(g_feats), byref(gs), _p(ws), _stream()),
               "nr_field_bwd")
-        return (g_feats, None, None, None, None, None, g_beta, None, *grads)
+        return (g_feats, None, None, None, None, None, None, g_beta, None, *grads)
 
 
 def field_mlp(feats: Tensor, strides: Tuple[int, int], feat_f: int, directions: Tensor, n_samples: int, n: int,
-              geo: Tuple[List[Tensor], List[Tensor]], feat: Tuple[List[Tensor], List[Tensor]], beta: Tensor):
+              geo: Tuple[List[Tensor], List[Tensor]], feat: Tuple[List[Tensor], List[Tensor]], beta: Tensor,
+              rows_sample_major: bool = False):
     """NeuRADField after the grid (neurad_field.py:137-148).  feats is the raw buffer written by
-    hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]."""
-    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, n, beta, len(geo[0]),
+    hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]
+    (always in [B,S] order; rows_sample_major: feats rows are s*B+b)."""
+    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, int(rows_sample_major), n, beta, len(geo[0]),
                         *geo[0], *geo[1], *feat[0], *feat[1])
 
 
@@ -199,29 +203,32 @@ def sh4(dirs01: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------ proposal head
 class _PropDensity(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, strides, feat_f, w, n):
+    def forward(ctx, feats, strides, feat_f, w, n, n_samples, rows_sm):
         sn, sl = strides
         density = torch.empty((n,), device=feats.device, dtype=torch.float32)
         wf = _f32(w, "decoder weight").reshape(-1)
-        check(_lib.lib().nr_prop_density_fwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, _p(density), _stream()),
-              "nr_prop_density_fwd")
+        check(_lib.lib().nr_prop_density_fwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, n_samples, rows_sm,
+                                             _p(density), _stream()), "nr_prop_density_fwd")
         ctx.save_for_backward(feats, wf, density)
-        ctx.meta = (strides, feat_f, n, w.shape)
+        ctx.meta = (strides, feat_f, n, w.shape, n_samples, rows_sm)
         return density
 
     @staticmethod
     def backward(ctx, g):
         feats, wf, density = ctx.saved_tensors
-        (sn, sl), feat_f, n, wshape = ctx.meta
+        (sn, sl), feat_f, n, wshape, n_samples, rows_sm = ctx.meta
         g_feats = torch.empty_like(feats)
         g_w = torch.zeros_like(wf)
-        check(_lib.lib().nr_prop_density_bwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, _p(density),
-                                             _p(g.contiguous()), _p(g_feats), _p(g_w), _stream()), "nr_prop_density_bwd")
-        return g_feats, None, None, g_w.view(wshape), None
+        check(_lib.lib().nr_prop_density_bwd(_p(feats), sn, sl, feat_f, _p(wf), wf.numel(), n, n_samples, rows_sm,
+                                             _p(density), _p(g.contiguous()), _p(g_feats), _p(g_w), _stream()),
+              "nr_prop_density_bwd")
+        return g_feats, None, None, g_w.view(wshape), None, None, None
 
 
-def prop_density(feats: Tensor, strides: Tuple[int, int], feat_f: int, w: Tensor, n: int) -> Tensor:
-    return _PropDensity.apply(feats, strides, feat_f, w, n)
+def prop_density(feats: Tensor, strides: Tuple[int, int], feat_f: int, w: Tensor, n: int, n_samples: int = 0,
+                 rows_sample_major: bool = False) -> Tensor:
+    """density [n] in [B,S] order; rows_sample_major: feats rows are s*B+b (needs n_samples)."""
+    return _PropDensity.apply(feats, strides, feat_f, w, n, n_samples, int(rows_sample_major))
 
 
 # ------------------------------------------------------------------------------------------------ sampling

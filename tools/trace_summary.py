@@ -38,4 +38,4 @@ for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{t / 1e3:9.1f} us  x{c:3d}  {k}")
 if len(sys.argv) > 2:
     for r in step:
-        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f}  {name(r)}")
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f}  q{r.get('Queue_Id', '?'):>2}  {name(r)}")
