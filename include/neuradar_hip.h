@@ -129,6 +129,8 @@ typedef struct nr_field {
   nr_mlp_t geo;        /* in_dim = L*F, out_dim = 1 + C */
   nr_mlp_t feat;       /* in_dim = C + 16, out_dim = C  */
   const float* beta;   /* SigmoidDensity.beta, 1 float */
+  const float* packed; /* NULL, or the weight image written by nr_field_pack for these weights:
+                          lets every block load the weights with one 16-byte-wide copy */
 } nr_field_t;
 
 typedef struct nr_field_grads {
@@ -141,8 +143,14 @@ int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t feat_strid
                  float* feature, float* sdf, float* alpha, nr_stream_t stream);
 /* Backward: grad_feature [n,C], grad_alpha [n], grad_sdf [n] (nullable) ->
  * grad_feats (same strides as feats, overwritten) and parameter grads +=.
- * workspace: n*(C+1) floats of caller-owned scratch (the two launches of the backward hand d_e and
- * d_sdf through it; the library allocates nothing). */
+ * workspace: nr_field_bwd_workspace_floats(field, n) floats of caller-owned, 16-byte aligned scratch
+ * (d_e / d_sdf rows handed from the feature half to the geometry half, and one weight-gradient slab
+ * per block that a last launch sums into the gradients; the library allocates nothing). */
+int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_t n);
+/* Weight image for nr_field_t.packed: nr_field_image_floats(field) floats, 16-byte aligned; rebuild it
+ * (nr_field_pack) whenever the weights change, i.e. once per optimizer step. */
+int64_t nr_field_image_floats(const nr_field_t* field);
+int nr_field_pack(const nr_field_t* field, float* image, nr_stream_t stream);
 int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
                  int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,
                  const float* grad_feature, const float* grad_alpha, const float* grad_sdf,
@@ -214,6 +222,20 @@ int nr_composite_bwd(const float* alpha, const float* feature, const float* eucl
 /* render_depth_simple alone (proposal depths, neuradar.py:527-528). */
 int nr_depth_from_weights(const float* weights, const float* euclid, int64_t n_rays, int n_samples,
                           float* depth, nr_stream_t stream);
+
+/* One-launch training tail of a ray batch: nr_composite_fwd, then the bench loss
+ *   rgb_mult * mean((features - target_features)^2) + depth_mult * mean(|depth - target_depth|)
+ *   + distortion_mult * distortion(spacing, weights[:, :S-1])      (losses.py:137-157)
+ * and its backward through nr_composite_bwd, all inside the ray's wavefront (the separate entry
+ * points above compute the same values; this one saves four launches and their round trips).
+ * alpha [n_rays,S], feature [n_rays*S,C], euclid/spacing [n_rays,S+1], targets [n_rays,C]/[n_rays];
+ * S <= 64, C <= 32.  Outputs: weights [n_rays,S], accumulation, depth [n_rays], features [n_rays,C],
+ * grad_alpha [n_rays,S], grad_feature [n_rays*S,C]; loss (NR_LOSS_SLOTS partial sums) +=. */
+int nr_render_train(const float* alpha, const float* feature, const float* euclid, const float* spacing,
+                    const float* target_features, const float* target_depth, int64_t n_rays, int n_samples,
+                    int n_channels, float rgb_mult, float depth_mult, float distortion_mult,
+                    float* weights, float* accumulation, float* features, float* depth,
+                    float* grad_alpha, float* grad_feature, float* loss, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sensor ray generation (device-side; the reference runs these on CPU workers)

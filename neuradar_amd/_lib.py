@@ -26,7 +26,7 @@ class NrMlpGrads(Structure):
 
 
 class NrField(Structure):
-    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p)]
+    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p)]
 
 
 class NrFieldGrads(Structure):
@@ -45,6 +45,9 @@ PROTOTYPES = {
     "nr_contract_gaussians": [P, P, P, P, L, I, F, I, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
+    "nr_field_bwd_workspace_floats": [POINTER(NrField), L],
+    "nr_field_image_floats": [POINTER(NrField)],
+    "nr_field_pack": [POINTER(NrField), P, P],
     "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P],
     "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
     "nr_sh4_fwd": [P, L, P, P],
@@ -56,6 +59,7 @@ PROTOTYPES = {
     "nr_pdf_resample": [P, P, P, P, P, L, I, I, F, F, F, P, P, P],
     "nr_composite_fwd": [P, P, P, L, I, I, P, P, P, P, P],
     "nr_composite_bwd": [P, P, P, P, P, P, P, P, L, I, I, P, P, P],
+    "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P],
     "nr_depth_from_weights": [P, P, L, I, P, P],
     "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
     "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
@@ -67,7 +71,7 @@ PROTOTYPES = {
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }
-_RESTYPES = {"nr_target_arch": c_char_p}
+_RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64}
 
 _lib = None
 

@@ -24,7 +24,7 @@ struct FieldImage {
   using F1 = Layer<kC + kSH, HID>; // mlp_feature.layers[0]
   using F2 = Layer<HID, HID>;
   using F3 = Layer<HID, kC>;
-  static constexpr int SDF = HID + 1 + ((HID + 1) & 1);  // row 0 of mlp_geo.layers[1] + its bias (padded even)
+  static constexpr int SDF = (HID + 1 + 3) / 4 * 4;  // row 0 of mlp_geo.layers[1] + its bias (padded to 16 bytes)
   // weight image offsets
   static constexpr int oG1 = 0, oG2 = oG1 + G1::SIZE, oSdf = oG2 + G2::SIZE, oF1 = oSdf + SDF,
                        oF2 = oF1 + F1::SIZE, oF3 = oF2 + F2::SIZE, W_TOTAL = oF3 + F3::SIZE;
@@ -35,9 +35,26 @@ struct FieldImage {
   static constexpr int HT = (HID + 31) / 32, IT = (IN + 31) / 32;
 };
 
+// Every block of the three field kernels needs the whole weight image in LDS.  Building it from the
+// torch-layout matrices costs five zero-fill + gather passes and barriers PER BLOCK (measured: ~20 us
+// of a 54 us forward); nr_field_pack builds it once per optimizer step into global memory and the
+// blocks copy it with 16-byte loads (f.packed; NULL -> build it here as before).
+template <int COUNT>
+__device__ __forceinline__ void copy_image(float* lw, const float* __restrict__ image) {
+  static_assert(COUNT % 4 == 0, "image prefix must be a multiple of 4 floats");
+  const float4* src = reinterpret_cast<const float4*>(image);
+  float4* dst = reinterpret_cast<float4*>(lw);
+  for (int i = threadIdx.x; i < COUNT / 4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
 template <int IN, int HID>
 __device__ __forceinline__ void load_field_weights(float* lw, const nr_field_t& f) {
   using I = FieldImage<IN, HID>;
+  if (f.packed != nullptr) {
+    copy_image<I::W_TOTAL>(lw, f.packed);
+    return;
+  }
   load_layer<IN, HID>(lw + I::oG1, f.geo.weight[0], f.geo.bias[0], 0);
   load_layer<HID, kC>(lw + I::oG2, f.geo.weight[1], f.geo.bias[1], 1);
   for (int k = threadIdx.x; k < I::SDF; k += blockDim.x)
@@ -97,7 +114,7 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
                  const float* __restrict__ dirs, int S, int rows_sm, int64_t n, float* __restrict__ feature,
                  float* __restrict__ sdf_out, float* __restrict__ alpha_out) {
   using I = FieldImage<IN, HID>;
-  __shared__ float lw[I::W_TOTAL];
+  __shared__ __attribute__((aligned(16))) float lw[I::W_TOTAL];
   load_field_weights<IN, HID>(lw, fld);
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const float beta = fabsf(fld.beta[0]) + kBetaMin;
@@ -153,13 +170,13 @@ __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                       const float* __restrict__ dirs, int S, int rows_sm, int64_t n, const float* __restrict__ g_feature,
                       const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ ws,
-                      nr_field_grads_t grads) {
+                      float* __restrict__ slab) {
   using I = FieldImage<IN, HID>;
   constexpr int kScrPerWave = kBwdScrTiles * kScrTile;
   constexpr int kImg = I::F1::G_SIZE + I::F2::G_SIZE + I::F3::G_SIZE + 2;
   constexpr int kScrTotal = 4 * kScrPerWave > kImg ? 4 * kScrPerWave : kImg;
   constexpr int oF1 = 0, oF2 = oF1 + I::F1::G_SIZE, oF3 = oF2 + I::F2::G_SIZE, oBeta = oF3 + I::F3::G_SIZE;
-  __shared__ float lw[I::W_TOTAL];
+  __shared__ __attribute__((aligned(16))) float lw[I::W_TOTAL];
   __shared__ float scr_all[kScrTotal];  // per-wave staging; reused as the block's gradient image at the end
   load_field_weights<IN, HID>(lw, fld);  // ends with __syncthreads()
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
@@ -227,28 +244,34 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
     }
     __syncthreads();
   }
-  flush_layer_grads<kC + kSH, HID>(img + oF1, grads.feat.weight[0], grads.feat.bias[0], 0);
-  flush_layer_grads<HID, HID>(img + oF2, grads.feat.weight[1], grads.feat.bias[1], 0);
-  flush_layer_grads<HID, kC>(img + oF3, grads.feat.weight[2], grads.feat.bias[2], 0);
-  if (threadIdx.x == 0 && grads.beta) unsafeAtomicAdd(grads.beta, img[oBeta]);
+  // the block's partial sums go to its own slab with plain stores; field_grad_reduce_kernel adds the
+  // slabs up (256 blocks flushing 13.6k floats each with atomics onto the SAME addresses cost ~50 us)
+  float* out = slab + (int64_t)blockIdx.x * I::G_TOTAL + I::gF1;
+  if (threadIdx.x == 0) img[oBeta + 1] = 0.0f;
+  __syncthreads();
+  for (int k = threadIdx.x; k < kImg; k += blockDim.x) out[k] = img[k];
 }
 
 template <int IN, int HID>
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F, int64_t n,
-                     const float* __restrict__ ws, float* __restrict__ g_feats, nr_field_grads_t grads) {
+                     const float* __restrict__ ws, float* __restrict__ g_feats, float* __restrict__ slab) {
   using I = FieldImage<IN, HID>;
   constexpr int kScrPerWave = kBwdScrTiles * kScrTile;
   constexpr int kImg = I::G1::G_SIZE + I::G2::G_SIZE + I::SDF;
   constexpr int kScrTotal = 4 * kScrPerWave > kImg ? 4 * kScrPerWave : kImg;
   constexpr int oG1 = 0, oG2 = oG1 + I::G1::G_SIZE, oSdf = oG2 + I::G2::G_SIZE;
-  __shared__ float lw[I::oF1];  // only the geometry MLP's weights
+  __shared__ __attribute__((aligned(16))) float lw[I::oF1];  // only the geometry MLP's weights: a prefix of the image
   __shared__ float scr_all[kScrTotal];
-  load_layer<IN, HID>(lw + I::oG1, fld.geo.weight[0], fld.geo.bias[0], 0);
-  load_layer<HID, kC>(lw + I::oG2, fld.geo.weight[1], fld.geo.bias[1], 1);
-  for (int k = threadIdx.x; k < I::SDF; k += blockDim.x)
-    lw[I::oSdf + k] = k < HID ? fld.geo.weight[1][k] : (k == HID ? fld.geo.bias[1][0] : 0.0f);
-  __syncthreads();
+  if (fld.packed != nullptr) {
+    copy_image<I::oF1>(lw, fld.packed);
+  } else {
+    load_layer<IN, HID>(lw + I::oG1, fld.geo.weight[0], fld.geo.bias[0], 0);
+    load_layer<HID, kC>(lw + I::oG2, fld.geo.weight[1], fld.geo.bias[1], 1);
+    for (int k = threadIdx.x; k < I::SDF; k += blockDim.x)
+      lw[I::oSdf + k] = k < HID ? fld.geo.weight[1][k] : (k == HID ? fld.geo.bias[1][0] : 0.0f);
+    __syncthreads();
+  }
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   float* scr = scr_all + wave * kScrPerWave;
   f32x16 aG1[I::HT][I::IT], aG2[1][I::HT], aSdf[I::HT];
@@ -324,12 +347,64 @@ field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn
     }
     __syncthreads();
   }
-  flush_layer_grads<IN, HID>(img + oG1, grads.geo.weight[0], grads.geo.bias[0], 0);
-  flush_layer_grads<HID, kC>(img + oG2, grads.geo.weight[1], grads.geo.bias[1], 1);
-  for (int k = threadIdx.x; k <= HID; k += blockDim.x) {
-    if (k < HID) unsafeAtomicAdd(grads.geo.weight[1] + k, img[oSdf + k]);
-    else unsafeAtomicAdd(grads.geo.bias[1], img[oSdf + HID]);
+  float* out = slab + (int64_t)blockIdx.x * I::G_TOTAL + I::gG1;
+  for (int k = HID + 1 + threadIdx.x; k < I::SDF; k += blockDim.x) img[oSdf + k] = 0.0f;  // padding
+  __syncthreads();
+  for (int k = threadIdx.x; k < kImg; k += blockDim.x) out[k] = img[k];
+}
+
+// destination of gradient-image element e in the torch-layout gradients (nullptr: padding)
+template <int IN, int HID>
+__device__ __forceinline__ float* grad_dst(int e, const nr_field_grads_t& g) {
+  using I = FieldImage<IN, HID>;
+  auto dense = [&](int j, int K, int M, float* w, float* b, int row0) -> float* {  // [M][K] then [M]
+    return j < M * K ? w + (int64_t)row0 * K + j : b + row0 + (j - M * K);
+  };
+  if (e < I::gG2) return dense(e - I::gG1, IN, HID, g.geo.weight[0], g.geo.bias[0], 0);
+  if (e < I::gSdf) return dense(e - I::gG2, HID, kC, g.geo.weight[1], g.geo.bias[1], 1);
+  if (e < I::gF1) {
+    const int j = e - I::gSdf;
+    return j < HID ? g.geo.weight[1] + j : (j == HID ? g.geo.bias[1] : nullptr);
   }
+  if (e < I::gF2) return dense(e - I::gF1, kC + kSH, HID, g.feat.weight[0], g.feat.bias[0], 0);
+  if (e < I::gF3) return dense(e - I::gF2, HID, HID, g.feat.weight[1], g.feat.bias[1], 0);
+  if (e < I::gBeta) return dense(e - I::gF3, HID, kC, g.feat.weight[2], g.feat.bias[2], 0);
+  return e == I::gBeta ? g.beta : nullptr;
+}
+
+// grads += sum over the blocks' slabs (one writer per element: plain read-modify-write).  Block =
+// 64 elements x 16 slab groups: every thread adds 16 slabs with independent loads, LDS combines the groups.
+template <int IN, int HID>
+__global__ void __launch_bounds__(1024)
+field_grad_reduce_kernel(const float* __restrict__ slab, int n_slabs, nr_field_grads_t grads) {
+  using I = FieldImage<IN, HID>;
+  __shared__ float part[16][64];
+  const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + ex;
+  float sum = 0.0f;
+  if (e < I::G_TOTAL) {
+#pragma unroll 8
+    for (int b = g; b < n_slabs; b += 16) sum += slab[(int64_t)b * I::G_TOTAL + e];
+  }
+  part[g][ex] = sum;
+  __syncthreads();
+  if (g == 0 && e < I::G_TOTAL) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) sum += part[k][ex];
+    float* dst = grad_dst<IN, HID>(e, grads);
+    if (dst != nullptr) *dst += sum;
+  }
+}
+
+// weight image for load_field_weights' fast path
+template <int IN, int HID>
+__global__ void __launch_bounds__(1024)
+field_pack_kernel(nr_field_t fld, float* __restrict__ image) {
+  using I = FieldImage<IN, HID>;
+  __shared__ __attribute__((aligned(16))) float lw[I::W_TOTAL];
+  fld.packed = nullptr;
+  load_field_weights<IN, HID>(lw, fld);
+  for (int k = threadIdx.x; k < I::W_TOTAL; k += blockDim.x) image[k] = lw[k];
 }
 
 // ---- generic MLP (drop-in for field_components/mlp.py:MLP, e.g. the lidar decoder 48->32->32->2) ----
@@ -530,6 +605,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
                             float* workspace, nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
+  if (((uintptr_t)workspace & 15u) != 0) return NR_EINVAL;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
       S < 0 || F < 1 || n < 0)
     return NR_EINVAL;
@@ -540,15 +616,44 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
   if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
     const int v = atoi(e);
-    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+    if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
+  float* slab = workspace + n * (kC + 1);  // [blocks][G_TOTAL] after the d_e / d_sdf rows
   if (hid == 32) {
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, *grads);
-    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
+    using I = FieldImage<32, 32>;
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);
+    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, slab);
+    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0, nr_s(stream), slab, (int)blocks, *grads);
   } else {
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, *grads);
-    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, *grads);
+    using I = FieldImage<32, 64>;
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);
+    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, slab);
+    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 64>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0, nr_s(stream), slab, (int)blocks, *grads);
   }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_t n) {
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || n < 0) return -1;
+  const int64_t g_total = hid == 32 ? FieldImage<32, 32>::G_TOTAL : FieldImage<32, 64>::G_TOTAL;
+  return n * (kC + 1) + 256 * g_total;  // d_e / d_sdf rows + one gradient slab per block (<= 256 blocks)
+}
+
+extern "C" int64_t nr_field_image_floats(const nr_field_t* field) {
+  int hid = 0;
+  if (check_field(field, &hid) != 0) return -1;
+  return hid == 32 ? FieldImage<32, 32>::W_TOTAL : FieldImage<32, 64>::W_TOTAL;
+}
+
+extern "C" int nr_field_pack(const nr_field_t* field, float* image, nr_stream_t stream) {
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || !image || ((uintptr_t)image & 15u) != 0) return NR_EINVAL;
+  if (hid == 32)
+    hipLaunchKernelGGL((field_pack_kernel<32, 32>), dim3(1), dim3(1024), 0, nr_s(stream), *field, image);
+  else
+    hipLaunchKernelGGL((field_pack_kernel<32, 64>), dim3(1), dim3(1024), 0, nr_s(stream), *field, image);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -97,6 +97,121 @@ composite_bwd_kernel(const float* __restrict__ alpha, const float* __restrict__ 
   if (lane < S) g_alpha[ray * S + lane] = T * (dw - Bv);
 }
 
+// ---- fused render + loss + render-backward of the training step -------------------------------
+// composite_fwd -> supervision loss -> distortion loss -> composite_bwd of ONE ray never leave its
+// wavefront: the five launches (and the weights / g_features / g_depth / g_w round trips between
+// them) become one.  Same arithmetic as the separate kernels, which remain the reference for it
+// (tests/test_gpu_parity.py::test_fused_render_matches_separate_kernels).
+// Lanes = samples for the scans; for the [S, C] feature block lane = (s parity, channel): 2 x 32
+// coalesced 128-B rows per load, kept in registers between the forward sum and the backward dot.
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int KH>  // S <= 2 * KH
+__global__ void __launch_bounds__(256)
+render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ feature, const float* __restrict__ euclid,
+                    const float* __restrict__ spacing, const float* __restrict__ target_f,
+                    const float* __restrict__ target_d, int64_t n_rays, int S, int C, float rgb_mult, float depth_mult,
+                    float dist_mult, float* __restrict__ weights, float* __restrict__ accumulation,
+                    float* __restrict__ features, float* __restrict__ depth, float* __restrict__ g_alpha,
+                    float* __restrict__ g_feature, float* __restrict__ loss) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  // ---- composite forward (neuradar.py:1016, renderers.py:349, neuradar.py:508, neurad.py:721-728) ----
+  const float a = lane < S ? alpha[ray * S + lane] : 0.0f;
+  const float T = excl_transmittance(1.0f - a, lane);
+  float w = lane < S ? a * T : 0.0f;
+  const float acc = nr_wave_sum(w);
+  if (lane == S - 1) w = w + 1.0f - acc;
+  if (lane < S) weights[ray * S + lane] = w;
+  const float* e = euclid + ray * (S + 1);
+  const float mid_e = lane < S - 1 ? (e[lane] + e[lane + 1]) / 2.0f : 0.0f;
+  const float d = nr_wave_sum(lane < S - 1 ? w * mid_e : 0.0f);
+  const int sh = lane >> 5, c = lane & 31;
+  const bool cvalid = c < C;
+  float fr[KH];  // feature[s][c] for s = 2k + sh
+  float fsum = 0.0f;
+  const float* frow = feature + ray * S * C + c;
+#pragma unroll
+  for (int k = 0; k < KH; ++k) {
+    const int s = 2 * k + sh;
+    const float w0 = readlane_f(w, 2 * k), w1 = readlane_f(w, 2 * k + 1);  // lanes past S hold 0
+    fr[k] = (cvalid && s < S) ? frow[(int64_t)s * C] : 0.0f;
+    fsum += fr[k] * (sh ? w1 : w0);
+  }
+  fsum += nr_xor32_f(fsum);  // FeatureRenderer (renderers.py:85)
+  if (lane == 0) {
+    accumulation[ray] = acc;
+    depth[ray] = d;
+  }
+  if (lane < C) features[ray * C + lane] = fsum;
+  // ---- supervision: rgb_mult * mean((f - t)^2) + depth_mult * mean(|d - t|) ----
+  const float kf = rgb_mult / (float)(n_rays * C), kd = depth_mult / (float)n_rays;
+  const float diff = cvalid ? fsum - target_f[ray * C + c] : 0.0f;
+  float lossv = sh == 0 ? kf * diff * diff : 0.0f;
+  const float gF = 2.0f * kf * diff;  // d loss / d features[c], in both halves
+  const float dd = d - target_d[ray];
+  if (lane == 0) lossv += kd * fabsf(dd);
+  const float gD = dd > 0.0f ? kd : (dd < 0.0f ? -kd : 0.0f);
+  // ---- distortion loss on the first S-1 samples (losses.py:137-157; sky sample dropped) ----
+  const int n_used = S - 1;
+  const bool on = lane < n_used;
+  const float* sp = spacing + ray * (S + 1);
+  const float c0 = on ? sp[lane] : 0.0f, c1 = on ? sp[lane + 1] : 0.0f;
+  const float wi = on ? w : 0.0f;
+  const float mid_c = (c1 + c0) / 2.0f;
+  float inner = 0.0f;
+#pragma unroll 1
+  for (int j = 0; j < n_used; ++j) inner += readlane_f(wi, j) * fabsf(mid_c - readlane_f(mid_c, j));
+  const float kdist = dist_mult / (float)n_rays;
+  if (on) lossv += kdist * (wi * inner + wi * wi * (c1 - c0) / 3.0f);
+  const float gW = on ? kdist * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
+  lossv = nr_wave_sum(lossv);
+  if (lane == 0 && lossv != 0.0f) unsafeAtomicAdd(loss + (blockIdx.x & (NR_LOSS_SLOTS - 1)), lossv);
+  // ---- composite backward ----
+  // g_feature[s][c] = gF_c * w_s ; dot_s = sum_c gF_c f[s][c]: 32 values reduced over the 32 lanes of
+  // each half by a halving butterfly (31 exchanges), after which lane (sh, j) holds dot_{2j+sh}
+  float* grow = g_feature + ray * S * C + c;
+  float v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < KH; ++k) {
+    v[k] = gF * fr[k];
+    const int s = 2 * k + sh;
+    const float w0 = readlane_f(w, 2 * k), w1 = readlane_f(w, 2 * k + 1);
+    if (cvalid && s < S) grow[(int64_t)s * C] = gF * (sh ? w1 : w0);
+  }
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {
+    const bool upper = (lane & half) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const float send = upper ? v[k] : v[k + half];
+      const float keep = upper ? v[k + half] : v[k];
+      v[k] = keep + __shfl_xor(send, half, NR_WAVE);
+    }
+  }
+  float G = __shfl(v[0], (lane & 1) * 32 + (lane >> 1), NR_WAVE);  // lane s <- dot_s
+  if (lane >= S) G = 0.0f;
+  G += gD * mid_e + gW;
+  const float G_last = __shfl(G, S - 1, NR_WAVE);
+  const float dw = lane < S ? G - G_last : 0.0f;
+  float A = __shfl_down(1.0f - a, 1, NR_WAVE), Bv = __shfl_down(dw * a, 1, NR_WAVE);
+  if (lane >= S - 1) { A = 0.0f; Bv = 0.0f; }
+#pragma unroll
+  for (int o = 1; o < NR_WAVE; o <<= 1) {
+    const float A2 = __shfl_down(A, o, NR_WAVE), B2 = __shfl_down(Bv, o, NR_WAVE);
+    if (lane + o < NR_WAVE) {
+      Bv = Bv + A * B2;
+      A = A * A2;
+    }
+  }
+  if (lane < S) g_alpha[ray * S + lane] = T * (dw - Bv);
+}
+
 __global__ void __launch_bounds__(256)
 depth_kernel(const float* __restrict__ weights, const float* __restrict__ euclid, int64_t n_rays, int S,
              float* __restrict__ depth) {
@@ -143,6 +258,28 @@ extern "C" int nr_depth_from_weights(const float* weights, const float* euclid, 
   if (!weights || !euclid || !depth || S < 1 || n_rays < 0) return NR_EINVAL;
   hipLaunchKernelGGL(depth_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream), weights,
                      euclid, n_rays, S, depth);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_render_train(const float* alpha, const float* feature, const float* euclid, const float* spacing,
+                               const float* target_features, const float* target_depth, int64_t n_rays, int S, int C,
+                               float rgb_mult, float depth_mult, float distortion_mult, float* weights,
+                               float* accumulation, float* features, float* depth, float* g_alpha, float* g_feature,
+                               float* loss, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!alpha || !feature || !euclid || !spacing || !target_features || !target_depth || !weights || !accumulation ||
+      !features || !depth || !g_alpha || !g_feature || !loss || S < 2 || S > NR_WAVE || C < 1 || C > 32 || n_rays < 0)
+    return NR_EINVAL;
+  const dim3 grid((unsigned)nr_cdiv(n_rays, kWavesPerBlock));
+  if (S <= 32)
+    hipLaunchKernelGGL(render_train_kernel<16>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
+                       target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
+                       accumulation, features, depth, g_alpha, g_feature, loss);
+  else
+    hipLaunchKernelGGL(render_train_kernel<32>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
+                       target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
+                       accumulation, features, depth, g_alpha, g_feature, loss);
   NR_LAUNCH_CHECK();
   return 0;
 }

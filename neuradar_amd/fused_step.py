@@ -81,11 +81,11 @@ class FusedTrainStep:
         self.g_depth = torch.empty(B, **f32)
         self.g_alpha = torch.empty(B * Sm, **f32)
         self.g_feature = torch.empty(B * Sm, C, **f32)
-        self.field_ws = torch.empty(B * Sm * (C + 1), **f32)  # nr_field_bwd workspace
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._structs()
+        self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
 
     def _side_streams(self):
         if self._streams is None:
@@ -100,6 +100,9 @@ class FusedTrainStep:
         self.field_struct = NrField()
         self.field_struct.geo, self.field_struct.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
         self.field_struct.beta = fld.sdf_to_density.beta.data_ptr()
+        # weight image every block of the field kernels copies into LDS; rebuilt at the start of each step
+        self.field_image = torch.empty(self.lib.nr_field_image_floats(byref(self.field_struct)), device=self.dev)
+        self.field_struct.packed = self.field_image.data_ptr()
         self.field_grads = NrFieldGrads()
         self.field_grads.geo = ops._mlp_grads_struct([w.grad for w in gw], [b.grad for b in gb])
         self.field_grads.feat = ops._mlp_grads_struct([w.grad for w in fw], [b.grad for b in fb])
@@ -124,6 +127,9 @@ class FusedTrainStep:
         bucket follow; Adam applies 1/world (DDP's mean)."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
+        assert target_features.shape[1] == self.C and self.C <= 32
+        self.loss.zero_()
+        check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), st), "field_pack")
         if optimizers is not None:
             for o_ in optimizers:
                 o_.advance()
@@ -157,12 +163,14 @@ class FusedTrainStep:
                                      mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
         check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.feature), p(self.sdf),
                                p(self.alpha), st), "field_fwd")
-        check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
-                                   p(self.features), p(self.depth), st), "composite_fwd")
-        # ---- loss tail + backward.  After compositing the step forks into three independent chains
-        #      (main field / proposal round 1 / proposal round 0) that only meet again in the optimizer;
-        #      each runs on its own stream so the mostly latency-bound kernels overlap. ----
-        self.loss.zero_()
+        # composite + supervision + distortion + composite backward of the main level: one launch
+        check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
+                                  p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
+                                  p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
+                                  p(self.g_feature), p(self.loss), st), "render_train")
+        # ---- backward.  After the render launch the step forks into three independent chains (main
+        #      field / proposal round 1 / proposal round 0) that only meet again in the optimizer; each
+        #      runs on its own stream so the mostly latency-bound kernels overlap. ----
         main = torch.cuda.current_stream()
         side = self._side_streams() if self.overlap else [main, main]
         for s_ in side:
@@ -183,14 +191,6 @@ class FusedTrainStep:
                 check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
                                              pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0,
                                              sp_), "hash_bwd")
-        check(lib.nr_supervision_loss(p(self.features), self.C, p(target_features), target_features.shape[1], p(self.depth),
-                                      p(target_depth), B, c.rgb_mult, c.depth_mult, p(self.g_features), p(self.g_depth),
-                                      p(self.loss), st), "supervision_loss")
-        check(lib.nr_distortion_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, B, c.distortion_loss_mult, p(self.g_w[2]),
-                                     p(self.loss), st), "distortion_loss")
-        check(lib.nr_composite_bwd(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.w[2]), p(self.g_features),
-                                   p(self.g_depth), None, p(self.g_w[2]), B, Sm, self.C, p(self.g_alpha), p(self.g_feature), st),
-              "composite_bwd")
         check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature),
                                p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
         check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,

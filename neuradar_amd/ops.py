@@ -176,7 +176,7 @@ class _Field(torch.autograd.Function):
         g_feature = torch.zeros((n, feat_w[-1].shape[0]), device=feats.device) if g_feature is None else g_feature.contiguous()
         g_alpha = torch.zeros((n,), device=feats.device) if g_alpha is None else g_alpha.contiguous()
         g_sdf = None if g_sdf is None else g_sdf.contiguous()
-        ws = torch.empty(n * (feat_w[-1].shape[0] + 1), device=feats.device, dtype=torch.float32)
+        ws = torch.empty(_lib.lib().nr_field_bwd_workspace_floats(byref(fld), n), device=feats.device, dtype=torch.float32)
         check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(g_feature), _p(g_alpha), _p(g_sdf), _p(g_feats), byref(gs), _p(ws), _stream()),
               "nr_field_bwd")

@@ -466,6 +466,42 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
     torch.testing.assert_close(gdp, gdr, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("S,C", [(32, 32), (48, 32), (64, 16), (7, 3)])
+def test_fused_render_matches_separate_kernels(S, C):
+    """nr_render_train == nr_composite_fwd -> nr_supervision_loss -> nr_distortion_loss -> nr_composite_bwd."""
+    from neuradar_amd import _lib, ops
+
+    lib, p, st = _lib.lib(), ops._p, ops._stream
+    torch.manual_seed(S * 100 + C)
+    B = 257
+    f32 = dict(device=DEV, dtype=torch.float32)
+    alpha = torch.rand(B, S, **f32)
+    alpha[::7] = alpha[::7] * 0.05  # some nearly empty rays: the sky fix-up carries most of the weight
+    feature = torch.randn(B * S, C, **f32)
+    sp = torch.sort(torch.rand(B, S + 1, **f32), dim=1).values
+    eu = sp * 80.0 + 0.5
+    tf, td = torch.rand(B, C, **f32), torch.rand(B, **f32) * 60
+    mults = (1.3, 0.02, 0.07)
+
+    def outs():
+        return dict(w=torch.empty(B, S, **f32), acc=torch.empty(B, **f32), f=torch.empty(B, C, **f32), d=torch.empty(B, **f32),
+                    ga=torch.empty(B, S, **f32), gf=torch.empty(B * S, C, **f32), loss=torch.zeros(_lib.NR_LOSS_SLOTS, **f32))
+
+    a, b = outs(), outs()
+    _lib.check(lib.nr_render_train(p(alpha), p(feature), p(eu), p(sp), p(tf), p(td), B, S, C, *mults, p(a["w"]), p(a["acc"]),
+                                   p(a["f"]), p(a["d"]), p(a["ga"]), p(a["gf"]), p(a["loss"]), st()), "render_train")
+    g_f, g_d, g_w = torch.empty(B, C, **f32), torch.empty(B, **f32), torch.empty(B, S, **f32)
+    _lib.check(lib.nr_composite_fwd(p(alpha), p(feature), p(eu), B, S, C, p(b["w"]), p(b["acc"]), p(b["f"]), p(b["d"]), st()), "fwd")
+    _lib.check(lib.nr_supervision_loss(p(b["f"]), C, p(tf), C, p(b["d"]), p(td), B, mults[0], mults[1], p(g_f), p(g_d),
+                                       p(b["loss"]), st()), "sup")
+    _lib.check(lib.nr_distortion_loss(p(sp), S + 1, p(b["w"]), S, S - 1, B, mults[2], p(g_w), p(b["loss"]), st()), "dist")
+    _lib.check(lib.nr_composite_bwd(p(alpha), p(feature), p(eu), p(b["w"]), p(g_f), p(g_d), None, p(g_w), B, S, C, p(b["ga"]),
+                                    p(b["gf"]), st()), "bwd")
+    for k in ("w", "acc", "f", "d", "ga", "gf"):
+        assert_close(cpu(a[k]), cpu(b[k]), rtol=2e-5, atol_scale=2e-6, what=k)
+    assert_close(cpu(a["loss"].sum()), cpu(b["loss"].sum()), rtol=1e-5, atol_scale=1e-6, what="loss")
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""

@@ -1,0 +1,17 @@
+"""Print the kernel timeline (start, duration, queue) of the second-to-last bench step from a
+rocprofv3 kernel_trace.csv (steps are delimited by the patch ray-generation kernel)."""
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+name = lambda r: re.sub(r"\(anonymous namespace\)::|at::native::|void ", "", r["Kernel_Name"])[:60]  # noqa: E731
+idx = [i for i, r in enumerate(rows) if "gen_rays_camera_patches" in r["Kernel_Name"]]
+a, b = idx[-2], idx[-1]
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
+    s = (int(r["Start_Timestamp"]) - t0) / 1e3
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print(f"{s:8.1f} +{d:6.1f} q{r['Queue_Id']} {name(r)}")
+print("step span", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3)
