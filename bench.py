@@ -113,7 +113,6 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
 
         n_p = n_rays // (scene.PATCH * scene.PATCH)
         n_t, n_u = n_rays * (S0 + 1), 3 * n_p
-        fars = torch.full((n_rays,), 1e6, device=dev)  # cameras.py:948
 
         def fwd_bwd():
             # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
@@ -121,7 +120,8 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
             bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
                                                           scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
-            return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], fars, tgt_f, tgt_d[:, 0],
+            # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
+            return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], None, tgt_f, tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None)

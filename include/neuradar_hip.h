@@ -293,6 +293,12 @@ int nr_distortion_loss(const float* c, int c_stride, const float* w, int w_strid
 int nr_interlevel_loss(const float* c, int c_stride, const float* w, int w_stride, int n_used, const float* cp,
                        const float* wp, int n_prop_samples, int64_t n_rays, float pulse, float mult, float* g_wp,
                        float* loss, nr_stream_t stream);
+/* nr_interlevel_loss followed by nr_weights_from_density_bwd of the proposal level in one launch:
+ * density_p [n_rays,Sp], euclid_p [n_rays,Sp+1] -> grad_density_p [n_rays,Sp] (overwritten). */
+int nr_interlevel_loss_to_density(const float* c, int c_stride, const float* w, int w_stride, int n_used,
+                                  const float* c_prop, const float* w_prop, const float* density_prop,
+                                  const float* euclid_prop, int n_prop, int64_t n_rays, float pulse_width,
+                                  float mult, float* grad_density_prop, float* loss, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: dense Adam/AdamW over a flat parameter buffer, one pass (param, grad, m, v), grad

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
+    "nr_interlevel_loss_to_density": [P, I, P, I, I, P, P, P, P, I, L, F, F, P, P, P],
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }

@@ -4,6 +4,7 @@
 // the gradient w.r.t. the weights it consumes in one pass (the inter-level target is detached in the
 // reference, so its gradient is elementwise in the proposal weights).  One wavefront per ray.
 #include "nr_common.h"
+#include "weights_dev.h"
 
 namespace {
 
@@ -65,10 +66,16 @@ distortion_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
 constexpr int kMaxKnots = 66;
 constexpr int kMaxProp = 256;
 
+// ITEMS > 0: the gradient is carried on through RaySamples.get_weights of the proposal level in the
+// same launch (density_p, euclid_p -> g_density_p; nr_weights_from_density_bwd's arithmetic), the
+// proposal-weight gradient never leaves the wavefront's LDS.
+template <int ITEMS>
 __global__ void __launch_bounds__(256)
 interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* __restrict__ w, int w_stride, int n_used,
                        const float* __restrict__ cp, const float* __restrict__ wp, int Sp, int64_t n_rays, float pulse,
-                       float mult, float* __restrict__ g_wp, float* __restrict__ loss) {
+                       float mult, float* __restrict__ g_wp, float* __restrict__ loss,
+                       const float* __restrict__ density_p, const float* __restrict__ euclid_p,
+                       float* __restrict__ g_density_p) {
   __shared__ float s_knot[kWavesPerBlock][kMaxKnots];   // c_  : [0, sorted knots, 1]
   __shared__ float s_val[kWavesPerBlock][kMaxKnots];    // w_  : blurred density at the knots
   __shared__ float s_cdf[kWavesPerBlock][kMaxKnots];    // cdf : integral of the piecewise-linear density
@@ -171,15 +178,38 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   // ---- loss and its gradient w.r.t. the proposal weights (:700-704) ----
   const float k = mult / (float)n_rays;
   float l = 0.0f;
-  for (int j = lane; j < Sp; j += NR_WAVE) {
-    const float target = q[j + 1] - q[j];
-    const float p = wp[ray * Sp + j];
-    const float ex = fmaxf(target - p, 0.0f), den = p + 1e-5f;
-    l += ex * ex / den;
-    g_wp[ray * Sp + j] = k * (-2.0f * ex / den - ex * ex / (den * den));
+  constexpr int kPerLane = kMaxProp / NR_WAVE;
+  float gj[kPerLane];
+#pragma unroll
+  for (int t = 0; t < kPerLane; ++t) {
+    const int j = lane + t * NR_WAVE;
+    gj[t] = 0.0f;
+    if (j < Sp) {
+      const float target = q[j + 1] - q[j];
+      const float p = wp[ray * Sp + j];
+      const float ex = fmaxf(target - p, 0.0f), den = p + 1e-5f;
+      l += ex * ex / den;
+      gj[t] = k * (-2.0f * ex / den - ex * ex / (den * den));
+      if (g_wp != nullptr) g_wp[ray * Sp + j] = gj[t];
+    }
   }
   l = nr_wave_sum(l);
   if (lane == 0) unsafeAtomicAdd(loss_slot(loss), k * l);
+  if constexpr (ITEMS > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read its q[j], q[j+1]
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < kPerLane; ++t) {
+      const int j = lane + t * NR_WAVE;
+      if (j < Sp) q[j] = gj[t];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    nr_weights_bwd_ray<ITEMS>(density_p + ray * Sp, euclid_p + ray * (Sp + 1), [&](int s) { return q[s]; }, Sp,
+                              g_density_p + ray * Sp);
+  }
 }
 
 }  // namespace
@@ -218,8 +248,26 @@ extern "C" int nr_interlevel_loss(const float* c, int c_stride, const float* w, 
   if (!c || !w || !cp || !wp || !g_wp || !loss || n_used < 1 || n_used > 31 || w_stride < n_used ||
       c_stride < n_used + 1 || Sp < 1 || Sp > kMaxProp || !(pulse > 0.0f) || n_rays < 0)
     return NR_EINVAL;
-  hipLaunchKernelGGL(interlevel_loss_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
-                     c, c_stride, w, w_stride, n_used, cp, wp, Sp, n_rays, pulse, mult, g_wp, loss);
+  hipLaunchKernelGGL(interlevel_loss_kernel<0>, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
+                     c, c_stride, w, w_stride, n_used, cp, wp, Sp, n_rays, pulse, mult, g_wp, loss, nullptr, nullptr, nullptr);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_interlevel_loss_to_density(const float* c, int c_stride, const float* w, int w_stride, int n_used,
+                                             const float* cp, const float* wp, const float* density_p,
+                                             const float* euclid_p, int Sp, int64_t n_rays, float pulse, float mult,
+                                             float* g_density_p, float* loss, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!c || !w || !cp || !wp || !density_p || !euclid_p || !g_density_p || !loss || n_used < 1 || n_used > 31 ||
+      w_stride < n_used || c_stride < n_used + 1 || Sp < 1 || Sp > kMaxProp || !(pulse > 0.0f) || n_rays < 0)
+    return NR_EINVAL;
+  const dim3 grid((unsigned)nr_cdiv(n_rays, kWavesPerBlock));
+#define CALL(I)                                                                                                          \
+  hipLaunchKernelGGL(interlevel_loss_kernel<I>, grid, dim3(256), 0, nr_s(stream), c, c_stride, w, w_stride, n_used, cp, wp, \
+                     Sp, n_rays, pulse, mult, nullptr, loss, density_p, euclid_p, g_density_p)
+  if (Sp <= 64) { CALL(1); } else if (Sp <= 128) { CALL(2); } else { CALL(4); }
+#undef CALL
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -2,6 +2,7 @@
 // and inverse-CDF resampling.  One wavefront (64 lanes) owns one ray; lanes hold consecutive
 // samples so the transmittance scan is a shuffle scan, and the CDF lives in LDS for the binary search.
 #include "nr_common.h"
+#include "weights_dev.h"
 
 namespace {
 
@@ -62,39 +63,8 @@ weights_bwd_kernel(const float* __restrict__ density, const float* __restrict__ 
                    int64_t n_rays, int S, float* __restrict__ gdensity) {
   const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
-  const int lane = nr_lane();
-  const float* e = euclid + ray * (S + 1);
-  float dd[ITEMS], delta[ITEMS], local = 0.0f;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const int s = lane * ITEMS + k;
-    delta[k] = s < S ? e[s + 1] - e[s] : 0.0f;
-    dd[k] = s < S ? delta[k] * density[ray * S + s] : 0.0f;
-    local += dd[k];
-  }
-  float excl = nr_wave_excl_sum(local);
-  // w_s = a_s T_s, T_s = exp(-P_s), P_s = sum_{j<s} dd_j
-  //   d dd_s = gw_s T_s exp(-dd_s)  -  sum_{j>s} gw_j w_j
-  float gT[ITEMS], gww[ITEMS], tail = 0.0f;
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const int s = lane * ITEMS + k;
-    const float T = expf(-excl), ex = expf(-dd[k]);
-    const float w = (1.0f - ex) * T;
-    float g = s < S ? gw[ray * S + s] : 0.0f;
-    if (isnan(w) || isinf(w)) g = 0.0f;  // nan_to_num passes no gradient there
-    gT[k] = g * T * ex;
-    gww[k] = g * w;
-    tail += gww[k];
-    excl += dd[k];
-  }
-  float after = nr_wave_excl_suffix_sum(tail);  // sum of g*w over later lanes
-#pragma unroll
-  for (int k = ITEMS - 1; k >= 0; --k) {
-    const int s = lane * ITEMS + k;
-    if (s < S) gdensity[ray * S + s] = (gT[k] - after) * delta[k];
-    after += gww[k];
-  }
+  const float* g = gw + ray * S;
+  nr_weights_bwd_ray<ITEMS>(density + ray * S, euclid + ray * (S + 1), [&](int s) { return g[s]; }, S, gdensity + ray * S);
 }
 
 // ---- PDFSampler (ray_samplers.py:305-376) -----------------------------------------------------

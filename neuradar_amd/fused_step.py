@@ -54,6 +54,7 @@ class FusedTrainStep:
         self.pgrid, self.mgrid = self.prop.hashgrid.static_grid, model.field.hashgrid.static_grid
         self.nears = torch.zeros(B, **f32)
         self.fars = torch.empty(B, **f32)
+        self._fars_is_sky = False
         self.sp, self.eu, self.x01, self.std, self.feats, self.g_feats = [], [], [], [], [], []
         for lvl, S in enumerate(self.S):
             grid = self.pgrid if lvl < 2 else self.mgrid
@@ -128,14 +129,27 @@ class FusedTrainStep:
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
         assert target_features.shape[1] == self.C and self.C <= 32
-        self.loss.zero_()
-        check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), st), "field_pack")
-        if optimizers is not None:
-            for o_ in optimizers:
-                o_.advance()
+        main = torch.cuda.current_stream()
+        side = self._side_streams() if self.overlap else [main, main]
+        # bookkeeping nothing on the sampling rounds depends on runs beside them: loss slots, the field's
+        # weight image, the optimizers' schedule kernels
+        if side[0] is not main:
+            side[0].wait_stream(main)
+        with torch.cuda.stream(side[0]):
+            self.loss.zero_()
+            check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), ops._stream()), "field_pack")
+            if optimizers is not None:
+                for o_ in optimizers:
+                    o_.advance()
         lam, scal = c.power_lambda, c.power_scaling
         o, d, area = p(origins), p(directions), p(pixel_area)
-        torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=self.fars)  # neuradar.py:573
+        if fars is None:  # camera rays: fars = 1e6 (cameras.py:948), clamped to the sky distance (neuradar.py:573)
+            if not self._fars_is_sky:
+                self.fars.fill_(SKY_DISTANCE)
+                self._fars_is_sky = True
+        else:
+            torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=self.fars)  # neuradar.py:573
+            self._fars_is_sky = False
         nears, far = p(self.nears), p(self.fars)
         scale = self.model.field.hashgrid.static_scale
         check(lib.nr_power_bins(nears, far, p(t_rand), B, self.S[0], lam, scal, p(self.sp[0]), p(self.eu[0]), st), "power_bins")
@@ -161,6 +175,8 @@ class FusedTrainStep:
         check(lib.nr_contract_gaussians(o, d, area, p(self.eu[2]), B, Sm, scale, 1, p(self.x01[2]), p(self.std[2]), st), "contract")
         check(lib.nr_hash_encode_fwd(p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
                                      mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
+        if side[0] is not main:
+            main.wait_stream(side[0])
         check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.feature), p(self.sdf),
                                p(self.alpha), st), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
@@ -171,8 +187,6 @@ class FusedTrainStep:
         # ---- backward.  After the render launch the step forks into three independent chains (main
         #      field / proposal round 1 / proposal round 0) that only meet again in the optimizer; each
         #      runs on its own stream so the mostly latency-bound kernels overlap. ----
-        main = torch.cuda.current_stream()
-        side = self._side_streams() if self.overlap else [main, main]
         for s_ in side:
             if s_ is not main:
                 s_.wait_stream(main)
@@ -181,11 +195,10 @@ class FusedTrainStep:
             with torch.cuda.stream(stream):
                 sp_ = ops._stream()
                 S, nl = self.S[lvl], B * self.S[lvl]
-                check(lib.nr_interlevel_loss(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]), p(self.w[lvl]),
-                                             S, B, losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_w[lvl]),
-                                             p(self.loss), sp_), "interlevel_loss")
-                check(lib.nr_weights_from_density_bwd(p(self.dens[lvl]), p(self.eu[lvl]), p(self.g_w[lvl]), B, S,
-                                                      p(self.g_dens[lvl]), sp_), "weights_bwd")
+                check(lib.nr_interlevel_loss_to_density(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]),
+                                                        p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
+                                                        losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
+                                                        p(self.loss), sp_), "interlevel_loss")
                 check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, 1, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
                 check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,

@@ -24,7 +24,7 @@ def _new(n, *shape, device, dtype=torch.float32):
 
 @dataclass
 class Cameras:
-    """Perspective cameras (CameraType.PERSPECTIVE, no lens distortion)."""
+    """Perspective / fisheye cameras with optional lens distortion and rolling shutter (cameras/cameras.py)."""
 
     camera_to_worlds: Tensor  # [C,3,4]
     fx: Tensor  # [C]
@@ -37,6 +37,7 @@ class Cameras:
     rolling_shutter_offsets: Optional[Tensor] = None  # [C,2]
     distortion_params: Optional[Tensor] = None  # [C,6] k1,k2,k3,k4,p1,p2 (cameras.py:100)
     camera_type: Optional[Tensor] = None  # [C] int32: 0 PERSPECTIVE, 1 FISHEYE (ZOD: zod_dataparser.py:261)
+    _far_cache: Optional[Tensor] = None
 
     def generate_rays(self, ray_indices: Tensor) -> RayBundle:
         """RayGenerator.forward: ray_indices [n,3] int64 (camera,row,col) -> RayBundle."""
@@ -72,7 +73,9 @@ class Cameras:
             p(self.height) if rs else None, p(self.distortion_params), p(self.camera_type), p(o), p(d), p(area), p(t), None,
             p(idx), ops._stream()),
             "nr_gen_rays_camera_patches")
-        return RayBundle(o, d, area[:, None], fars=torch.full((n, 1), FAR, device=dev), times=t[:, None]), idx
+        if self._far_cache is None or self._far_cache.shape[0] != n or self._far_cache.device != o.device:
+            self._far_cache = torch.full((n, 1), FAR, device=dev)  # constant (cameras.py:948): one fill, not one per step
+        return RayBundle(o, d, area[:, None], fars=self._far_cache, times=t[:, None]), idx
 
 
 @dataclass

@@ -502,6 +502,31 @@ def test_fused_render_matches_separate_kernels(S, C):
     assert_close(cpu(a["loss"].sum()), cpu(b["loss"].sum()), rtol=1e-5, atol_scale=1e-6, what="loss")
 
 
+@pytest.mark.parametrize("Sp", [64, 128, 200])
+def test_fused_interlevel_to_density_matches_separate_kernels(Sp):
+    from neuradar_amd import _lib, ops
+
+    lib, p, st = _lib.lib(), ops._p, ops._stream
+    torch.manual_seed(Sp)
+    B, S = 130, 32
+    f32 = dict(device=DEV, dtype=torch.float32)
+    c = torch.sort(torch.rand(B, S + 1, **f32), dim=1).values
+    w = torch.softmax(torch.randn(B, S, **f32), dim=1) * 0.9
+    cp = torch.sort(torch.rand(B, Sp + 1, **f32), dim=1).values
+    eup = cp * 70 + 0.1
+    dens = torch.rand(B, Sp, **f32) * 0.3
+    wp = torch.empty(B, Sp, **f32)
+    _lib.check(lib.nr_weights_from_density_fwd(p(dens), p(eup), B, Sp, p(wp), st()), "w")
+    g_w, g_d1, g_d2 = torch.empty(B, Sp, **f32), torch.empty(B, Sp, **f32), torch.empty(B, Sp, **f32)
+    l1, l2 = torch.zeros(_lib.NR_LOSS_SLOTS, **f32), torch.zeros(_lib.NR_LOSS_SLOTS, **f32)
+    _lib.check(lib.nr_interlevel_loss(p(c), S + 1, p(w), S, S - 1, p(cp), p(wp), Sp, B, 0.03, 1.7, p(g_w), p(l1), st()), "il")
+    _lib.check(lib.nr_weights_from_density_bwd(p(dens), p(eup), p(g_w), B, Sp, p(g_d1), st()), "wb")
+    _lib.check(lib.nr_interlevel_loss_to_density(p(c), S + 1, p(w), S, S - 1, p(cp), p(wp), p(dens), p(eup), Sp, B, 0.03, 1.7,
+                                                 p(g_d2), p(l2), st()), "fused")
+    assert_close(cpu(g_d2), cpu(g_d1), rtol=1e-6, atol_scale=1e-7, what="g_density")
+    assert_close(cpu(l2.sum()), cpu(l1.sum()), rtol=1e-6, atol_scale=1e-7, what="loss")
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
