@@ -183,6 +183,12 @@ int nr_prop_density_bwd(const float* feats, int64_t feat_stride_n, int64_t feat_
  * NULL (eval).  -> spacing [n_rays,S+1] (s-space edges), euclid [n_rays,S+1] (metres). */
 int nr_power_bins(const float* nears, const float* fars, const float* t_rand, int64_t n_rays, int n_samples,
                   float lambda, float scaling, float* spacing, float* euclid, nr_stream_t stream);
+/* nr_power_bins followed by nr_contract_gaussians of the same samples in one launch (the step's first
+ * hash-grid launch can follow directly). */
+int nr_power_bins_contract(const float* nears, const float* fars, const float* t_rand, const float* origins,
+                           const float* directions, const float* pixel_area, int64_t n_rays, int n_samples,
+                           float lambda, float scaling, float contraction_scale, int sample_major_rows,
+                           float* spacing, float* euclid, float* x01, float* std01, nr_stream_t stream);
 
 /* RaySamples.get_weights (cameras/rays.py:188-210): density [n_rays,S], euclid [n_rays,S+1] ->
  * weights [n_rays,S] (wavefront scan). */
@@ -201,6 +207,17 @@ int nr_pdf_resample(const float* weights, const float* spacing_in, const float* 
                     const float* nears, const float* fars, int64_t n_rays, int n_in, int n_out,
                     float lambda, float scaling, float sky_distance, float* spacing_out, float* euclid_out,
                     nr_stream_t stream);
+/* One proposal round after its density launch (ProposalNetworkSampler.generate_ray_samples,
+ * ray_samplers.py:623-666, one iteration) in ONE launch: nr_weights_from_density_fwd ->
+ * nr_depth_from_weights -> nr_pdf_resample -> nr_contract_gaussians of the n_out new samples.
+ * density [n_rays,S], euclid/spacing_in [n_rays,S+1] -> weights [n_rays,S], depth [n_rays],
+ * spacing_out/euclid_out [n_rays,n_out+1], x01 [n_rays*n_out,3], std01 [n_rays*n_out]. */
+int nr_proposal_round(const float* density, const float* euclid, const float* spacing_in, const float* jitter,
+                      const float* nears, const float* fars, const float* origins, const float* directions,
+                      const float* pixel_area, int64_t n_rays, int n_samples, int n_out, float lambda,
+                      float scaling, float sky_distance, float contraction_scale, int sample_major_rows,
+                      float* weights, float* depth, float* spacing_out, float* euclid_out, float* x01,
+                      float* std01, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Compositing  -- replaces nerfacc.render_weight_from_alpha + accumulate_along_rays (batched

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "nr_prop_density_fwd": [P, L, L, I, P, I, L, I, I, P, P],
     "nr_prop_density_bwd": [P, L, L, I, P, I, L, I, I, P, P, P, P, P],
     "nr_power_bins": [P, P, P, L, I, F, F, P, P, P],
+    "nr_power_bins_contract": [P, P, P, P, P, P, L, I, F, F, F, I, P, P, P, P, P],
+    "nr_proposal_round": [P, P, P, P, P, P, P, P, P, L, I, I, F, F, F, F, I, P, P, P, P, P, P, P],
     "nr_weights_from_density_fwd": [P, P, L, I, P, P],
     "nr_weights_from_density_bwd": [P, P, P, L, I, P, P],
     "nr_pdf_resample": [P, P, P, P, P, L, I, I, F, F, F, P, P, P],

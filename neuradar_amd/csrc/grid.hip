@@ -429,30 +429,12 @@ contract_gaussians_kernel(const float* __restrict__ origins, const float* __rest
     b = i / S;
     s = (int)(i - b * S);
   }
-  const float e0 = edges[b * (S + 1) + s], e1 = edges[b * (S + 1) + s + 1];
-  // Frustums.get_fast_isotropic_gaussian, one multisample (cameras/rays.py:118-123)
-  const float half = (e1 - e0) / 2.0f;
-  const float t = e0 + 1.0f * half;
-  const float cross = pixel_area[b] * (t * t);
-  float sd = powf(cross * half, 1.0f / 3.0f);
-  float m[3];
-  float mag = 0.0f;
+  float x[3], sd;
+  nr_contract_sample(origins + b * 3, directions + b * 3, pixel_area[b], edges[b * (S + 1) + s], edges[b * (S + 1) + s + 1],
+                     scale, x, sd);
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    m[a] = (origins[b * 3 + a] + directions[b * 3 + a] * t) / scale;  // spatial_distortions.py:133
-    mag = fmaxf(mag, fabsf(m[a]));
-  }
-  sd = sd / scale;
-  if (!(mag < 1.0f)) {  // spatial_distortions.py:107-112 (L-inf norm)
-    const float cm = fmaxf(mag, 1.0f);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) m[a] = (2.0f - (1.0f / cm)) * (m[a] / cm);
-    const float k = powf(2.0f * cm - 1.0f, 1.0f / 3.0f) / cm;
-    sd = sd * (k * k);
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) x01[i * 3 + a] = (m[a] + 2.0f) / 4.0f;  // :135
-  std01[i] = sd / 4.0f;                                               // :136
+  for (int a = 0; a < 3; ++a) x01[i * 3 + a] = x[a];
+  std01[i] = sd;
 }
 
 }  // namespace

@@ -49,6 +49,36 @@ __device__ __forceinline__ NrRowMap nr_row_map(int64_t j, int64_t n, int S, bool
   return m;
 }
 
+// ---- frustum sample -> contracted isotropic Gaussian --------------------------------------------
+// Frustums.get_fast_isotropic_gaussian, one multisample (cameras/rays.py:109-124) followed by
+// ScaledSceneContraction(order=inf) on the GaussiansStd (spatial_distortions.py:103-113,126-136).
+__device__ __forceinline__ void nr_contract_sample(const float* __restrict__ origin, const float* __restrict__ direction,
+                                                   float pixel_area, float e0, float e1, float scale, float (&x01)[3],
+                                                   float& std01) {
+  const float half = (e1 - e0) / 2.0f;
+  const float t = e0 + 1.0f * half;
+  const float cross = pixel_area * (t * t);
+  float sd = powf(cross * half, 1.0f / 3.0f);
+  float m[3];
+  float mag = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    m[a] = (origin[a] + direction[a] * t) / scale;  // spatial_distortions.py:133
+    mag = fmaxf(mag, fabsf(m[a]));
+  }
+  sd = sd / scale;
+  if (!(mag < 1.0f)) {  // spatial_distortions.py:107-112 (L-inf norm)
+    const float cm = fmaxf(mag, 1.0f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m[a] = (2.0f - (1.0f / cm)) * (m[a] / cm);
+    const float k = powf(2.0f * cm - 1.0f, 1.0f / 3.0f) / cm;
+    sd = sd * (k * k);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x01[a] = (m[a] + 2.0f) / 4.0f;  // :135
+  std01 = sd / 4.0f;                                           // :136
+}
+
 // ---- ZipNeRF power transform (utils/math.py:541-579), finite-lambda branch ---------------------
 // torch.pow special-cases exponent -1 as a reciprocal; NeuRadar uses lambda = -1.
 __device__ __forceinline__ float nr_pow_lam(float base, float lam) {

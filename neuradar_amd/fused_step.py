@@ -7,6 +7,7 @@ Sequence = models/neuradar.py:495-548 (get_nff_outputs, training branch) + the b
  + backward + optimizer.  Checked against the autograd path and the oracle in
 tests/test_gpu_parity.py::test_fused_step_matches_autograd_path.
 """
+import os
 from ctypes import byref, c_void_p
 from typing import Dict, List, Optional
 
@@ -39,7 +40,7 @@ def flatten_parameters(params: List[nn.Parameter]) -> Dict[str, Tensor]:
 class FusedTrainStep:
     def __init__(self, model: NeuRadarHotPath, n_rays: int, overlap: bool = True) -> None:
         c = model.config
-        self.overlap = overlap
+        self.overlap = overlap and os.environ.get("NR_STEP_OVERLAP", "1") != "0"  # tuning knob
         self._streams = None
         assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
         assert len(c.num_proposal_samples) == 2
@@ -152,27 +153,28 @@ class FusedTrainStep:
             self._fars_is_sky = False
         nears, far = p(self.nears), p(self.fars)
         scale = self.model.field.hashgrid.static_scale
-        check(lib.nr_power_bins(nears, far, p(t_rand), B, self.S[0], lam, scal, p(self.sp[0]), p(self.eu[0]), st), "power_bins")
+        # launches of the sampling part: bins+contraction, then per round hash grid -> density -> [weights, depth,
+        # resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
+        # gradients) are kept SAMPLE-major, row s*B+b (include/neuradar_hip.h, nr_contract_gaussians);
+        # per-ray arrays stay [B,S].
+        check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, 1, p(self.sp[0]),
+                                         p(self.eu[0]), p(self.x01[0]), p(self.std[0]), st), "power_bins")
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
             S, n = self.S[lvl], B * self.S[lvl]
-            # per-sample rows (positions, grid features, their gradients) are kept SAMPLE-major, row s*B+b
-            # (include/neuradar_hip.h, nr_contract_gaussians); per-ray arrays stay [B,S]
-            check(lib.nr_contract_gaussians(o, d, area, p(self.eu[lvl]), B, S, scale, 1, p(self.x01[lvl]), p(self.std[lvl]), st), "contract")
             check(lib.nr_hash_encode_fwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels,
                                          pg.features_per_level, pg.log2_hashmap_size, p(self.feats[lvl]),
                                          pg.features_per_level, n * pg.features_per_level, n, 0, st), "hash_fwd")
             check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
                                           pg.features_per_level, p(w_dec), w_dec.numel(), n, S, 1, p(self.dens[lvl]), st), "prop_density")
-            check(lib.nr_weights_from_density_fwd(p(self.dens[lvl]), p(self.eu[lvl]), B, S, p(self.w[lvl]), st), "weights")
-            check(lib.nr_depth_from_weights(p(self.w[lvl]), p(self.eu[lvl]), B, S, p(self.prop_depth[lvl]), st), "prop depth")
-            check(lib.nr_pdf_resample(p(self.w[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, B, S, self.S[lvl + 1], lam, scal,
-                                      SKY_DISTANCE if lvl == 1 else 0.0, p(self.sp[lvl + 1]), p(self.eu[lvl + 1]), st), "pdf_resample")
+            check(lib.nr_proposal_round(p(self.dens[lvl]), p(self.eu[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, o, d, area,
+                                        B, S, self.S[lvl + 1], lam, scal, SKY_DISTANCE if lvl == 1 else 0.0, scale, 1,
+                                        p(self.w[lvl]), p(self.prop_depth[lvl]), p(self.sp[lvl + 1]), p(self.eu[lvl + 1]),
+                                        p(self.x01[lvl + 1]), p(self.std[lvl + 1]), st), "proposal_round")
         mg, Sm = self.mgrid, self.S[2]
         n = B * Sm
         F = mg.features_per_level
-        check(lib.nr_contract_gaussians(o, d, area, p(self.eu[2]), B, Sm, scale, 1, p(self.x01[2]), p(self.std[2]), st), "contract")
         check(lib.nr_hash_encode_fwd(p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
                                      mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
         if side[0] is not main:

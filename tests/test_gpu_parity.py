@@ -527,6 +527,49 @@ def test_fused_interlevel_to_density_matches_separate_kernels(Sp):
     assert_close(cpu(l2.sum()), cpu(l1.sum()), rtol=1e-6, atol_scale=1e-7, what="loss")
 
 
+@pytest.mark.parametrize("S,S_out,sky", [(128, 64, 0.0), (64, 32, 20000.0), (48, 48, 0.0)])
+@pytest.mark.parametrize("rows_sm", [0, 1])
+def test_fused_proposal_round_matches_separate_kernels(S, S_out, sky, rows_sm):
+    from neuradar_amd import _lib, ops
+
+    lib, p, st = _lib.lib(), ops._p, ops._stream
+    torch.manual_seed(S + S_out)
+    B = 203
+    f32 = dict(device=DEV, dtype=torch.float32)
+    o, d = torch.randn(B, 3, **f32) * 5, torch.nn.functional.normalize(torch.randn(B, 3, **f32), dim=-1)
+    area = torch.rand(B, **f32) * 1e-5 + 1e-6
+    nears, fars = torch.zeros(B, **f32), torch.full((B,), 20000.0, **f32)
+    t_rand, jit = torch.rand(B, S + 1, **f32), torch.rand(B, **f32)
+    lam, scal, scale = -1.0, 0.1, 100.0
+    # level 0: bins (+ contraction)
+    sp_a, eu_a = torch.empty(B, S + 1, **f32), torch.empty(B, S + 1, **f32)
+    sp_b, eu_b = torch.empty_like(sp_a), torch.empty_like(eu_a)
+    x_a, sd_a, x_b, sd_b = torch.empty(B * S, 3, **f32), torch.empty(B * S, **f32), torch.empty(B * S, 3, **f32), torch.empty(B * S, **f32)
+    _lib.check(lib.nr_power_bins(p(nears), p(fars), p(t_rand), B, S, lam, scal, p(sp_a), p(eu_a), st()), "pb")
+    _lib.check(lib.nr_contract_gaussians(p(o), p(d), p(area), p(eu_a), B, S, scale, rows_sm, p(x_a), p(sd_a), st()), "cg")
+    _lib.check(lib.nr_power_bins_contract(p(nears), p(fars), p(t_rand), p(o), p(d), p(area), B, S, lam, scal, scale, rows_sm,
+                                          p(sp_b), p(eu_b), p(x_b), p(sd_b), st()), "pbc")
+    for got, ref, what in ((sp_b, sp_a, "spacing"), (eu_b, eu_a, "euclid"), (x_b, x_a, "x01"), (sd_b, sd_a, "std01")):
+        assert_close(cpu(got), cpu(ref), rtol=1e-6, atol_scale=1e-7, what=what)
+    # one round
+    dens = torch.rand(B, S, **f32) * 0.2
+    dens[::5] = 0.0
+    w_a, dep_a = torch.empty(B, S, **f32), torch.empty(B, **f32)
+    sp2_a, eu2_a = torch.empty(B, S_out + 1, **f32), torch.empty(B, S_out + 1, **f32)
+    x2_a, sd2_a = torch.empty(B * S_out, 3, **f32), torch.empty(B * S_out, **f32)
+    _lib.check(lib.nr_weights_from_density_fwd(p(dens), p(eu_a), B, S, p(w_a), st()), "w")
+    _lib.check(lib.nr_depth_from_weights(p(w_a), p(eu_a), B, S, p(dep_a), st()), "d")
+    _lib.check(lib.nr_pdf_resample(p(w_a), p(sp_a), p(jit), p(nears), p(fars), B, S, S_out, lam, scal, sky, p(sp2_a), p(eu2_a), st()), "pdf")
+    _lib.check(lib.nr_contract_gaussians(p(o), p(d), p(area), p(eu2_a), B, S_out, scale, rows_sm, p(x2_a), p(sd2_a), st()), "cg2")
+    w_b, dep_b = torch.empty_like(w_a), torch.empty_like(dep_a)
+    sp2_b, eu2_b, x2_b, sd2_b = torch.empty_like(sp2_a), torch.empty_like(eu2_a), torch.empty_like(x2_a), torch.empty_like(sd2_a)
+    _lib.check(lib.nr_proposal_round(p(dens), p(eu_a), p(sp_a), p(jit), p(nears), p(fars), p(o), p(d), p(area), B, S, S_out, lam,
+                                     scal, sky, scale, rows_sm, p(w_b), p(dep_b), p(sp2_b), p(eu2_b), p(x2_b), p(sd2_b), st()), "round")
+    for got, ref, what in ((w_b, w_a, "weights"), (dep_b, dep_a, "depth"), (sp2_b, sp2_a, "spacing_out"), (eu2_b, eu2_a, "euclid_out"),
+                           (x2_b, x2_a, "x01_out"), (sd2_b, sd2_a, "std01_out")):
+        assert_close(cpu(got), cpu(ref), rtol=2e-6, atol_scale=1e-6, what=what)
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
