@@ -90,6 +90,19 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   float* q = s_q[wave];
   const int E = n_used + 1;  // edges of the final level
   const int K = 2 * E;       // blur knots
+  // every global input of the ray is requested up front: the wave is latency-bound, and the LDS fences
+  // below would otherwise pin each load to the phase that consumes it
+  constexpr int kPerLane = kMaxProp / NR_WAVE;
+  float xq[kPerLane + 1], pw[kPerLane];
+#pragma unroll
+  for (int t = 0; t <= kPerLane; ++t) {
+    const int j = lane + t * NR_WAVE;
+    xq[t] = j <= Sp ? cp[ray * (Sp + 1) + j] : 0.0f;
+    if (t < kPerLane) pw[t] = j < Sp ? wp[ray * Sp + j] : 0.0f;
+  }
+  constexpr int NI = ITEMS > 0 ? ITEMS : 1;
+  float dens_p[NI], delta_p[NI];
+  if constexpr (ITEMS > 0) nr_weights_bwd_load<ITEMS>(density_p + ray * Sp, euclid_p + ray * (Sp + 1), Sp, dens_p, delta_p);
   // ---- final-level histogram, remaining mass on the last kept sample (:663-664) ----
   const float wi = lane < n_used ? w[ray * w_stride + lane] : 0.0f;
   const float acc = nr_wave_sum(wi);
@@ -158,8 +171,11 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // ---- query the piecewise-quadratic cdf at the proposal edges (:638-651) ----
   const int NK = K + 2;
-  for (int j = lane; j <= Sp; j += NR_WAVE) {
-    const float x = cp[ray * (Sp + 1) + j];
+#pragma unroll
+  for (int tq = 0; tq <= kPerLane; ++tq) {
+    const int j = lane + tq * NR_WAVE;
+    if (j > Sp) continue;
+    const float x = xq[tq];
     int lo = 0, hi = NK;  // searchsorted(left): first index with knot >= x
     while (lo < hi) {
       const int m = (lo + hi) >> 1;
@@ -178,7 +194,6 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   // ---- loss and its gradient w.r.t. the proposal weights (:700-704) ----
   const float k = mult / (float)n_rays;
   float l = 0.0f;
-  constexpr int kPerLane = kMaxProp / NR_WAVE;
   float gj[kPerLane];
 #pragma unroll
   for (int t = 0; t < kPerLane; ++t) {
@@ -186,7 +201,7 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     gj[t] = 0.0f;
     if (j < Sp) {
       const float target = q[j + 1] - q[j];
-      const float p = wp[ray * Sp + j];
+      const float p = pw[t];
       const float ex = fmaxf(target - p, 0.0f), den = p + 1e-5f;
       l += ex * ex / den;
       gj[t] = k * (-2.0f * ex / den - ex * ex / (den * den));
@@ -207,8 +222,7 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    nr_weights_bwd_ray<ITEMS>(density_p + ray * Sp, euclid_p + ray * (Sp + 1), [&](int s) { return q[s]; }, Sp,
-                              g_density_p + ray * Sp);
+    nr_weights_bwd_ray<ITEMS>(dens_p, delta_p, [&](int s) { return q[s]; }, Sp, g_density_p + ray * Sp);
   }
 }
 

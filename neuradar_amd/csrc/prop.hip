@@ -18,31 +18,47 @@ prop_density_fwd_kernel(const float* __restrict__ feats, int64_t sn, int64_t sl,
   density[nr_row_map(i, n, S, rows_sample_major).out] = expf(x);  // trunc_exp forward (activations.py:33-35)
 }
 
+constexpr int kPropMaxIn = 64;
+
+// IN = compile-time in_dim (0: runtime, up to kPropMaxIn): the weight-gradient partials stay in
+// registers over the thread's whole grid-stride loop and are reduced once per block.
+template <int IN>
 __global__ void __launch_bounds__(256)
 prop_density_bwd_kernel(const float* __restrict__ feats, int64_t sn, int64_t sl, int F, const float* __restrict__ w,
-                        int in_dim, int64_t n, int S, int rows_sample_major, const float* __restrict__ g_density,
+                        int in_dim_rt, int64_t n, int S, int rows_sample_major, const float* __restrict__ g_density,
                         float* __restrict__ g_feats, float* __restrict__ g_w) {
-  __shared__ float s_gw[64];
-  if (threadIdx.x < 64) s_gw[threadIdx.x] = 0.0f;
-  __syncthreads();
-  // block-uniform loop: every lane takes part in the wave reductions, tail lanes contribute zero
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    float x = 0.0f;
-    if (valid)
-      for (int k = 0; k < in_dim; ++k) x += feat_at(feats, i, k, sn, sl, F) * w[k];
-    const float g = valid ? g_density[nr_row_map(i, n, S, rows_sample_major).out] * expf(fminf(fmaxf(x, -15.0f), 15.0f)) : 0.0f;  // activations.py:38-41
-    for (int k = 0; k < in_dim; ++k) {
-      const float f = valid ? feat_at(feats, i, k, sn, sl, F) : 0.0f;
-      if (valid) g_feats[i * sn + (int64_t)(k / F) * sl + (k % F)] = g * w[k];
-      // per-wave reduction of the weight gradient, one LDS atomic per wave and k
-      const float part = nr_wave_sum(g * f);
-      if (nr_lane() == 0) atomicAdd(&s_gw[k], part);
+  constexpr int NI = IN > 0 ? IN : kPropMaxIn;
+  const int in_dim = IN > 0 ? IN : in_dim_rt;
+  __shared__ float s_gw[4][NI];
+  float wk[NI], part[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    wk[k] = k < in_dim ? w[k] : 0.0f;
+    part[k] = 0.0f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float f[NI], x = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      f[k] = k < in_dim ? feat_at(feats, i, k, sn, sl, F) : 0.0f;
+      x += f[k] * wk[k];
+    }
+    const float g = g_density[nr_row_map(i, n, S, rows_sample_major).out] * expf(fminf(fmaxf(x, -15.0f), 15.0f));  // activations.py:38-41
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      if (k < in_dim) g_feats[i * sn + (int64_t)(k / F) * sl + (k % F)] = g * wk[k];
+      part[k] += g * f[k];
     }
   }
+  const int lane = nr_lane(), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const float t = nr_wave_sum(part[k]);
+    if (lane == 0) s_gw[wave][k] = t;
+  }
   __syncthreads();
-  if (threadIdx.x < in_dim) unsafeAtomicAdd(g_w + threadIdx.x, s_gw[threadIdx.x]);
+  if (threadIdx.x < in_dim)
+    unsafeAtomicAdd(g_w + threadIdx.x, s_gw[0][threadIdx.x] + s_gw[1][threadIdx.x] + s_gw[2][threadIdx.x] + s_gw[3][threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -166,9 +182,12 @@ extern "C" int nr_prop_density_bwd(const float* feats, int64_t sn, int64_t sl, i
   if (n == 0) return 0;
   if (!feats || !w || !g_density || !g_feats || !g_w || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
   if (rows_sample_major && (n_samples < 1 || n % n_samples != 0)) return NR_EINVAL;
-  const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < 2048 ? nr_cdiv(n, 256) : 2048);
-  hipLaunchKernelGGL(prop_density_bwd_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n,
-                     n_samples, rows_sample_major, g_density, g_feats, g_w);
+  const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < 1024 ? nr_cdiv(n, 256) : 1024);
+#define CALL(IN)                                                                                                       \
+  hipLaunchKernelGGL(prop_density_bwd_kernel<IN>, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n, \
+                     n_samples, rows_sample_major, g_density, g_feats, g_w)
+  if (in_dim == 6) { CALL(6); } else if (in_dim == 4) { CALL(4); } else if (in_dim == 8) { CALL(8); } else { CALL(0); }
+#undef CALL
   NR_LAUNCH_CHECK();
   return 0;
 }

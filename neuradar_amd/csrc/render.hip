@@ -189,8 +189,12 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
     const bool upper = (lane & half) != 0;
 #pragma unroll
     for (int k = 0; k < half; ++k) {
-      const float send = upper ? v[k] : v[k + half];
-      const float keep = upper ? v[k + half] : v[k];
+      float lo = v[k], hi = v[k + half];
+      // opaque to the optimiser: otherwise the two selects become ONE dynamically indexed read of v[],
+      // which it lowers to a 32-way compare/select chain per element (measured: 4,800 VALU per ray)
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const float send = upper ? lo : hi;
+      const float keep = upper ? hi : lo;
       v[k] = keep + __shfl_xor(send, half, NR_WAVE);
     }
   }

@@ -99,7 +99,9 @@ weights_bwd_kernel(const float* __restrict__ density, const float* __restrict__ 
   const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const float* g = gw + ray * S;
-  nr_weights_bwd_ray<ITEMS>(density + ray * S, euclid + ray * (S + 1), [&](int s) { return g[s]; }, S, gdensity + ray * S);
+  float dens[ITEMS], delta[ITEMS];
+  nr_weights_bwd_load<ITEMS>(density + ray * S, euclid + ray * (S + 1), S, dens, delta);
+  nr_weights_bwd_ray<ITEMS>(dens, delta, [&](int s) { return g[s]; }, S, gdensity + ray * S);
 }
 
 // ---- PDFSampler (ray_samplers.py:305-376) -----------------------------------------------------

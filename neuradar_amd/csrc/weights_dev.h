@@ -3,17 +3,28 @@
 #pragma once
 #include "nr_common.h"
 
-// gw(s) -> dL/dw_s of this ray; writes gdensity[s] for s < S
-template <int ITEMS, typename GwFn>
-__device__ __forceinline__ void nr_weights_bwd_ray(const float* __restrict__ density, const float* __restrict__ e, GwFn gw,
-                                                   int S, float* __restrict__ gdensity) {
+// inputs of one lane: sample lane * ITEMS + k has density dens[k] and width delta[k] (0 past S)
+template <int ITEMS>
+__device__ __forceinline__ void nr_weights_bwd_load(const float* __restrict__ density, const float* __restrict__ e, int S,
+                                                    float (&dens)[ITEMS], float (&delta)[ITEMS]) {
   const int lane = nr_lane();
-  float dd[ITEMS], delta[ITEMS], local = 0.0f;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     const int s = lane * ITEMS + k;
     delta[k] = s < S ? e[s + 1] - e[s] : 0.0f;
-    dd[k] = s < S ? delta[k] * density[s] : 0.0f;
+    dens[k] = s < S ? density[s] : 0.0f;
+  }
+}
+
+// gw(s) -> dL/dw_s of this ray; writes gdensity[s] for s < S
+template <int ITEMS, typename GwFn>
+__device__ __forceinline__ void nr_weights_bwd_ray(const float (&dens)[ITEMS], const float (&delta)[ITEMS], GwFn gw, int S,
+                                                   float* __restrict__ gdensity) {
+  const int lane = nr_lane();
+  float dd[ITEMS], local = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    dd[k] = delta[k] * dens[k];
     local += dd[k];
   }
   float excl = nr_wave_excl_sum(local);
