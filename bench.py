@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch threads of the CPU baseline (intra-op scaling of "
                     "the oracle saturates well below the host's core count)")
     ap.add_argument("--bf16-allreduce", action="store_true", help="all-reduce the table gradients in bf16")
+    ap.add_argument("--dense-allreduce", action="store_true",
+                    help="all-reduce the main table's gradient densely instead of exchanging its non-zero rows")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' + "
                     "--single-device lets the multi-rank code path be exercised on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (functional testing only)")
@@ -290,7 +292,8 @@ def main():
             FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3,
                      max_steps=20001, warmup_steps=500, skip=unused)]
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
-                             table_dtype=torch.bfloat16 if args.bf16_allreduce else None)
+                             table_dtype=torch.bfloat16 if args.bf16_allreduce else None,
+                             sparse_tables=not args.dense_allreduce and not args.autograd)
     scene = SyntheticScene(device, seed=1000 + rank)  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
@@ -399,7 +402,10 @@ def main():
             "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
                        "graph": bool(use_graph), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": reducer.bytes_per_step() if world > 1 else 0},
+                       "grad_allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
+                                                                           if reducer.last_sparse.get("mode") == "sparse" else 0))
+                       if world > 1 else 0,
+                       "main_table_exchange": (reducer.last_sparse or "dense") if world > 1 else None},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -336,6 +336,19 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, i
 int nr_adam_hyper(float* step_t, float* dev_hyper, float lr, float lr_final, int warmup, int max_steps,
                   float beta1, float beta2, nr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sparse exchange of a hash table's gradient between data-parallel ranks (replaces the dense DDP
+ * all-reduce of pipelines/base_pipeline.py:305-307 for tables of which a step touches ~1 % of the rows).
+ * nr_grad_compact: grad [rows, F]; every non-zero row is moved to (idx[pos], val[pos,F]) and zeroed;
+ *   *count += number of non-zero rows (the caller zeroes it); rows beyond `cap` stay in grad.
+ * nr_grad_apply: grad[idx[i]] += val[i] for i < min(*count, cap); indices of one list are unique, the
+ *   caller applies the ranks' lists one after the other so that every rank adds in the same order.
+ * ---------------------------------------------------------------------------------------------- */
+int nr_grad_compact(float* grad, int64_t rows, int row_width, int64_t cap, int* idx, float* val, int* count,
+                    nr_stream_t stream);
+int nr_grad_apply(const int* idx, const float* val, const int* count, int64_t cap, int row_width, float* grad,
+                  nr_stream_t stream);
+
 /* On-device batch assembly for camera patches (the reference samples patches
  * in data/pixel_samplers.py and generates rays on CPU workers): u [n_patches,3] uniform [0,1) ->
  * patch (camera, y0, x0) = (floor(u0*n_cams), floor(u1*(H-span)), floor(u2*(W-span))), span =

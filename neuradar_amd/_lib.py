@@ -72,6 +72,8 @@ PROTOTYPES = {
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
     "nr_interlevel_loss_to_density": [P, I, P, I, I, P, P, P, P, I, L, F, F, P, P, P],
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
+    "nr_grad_compact": [P, L, I, L, P, P, P, P],
+    "nr_grad_apply": [P, P, P, L, I, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64}

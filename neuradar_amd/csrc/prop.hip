@@ -152,7 +152,91 @@ __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict_
   hyper[2] = (float)sqrt(1.0 - pow((double)beta2, k));
 }
 
+// ---- sparse exchange of a hash table's gradient between data-parallel ranks ----------------------
+// A step touches ~1 % of the main table's rows, so the ranks exchange (row, values) lists instead of
+// all-reducing the dense table.  compact: every non-zero row is appended to the list (wave-aggregated
+// counter) and cleared in the table; rows that do not fit `cap` stay where they are and `count` exceeds
+// `cap` (the caller then falls back to the dense all-reduce).  apply: table[row] += values, one list
+// at a time in rank order with plain adds -> every rank computes bit-identical sums.
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_compact_kernel(float* __restrict__ grad, int64_t rows, int64_t cap, int* __restrict__ idx, float* __restrict__ val,
+                    int* __restrict__ count) {
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < rows; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = base + threadIdx.x;
+    float v[F];
+    bool nz = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      v[f] = r < rows ? grad[r * F + f] : 0.0f;
+      nz |= v[f] != 0.0f;
+    }
+    const unsigned long long m = __ballot(nz);
+    if (m == 0) continue;
+    const int lane = nr_lane();
+    int start = 0;
+    if (lane == 0) start = atomicAdd(count, __popcll(m));
+    start = __shfl(start, 0, NR_WAVE);
+    const int64_t pos = start + __popcll(m & ((1ull << lane) - 1ull));
+    if (nz && pos < cap) {
+      idx[pos] = (int)r;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        val[pos * F + f] = v[f];
+        grad[r * F + f] = 0.0f;
+      }
+    }
+  }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_apply_kernel(const int* __restrict__ idx, const float* __restrict__ val, const int* __restrict__ count, int64_t cap,
+                  float* __restrict__ grad) {
+  const int64_t n = *count < cap ? *count : cap;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) grad[r * F + f] += val[i * F + f];
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_grad_compact(float* grad, int64_t rows, int F, int64_t cap, int* idx, float* val, int* count,
+                               nr_stream_t stream) {
+  if (rows == 0) return 0;
+  if (!grad || !idx || !val || !count || rows < 0 || rows > 0x7fffffff || cap < 1) return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(rows, 256) < 2048 ? nr_cdiv(rows, 256) : 2048);
+#define CALL(FF) hipLaunchKernelGGL(grad_compact_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), grad, rows, cap, idx, val, count)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_grad_apply(const int* idx, const float* val, const int* count, int64_t cap, int F, float* grad,
+                             nr_stream_t stream) {
+  if (!idx || !val || !count || !grad || cap < 1) return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(cap, 256) < 1024 ? nr_cdiv(cap, 256) : 1024);
+#define CALL(FF) hipLaunchKernelGGL(grad_apply_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), idx, val, count, cap, grad)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_adam_hyper(float* step_t, float* hyper, float lr, float lr_final, int warmup, int max_steps,
                              float beta1, float beta2, nr_stream_t stream) {

@@ -222,8 +222,11 @@ class FusedTrainStep:
                     reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
                 table_opt.step_buffer(i_prop, scale)
             if reducer is not None:
-                reducer.start(table_opt.buffers[i_main][1])
-                reducer.wait_all()
+                if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
+                    reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
+                else:
+                    reducer.start(table_opt.buffers[i_main][1])
+                    reducer.wait_all()
             table_opt.step_buffer(i_main, scale)
         for s_ in side:
             if s_ is not main:

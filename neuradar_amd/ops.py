@@ -372,3 +372,17 @@ def interlevel_loss(spacing: Tensor, weights: Tensor, n_used: int, prop_spacing:
                                         _p(prop_spacing), _p(prop_weights), prop_weights.shape[1], weights.shape[0],
                                         pulse, mult, _p(g_wp), _p(loss), _stream()), "nr_interlevel_loss")
     return g_wp
+
+
+# ------------------------------------------------------------------------------------------------ sparse gradient lists
+def grad_compact(grad: Tensor, row_width: int, idx: Tensor, val: Tensor, count: Tensor) -> None:
+    """Move the non-zero rows of grad [rows*row_width] into (idx, val), zero them in grad; count += rows found."""
+    g = _f32(grad, "grad")
+    check(_lib.lib().nr_grad_compact(_p(g), g.numel() // row_width, row_width, idx.numel(), _p(idx), _p(val), _p(count),
+                                     _stream()), "nr_grad_compact")
+
+
+def grad_apply(idx: Tensor, val: Tensor, count: Tensor, row_width: int, grad: Tensor) -> None:
+    """grad[idx[i]] += val[i] for i < min(count, len(idx))."""
+    check(_lib.lib().nr_grad_apply(_p(idx), _p(val), _p(count), idx.numel(), row_width, _p(_f32(grad, "grad")), _stream()),
+          "nr_grad_apply")

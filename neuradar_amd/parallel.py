@@ -47,10 +47,14 @@ class GradAllReducer:
     """Mean all-reduce of `.grad` over the world: big tensors in place, small ones via one flat bucket."""
 
     def __init__(self, params: Optional[Iterable[nn.Parameter]], group=None, table_dtype: Optional[torch.dtype] = None,
-                 buffers: Optional[List[torch.Tensor]] = None):
+                 buffers: Optional[List[torch.Tensor]] = None, sparse_tables: bool = True):
         """`params`: parameters whose .grad is reduced; or `buffers`: ready-made flat gradient buffers
-        (FlatAdam.grad_buffers(): one per hash table + one holding every small parameter)."""
+        (FlatAdam.grad_buffers(): one per hash table + one holding every small parameter).
+        sparse_tables: the fused step exchanges the main table's gradient as (row, value) lists
+        (reduce_sparse) instead of all-reducing the dense table."""
         self.group = group
+        self.sparse_tables = sparse_tables
+        self.last_sparse: dict = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.table_dtype = table_dtype
         self._flat: Optional[torch.Tensor] = None
@@ -82,6 +86,55 @@ class GradAllReducer:
             if low is not None:
                 grad.copy_(low)
         self._pending = []
+
+    # ---- sparse table exchange ---------------------------------------------------------------------
+    def reduce_sparse(self, grad: torch.Tensor, row_width: int, cap_rows: Optional[int] = None, ops=None) -> dict:
+        """SUM of `grad` (flat view of a [rows, row_width] table gradient) over the ranks by exchanging the
+        non-zero rows only; result bit-identical on every rank (lists are added in rank order).  Falls back
+        to the dense all-reduce when some rank's list exceeds `cap_rows` (default rows/16).  Synchronous
+        with respect to the current stream; one small host read (the ranks' row counts) per call.
+        `ops`: (compact, apply) callables; default = the HIP kernels (neuradar_amd.ops)."""
+        if self.world == 1:
+            return {"mode": "single"}
+        if ops is None:
+            from . import ops as hip_ops
+            ops = (hip_ops.grad_compact, hip_ops.grad_apply)
+        compact, apply = ops
+        rows = grad.numel() // row_width
+        cap = int(cap_rows) if cap_rows is not None else max(rows // 16, 1)
+        key = (grad.data_ptr(), cap, row_width)
+        st = getattr(self, "_sparse_state", {}).get(key)
+        if st is None:
+            dev = grad.device
+            st = dict(send=torch.zeros(cap * (1 + row_width) + 1, device=dev, dtype=torch.float32),
+                      counts=torch.zeros(self.world, device=dev, dtype=torch.int32))
+            self.__dict__.setdefault("_sparse_state", {})[key] = st
+        send = st["send"]  # [count | idx (int32 bits) x cap | val x cap*row_width]
+        count = send[:1].view(torch.int32)
+        idx = send[1:1 + cap].view(torch.int32)
+        val = send[1 + cap:]
+        count.zero_()
+        compact(grad, row_width, idx, val, count)
+        counts = [st["counts"][r:r + 1] for r in range(self.world)]
+        dist.all_gather(counts, count, group=self.group)
+        n_rows = st["counts"].cpu()
+        max_rows = int(n_rows.max())
+        if max_rows > cap:  # a rank's list does not fit: put the local rows back, reduce densely
+            apply(idx, val, count, row_width, grad)
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_sparse = {"mode": "dense", "rows": n_rows.tolist(), "bytes": grad.numel() * 4}
+            return self.last_sparse
+        m = min(cap, (max_rows + 255) // 256 * 256)
+        # one collective: [count, idx[:m], val[:m*row_width]] of every rank
+        piece = 1 + m + m * row_width
+        out = torch.empty(self.world * piece, device=grad.device, dtype=torch.float32)
+        mine = torch.cat([send[:1 + m], val[:m * row_width]])
+        dist.all_gather([out[r * piece:(r + 1) * piece] for r in range(self.world)], mine, group=self.group)
+        for r in range(self.world):
+            seg = out[r * piece:(r + 1) * piece]
+            apply(seg[1:1 + m].view(torch.int32), seg[1 + m:], seg[:1].view(torch.int32), row_width, grad)
+        self.last_sparse = {"mode": "sparse", "rows": n_rows.tolist(), "bytes": self.world * piece * 4}
+        return self.last_sparse
 
     def bytes_per_step(self) -> int:
         esz = 4 if self.table_dtype is None else torch.empty((), dtype=self.table_dtype).element_size()

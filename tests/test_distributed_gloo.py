@@ -62,6 +62,53 @@ def _worker(rank, world, port, bf16):
     dist.destroy_process_group()
 
 
+def _torch_compact(grad, row_width, idx, val, count):
+    """Test-side CPU stand-in for nr_grad_compact (the product default is the HIP kernel)."""
+    g = grad.view(-1, row_width)
+    rows = (g != 0).any(dim=1).nonzero()[:, 0]
+    k = min(rows.numel(), idx.numel())
+    idx[:k] = rows[:k].to(torch.int32)
+    val[:k * row_width] = g[rows[:k]].reshape(-1)
+    g[rows[:k]] = 0
+    count += rows.numel()
+
+
+def _torch_apply(idx, val, count, row_width, grad):
+    k = min(int(count), idx.numel())
+    grad.view(-1, row_width).index_add_(0, idx[:k].long(), val[:k * row_width].view(k, row_width))
+
+
+def _sparse_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from neuradar_amd.parallel import GradAllReducer, init_distributed
+
+    init_distributed(backend="gloo")
+    rows, F = 1 << 14, 2
+    red = GradAllReducer(None, buffers=[])
+    for trial, density in enumerate((0.01, 0.5)):  # sparse exchange, then the dense fallback (list > rows/16)
+        g = torch.Generator().manual_seed(7 * trial + rank)
+        grad = torch.zeros(rows, F)
+        hit = torch.randperm(rows, generator=g)[:int(rows * density)]
+        grad[hit] = torch.randn(hit.numel(), F, generator=g)
+        dense = grad.clone()
+        dist.all_reduce(dense)
+        flat = grad.view(-1)
+        info = red.reduce_sparse(flat, F, ops=(_torch_compact, _torch_apply))
+        assert info["mode"] == ("sparse" if density < 0.05 else "dense"), info
+        assert torch.allclose(flat.view(rows, F), dense, rtol=1e-6, atol=1e-6)
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(t, gathered[0]) for t in gathered), "ranks disagree bitwise"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sparse_table_exchange():
+    mp.spawn(_sparse_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def _run(bf16):
     mp.spawn(_worker, args=(2, _free_port(), bf16), nprocs=2, join=True)
 

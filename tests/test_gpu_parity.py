@@ -570,6 +570,40 @@ def test_fused_proposal_round_matches_separate_kernels(S, S_out, sky, rows_sm):
         assert_close(cpu(got), cpu(ref), rtol=2e-6, atol_scale=1e-6, what=what)
 
 
+@pytest.mark.parametrize("F", [1, 2, 4])
+def test_sparse_gradient_lists_roundtrip(F):
+    """nr_grad_compact moves exactly the non-zero rows out of the table; nr_grad_apply adds a list back."""
+    from neuradar_amd import ops
+
+    torch.manual_seed(F)
+    rows = 300_001
+    grad = torch.zeros(rows, F, device=DEV)
+    hit = torch.randperm(rows, device=DEV)[:5000]
+    grad[hit] = torch.randn(5000, F, device=DEV)
+    grad[hit[:10], 0] = 0.0  # rows with a zero component still count when another one is non-zero
+    if F == 1:
+        grad[hit[:10]] = 1.0
+    ref = grad.clone()
+    cap = 8192
+    idx = torch.zeros(cap, dtype=torch.int32, device=DEV)
+    val = torch.zeros(cap * F, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.grad_compact(grad.view(-1), F, idx, val, count)
+    n = int(count)
+    assert n == int((ref != 0).any(dim=1).sum()) and float(grad.abs().max()) == 0.0
+    assert torch.equal(torch.sort(idx[:n]).values.long(), torch.sort((ref != 0).any(dim=1).nonzero()[:, 0]).values)
+    ops.grad_apply(idx, val, count, F, grad.view(-1))
+    assert torch.equal(grad, ref)
+    # overflow: rows beyond the capacity stay in the table, count reports the true number
+    small_idx = torch.zeros(1000, dtype=torch.int32, device=DEV)
+    small_val = torch.zeros(1000 * F, device=DEV)
+    count.zero_()
+    ops.grad_compact(grad.view(-1), F, small_idx, small_val, count)
+    assert int(count) == n
+    ops.grad_apply(small_idx, small_val, count, F, grad.view(-1))
+    assert torch.equal(grad, ref)
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
