@@ -114,17 +114,20 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         n_p = n_rays // (scene.PATCH * scene.PATCH)
         n_t, n_u = n_rays * (S0 + 1), 3 * n_p
 
+        # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
+        # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly.
+        # The buffer is refilled for the NEXT step on a side stream as soon as the sampling rounds have read it.
+        r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
+
         def fwd_bwd():
-            # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
-            # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly
-            r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
             bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
                                                           scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
             # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
             return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], None, tgt_f, tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
-                                            reducer=reducer if (fuse_optimizer and reducer.world > 1) else None)
+                                            reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
+                                            after_sampling=r.uniform_)
     else:
         def fwd_bwd():
             bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))

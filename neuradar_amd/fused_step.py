@@ -113,7 +113,7 @@ class FusedTrainStep:
     # -------------------------------------------------------------------------------------------
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
-                         jitter2: Tensor, optimizers=None, reducer=None) -> Tensor:
+                         jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
@@ -122,6 +122,10 @@ class FusedTrainStep:
         training only -- with several ranks the gradient all-reduce has to come first): the proposal
         table is stepped on its side stream as soon as both proposal chains are done, overlapping the
         main field's backward.
+
+        after_sampling: optional callable run on a side stream once the sampling rounds have consumed the
+        step's random numbers (t_rand, jitters) -- the caller refills them there for the NEXT step, off the
+        critical path.
 
         reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The SUM
         all-reduce of the proposal table's gradient is issued as soon as both proposal chains finish and
@@ -179,6 +183,11 @@ class FusedTrainStep:
                                      mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
         if side[0] is not main:
             main.wait_stream(side[0])
+        if after_sampling is not None:
+            if side[1] is not main:
+                side[1].wait_stream(main)
+            with torch.cuda.stream(side[1]):
+                after_sampling()
         check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.feature), p(self.sdf),
                                p(self.alpha), st), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
