@@ -117,7 +117,11 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
         # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly.
         # The buffer is refilled for the NEXT step on a side stream as soon as the sampling rounds have read it.
+        from neuradar_amd import ops as hip_ops
+
         r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
+        seed = 0x5EED0000 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)  # seed + rank
+        epoch = opts[0].step_t  # device-resident step counter (advanced by the optimizer's schedule kernel)
 
         def fwd_bwd():
             bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
@@ -127,7 +131,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
-                                            after_sampling=r.uniform_)
+                                            after_sampling=lambda: hip_ops.uniform_fill(r, seed, epoch))
     else:
         def fwd_bwd():
             bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))

@@ -364,6 +364,11 @@ int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, in
                                float* pixel_area, float* times, float* directions_norm, int64_t* ray_indices,
                                nr_stream_t stream);
 
+/* U[0,1) numbers for the per-step jitters (the reference uses torch.rand: ray_samplers.py:111,326,
+ * pixel_samplers.py): counter-based, value i of draw number *epoch (a device-resident float counter, e.g.
+ * the optimizer's step; NULL = 0) for this seed.  24 random bits per value, like torch's float32 rand. */
+int nr_uniform_fill(float* out, int64_t n, uint32_t seed, const float* epoch, nr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

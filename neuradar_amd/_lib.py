@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C neuradar_amd/csrc`).
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
@@ -75,6 +75,7 @@ PROTOTYPES = {
     "nr_grad_compact": [P, L, I, L, P, P, P, P],
     "nr_grad_apply": [P, P, P, L, I, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
+    "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64}
 

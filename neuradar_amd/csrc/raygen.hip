@@ -213,7 +213,36 @@ gen_rays_radar_kernel(const int64_t* __restrict__ scan_indices, int64_t n_scans,
   spher[i * 2 + 1] = el;
 }
 
+// ---- counter-based uniform numbers for the per-step jitters ---------------------------------------
+// The reference draws them with torch.rand (ray_samplers.py:111,326; pixel_samplers.py); any U[0,1)
+// source serves.  Inside a replayed hipGraph torch's generator costs two extra bookkeeping launches per
+// replay, so the step uses this: value i of draw `epoch` = 24 random bits of a PCG-style hash.
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+  uint32_t state = v * 747796405u + 2891336453u;
+  uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+  return (word >> 22u) ^ word;
+}
+
+__global__ void __launch_bounds__(256)
+uniform_fill_kernel(float* __restrict__ out, int64_t n, uint32_t seed, const float* __restrict__ epoch) {
+  const uint32_t e = epoch != nullptr ? (uint32_t)epoch[0] : 0u;
+  const uint32_t key = pcg_hash(seed ^ pcg_hash(e * 0x9E3779B9u + 0x85EBCA6Bu));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = pcg_hash((uint32_t)i ^ pcg_hash((uint32_t)(i >> 32) + key));
+    out[i] = (float)(h >> 8) * (1.0f / 16777216.0f);
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_uniform_fill(float* out, int64_t n, uint32_t seed, const float* epoch, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!out || n < 0) return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(n, 1024) < 2048 ? nr_cdiv(n, 1024) : 2048);
+  hipLaunchKernelGGL(uniform_fill_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), out, n, seed, epoch);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_gen_rays_camera(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy,
                                   const float* cx, const float* cy, const float* cam_times, const float* velocities,

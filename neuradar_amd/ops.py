@@ -386,3 +386,9 @@ def grad_apply(idx: Tensor, val: Tensor, count: Tensor, row_width: int, grad: Te
     """grad[idx[i]] += val[i] for i < min(count, len(idx))."""
     check(_lib.lib().nr_grad_apply(_p(idx), _p(val), _p(count), idx.numel(), row_width, _p(_f32(grad, "grad")), _stream()),
           "nr_grad_apply")
+
+
+def uniform_fill(out: Tensor, seed: int, epoch: Optional[Tensor] = None) -> Tensor:
+    """out <- U[0,1), draw number `epoch[0]` (device float counter) of the stream `seed` (nr_uniform_fill)."""
+    check(_lib.lib().nr_uniform_fill(_p(_f32(out, "out")), out.numel(), seed & 0xFFFFFFFF, _p(epoch), _stream()), "nr_uniform_fill")
+    return out

@@ -604,6 +604,27 @@ def test_sparse_gradient_lists_roundtrip(F):
     assert torch.equal(grad, ref)
 
 
+def test_uniform_fill_is_uniform_and_counter_based():
+    from neuradar_amd import ops
+
+    n = 1 << 20
+    a, b, c = (torch.empty(n, device=DEV) for _ in range(3))
+    epoch = torch.tensor([3.0], device=DEV)
+    ops.uniform_fill(a, 1234, epoch)
+    ops.uniform_fill(b, 1234, epoch)
+    assert torch.equal(a, b)  # same (seed, epoch) -> same numbers
+    epoch += 1
+    ops.uniform_fill(c, 1234, epoch)
+    assert not torch.equal(a, c)
+    for t in (a, c):
+        assert float(t.min()) >= 0.0 and float(t.max()) < 1.0
+        assert abs(float(t.mean()) - 0.5) < 2e-3 and abs(float(t.var()) - 1.0 / 12.0) < 1e-3
+        hist = torch.histc(t, bins=64, min=0.0, max=1.0) / n
+        assert float((hist - 1.0 / 64).abs().max()) < 1e-3
+    assert abs(float(torch.corrcoef(torch.stack([a, c]))[0, 1])) < 5e-3
+    assert abs(float(torch.corrcoef(torch.stack([a[:-1], a[1:]]))[0, 1])) < 5e-3
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
