@@ -40,6 +40,10 @@ WORKLOADS = {
                                                     log2_hashmap_size=22), hidden=32),
     "cam16384_l16f2_w64": dict(rays=16384, grid=dict(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024,
                                                      log2_hashmap_size=19), hidden=64),
+    # BASELINE.json configs[2] shape: 8 192 camera rays (8 patches) + 4 661 lidar points + 1 ZOD radar scan
+    # (107 x 33 = 3 531 rays) = 16 384 rays, NeuRadar's own field; fp32 (the bf16 MLP of configs[2] is not built)
+    "mixed16384_neuradar": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1,
+                                grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
 }
 
 
@@ -82,6 +86,29 @@ class SyntheticScene:
                                torch.tensor([[-0.015, 0.015]]).repeat(n, 1).to(device))
         self.n_cams = n
         self.device = device
+        # lidar on the roof, radar in the bumper, same trajectory: 64-beam sweep, ranges U(2,150) m,
+        # 10 % non-returns (range 2000 m > the 1e3 m did_return threshold, lidars.py:404); ZOD radar FOV grid
+        from neuradar_amd.sensors import Lidars, Radars
+
+        l2w = torch.zeros(n, 3, 4)
+        l2w[:, :, :3] = torch.eye(3)
+        l2w[:, 0, 3] = -50.0 + 5.0 * t
+        l2w[:, 2, 3] = 1.9
+        self.lidars = Lidars(l2w.to(device), t.to(device), torch.tensor([[5.0, 0.0, 0.0]]).repeat(n, 1).to(device))
+        n_pts = 200_000
+        az = 2 * math.pi * torch.rand(n_pts, generator=g)
+        el = torch.deg2rad(-25.0 + 40.0 * torch.randint(0, 64, (n_pts,), generator=g).float() / 63.0)
+        rng = 2.0 + 148.0 * torch.rand(n_pts, generator=g)
+        rng[torch.rand(n_pts, generator=g) < 0.1] = 2000.0
+        pts = torch.stack([rng * torch.cos(el) * torch.cos(az), rng * torch.cos(el) * torch.sin(az), rng * torch.sin(el),
+                           torch.rand(n_pts, generator=g), 0.1 * torch.rand(n_pts, generator=g)], dim=1)
+        self.lidar_points = pts.to(device)
+        self.lidar_owner = torch.randint(0, n, (n_pts,), generator=g).to(device)
+        r2w = l2w.clone()
+        r2w[:, 2, 3] = 0.5
+        self.radars = Radars(r2w.to(device), t.to(device), radar_azimuth_ray_divergence=0.015,  # zod_dataparser.py:138-140
+                             radar_elevation_ray_divergence=0.015, min_azimuth=-0.80, max_azimuth=0.80,
+                             min_elevation=-0.08, max_elevation=0.4)
         ar = torch.arange(self.PATCH, device=device) * self.STRIDE
         self.dy, self.dx = torch.meshgrid(ar, ar, indexing="ij")
 
@@ -96,7 +123,7 @@ class SyntheticScene:
         return idx.reshape(-1, 3)
 
 
-def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=False):
+def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=False, mixed=None):
     """Returns (fwd_bwd, optim) closures; together they are one training step.
 
     fused=True: the autograd-free FusedTrainStep (the same kernels, chained by hand over preallocated
@@ -111,19 +138,45 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         S0 = model.config.num_proposal_samples[0]
         dev = tgt_f.device
 
-        n_p = n_rays // (scene.PATCH * scene.PATCH)
+        n_cam = mixed["cam_rays"] if mixed is not None else n_rays
+        n_lidar, n_scans = (mixed["lidar_rays"], mixed["radar_scans"]) if mixed is not None else (0, 0)
+        n_p = n_cam // (scene.PATCH * scene.PATCH)
         n_t, n_u = n_rays * (S0 + 1), 3 * n_p
+        if mixed is not None:
+            n_az, n_el = scene.radars.grid_shape()
+            assert n_cam + n_lidar + n_scans * n_az * n_el == n_rays, "mixed workload: ray counts must add up"
 
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
         # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly.
         # The buffer is refilled for the NEXT step on a side stream as soon as the sampling rounds have read it.
         from neuradar_amd import ops as hip_ops
 
-        r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
+        r = torch.rand(n_t + 2 * n_rays + n_u + n_lidar + n_scans, device=dev)
         seed = 0x5EED0000 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)  # seed + rank
         epoch = opts[0].step_t  # device-resident step counter (advanced by the optimizer's schedule kernel)
 
+        def fwd_bwd_mixed():
+            # camera patches + lidar points + one radar scan, merged like _merge_img_lidar_radar
+            # (image_lidar_radar_datamanager.py:335-409); sensor indices come from the same uniform buffer
+            from neuradar_amd.sensors import merge_bundles
+
+            u = r[n_t + 2 * n_rays:]
+            cam, _ = scene.cameras.generate_patch_rays(u[:n_u].view(n_p, 3), scene.PATCH, scene.STRIDE, scene.H, scene.W,
+                                                       area_scale=9.0)
+            pick = (u[n_u:n_u + n_lidar] * scene.lidar_points.shape[0]).long().clamp_(max=scene.lidar_points.shape[0] - 1)
+            lid = scene.lidars.generate_rays(scene.lidar_owner[pick], scene.lidar_points[pick])
+            scans = (u[n_u + n_lidar:n_u + n_lidar + n_scans] * scene.n_cams).long().clamp_(max=scene.n_cams - 1)
+            rad = scene.radars.generate_rays(scans)
+            b = merge_bundles(cam, lid, rad)
+            return stepper.forward_backward(b.origins, b.directions, b.pixel_area[:, 0], b.fars[:, 0], tgt_f, tgt_d[:, 0],
+                                            r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
+                                            optimizers=opts if fuse_optimizer else None,
+                                            reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
+                                            after_sampling=lambda: hip_ops.uniform_fill(r, seed, epoch))
+
         def fwd_bwd():
+            if mixed is not None:
+                return fwd_bwd_mixed()
             bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
                                                           scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
             # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
@@ -148,7 +201,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         for o in opts:
             o.step()
 
-    return fwd_bwd, optim
+    return fwd_bwd, optim, (stepper if fused else None)
 
 
 def time_kernel(fn, iters=20):
@@ -306,8 +359,8 @@ def main():
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
     # fused step: optimizer (and for world > 1 the overlapped gradient all-reduce) inside forward_backward
     fuse_opt = not args.autograd
-    fwd_bwd, optim = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd,
-                               fuse_optimizer=fuse_opt)
+    fwd_bwd, optim, stepper = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd,
+                                        fuse_optimizer=fuse_opt, mixed=wl if "cam_rays" in wl else None)
 
     # world > 1: the RCCL collectives are issued between kernels of the step, so the step is launched
     # eagerly (the fused step is ~45 launches: the CPU stays ahead of the GPU)
@@ -385,15 +438,42 @@ def main():
     value = world * n_rays * args.steps / elapsed
 
     roof, cpu = None, None
-    if rank == 0 and not args.no_roofline:
+    mlp_times = {}
+    if not args.no_roofline and stepper is not None:
+        # the hash-grid (and field) launches timed LIVE inside the step: HIP events on the stream each launch
+        # runs on, the same eager step as above (graph replays cannot carry per-kernel events), 20 steps
+        stepper.timers = {}
+        for _ in range(20):
+            fwd_bwd()
+            optim()
+        barrier()
+        times = stepper.kernel_times()
+        stepper.timers = None
+        S0, S1 = model.config.num_proposal_samples
+        Sm = model.config.num_nerf_samples
+        pgd, mgd = model.proposal_fields[1].hashgrid.static_grid, model.field.hashgrid.static_grid
+        shapes = {f"prop_s{S0}": (n_rays * S0, pgd), f"prop_s{S1}": (n_rays * S1, pgd), f"main_s{Sm}": (n_rays * Sm, mgd)}
+        rows = []
+        for name, sec in times.items():
+            if not name.startswith("hash_encode"):
+                mlp_times[name] = sec
+                continue
+            nn, gd = shapes[name[name.index("[") + 1:-1]]
+            fwd_bytes = nn * gd.num_levels * 8 * gd.features_per_level * 4  # N*L*8*F*4 B gathered
+            rows.append(dict(kernel=name, seconds=sec, bytes=fwd_bytes * (2 if "bwd" in name else 1)))
+    elif rank == 0 and not args.no_roofline:
         rows = roofline_probe(model, scene, n_rays)
+    if rank == 0 and not args.no_roofline:
         dom = max(rows, key=lambda r: r["seconds"])
         achieved = dom["bytes"] / dom["seconds"] / 1e9
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.workload, dom["kernel"]),
                 "avg_us": round(dom["seconds"] * 1e6, 2), "bytes_per_launch": dom["bytes"],
+                "timing": "HIP events around the launch inside the running step (other streams' kernels overlap it)"
+                if stepper is not None else "HIP events, kernel alone",
                 "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
-                                      "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows]}
+                                      "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows],
+                "field_mlp_us": {k: round(v * 1e6, 2) for k, v in mlp_times.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(args.cpu_threads, os.cpu_count() or 1)
         cpu_rate, n_timed = cpu_baseline(wl, args.cpu_sample_rays, threads)

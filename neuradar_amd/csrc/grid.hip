@@ -114,23 +114,25 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 //      atomics (ds_add_f32 / ds_cmpst) measured an order of magnitude slower than plain LDS traffic,
 //      so the table uses none: a wave owns its table exclusively, slots are claimed by
 //      write-then-read-back, and lanes that target the same slot take turns through an owner word;
-//   4. when the table is three quarters full, and after kBwdChunk samples, every occupied entry is
-//      flushed with 8*F global atomics.  A contribution that finds no slot in four probes goes straight
-//      to memory (incoherent lidar/radar rays: the worst case is the plain-atomic kernel plus a fixed
-//      scan cost).
+//   4. before an insert would push the table past three quarters full, and after the wave's CHUNK
+//      samples, the occupied entries are flushed: their slots are compacted into a list first, then
+//      lane = (entry, corner, feature) with the feature index fastest, so the F floats of a corner are F
+//      adjacent lanes of ONE atomic wave-instruction and leave the L2 as one request (consecutive
+//      instructions of one lane never merge: the F = 4 flush went from 189 to 87 us, incoherent lidar
+//      rays from 2.0 to 0.55 ms).  A contribution that still finds no slot in four probes goes straight
+//      to memory.
 // The wave's inputs for iteration i+1 are requested before iteration i is processed (the loop holds no
 // global atomics on its common path, so the loads stay in flight across it), and the sample-major
-// index is advanced incrementally instead of divided out per sample.  PMC (profiles/): the kernel
-// is bound by the memory-side atomic rate on the proposal grids and by per-wave latency on the
-// coarse levels of the main grid.
-#ifndef NR_BWD_CHUNK
-#define NR_BWD_CHUNK 512
-#endif
-#ifndef NR_BWD_VALS
-#define NR_BWD_VALS 2048
-#endif
-constexpr int kBwdChunk = NR_BWD_CHUNK;    // samples per WAVE (of one level)
-constexpr int kBwdValFloats = NR_BWD_VALS; // floats of accumulators per wave: capacity = NR_BWD_VALS / (8 F) cells
+// index is advanced incrementally instead of divided out per sample.  PMC (profiles/): with the step's
+// real gradients the kernel is bound by per-wave latency / VALU issue, not by the atomic rate.
+// Per feature width: samples per wave (CHUNK), cells per wave table (CAP), waves per block (W; bounded by
+// the 64 KB static LDS of a block).  Tuned on the bench's camera patches AND on incoherent lidar rays
+// (tools/scatter_real.py, tools/probe_incoherent.py).
+template <int F> struct BwdCfg;
+template <> struct BwdCfg<1> { static constexpr int CHUNK = 512, CAP = 256, W = 4; };
+template <> struct BwdCfg<2> { static constexpr int CHUNK = 512, CAP = 128, W = 4; };
+template <> struct BwdCfg<4> { static constexpr int CHUNK = 256, CAP = 128, W = 2; };
+template <> struct BwdCfg<8> { static constexpr int CHUNK = 256, CAP = 64, W = 2; };
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 __device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
@@ -146,38 +148,46 @@ __device__ __forceinline__ void wave_fence() {
 }
 
 template <int F, int CAP>
-__device__ __forceinline__ void flush_table(unsigned long long* keys, float* vals, float* base, uint32_t mask, int lane,
-                                            bool reset) {
+__device__ __forceinline__ void flush_table(unsigned long long* keys, float* vals, int* list, float* base, uint32_t mask,
+                                            int lane, bool reset) {
+  // occupied slots first (list = the owner words, idle outside the insert phase): the flush then costs
+  // occupied * 8 * F / 64 wave-instructions instead of CAP * 8 * F / 64
+  int n_occ = 0;
 #pragma unroll 1
-  for (int k = lane; k < CAP * 8; k += NR_WAVE) {
-    const int slot = k >> 3, corner = k & 7;
+  for (int k0 = 0; k0 < CAP; k0 += NR_WAVE) {
+    const int k = k0 + lane;
+    const bool occ = k < CAP && keys[k] != kEmptyKey;
+    const unsigned long long m = __ballot(occ);
+    if (occ) list[n_occ + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    n_occ += __popcll(m);
+  }
+  wave_fence();
+#pragma unroll 1
+  for (int kk = lane; kk < n_occ * 8 * F; kk += NR_WAVE) {
+    const int e = kk / (8 * F), r = kk - e * (8 * F);
+    const int corner = r / F, f = r - corner * F;
+    const int slot = list[e];
     const unsigned long long key = keys[slot];
-    if (key == kEmptyKey) continue;
     const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
     const int cy = ((int)((uint32_t)((key >> 21) & 0x1FFFFF) << 11)) >> 11;
     const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
     const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      const float t = vals[k * F + f];
-      if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
-      if (reset) vals[k * F + f] = 0.0f;
-    }
+    const float t = vals[slot * 8 * F + r];
+    if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
+    if (reset) vals[slot * 8 * F + r] = 0.0f;
   }
   if (reset) {
     wave_fence();
-    for (int k = lane; k < CAP; k += NR_WAVE) keys[k] = kEmptyKey;
+    for (int e = lane; e < n_occ; e += NR_WAVE) keys[list[e]] = kEmptyKey;
     wave_fence();
   }
 }
 
-template <int F>
-__global__ void __launch_bounds__(256)
+template <int F, int CHUNK, int CAP, int W>
+__global__ void __launch_bounds__(W * 64)
 hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int log2T,
            const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int S) {
-  constexpr int NV = 8 * F;                   // accumulators per cell
-  constexpr int CAP = kBwdValFloats / NV;     // cells per wave table
-  constexpr int W = 4, CHUNK = kBwdChunk;
+  constexpr int NV = 8 * F;
   __shared__ unsigned long long s_key[W][CAP];
   __shared__ float s_val[W][CAP * NV];
   __shared__ int s_owner[W][CAP];
@@ -314,6 +324,13 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
       for (int f = 0; f < F; ++f) mag += fabsf(v[corner][f]);
     const bool nz = mag != 0.0f;
     const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
+    {  // make room BEFORE inserting: with <= 3/4 load the probes (almost) always succeed
+      const int need = __popcll(__ballot(want));
+      if (fill + need > CAP * 3 / 4 && fill > 0) {
+        flush_table<F, CAP>(keys, vals, owner, base, mask, lane, true);
+        fill = 0;
+      }
+    }
     const unsigned long long key = pack_cell(lo);
     uint32_t s0 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
     int slot = -1;
@@ -359,13 +376,9 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
       }
       fill = CAP;  // crowded around some hash: make room
     }
-    if (fill >= CAP * 3 / 4 && i + NR_WAVE < chunk0 + CHUNK) {
-      flush_table<F, CAP>(keys, vals, base, mask, lane, true);
-      fill = 0;
-    }
   }
   wave_fence();
-  flush_table<F, CAP>(keys, vals, base, mask, lane, false);
+  flush_table<F, CAP>(keys, vals, owner, base, mask, lane, false);
 }
 
 // Gradient w.r.t. the input positions (needed only where positions depend on parameters: samples
@@ -463,14 +476,21 @@ extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float*
   if (n == 0) return 0;
   if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
-  dim3 grid((unsigned)nr_cdiv(n, 4 * kBwdChunk), (unsigned)L), block(256);
+#define CALL(FF)                                                                                                  \
+  {                                                                                                               \
+    using C = BwdCfg<FF>;                                                                                         \
+    dim3 grid((unsigned)nr_cdiv(n, (int64_t)C::W * C::CHUNK), (unsigned)L), block(C::W * 64);                      \
+    hipLaunchKernelGGL((hash_encode_bwd_kernel<FF, C::CHUNK, C::CAP, C::W>), grid, block, 0, nr_s(stream), x, std, \
+                       scalings, log2T, gout, sn, sl, gtable, n, sample_major);                                   \
+  }
   switch (F) {
-    case 1: hipLaunchKernelGGL(hash_encode_bwd_kernel<1>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
-    case 2: hipLaunchKernelGGL(hash_encode_bwd_kernel<2>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
-    case 4: hipLaunchKernelGGL(hash_encode_bwd_kernel<4>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
-    case 8: hipLaunchKernelGGL(hash_encode_bwd_kernel<8>, grid, block, 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl, gtable, n, sample_major); break;
+    case 1: CALL(1) break;
+    case 2: CALL(2) break;
+    case 4: CALL(4) break;
+    case 8: CALL(8) break;
     default: return NR_EINVAL;
   }
+#undef CALL
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -153,9 +153,6 @@ __device__ __forceinline__ void dense_bwd_dw(const f32x16 (&dz)[(M + 31) / 32], 
                                              float* lg, float extra, float* lg_extra, float* scrA, float* scrB,
                                              float* scrE, int i, int h) {
   using L = Layer<K, M>;
-#ifdef NR_ABLATE_DW
-  return;
-#endif
   if (EXTRA) {
     if (h == 0) scrE[i] = extra;
   }
@@ -183,13 +180,7 @@ __device__ __forceinline__ void dense_bwd_dw(const f32x16 (&dz)[(M + 31) / 32], 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mt * 32 + rowmap(r, 0) + 4 * h;
-#if defined(NR_ABLATE_DSADD)
-        if (m < M && k < K && acc[r] == 123.456f) lg[m * K + k] = acc[r];
-#elif defined(NR_ABLATE_PLAINRMW)
-        if (m < M && k < K) lg[m * K + k] += acc[r];
-#else
         if (m < M && k < K) atomicAdd(&lg[m * K + k], acc[r]);
-#endif
       }
       if (kt == 0 && mt * 32 + i < M) atomicAdd(&lg[M * K + mt * 32 + i], rowsum);
     }

@@ -42,6 +42,7 @@ class FusedTrainStep:
         c = model.config
         self.overlap = overlap and os.environ.get("NR_STEP_OVERLAP", "1") != "0"  # tuning knob
         self._streams = None
+        self.timers = None  # dict name -> [(start, end) events]: set by a caller that wants in-step kernel times (eager only)
         assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
@@ -88,6 +89,22 @@ class FusedTrainStep:
                 p.grad = torch.zeros_like(p)
         self._structs()
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
+
+    def _timed(self, name: str, launch):
+        """Run `launch()` (one library call on the current stream); with self.timers set, bracket it with
+        HIP events recorded on that stream."""
+        if self.timers is None:
+            return launch()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = launch()
+        b.record()
+        self.timers.setdefault(name, []).append((a, b))
+        return rc
+
+    def kernel_times(self) -> Dict[str, float]:
+        """Mean seconds per timed launch (call after torch.cuda.synchronize())."""
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) * 1e-3 for k, v in (self.timers or {}).items()}
 
     def _side_streams(self):
         if self._streams is None:
@@ -167,9 +184,9 @@ class FusedTrainStep:
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
             S, n = self.S[lvl], B * self.S[lvl]
-            check(lib.nr_hash_encode_fwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels,
-                                         pg.features_per_level, pg.log2_hashmap_size, p(self.feats[lvl]),
-                                         pg.features_per_level, n * pg.features_per_level, n, 0, st), "hash_fwd")
+            check(self._timed(f"hash_encode_fwd[prop_s{S}]", lambda: lib.nr_hash_encode_fwd(
+                p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
+                pg.log2_hashmap_size, p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, 0, st)), "hash_fwd")
             check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
                                           pg.features_per_level, p(w_dec), w_dec.numel(), n, S, 1, p(self.dens[lvl]), st), "prop_density")
             check(lib.nr_proposal_round(p(self.dens[lvl]), p(self.eu[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, o, d, area,
@@ -179,8 +196,9 @@ class FusedTrainStep:
         mg, Sm = self.mgrid, self.S[2]
         n = B * Sm
         F = mg.features_per_level
-        check(lib.nr_hash_encode_fwd(p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
-                                     mg.log2_hashmap_size, p(self.feats[2]), F, n * F, n, 0, st), "hash_fwd")
+        check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
+            p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
+            p(self.feats[2]), F, n * F, n, 0, st)), "hash_fwd")
         if side[0] is not main:
             main.wait_stream(side[0])
         if after_sampling is not None:
@@ -188,8 +206,8 @@ class FusedTrainStep:
                 side[1].wait_stream(main)
             with torch.cuda.stream(side[1]):
                 after_sampling()
-        check(lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.feature), p(self.sdf),
-                               p(self.alpha), st), "field_fwd")
+        check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n,
+                                                                 p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
         check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
                                   p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
@@ -212,13 +230,15 @@ class FusedTrainStep:
                                                         p(self.loss), sp_), "interlevel_loss")
                 check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, 1, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
-                check(lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp,
-                                             pg.log2_hashmap_size, p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0,
-                                             sp_), "hash_bwd")
-        check(lib.nr_field_bwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature),
-                               p(self.g_alpha), None, p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st), "field_bwd")
-        check(lib.nr_hash_encode_bwd(p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
-                                     p(self.g_feats[2]), F, n * F, p(mg.hash_table.grad), n, 0, st), "hash_bwd")
+                check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
+                    p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,
+                    p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
+        check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
+            byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature), p(self.g_alpha), None,
+            p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
+        check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
+            p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
+            p(mg.hash_table.grad), n, 0, st)), "hash_bwd")
         if optimizers is not None:
             table_opt, field_opt = optimizers
             scale = 1.0 if reducer is None else 1.0 / reducer.world

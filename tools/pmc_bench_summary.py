@@ -1,0 +1,63 @@
+"""Summarise tools/pmc_bench.sh passes into profiles/<round>_hash_kernels_pmc.json.
+usage: python tools/pmc_bench_summary.py gpurun_out/pmc_bench_ profiles/r01_hash_kernels_pmc.json [rays]"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+prefix, out_path = sys.argv[1], sys.argv[2]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+        if not (k.startswith("hash_encode") or k.startswith("field_")):
+            continue
+        res[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in sorted(glob.glob(prefix + "*/out_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+        g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        if (k, g) in res:
+            dur[(k, g)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+
+
+def tag(k, g):
+    if not k.startswith("hash_encode"):
+        return k
+    # fwd: grid = N*L threads; bwd: grid = ceil(N / (W*CHUNK)) * L * W*64 threads  (N = B*S; BwdCfg in grid.hip)
+    cfg = {"<1>": (512, 4), "<2>": (512, 4), "<4>": (256, 2), "<8>": (256, 2)}
+    for S, name, L in ((128, "prop_s128", 6), (64, "prop_s64", 6), (32, "main_s32", None)):
+        n = B * S
+        for Lv in ([L] if L else [8, 16]):
+            if "fwd" in k and g == -(-n // 256) * 256 * Lv:
+                return f"{k} {name}"
+            for fk, (chunk, w) in cfg.items():
+                if "bwd" in k and fk in k and g == -(-n // (w * chunk)) * Lv * w * 64:
+                    return f"{k} {name}"
+    return f"{k} grid{g}"
+
+
+kernels = {}
+for (k, g), c in sorted(res.items()):
+    e = {n: round(sum(v) / len(v), 1) for n, v in c.items()}
+    d = dur.get((k, g), [])
+    if d:
+        e["avg_us_serialised"] = round(sum(d) / len(d), 1)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
+        e["mfma_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * e["GRBM_GUI_ACTIVE"] / 8), 3)  # 1024 SIMDs, 8 XCD clocks summed
+    if "TCC_HIT_sum" in e:
+        e["l2_hit_rate"] = round(e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + e["TCC_MISS_sum"], 1), 3)
+    kernels[f"{tag(k, g)} (grid {g})"] = e
+doc = {
+    "source": "rocprofv3 --pmc over `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline` (tools/pmc_bench.sh): one "
+              "counter set per pass, averages per launch; PMC collection serialises the step's streams",
+    "units": "FETCH_SIZE / WRITE_SIZE in KiB as reported.  gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads "
+             "(x2 for those); 4-8 B/lane gathers are uncalibrated, Infinity-Cache hits are counted.  WRITE_SIZE is exact for float atomics.",
+    "kernels": kernels,
+}
+json.dump(doc, open(out_path, "w"), indent=1)
+print(json.dumps(doc, indent=1)[:6000])

@@ -67,6 +67,44 @@ __device__ __forceinline__ void vertex_add(uint32_t* vkeys, float* vvals, int* o
 // v8: production design + (a) all inputs of iteration i+1 requested before iteration i is processed,
 // (b) no division in the loop, (c) the table is flushed when it fills up instead of spilling every
 // later contribution straight to memory.  flags bit0: skip global atomics (timing ablation).
+// v9 flush: lane = (entry, corner, f) with f fastest -> the F floats of a corner are F adjacent lanes of ONE
+// atomic wave-instruction, which leaves the L2 as one request (a lane's own consecutive instructions never merge)
+template <int F, int CAP>
+__device__ __forceinline__ void flush_table_v9(unsigned long long* keys, float* vals, int* list, float* base, uint32_t mask,
+                                               int lane, int flags, bool reset) {
+  // occupied slots first (list = the owner words, idle outside the insert phase): the flush then costs
+  // occupied * 8 * F / 64 wave-instructions instead of CAP * 8 * F / 64
+  int n_occ = 0;
+#pragma unroll 1
+  for (int k0 = 0; k0 < CAP; k0 += NR_WAVE) {
+    const int k = k0 + lane;
+    const bool occ = k < CAP && keys[k] != kEmptyKey;
+    const unsigned long long m = __ballot(occ);
+    if (occ) list[n_occ + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    n_occ += __popcll(m);
+  }
+  wave_fence();
+#pragma unroll 1
+  for (int kk = lane; kk < n_occ * 8 * F; kk += NR_WAVE) {
+    const int e = kk / (8 * F), r = kk - e * (8 * F);
+    const int corner = r / F, f = r - corner * F;
+    const int slot = list[e];
+    const unsigned long long key = keys[slot];
+    const int cx = ((int)((uint32_t)(key & 0x1FFFFF) << 11)) >> 11;
+    const int cy = ((int)((uint32_t)((key >> 21) & 0x1FFFFF) << 11)) >> 11;
+    const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
+    const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
+    const float t = vals[slot * 8 * F + r];
+    if (t != 0.0f && !(flags & 1)) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
+    if (reset) vals[slot * 8 * F + r] = 0.0f;
+  }
+  if (reset) {
+    wave_fence();
+    for (int e = lane; e < n_occ; e += NR_WAVE) keys[list[e]] = kEmptyKey;
+    wave_fence();
+  }
+}
+
 template <int F, int CAP>
 __device__ __forceinline__ void flush_table(unsigned long long* keys, float* vals, float* base, uint32_t mask, int lane,
                                             int flags, bool reset) {
@@ -93,7 +131,7 @@ __device__ __forceinline__ void flush_table(unsigned long long* keys, float* val
   }
 }
 
-template <int F, int CHUNK, int CAP, int W, bool LDSATOMIC = false>
+template <int F, int CHUNK, int CAP, int W, bool LDSATOMIC = false, bool V9 = false>
 __global__ void __launch_bounds__(W * 64)
 scatter_v8(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int log2T,
            const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int S, int flags) {
@@ -234,6 +272,13 @@ scatter_v8(const float* __restrict__ x, const float* __restrict__ std, const flo
       for (int f = 0; f < F; ++f) mag += fabsf(v[corner][f]);
     const bool nz = mag != 0.0f;
     const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
+    if constexpr (V9) {  // make room BEFORE inserting: with <= 3/4 load the probes (almost) always succeed
+      const int need = __popcll(__ballot(want));
+      if (fill + need > CAP * 3 / 4 && fill > 0) {
+        flush_table_v9<F, CAP>(keys, vals, owner, base, mask, lane, flags, true);
+        fill = 0;
+      }
+    }
     const unsigned long long key = pack_cell(lo);
     uint32_t s0 = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
     int slot = -1;
@@ -288,20 +333,23 @@ scatter_v8(const float* __restrict__ x, const float* __restrict__ std, const flo
       }
       fill = CAP;  // crowded around some hash: make room
     }
-    if (fill >= CAP * 3 / 4 && i + NR_WAVE < chunk0 + CHUNK) {
-      flush_table<F, CAP>(keys, vals, base, mask, lane, flags, true);
-      fill = 0;
+    if constexpr (!V9) {
+      if (fill >= CAP * 3 / 4 && i + NR_WAVE < chunk0 + CHUNK) {
+        flush_table<F, CAP>(keys, vals, base, mask, lane, flags, true);
+        fill = 0;
+      }
     }
   }
   wave_fence();
-  flush_table<F, CAP>(keys, vals, base, mask, lane, flags, false);
+  if constexpr (V9) flush_table_v9<F, CAP>(keys, vals, owner, base, mask, lane, flags, false);
+  else flush_table<F, CAP>(keys, vals, base, mask, lane, flags, false);
 }
 
-template <int F, int CHUNK, int CAP, int W, bool LDSATOMIC = false>
+template <int F, int CHUNK, int CAP, int W, bool LDSATOMIC = false, bool V9 = false>
 int launch_v8(const float* x, const float* std, const float* scalings, int L, int log2T, const float* gout, int64_t sn,
               int64_t sl, float* gtable, int64_t n, int S, int flags, hipStream_t stream) {
   dim3 grid((unsigned)nr_cdiv(n, (int64_t)W * CHUNK), (unsigned)L), block(W * 64);
-  hipLaunchKernelGGL((scatter_v8<F, CHUNK, CAP, W, LDSATOMIC>), grid, block, 0, stream, x, std, scalings, log2T, gout, sn, sl,
+  hipLaunchKernelGGL((scatter_v8<F, CHUNK, CAP, W, LDSATOMIC, V9>), grid, block, 0, stream, x, std, scalings, log2T, gout, sn, sl,
                      gtable, n, S, flags);
   return (int)hipGetLastError();
 }
@@ -313,31 +361,18 @@ extern "C" int lab_scatter(int variant, const float* x, const float* std, const 
                            const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, int S, int flags,
                            void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define CASE(id, f, chunk, cap, w) \
-  if (variant == id && F == f) return launch_v8<f, chunk, cap, w>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  CASE(0, 1, 1024, 256, 4)
-  CASE(1, 1, 1024, 128, 4)
-  CASE(2, 1, 512, 256, 4)
-  CASE(3, 1, 512, 128, 4)
-  CASE(4, 1, 256, 128, 4)
-  if (variant == 5 && F == 1) return launch_v8<1, 1024, 256, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  if (variant == 6 && F == 1) return launch_v8<1, 512, 128, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  if (variant == 7 && F == 1) return launch_v8<1, 256, 128, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  CASE(0, 2, 1024, 128, 4)
-  CASE(1, 2, 1024, 64, 4)
-  CASE(2, 2, 512, 128, 4)
-  CASE(3, 2, 512, 64, 4)
-  CASE(4, 2, 256, 64, 4)
-  if (variant == 5 && F == 2) return launch_v8<2, 1024, 128, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  if (variant == 6 && F == 2) return launch_v8<2, 512, 128, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  if (variant == 7 && F == 2) return launch_v8<2, 256, 64, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  CASE(0, 4, 1024, 64, 4)
-  CASE(1, 4, 512, 64, 4)
-  CASE(2, 4, 256, 32, 4)
-  CASE(3, 4, 1024, 128, 2)
-  CASE(4, 4, 512, 32, 4)
-  if (variant == 5 && F == 4) return launch_v8<4, 1024, 64, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
-  if (variant == 6 && F == 4) return launch_v8<4, 512, 64, 4, true>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
+#define CASE(id, f, chunk, cap, w, v9) \
+  if (variant == id && F == f) return launch_v8<f, chunk, cap, w, false, v9>(x, std, scalings, L, log2T, gout, sn, sl, gtable, n, S, flags, st);
+  CASE(0, 1, 512, 256, 4, false)   // production
+  CASE(1, 1, 512, 256, 4, true)
+  CASE(2, 1, 512, 128, 4, true)
+  CASE(0, 2, 512, 128, 4, false)   // production
+  CASE(1, 2, 512, 128, 4, true)
+  CASE(2, 2, 512, 256, 2, true)
+  CASE(0, 4, 512, 64, 4, false)    // production
+  CASE(1, 4, 512, 64, 4, true)
+  CASE(2, 4, 512, 128, 2, true)
+  CASE(3, 4, 256, 128, 2, true)
 #undef CASE
   return -1;
 }

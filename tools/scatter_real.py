@@ -46,12 +46,20 @@ for lvl, tag in ((0, "prop_s128"), (1, "prop_s64"), (2, "main_s32")):
     prod_r = lambda: lib.nr_hash_encode_bwd(p(x01), p(std), p(g.scalings), Lv, F, g.log2_hashmap_size, p(grand), F, n * F, p(scratch), n, 0, st())  # noqa: E731
     tr = bench.time_kernel(prod_r, 20)
     print(f"{tag}: real gradients ({nzfrac * 100:.1f} % non-zero) {t * 1e6:7.1f} us; random gradients {tr * 1e6:7.1f} us")
-    for variant in (2,):
+    for variant in (0, 1, 2, 3):
         for flags, what in ((0, "with atomics"), (1, "no global atomics")):
             fn = lambda: lab.lab_scatter(variant, p(x01), p(std), p(g.scalings), Lv, F, g.log2_hashmap_size, p(gbuf), F, n * F, p(scratch), n, 0, flags, st())  # noqa: E731
             if fn() != 0:
                 continue
             print(f"   lab v8[{variant}] {what}: {bench.time_kernel(fn, 20) * 1e6:7.1f} us")
+    ref = torch.zeros_like(g.hash_table)
+    prod_into = lambda gt: lib.nr_hash_encode_bwd(p(x01), p(std), p(g.scalings), Lv, F, g.log2_hashmap_size, p(gbuf), F, n * F, p(gt), n, 0, st())  # noqa: E731
+    prod_into(ref)
+    for variant in (1, 2, 3):
+        got = torch.zeros_like(g.hash_table)
+        if lab.lab_scatter(variant, p(x01), p(std), p(g.scalings), Lv, F, g.log2_hashmap_size, p(gbuf), F, n * F, p(got), n, 0, 0, st()) == 0:
+            torch.cuda.synchronize()
+            print(f"   lab variant {variant} max rel err vs production: {float((got - ref).abs().max() / ref.abs().max()):.2e}")
     # per-level on real gradients
     T = 1 << g.log2_hashmap_size
     lv = []
