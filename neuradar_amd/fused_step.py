@@ -213,13 +213,18 @@ class FusedTrainStep:
                                   p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
                                   p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
                                   p(self.g_feature), p(self.loss), st), "render_train")
-        # ---- backward.  After the render launch the step forks into three independent chains (main
-        #      field / proposal round 1 / proposal round 0) that only meet again in the optimizer; each
-        #      runs on its own stream so the mostly latency-bound kernels overlap. ----
+        # ---- backward.  The field's MFMA backward runs first, by itself: its workgroups need 1 wave/SIMD worth of
+        #      registers and ~127 KB of LDS, so anything sharing the CUs with it (and it with them) crawls -- measured
+        #      0.73 vs 0.78 ms per step against forking right after the render launch.  Then the step forks into
+        #      three independent chains (main grid scatter + Adam / proposal round 1 / proposal round 0), each on
+        #      its own stream, that only meet again in the optimizer. ----
+        Fp = pg.features_per_level
+        check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
+            byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature), p(self.g_alpha), None,
+            p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
         for s_ in side:
             if s_ is not main:
                 s_.wait_stream(main)
-        Fp = pg.features_per_level
         for lvl, stream in zip((1, 0), side):
             with torch.cuda.stream(stream):
                 sp_ = ops._stream()
@@ -233,9 +238,6 @@ class FusedTrainStep:
                 check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
                     p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,
                     p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
-        check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
-            byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature), p(self.g_alpha), None,
-            p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
         check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
             p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
             p(mg.hash_table.grad), n, 0, st)), "hash_bwd")
