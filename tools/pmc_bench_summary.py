@@ -29,7 +29,7 @@ def tag(k, g):
     if not k.startswith("hash_encode"):
         return k
     # fwd: grid = N*L threads; bwd: grid = ceil(N / (W*CHUNK)) * L * W*64 threads  (N = B*S; BwdCfg in grid.hip)
-    cfg = {"<1>": (512, 4), "<2>": (512, 4), "<4>": (256, 2), "<8>": (256, 2)}
+    cfg = {"kernel<1,": (512, 4), "kernel<2,": (512, 4), "kernel<4,": (256, 2), "kernel<8,": (256, 2)}
     for S, name, L in ((128, "prop_s128", 6), (64, "prop_s64", 6), (32, "main_s32", None)):
         n = B * S
         for Lv in ([L] if L else [8, 16]):
