@@ -245,13 +245,8 @@ class FusedTrainStep:
             table_opt, field_opt = optimizers
             scale = 1.0 if reducer is None else 1.0 / reducer.world
             i_prop, i_main = table_opt.buffer_of(pg.hash_table), table_opt.buffer_of(mg.hash_table)
-            if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main backward
-                side[0].wait_stream(side[1])
-            with torch.cuda.stream(side[0]):
-                if reducer is not None:
-                    reducer.start(table_opt.buffers[i_prop][1])
-                    reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
-                table_opt.step_buffer(i_prop, scale)
+            # main table first: its list exchange holds the step's only host read, and issuing it before the
+            # proposal table's all-reduce keeps the CPU from parking behind the proposal chains
             if reducer is not None:
                 if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
                     reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
@@ -259,6 +254,13 @@ class FusedTrainStep:
                     reducer.start(table_opt.buffers[i_main][1])
                     reducer.wait_all()
             table_opt.step_buffer(i_main, scale)
+            if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
+                side[0].wait_stream(side[1])
+            with torch.cuda.stream(side[0]):
+                if reducer is not None:
+                    reducer.start(table_opt.buffers[i_prop][1])
+                    reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
+                table_opt.step_buffer(i_prop, scale)
         for s_ in side:
             if s_ is not main:
                 main.wait_stream(s_)

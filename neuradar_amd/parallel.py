@@ -53,8 +53,13 @@ class GradAllReducer:
         sparse_tables: the fused step exchanges the main table's gradient as (row, value) lists
         (reduce_sparse) instead of all-reducing the dense table."""
         self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sparse_tables = sparse_tables
         self.last_sparse: dict = {}
+        # the list exchange gets a communicator of its own: collectives of ONE communicator execute in issue
+        # order, and the main table's lists must not queue behind the proposal table's dense all-reduce
+        # (which waits for the proposal chains on another stream)
+        self.sparse_group = dist.new_group() if (self.world > 1 and sparse_tables) else group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.table_dtype = table_dtype
         self._flat: Optional[torch.Tensor] = None
@@ -116,12 +121,12 @@ class GradAllReducer:
         count.zero_()
         compact(grad, row_width, idx, val, count)
         counts = [st["counts"][r:r + 1] for r in range(self.world)]
-        dist.all_gather(counts, count, group=self.group)
+        dist.all_gather(counts, count, group=self.sparse_group)
         n_rows = st["counts"].cpu()
         max_rows = int(n_rows.max())
         if max_rows > cap:  # a rank's list does not fit: put the local rows back, reduce densely
             apply(idx, val, count, row_width, grad)
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.sparse_group)
             self.last_sparse = {"mode": "dense", "rows": n_rows.tolist(), "bytes": grad.numel() * 4}
             return self.last_sparse
         m = min(cap, (max_rows + 255) // 256 * 256)
@@ -129,7 +134,7 @@ class GradAllReducer:
         piece = 1 + m + m * row_width
         out = torch.empty(self.world * piece, device=grad.device, dtype=torch.float32)
         mine = torch.cat([send[:1 + m], val[:m * row_width]])
-        dist.all_gather([out[r * piece:(r + 1) * piece] for r in range(self.world)], mine, group=self.group)
+        dist.all_gather([out[r * piece:(r + 1) * piece] for r in range(self.world)], mine, group=self.sparse_group)
         for r in range(self.world):
             seg = out[r * piece:(r + 1) * piece]
             apply(seg[1:1 + m].view(torch.int32), seg[1 + m:], seg[:1].view(torch.int32), row_width, grad)
