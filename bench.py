@@ -134,7 +134,8 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
     if fused:
         from neuradar_amd.fused_step import FusedTrainStep
 
-        stepper = FusedTrainStep(model, n_rays)
+        # camera patches are coherent (sample-major rows), lidar / radar rays are not (ray-major rows)
+        stepper = FusedTrainStep(model, n_rays, coherent_rays=mixed["cam_rays"] if mixed is not None else None)
         S0 = model.config.num_proposal_samples[0]
         dev = tgt_f.device
 

@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 2
+#define NR_ABI_VERSION 3
 #define NR_LOSS_SLOTS 64   /* loss kernels add into loss[0..63]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
@@ -80,11 +80,13 @@ int nr_hash_encode_bwd_input(const float* x, const float* std, const float* tabl
  * (field_components/spatial_distortions.py:103-113,126-136):
  *   origins, directions [n_rays,3]; pixel_area [n_rays]; edges [n_rays, n_samples+1] (metres)
  *   -> x01 [n_rays*n_samples, 3] in [0,1], std01 [n_rays*n_samples].
- * Row order of the outputs: sample_major_rows = 0: row b*S+s (the reference's [B,S] flattening);
- * 1: row s*B+b.  The second form is what the fused step feeds the hash grid and the MLP kernels
- * (rows_sample_major below): 64 consecutive rows are then 64 neighbouring rays at one sample slot,
- * which makes every per-sample load coalesced and the touched grid cells coherent.  Per-ray arrays
- * (densities, alphas, weights, rendered features) always stay in the reference's [B,S] order. */
+ * Row order of the outputs: sample_major_rows = number of LEADING rays whose rows are stored
+ * sample-major, row s*sm+b (b < sm); the remaining rays keep row b*S+s (the reference's [B,S]
+ * flattening; 0 = all of them).  Sample-major rows are what the fused step feeds the hash grid and the
+ * MLP kernels for camera patches (rows_sample_major below, same meaning): 64 consecutive rows are then
+ * 64 neighbouring rays at one sample slot, which makes every per-sample load coalesced and the touched
+ * grid cells coherent; incoherent lidar / radar rays stay ray-major (neighbouring samples of one ray
+ * share coarse cells).  Per-ray arrays (densities, alphas, weights, rendered features) are always [B,S]. */
 int nr_contract_gaussians(const float* origins, const float* directions, const float* pixel_area,
                           const float* edges, int64_t n_rays, int n_samples, float scale,
                           int sample_major_rows, float* x01, float* std01, nr_stream_t stream);
@@ -123,8 +125,8 @@ int nr_mlp_bwd(const nr_mlp_t* mlp, const float* x, const float* grad_y, int64_t
  * ray i / n_samples; n_samples == 0 means directions are per SAMPLE [n,3] (dynamic actors rotate the
  * view direction of the samples inside their boxes, neurad_encoding.py:210-215).
  * Outputs feature [n,C], sdf [n], alpha [n].
- * rows_sample_major = 1 (needs n_samples > 0): row j of feats / grad_feats is sample (b = j % B,
- * s = j / B), B = n / n_samples; outputs and their gradients stay at row b*n_samples + s. */
+ * rows_sample_major = sm > 0 (needs n_samples > 0): the first sm rays' rows of feats / grad_feats are
+ * sample-major (row s*sm+b), see nr_contract_gaussians; outputs and their gradients stay at b*n_samples+s. */
 typedef struct nr_field {
   nr_mlp_t geo;        /* in_dim = L*F, out_dim = 1 + C */
   nr_mlp_t feat;       /* in_dim = C + 16, out_dim = C  */
@@ -164,8 +166,8 @@ int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t stream);
  * Proposal field head  -- NeuRADProposalField.get_density after the grid
  * (fields/neurad_field.py:211-212): density = trunc_exp(feats . w), w [in_dim] (Linear(L*F,1,
  * bias=False)).  Backward uses exp(clamp(x,-15,15)) (field_components/activations.py:28-41).
- * rows_sample_major = 1 (needs n_samples): feats / grad_feats rows are s*B+b, density and
- * grad_density stay [B,S] (see nr_contract_gaussians).
+ * rows_sample_major = sm (needs n_samples): feats / grad_feats rows of the first sm rays are s*sm+b,
+ * density and grad_density stay [B,S] (see nr_contract_gaussians).
  * ---------------------------------------------------------------------------------------------- */
 int nr_prop_density_fwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
                         const float* w, int in_dim, int64_t n, int n_samples, int rows_sample_major,

@@ -433,15 +433,9 @@ contract_gaussians_kernel(const float* __restrict__ origins, const float* __rest
                           int S, float scale, int sample_major, float* __restrict__ x01, float* __restrict__ std01) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // output row
   if (i >= n_rays * S) return;
-  int64_t b;
-  int s;
-  if (sample_major) {
-    s = (int)(i / n_rays);
-    b = i - (int64_t)s * n_rays;
-  } else {
-    b = i / S;
-    s = (int)(i - b * S);
-  }
+  const NrRowMap rm = nr_row_map(i, n_rays * S, S, sample_major);  // sample_major = rays stored sample-major
+  const int64_t b = rm.ray;
+  const int s = (int)(rm.out - b * S);
   float x[3], sd;
   nr_contract_sample(origins + b * 3, directions + b * 3, pixel_area[b], edges[b * (S + 1) + s], edges[b * (S + 1) + s + 1],
                      scale, x, sd);

@@ -584,7 +584,7 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
   if (n == 0) return 0;
   int hid = 0;
   if (check_field(field, &hid) != 0 || !feats || !dirs || !feature || !sdf || !alpha || S < 0 || F < 1 || n < 0) return NR_EINVAL;
-  if (rows_sample_major && (S < 1 || n % S != 0)) return NR_EINVAL;
+  if (rows_sample_major < 0 || (rows_sample_major && (S < 1 || n % S != 0 || rows_sample_major > n / S))) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
   if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
@@ -609,7 +609,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
       S < 0 || F < 1 || n < 0)
     return NR_EINVAL;
-  if (rows_sample_major && (S < 1 || n % S != 0)) return NR_EINVAL;
+  if (rows_sample_major < 0 || (rows_sample_major && (S < 1 || n % S != 0 || rows_sample_major > n / S))) return NR_EINVAL;
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);

@@ -27,23 +27,27 @@ __device__ __forceinline__ uint32_t nr_hash3(int ix, int iy, int iz, uint32_t ma
 }
 
 // ---- per-sample row order ------------------------------------------------------------------------
-// The fused step keeps the per-sample arrays that only the hash grid and the MLPs touch (positions,
-// per-level features and their gradients) in SAMPLE-major order, row j = s * B + b, so that a wave's
-// 64 rows are 64 neighbouring rays at one sample slot: coalesced loads AND coherent grid cells.
-// Per-ray scans (weights, resampling, compositing) keep the ray-major order b * S + s; this maps a
-// sample-major row to it.
+// The per-sample arrays that only the hash grid and the MLPs touch (positions, per-level features and
+// their gradients) may keep the rows of the first `sm` rays SAMPLE-major, row = s * sm + b: a wave's 64
+// rows are then 64 neighbouring rays at one sample slot -- coalesced loads AND coherent grid cells, which
+// is what camera patches want.  Rays b >= sm (and everything when sm = 0) keep the reference's ray-major
+// row b * S + s, which is what incoherent lidar / radar rays want (neighbouring samples of ONE ray share
+// coarse cells).  Per-ray scans (weights, resampling, compositing) always use b * S + s.
+__device__ __forceinline__ int64_t nr_row_of(int64_t b, int s, int S, int64_t sm) {
+  return b < sm ? (int64_t)s * sm + b : b * S + s;
+}
 struct NrRowMap {
   int64_t ray, out;  // ray index, ray-major sample index
 };
-__device__ __forceinline__ NrRowMap nr_row_map(int64_t j, int64_t n, int S, bool sample_major) {
+__device__ __forceinline__ NrRowMap nr_row_map(int64_t j, int64_t n, int S, int64_t sm) {
   NrRowMap m;
   if (S <= 0) {
     m.ray = j; m.out = j;
-  } else if (!sample_major) {
+  } else if (j >= sm * S) {
     m.ray = j / S; m.out = j;
   } else {
-    const int64_t B = n / S, s = j / B;
-    m.ray = j - s * B;
+    const int64_t s = j / sm;
+    m.ray = j - s * sm;
     m.out = m.ray * S + s;
   }
   return m;

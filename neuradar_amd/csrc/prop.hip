@@ -252,7 +252,7 @@ extern "C" int nr_prop_density_fwd(const float* feats, int64_t sn, int64_t sl, i
                                    nr_stream_t stream) {
   if (n == 0) return 0;
   if (!feats || !w || !density || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
-  if (rows_sample_major && (n_samples < 1 || n % n_samples != 0)) return NR_EINVAL;
+  if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples))) return NR_EINVAL;
   hipLaunchKernelGGL(prop_density_fwd_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), feats, sn,
                      sl, F, w, in_dim, n, n_samples, rows_sample_major, density);
   NR_LAUNCH_CHECK();
@@ -265,7 +265,7 @@ extern "C" int nr_prop_density_bwd(const float* feats, int64_t sn, int64_t sl, i
   (void)density;  // the clamped backward needs the pre-activation, which is recomputed from feats
   if (n == 0) return 0;
   if (!feats || !w || !g_density || !g_feats || !g_w || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
-  if (rows_sample_major && (n_samples < 1 || n % n_samples != 0)) return NR_EINVAL;
+  if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples))) return NR_EINVAL;
   const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < 1024 ? nr_cdiv(n, 256) : 1024);
 #define CALL(IN)                                                                                                       \
   hipLaunchKernelGGL(prop_density_bwd_kernel<IN>, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n, \

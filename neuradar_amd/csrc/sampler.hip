@@ -47,7 +47,7 @@ power_bins_kernel(const float* __restrict__ nears, const float* __restrict__ far
       const float e1 = nr_spacing_to_euclid(power_bin(S, j + 1, tr), s_near, s_far, lam, scaling);
       float x[3], sd;
       nr_contract_sample(origins + b * 3, directions + b * 3, pixel_area[b], e0, e1, scale, x, sd);
-      const int64_t row = sample_major ? (int64_t)j * n_rays + b : b * S + j;
+      const int64_t row = nr_row_of(b, j, S, sample_major);
 #pragma unroll
       for (int a = 0; a < 3; ++a) x01[row * 3 + a] = x[a];
       std01[row] = sd;
@@ -260,7 +260,7 @@ proposal_round_kernel(const float* __restrict__ density, const float* __restrict
   for (int j = lane; j < S_out; j += NR_WAVE) {
     float x[3], sd;
     nr_contract_sample(origins + ray * 3, directions + ray * 3, area, bins[j], bins[j + 1], scale, x, sd);
-    const int64_t row = sample_major ? (int64_t)j * n_rays + ray : ray * S_out + j;
+    const int64_t row = nr_row_of(ray, j, S_out, sample_major);
 #pragma unroll
     for (int a = 0; a < 3; ++a) x01[row * 3 + a] = x[a];
     std01[row] = sd;

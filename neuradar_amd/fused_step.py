@@ -38,7 +38,10 @@ def flatten_parameters(params: List[nn.Parameter]) -> Dict[str, Tensor]:
 
 
 class FusedTrainStep:
-    def __init__(self, model: NeuRadarHotPath, n_rays: int, overlap: bool = True) -> None:
+    def __init__(self, model: NeuRadarHotPath, n_rays: int, overlap: bool = True, coherent_rays: Optional[int] = None) -> None:
+        """coherent_rays: number of LEADING rays that come in spatially coherent groups (camera patches); their
+        per-sample rows are stored sample-major, the remaining (lidar / radar) rays ray-major -- see
+        nr_contract_gaussians in include/neuradar_hip.h.  Default: all rays."""
         c = model.config
         self.overlap = overlap and os.environ.get("NR_STEP_OVERLAP", "1") != "0"  # tuning knob
         self._streams = None
@@ -46,6 +49,7 @@ class FusedTrainStep:
         assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
+        self.sm = n_rays if coherent_rays is None else int(coherent_rays)
         self.lib = _lib.lib()
         dev = next(model.parameters()).device
         self.dev = dev
@@ -178,7 +182,7 @@ class FusedTrainStep:
         # resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
         # gradients) are kept SAMPLE-major, row s*B+b (include/neuradar_hip.h, nr_contract_gaussians);
         # per-ray arrays stay [B,S].
-        check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, 1, p(self.sp[0]),
+        check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, self.sm, p(self.sp[0]),
                                          p(self.eu[0]), p(self.x01[0]), p(self.std[0]), st), "power_bins")
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
@@ -188,9 +192,9 @@ class FusedTrainStep:
                 p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
                 pg.log2_hashmap_size, p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, 0, st)), "hash_fwd")
             check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
-                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, S, 1, p(self.dens[lvl]), st), "prop_density")
+                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, S, self.sm, p(self.dens[lvl]), st), "prop_density")
             check(lib.nr_proposal_round(p(self.dens[lvl]), p(self.eu[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, o, d, area,
-                                        B, S, self.S[lvl + 1], lam, scal, SKY_DISTANCE if lvl == 1 else 0.0, scale, 1,
+                                        B, S, self.S[lvl + 1], lam, scal, SKY_DISTANCE if lvl == 1 else 0.0, scale, self.sm,
                                         p(self.w[lvl]), p(self.prop_depth[lvl]), p(self.sp[lvl + 1]), p(self.eu[lvl + 1]),
                                         p(self.x01[lvl + 1]), p(self.std[lvl + 1]), st), "proposal_round")
         mg, Sm = self.mgrid, self.S[2]
@@ -206,7 +210,7 @@ class FusedTrainStep:
                 side[1].wait_stream(main)
             with torch.cuda.stream(side[1]):
                 after_sampling()
-        check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n,
+        check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n,
                                                                  p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
         check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
@@ -220,7 +224,7 @@ class FusedTrainStep:
         #      its own stream, that only meet again in the optimizer. ----
         Fp = pg.features_per_level
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
-            byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, 1, n, p(self.g_feature), p(self.g_alpha), None,
+            byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
             p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
         for s_ in side:
             if s_ is not main:
@@ -233,7 +237,7 @@ class FusedTrainStep:
                                                         p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
                                                         losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
                                                         p(self.loss), sp_), "interlevel_loss")
-                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, 1, p(self.dens[lvl]),
+                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
                 check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
                     p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,

@@ -73,16 +73,22 @@ def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
     return _HashEncode.apply(x, std, table, scalings, log2_hashmap_size, level_major, sample_major)
 
 
+def _sm_rays(flag, n_rays: int) -> int:
+    """Row-order argument of the ABI: number of leading rays stored sample-major (True = all)."""
+    return n_rays if flag is True else int(flag)
+
+
 def contract_gaussians(origins: Tensor, directions: Tensor, pixel_area: Tensor, euclid: Tensor, scale: float,
-                       sample_major_rows: bool = False) -> Tuple[Tensor, Tensor]:
+                       sample_major_rows=False) -> Tuple[Tensor, Tensor]:
     """Frustum samples -> contracted (x01 [B*S,3], std01 [B*S]).  No gradient (static scene).
-    sample_major_rows: row s*B+b instead of b*S+s (include/neuradar_hip.h, nr_contract_gaussians)."""
+    sample_major_rows: True = every ray, or the number of leading rays, stored at row s*sm+b instead of
+    b*S+s (include/neuradar_hip.h, nr_contract_gaussians)."""
     B, S = euclid.shape[0], euclid.shape[1] - 1
     x01 = torch.empty((B * S, 3), device=euclid.device, dtype=torch.float32)
     std01 = torch.empty((B * S,), device=euclid.device, dtype=torch.float32)
     check(_lib.lib().nr_contract_gaussians(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
                                            _p(_f32(pixel_area, "pixel_area")), _p(_f32(euclid, "euclid")), B, S,
-                                           float(scale), int(sample_major_rows), _p(x01), _p(std01), _stream()),
+                                           float(scale), _sm_rays(sample_major_rows, B), _p(x01), _p(std01), _stream()),
           "nr_contract_gaussians")
     return x01, std01
 
@@ -189,7 +195,8 @@ def field_mlp(feats: Tensor, strides: Tuple[int, int], feat_f: int, directions: 
     """NeuRADField after the grid (neurad_field.py:137-148).  feats is the raw buffer written by
     hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]
     (always in [B,S] order; rows_sample_major: feats rows are s*B+b)."""
-    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, int(rows_sample_major), n, beta, len(geo[0]),
+    sm = _sm_rays(rows_sample_major, n // n_samples if n_samples else 0)
+    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, sm, n, beta, len(geo[0]),
                         *geo[0], *geo[1], *feat[0], *feat[1])
 
 
@@ -228,7 +235,7 @@ class _PropDensity(torch.autograd.Function):
 def prop_density(feats: Tensor, strides: Tuple[int, int], feat_f: int, w: Tensor, n: int, n_samples: int = 0,
                  rows_sample_major: bool = False) -> Tensor:
     """density [n] in [B,S] order; rows_sample_major: feats rows are s*B+b (needs n_samples)."""
-    return _PropDensity.apply(feats, strides, feat_f, w, n, n_samples, int(rows_sample_major))
+    return _PropDensity.apply(feats, strides, feat_f, w, n, n_samples, _sm_rays(rows_sample_major, n // n_samples if n_samples else 0))
 
 
 # ------------------------------------------------------------------------------------------------ sampling

@@ -528,7 +528,7 @@ def test_fused_interlevel_to_density_matches_separate_kernels(Sp):
 
 
 @pytest.mark.parametrize("S,S_out,sky", [(128, 64, 0.0), (64, 32, 20000.0), (48, 48, 0.0)])
-@pytest.mark.parametrize("rows_sm", [0, 1])
+@pytest.mark.parametrize("rows_sm", [0, 203, 77])  # rays stored sample-major: none, all, the leading 77 (mixed batch)
 def test_fused_proposal_round_matches_separate_kernels(S, S_out, sky, rows_sm):
     from neuradar_amd import _lib, ops
 
@@ -623,6 +623,56 @@ def test_uniform_fill_is_uniform_and_counter_based():
         assert float((hist - 1.0 / 64).abs().max()) < 1e-3
     assert abs(float(torch.corrcoef(torch.stack([a, c]))[0, 1])) < 5e-3
     assert abs(float(torch.corrcoef(torch.stack([a[:-1], a[1:]]))[0, 1])) < 5e-3
+
+
+def test_reference_pinned_vectors_on_the_hip_path():
+    """The reference's own value-pinning tests through the C ABI: frustum midpoint
+    (tests/cameras/test_rays.py:12-34), SH orthonormality (tests/utils/test_math.py:7-16), pinhole
+    origin (tests/cameras/test_cameras.py:109-121)."""
+    from neuradar_amd import ops
+    from neuradar_amd.sensors import Cameras
+
+    o, d = torch.tensor([[0.0, 1.0, 2.0]], device=DEV), torch.tensor([[0.0, 1.0, 0.0]], device=DEV)
+    x01, _ = ops.contract_gaussians(o, d, torch.ones(1, device=DEV), torch.tensor([[2.0, 3.0]], device=DEV), 100.0)
+    assert torch.allclose(x01[0] * 4.0 - 2.0, torch.tensor([0.0, 3.5, 2.0], device=DEV) / 100.0, atol=1e-6)  # inside the unit box: no contraction
+    torch.manual_seed(0)
+    n = 1_000_000
+    dirs = torch.nn.functional.normalize(torch.normal(0, 1, size=(n, 3), device=DEV), dim=-1)
+    sh = ops.sh4(dirs).double()
+    torch.testing.assert_close(cpu((sh.T @ sh) / n * 4 * torch.pi), torch.eye(16, dtype=torch.float64), rtol=0, atol=1.5e-2)
+    one = torch.ones(1, device=DEV)
+    cam = Cameras(torch.eye(4, device=DEV)[None, :3, :].contiguous(), 10 * one, 10 * one, 400 * one, 400 * one, 800 * one, 0 * one)
+    b = cam.generate_rays(torch.tensor([[0, 0, 0], [0, 400, 400], [0, 799, 13]], device=DEV))
+    assert torch.allclose(b.origins, torch.zeros(3, 3, device=DEV))
+    assert torch.allclose(b.directions.norm(dim=-1), torch.ones(3, device=DEV), atol=1e-6)
+
+
+def test_row_orders_are_permutations_of_one_result():
+    """Sample-major / hybrid / ray-major row storage (nr_contract_gaussians' sample_major_rows) only permutes
+    rows: grid features, densities and the table gradient agree exactly."""
+    from neuradar_amd import ops
+
+    g = load_golden("field_neurad")
+    pf = make_prop(g)
+    rs = samples_from_edges(g, g["edges"])
+    B, S = rs.shape
+    grid = pf.hashgrid.static_grid
+    ref_d, ref_gt = None, None
+    for sm in (0, B, B // 3 + 1):
+        x01, std = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, pf.hashgrid.static_scale,
+                                          sample_major_rows=sm)
+        table = grid.hash_table.detach().clone().requires_grad_(True)
+        buf = ops.hash_encode(x01, table, grid.scalings, grid.log2_hashmap_size, std=std, level_major=True)
+        n = B * S
+        dens = ops.prop_density(buf, (grid.features_per_level, n * grid.features_per_level), grid.features_per_level,
+                                pf.density_decoder.weight, n, n_samples=S, rows_sample_major=sm)
+        (gt,) = torch.autograd.grad((dens * dev(g["prop_g_density"]).reshape(-1)).sum(), [table])
+        if ref_d is None:
+            ref_d, ref_gt = dens, gt
+            assert_close(cpu(dens.view(B, S, 1)), g["prop_density"], rtol=1e-4, atol_scale=1e-5)
+        else:
+            assert torch.equal(dens, ref_d), f"densities differ for sm={sm}"
+            assert_close(cpu(gt), cpu(ref_gt), rtol=1e-5, atol_scale=1e-6, what=f"table grad sm={sm}")
 
 
 def test_fused_step_matches_autograd_path():

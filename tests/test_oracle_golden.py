@@ -242,3 +242,35 @@ def test_dynamic_actors_eval_and_train_with_trajectory_grads():
             "hashgrid_actors_actor_positions", "hashgrid_actors_actor_rotations_6d", "mlp_geo_layers_0_weight"]
     for k, gr in zip(keys, torch.autograd.grad(loss, wrt)):
         assert_close(gr, g["grad_" + k], rtol=1e-4, atol_scale=1e-5, what="grad " + k)
+
+
+# ---- the reference's own tests that pin values on the path, restated on the oracle ----
+def test_reference_frustum_midpoint_vector():
+    """tests/cameras/test_rays.py:12-34: origin (0,1,2), direction (0,1,0), start 2, end 3 -> position (0,3.5,2)."""
+    from oracle import field as ofield
+
+    mean, _ = ofield.isotropic_gaussian(torch.tensor([[0.0, 1.0, 2.0]]), torch.tensor([[0.0, 1.0, 0.0]]), torch.tensor([[2.0]]),
+                                        torch.tensor([[3.0]]), torch.ones(1, 1))
+    assert torch.allclose(mean[0, 0], torch.tensor([0.0, 3.5, 2.0]), atol=1e-6)
+
+
+def test_reference_spherical_harmonics_orthonormality():
+    """tests/utils/test_math.py:7-16 (degree 4): (sh^T sh)/N * 4 pi == I, atol 1.5e-2."""
+    from oracle import field as ofield
+
+    torch.manual_seed(0)
+    n = 1_000_000
+    d = torch.nn.functional.normalize(torch.normal(0, 1, size=(n, 3)), dim=-1)
+    sh = ofield.sh4(d)
+    torch.testing.assert_close((sh.T @ sh) / n * 4 * torch.pi, torch.eye(16), rtol=0, atol=1.5e-2)
+
+
+def test_reference_pinhole_camera_origin():
+    """tests/cameras/test_cameras.py:109-121: identity pose, cx=cy=400, fx=fy=10 -> ray origins at 0."""
+    from oracle import raygen
+
+    idx = torch.tensor([[0, 0, 0], [0, 400, 400], [0, 799, 13]])
+    out = raygen.camera_rays(idx, torch.eye(4)[None, :3, :], torch.tensor([10.0]), torch.tensor([10.0]), torch.tensor([400.0]),
+                             torch.tensor([400.0]), torch.zeros(1))
+    assert torch.allclose(out["origins"], torch.zeros(3, 3))
+    assert torch.allclose(out["directions"].norm(dim=-1), torch.ones(3), atol=1e-6)

@@ -25,11 +25,11 @@ from ctypes import byref  # noqa: E402
 lib, p, s = st.lib, ops._p, ops._stream
 for fb in os.environ.get("FWD_BLOCKS", "256,512").split(","):
     os.environ["NR_FIELD_FWD_BLOCKS"] = fb
-    t = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 1, n, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
+    t = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, B, n, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
     print(f"field_fwd blocks={fb}: {t * 1e6:7.1f} us")
 for bb in os.environ.get("BWD_BLOCKS", "128,256").split(","):
     os.environ["NR_FIELD_BWD_BLOCKS"] = bb
-    t = bench.time_kernel(lambda: lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 1, n, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s()), 20)
+    t = bench.time_kernel(lambda: lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, B, n, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s()), 20)
     print(f"field_bwd blocks={bb}: {t * 1e6:7.1f} us")
 # fixed cost vs per-tile cost: shrink n at a fixed grid
 for frac in (1.0, 0.5, 0.25, 0.125, 1.0 / 64):
