@@ -1,7 +1,10 @@
 """The two per-ray regularisers that consume the path's weight lists (reference:
-model_components/losses.py:107-112,137-156,626-705).  SURVEY section 8 row f-3 ("next"): they are not
-yet HIP kernels -- plain torch ops on the device, used only to give the training step the
-reference's gradient sources (the inter-level loss is the ONLY thing that trains the proposal fields).
+model_components/losses.py:107-112,137-156,626-705).  The inter-level loss is
+the ONLY thing that trains the proposal fields.
+
+`distortion_loss` / `zipnerf_interlevel_loss` run the HIP kernels (nr_distortion_loss,
+nr_interlevel_loss: value and gradient in one pass each) behind torch.autograd; the `*_torch` versions
+are the op-by-op restatement of the reference they are tested against (~200 launches per step).
 
 Flat inputs: `c` = s-space bin edges [B,S+1], `w` = weights [B,S].
 """
@@ -10,10 +13,56 @@ from typing import List
 import torch
 from torch import Tensor
 
+from . import _lib, ops
+
 PULSE_WIDTHS = (0.03, 0.003)  # losses.py:660
 
 
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, w):
+        slots = torch.zeros(_lib.NR_LOSS_SLOTS, device=w.device, dtype=torch.float32)
+        g_w = ops.distortion_loss(c.contiguous(), w.contiguous(), w.shape[1], 1.0, slots)
+        ctx.save_for_backward(g_w)
+        return slots.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_w,) = ctx.saved_tensors
+        return None, g_w * g
+
+
+class _Interlevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, w, cp, wp, pulse):
+        slots = torch.zeros(_lib.NR_LOSS_SLOTS, device=wp.device, dtype=torch.float32)
+        g_wp = ops.interlevel_loss(c.contiguous(), w.contiguous(), w.shape[1], cp.contiguous(), wp.contiguous(), pulse, 1.0, slots)
+        ctx.save_for_backward(g_wp)
+        return slots.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_wp,) = ctx.saved_tensors
+        return None, None, None, g_wp * g, None
+
+
 def distortion_loss(c: Tensor, w: Tensor) -> Tensor:
+    """mip-NeRF 360 distortion of the final level, mean over rays (losses.py:137-157): one launch."""
+    return _Distortion.apply(c.detach(), w)
+
+
+def zipnerf_interlevel_loss(c_list: List[Tensor], w_list: List[Tensor]) -> Tensor:
+    """Anti-aliased inter-level loss (losses.py:654-705); proposal levels first, final level last: one
+    launch per proposal level.  The final level is detached in the reference (:661-662), and so is every
+    edge position (the samplers detach them, ray_samplers.py:364)."""
+    c, w = c_list[-1].detach(), w_list[-1].detach()
+    loss = 0
+    for i, (cp, wp) in enumerate(zip(c_list[:-1], w_list[:-1])):
+        loss = loss + _Interlevel.apply(c, w, cp.detach(), wp, PULSE_WIDTHS[i])
+    return loss
+
+
+def distortion_loss_torch(c: Tensor, w: Tensor) -> Tensor:
     """mip-NeRF 360 distortion of the final level, mean over rays (losses.py:137-157)."""
     mid = (c[..., 1:] + c[..., :-1]) / 2
     pair = torch.abs(mid[..., :, None] - mid[..., None, :])
@@ -52,7 +101,7 @@ def _resampled_target(c: Tensor, w: Tensor, cp: Tensor, pulse: float) -> Tensor:
     return torch.diff(cdf_at, dim=-1)
 
 
-def zipnerf_interlevel_loss(c_list: List[Tensor], w_list: List[Tensor]) -> Tensor:
+def zipnerf_interlevel_loss_torch(c_list: List[Tensor], w_list: List[Tensor]) -> Tensor:
     """Anti-aliased inter-level loss (losses.py:654-705); proposal levels first, final level last."""
     c, w = c_list[-1].detach(), w_list[-1].detach()
     loss = 0

@@ -332,22 +332,31 @@ def test_pipeline_end_to_end_vs_reference_golden():
     grads = torch.autograd.grad(loss, list(names.values()) + [p0], allow_unused=True)
     assert grads[-1] is None
     for (n, _), gr in zip(names.items(), grads):
-        assert_close(cpu(gr), g["grad_" + n], rtol=1e-3, atol_scale=1e-4, what="grad " + n)
+        # the proposal parameters are trained by the inter-level loss alone, now the one-launch HIP kernel: its
+        # fine-pulse gradient carries summation-order noise of ~1e-4 of the largest entry (see
+        # test_loss_kernels_vs_reference_golden_and_oracle), hence the wider floor for them
+        assert_close(cpu(gr), g["grad_" + n], rtol=1e-3, atol_scale=3e-4 if n.startswith("prop1") else 1e-4, what="grad " + n)
 
 
 def test_regularisers_product_vs_reference_golden():
+    """Both forms of the regularisers behind torch.autograd: the op-by-op torch restatement (tight) and
+    the one-launch HIP kernels the modular path uses (kernel tolerances, see test_loss_kernels_*)."""
     from neuradar_amd import losses
 
     g = load_golden("losses")
-    ws = [dev(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
     cs = [dev(g[f"c{i}"]) for i in range(3)]
-    inter = losses.zipnerf_interlevel_loss(cs, ws)
-    dist = losses.distortion_loss(cs[-1], ws[-1])
-    assert_close(cpu(inter), g["interlevel"], rtol=1e-4, atol_scale=1e-6)
-    assert_close(cpu(dist), g["distortion"], rtol=1e-4, atol_scale=1e-6)
-    gi = torch.autograd.grad(inter, ws[:2])
-    assert_close(cpu(gi[0]), g["g_inter_w0"], rtol=1e-3, atol_scale=1e-5)
-    assert_close(cpu(gi[1]), g["g_inter_w1"], rtol=1e-3, atol_scale=1e-5)
+    for inter_fn, dist_fn, tol1 in ((losses.zipnerf_interlevel_loss_torch, losses.distortion_loss_torch, 1e-3),
+                                    (losses.zipnerf_interlevel_loss, losses.distortion_loss, 3e-2)):
+        ws = [dev(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
+        inter = inter_fn(cs, ws)
+        dist = dist_fn(cs[-1], ws[-1])
+        assert_close(cpu(inter), g["interlevel"], rtol=1e-4, atol_scale=1e-6)
+        assert_close(cpu(dist), g["distortion"], rtol=1e-4, atol_scale=1e-6)
+        gi = torch.autograd.grad(2.0 * inter, ws[:2])  # upstream factor 2 exercises backward's scaling
+        assert_close(cpu(gi[0]) / 2, g["g_inter_w0"], rtol=1e-3, atol_scale=1e-4 if tol1 > 1e-3 else 1e-5)
+        assert_close(cpu(gi[1]) / 2, g["g_inter_w1"], rtol=tol1, atol_scale=1e-4 if tol1 > 1e-3 else 1e-5)
+        (gd,) = torch.autograd.grad(dist, [ws[2]])
+        assert_close(cpu(gd), g["g_dist_w2"], rtol=1e-4, atol_scale=1e-5)
 
 
 # ------------------------------------------------------------------------------------------------ a1 a2 a3
