@@ -364,7 +364,7 @@ def main():
                                         fuse_optimizer=fuse_opt, mixed=wl if "cam_rays" in wl else None)
 
     # world > 1: the RCCL collectives are issued between kernels of the step, so the step is launched
-    # eagerly (the fused step is ~45 launches: the CPU stays ahead of the GPU)
+    # eagerly (the fused step is 29 launches: the CPU stays ahead of the GPU)
     use_graph = not args.no_graph and world == 1
     graphs = []
     if use_graph:
