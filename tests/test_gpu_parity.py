@@ -684,6 +684,40 @@ def test_row_orders_are_permutations_of_one_result():
             assert_close(cpu(gt), cpu(ref_gt), rtol=1e-5, atol_scale=1e-6, what=f"table grad sm={sm}")
 
 
+def test_field_row_orders_are_permutations_of_one_result():
+    """nr_field_fwd/bwd with ray-major, sample-major and hybrid rows: identical outputs, matching gradients."""
+    from neuradar_amd import ops
+
+    g = load_golden("field_neurad")
+    fld = make_field(g)
+    rs = samples_from_edges(g, g["edges"])
+    B, S = rs.shape
+    grid = fld.hashgrid.static_grid
+    n, F = B * S, grid.features_per_level
+    ref = None
+    for sm in (0, B, B // 3 + 1):
+        x01, std = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, fld.hashgrid.static_scale,
+                                          sample_major_rows=sm)
+        table = grid.hash_table.detach().clone().requires_grad_(True)
+        buf = ops.hash_encode(x01, table, grid.scalings, grid.log2_hashmap_size, std=std, level_major=True)
+        params = [p_.detach().clone().requires_grad_(True) for p_ in (*fld.mlp_geo.weights()[0], *fld.mlp_geo.weights()[1],
+                                                                       *fld.mlp_feature.weights()[0], *fld.mlp_feature.weights()[1])]
+        ng, nf = len(fld.mlp_geo.weights()[0]), len(fld.mlp_feature.weights()[0])
+        geo = (params[:ng], params[ng:2 * ng])
+        feat = (params[2 * ng:2 * ng + nf], params[2 * ng + nf:])
+        beta = fld.sdf_to_density.beta.detach().clone().requires_grad_(True)
+        feature, sdf, alpha = ops.field_mlp(buf, (F, n * F), F, rs.directions, S, n, geo, feat, beta, rows_sample_major=sm)
+        loss = (feature.view(B, S, -1) * dev(g["g_feature"])).sum() + (alpha.view(B, S, 1) * dev(g["g_alpha"])).sum()
+        grads = torch.autograd.grad(loss, [table, beta, *params])
+        if ref is None:
+            ref = (feature, sdf, alpha, grads)
+            assert_close(cpu(feature.view(B, S, -1)), g["feature"], rtol=1e-4, atol_scale=1e-5, what="feature")
+        else:
+            assert torch.equal(feature, ref[0]) and torch.equal(sdf, ref[1]) and torch.equal(alpha, ref[2]), f"outputs differ, sm={sm}"
+            for a_, b_ in zip(grads, ref[3]):
+                assert_close(cpu(a_), cpu(b_), rtol=1e-4, atol_scale=1e-5, what=f"grad sm={sm}")
+
+
 def test_fused_step_matches_autograd_path():
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
