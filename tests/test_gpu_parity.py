@@ -718,7 +718,8 @@ def test_field_row_orders_are_permutations_of_one_result():
                 assert_close(cpu(a_), cpu(b_), rtol=1e-4, atol_scale=1e-5, what=f"grad sm={sm}")
 
 
-def test_fused_step_matches_autograd_path():
+@pytest.mark.parametrize("coherent", [None, 0.4, 0.0])  # all rays sample-major (camera), a mixed batch, all ray-major
+def test_fused_step_matches_autograd_path(coherent):
     """The autograd-free fused step (what bench.py times) reproduces outputs, loss and EVERY parameter
     gradient of the modular autograd path, which the tests above pin to the reference goldens."""
     from neuradar_amd.fused_step import FusedTrainStep
@@ -733,7 +734,7 @@ def test_fused_step_matches_autograd_path():
     loss = model.bench_loss(out, tf, td)
     params = [p for p in model.parameters() if p.requires_grad]
     ref_grads = torch.autograd.grad(loss, params, allow_unused=True)
-    fused = FusedTrainStep(model, o.shape[0])
+    fused = FusedTrainStep(model, o.shape[0], coherent_rays=None if coherent is None else int(coherent * o.shape[0]))
     for p in params:
         p.grad.zero_()
     floss = fused.forward_backward(o, d, area[:, 0].contiguous(), fars[:, 0].contiguous(), tf, td[:, 0].contiguous(), t_rand,
