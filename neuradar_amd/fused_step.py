@@ -139,19 +139,18 @@ class FusedTrainStep:
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
 
-        optimizers = (table_opt, field_opt) (FlatAdam) fuses the optimizer into the step (single-process
-        training only -- with several ranks the gradient all-reduce has to come first): the proposal
-        table is stepped on its side stream as soon as both proposal chains are done, overlapping the
-        main field's backward.
+        optimizers = (table_opt, field_opt) (FlatAdam) fuses the optimizer into the step: each table is stepped on
+        the stream of its own chain as soon as its scatter (and, with several ranks, its gradient exchange) is
+        done; the small parameters follow when every chain has finished.
 
         after_sampling: optional callable run on a side stream once the sampling rounds have consumed the
         step's random numbers (t_rand, jitters) -- the caller refills them there for the NEXT step, off the
         critical path.
 
-        reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The SUM
-        all-reduce of the proposal table's gradient is issued as soon as both proposal chains finish and
-        runs over RCCL/xGMI underneath the main field's backward; the main table and the small-parameter
-        bucket follow; Adam applies 1/world (DDP's mean)."""
+        reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The main table's
+        gradient is exchanged as (row, value) lists right after its scatter (reduce_sparse), the proposal table's
+        dense SUM all-reduce is issued on its side stream when both proposal scatters are done and runs over
+        RCCL/xGMI beside the main chain, the small-parameter bucket last; Adam applies 1/world (DDP's mean)."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
         assert target_features.shape[1] == self.C and self.C <= 32
@@ -180,8 +179,8 @@ class FusedTrainStep:
         scale = self.model.field.hashgrid.static_scale
         # launches of the sampling part: bins+contraction, then per round hash grid -> density -> [weights, depth,
         # resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
-        # gradients) are kept SAMPLE-major, row s*B+b (include/neuradar_hip.h, nr_contract_gaussians);
-        # per-ray arrays stay [B,S].
+        # gradients) of the first self.sm rays are kept SAMPLE-major, row s*sm+b (include/neuradar_hip.h,
+        # nr_contract_gaussians); per-ray arrays stay [B,S].
         check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, self.sm, p(self.sp[0]),
                                          p(self.eu[0]), p(self.x01[0]), p(self.std[0]), st), "power_bins")
         jit = (jitter1, jitter2)
