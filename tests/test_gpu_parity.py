@@ -81,6 +81,35 @@ def test_hash_encode_fwd_bwd_vs_reference_golden(tag, level_major):
     assert_close(cpu(gt), g[f"{tag}_gtable"], rtol=1e-4, atol_scale=1e-5, what=tag + " grad")
 
 
+@pytest.mark.parametrize("F", [8, 4, 2, 1])
+@pytest.mark.parametrize("coherent", [True, False])
+def test_hash_encode_every_width_vs_oracle(F, coherent):
+    """All four feature widths of the kernels (the goldens hold F = 1, 2, 4) against the oracle, on clustered
+    positions (the on-chip dedup path of the scatter) and on uniformly random ones (table pressure, flushes)."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    torch.manual_seed(F)
+    L, log2t, n = 3, 12, 20_000
+    sc = hashgrid.level_scalings(L, 16, 512)
+    table = hashgrid.init_table(L, log2t, F, scale=1.0)
+    if coherent:  # a few tight clusters: many samples per cell
+        centres = torch.rand(40, 3)
+        x = (centres[torch.randint(0, 40, (n,))] + 0.002 * torch.randn(n, 3)).clamp(0, 1)
+    else:
+        x = torch.rand(n, 3)
+    x[:7] = torch.tensor([0.0, 0.25, 0.5])  # exact grid planes
+    gout = torch.randn(n, L * F)
+    tr = table.clone().requires_grad_(True)
+    ref = hashgrid.encode(x, tr, sc, 2**log2t)
+    (gref,) = torch.autograd.grad(ref, tr, gout)
+    td = dev(table).requires_grad_(True)
+    out = ops.hash_encode(dev(x), td, dev(sc), log2t)
+    (gt,) = torch.autograd.grad(out, td, dev(gout))
+    assert_close(cpu(out), ref.detach(), rtol=1e-5, atol_scale=1e-6, what=f"F={F} fwd")
+    assert_close(cpu(gt), gref, rtol=1e-4, atol_scale=1e-5, what=f"F={F} table grad")
+
+
 def test_hash_encode_module_is_dropin_and_linear_in_table():
     """HashEncoding keeps the reference's surface (scalings buffer, hash_table parameter, out dim) and
     the encoding is linear in the table (size-independent property, checked at a large n)."""
