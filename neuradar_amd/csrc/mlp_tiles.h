@@ -102,7 +102,9 @@ __device__ __forceinline__ void dense_fwd(const f32x16 (&x)[(K + 31) / 32], f32x
     }
     if (RELU) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+      // relu as ONE v_max_i32 on the bit pattern (negative floats are negative ints; -0.0 -> +0.0);
+      // fmaxf costs two v_max_f32 (the IEEE-mode canonicalisation of its operand comes first)
+      for (int r = 0; r < 16; ++r) acc[r] = __int_as_float(max(__float_as_int(acc[r]), 0));
     }
     y[mt] = acc;
   }
