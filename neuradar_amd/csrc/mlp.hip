@@ -108,7 +108,7 @@ __device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], co
 #define NR_MLP_BWD_WAVES 1
 #endif
 
-template <int IN, int HID>
+template <int IN, int HID, int FW>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_FWD_WAVES)
 field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                  const float* __restrict__ dirs, int S, int rows_sm, int64_t n, float* __restrict__ feature,
@@ -124,7 +124,7 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     const bool valid = smp < n;
     f32x16 x0[I::IT], h1[I::HT], e[1], cat[2], f1[I::HT], f2[I::HT], o[1];
     load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
-                  [&](int k) { return (int64_t)(k / F) * sl + (k % F); });
+                  [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); });
     dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
     dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
     const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
@@ -165,7 +165,7 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f
 //     (the sdf row via per-lane partial products); writes grad_feats.
 constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
 
-template <int IN, int HID>
+template <int IN, int HID, int FW>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                       const float* __restrict__ dirs, int S, int rows_sm, int64_t n, const float* __restrict__ g_feature,
@@ -197,7 +197,8 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
     float sdf;
     {
       f32x16 x0[I::IT], h1[I::HT], e[1];
-      load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, [&](int k) { return (int64_t)(k / F) * sl + (k % F); });
+      load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
+                    [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); });
       dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
       dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
       sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
@@ -252,7 +253,7 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
   for (int k = threadIdx.x; k < kImg; k += blockDim.x) out[k] = img[k];
 }
 
-template <int IN, int HID>
+template <int IN, int HID, int FW>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F, int64_t n,
                      const float* __restrict__ ws, float* __restrict__ g_feats, float* __restrict__ slab) {
@@ -285,7 +286,7 @@ field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
     f32x16 x0[I::IT], h1[I::HT], d_e[1], d_h1[I::HT], d_x0[I::IT];
-    auto foff = [&](int k) { return (int64_t)(k / F) * sl + (k % F); };
+    auto foff = [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); };
     load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
     dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
     load_rows<kC>(d_e, ws + (valid ? smp * (kC + 1) : 0), valid, h, [](int k) { return (int64_t)k; });
@@ -591,10 +592,17 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
     const int v = atoi(e);
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
-  if (hid == 32)
-    hipLaunchKernelGGL((field_fwd_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha);
-  else
-    hipLaunchKernelGGL((field_fwd_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha);
+#define LAUNCH_FWD(FWC)                                                                                               \
+  {                                                                                                                    \
+    if (hid == 32)                                                                                                     \
+      hipLaunchKernelGGL((field_fwd_kernel<32, 32, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
+                         F, dirs, S, rows_sample_major, n, feature, sdf, alpha);                                       \
+    else                                                                                                               \
+      hipLaunchKernelGGL((field_fwd_kernel<32, 64, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
+                         F, dirs, S, rows_sample_major, n, feature, sdf, alpha);                                       \
+  }
+  if (F == 2) LAUNCH_FWD(2) else if (F == 4) LAUNCH_FWD(4) else LAUNCH_FWD(0)
+#undef LAUNCH_FWD
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -619,17 +627,22 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
   float* slab = workspace + n * (kC + 1);  // [blocks][G_TOTAL] after the d_e / d_sdf rows
-  if (hid == 32) {
-    using I = FieldImage<32, 32>;
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);
-    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 32>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, slab);
-    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0, nr_s(stream), slab, (int)blocks, *grads);
-  } else {
-    using I = FieldImage<32, 64>;
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);
-    hipLaunchKernelGGL((field_bwd_geo_kernel<32, 64>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, F, n, workspace, g_feats, slab);
-    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 64>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0, nr_s(stream), slab, (int)blocks, *grads);
+#define LAUNCH_BWD(HIDC, FWC)                                                                                          \
+  {                                                                                                                     \
+    using I = FieldImage<32, HIDC>;                                                                                     \
+    hipLaunchKernelGGL((field_bwd_feat_kernel<32, HIDC, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, \
+                       sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);               \
+    hipLaunchKernelGGL((field_bwd_geo_kernel<32, HIDC, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn,  \
+                       sl, F, n, workspace, g_feats, slab);                                                             \
+    hipLaunchKernelGGL((field_grad_reduce_kernel<32, HIDC>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0,     \
+                       nr_s(stream), slab, (int)blocks, *grads);                                                        \
   }
+  if (hid == 32) {
+    if (F == 2) LAUNCH_BWD(32, 2) else if (F == 4) LAUNCH_BWD(32, 4) else LAUNCH_BWD(32, 0)
+  } else {
+    if (F == 2) LAUNCH_BWD(64, 2) else if (F == 4) LAUNCH_BWD(64, 4) else LAUNCH_BWD(64, 0)
+  }
+#undef LAUNCH_BWD
   NR_LAUNCH_CHECK();
   return 0;
 }
