@@ -26,8 +26,8 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 3
-#define NR_LOSS_SLOTS 64   /* loss kernels add into loss[0..63]; the loss value is the sum of the slots */
+#define NR_ABI_VERSION 4
+#define NR_LOSS_SLOTS 1024 /* loss kernels add into loss[0..1023]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
 
@@ -291,7 +291,7 @@ int nr_gen_rays_radar(const int64_t* scan_indices, int64_t n_scans, const float*
 
 /* ------------------------------------------------------------------------------------------------
  * Loss tail of a training step.  Each entry adds its (already weighted)
- * loss value into the NR_LOSS_SLOTS partial sums loss[0..63] (their sum is the loss) and writes the gradient w.r.t. the tensors it consumes, so no autograd graph
+ * loss value into the NR_LOSS_SLOTS partial sums loss[0..NR_LOSS_SLOTS-1] (their sum is the loss) and writes the gradient w.r.t. the tensors it consumes, so no autograd graph
  * is needed between compositing and the backward kernels.
  * ---------------------------------------------------------------------------------------------- */
 /* rgb_mult*mean((features[:, :C] - target_f)^2) + depth_mult*mean(|depth - target_d|): the stand-in

@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
-NR_LOSS_SLOTS = 64
+NR_LOSS_SLOTS = 1024
 
 
 class NrMlp(Structure):
@@ -108,7 +108,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 3:
+        if handle.nr_abi_version() != 4:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -9,9 +9,9 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-// loss values are summed into NR_LOSS_SLOTS partial sums (slot = block index mod slots): thousands of
+// loss values are summed into NR_LOSS_SLOTS partial sums (slot = global wave index mod slots): thousands of
 // atomics on ONE address serialise at the memory side (~15 ns each), spread over 64 they do not.
-__device__ __forceinline__ float* loss_slot(float* loss) { return loss + (blockIdx.x & (NR_LOSS_SLOTS - 1)); }
+__device__ __forceinline__ float* loss_slot(float* loss) { return loss + nr_loss_slot_index(); }
 
 __global__ void __launch_bounds__(256)
 supervision_loss_kernel(const float* __restrict__ features, int feat_stride, const float* __restrict__ target_f, int C,

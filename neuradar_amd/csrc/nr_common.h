@@ -26,6 +26,15 @@ __device__ __forceinline__ uint32_t nr_hash3(int ix, int iy, int iz, uint32_t ma
   return (((uint32_t)ix * 1u) ^ ((uint32_t)iy * 2654435761u) ^ ((uint32_t)iz * 805459861u)) & mask;
 }
 
+// ---- loss partial sums ---------------------------------------------------------------------------
+// Every wave adds its loss into slot (global wave index mod NR_LOSS_SLOTS).  Same-address float atomics
+// are applied one after the other at the memory side (~0.4 us each, measured): with 64 slots the
+// 4 096 waves of a 4 096-ray launch queued 64 deep and that queue WAS the kernel (inter-level loss
+// 30 us, flat in its proposal size; 1 024 slots: 4 deep).
+__device__ __forceinline__ int nr_loss_slot_index() {
+  return (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (NR_LOSS_SLOTS - 1));
+}
+
 // ---- per-sample row order ------------------------------------------------------------------------
 // The per-sample arrays that only the hash grid and the MLPs touch (positions, per-level features and
 // their gradients) may keep the rows of the first `sm` rays SAMPLE-major, row = s * sm + b: a wave's 64

@@ -169,7 +169,7 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
   if (on) lossv += kdist * (wi * inner + wi * wi * (c1 - c0) / 3.0f);
   const float gW = on ? kdist * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
   lossv = nr_wave_sum(lossv);
-  if (lane == 0 && lossv != 0.0f) unsafeAtomicAdd(loss + (blockIdx.x & (NR_LOSS_SLOTS - 1)), lossv);
+  if (lane == 0 && lossv != 0.0f) unsafeAtomicAdd(loss + nr_loss_slot_index(), lossv);
   // ---- composite backward ----
   // g_feature[s][c] = gF_c * w_s ; dot_s = sum_c gF_c f[s][c]: 32 values reduced over the 32 lanes of
   // each half by a halving butterfly (31 exchanges), after which lane (sh, j) holds dot_{2j+sh}

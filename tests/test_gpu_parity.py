@@ -473,7 +473,7 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
     B = c2.shape[0]
     c_full = torch.cat([c2, torch.ones(B, 1, device=DEV)], 1).contiguous()
     w_full = torch.cat([w2, torch.full((B, 1), 0.123, device=DEV)], 1).contiguous()
-    loss = torch.zeros(64, device=DEV)  # NR_LOSS_SLOTS partial sums
+    loss = torch.zeros(1024, device=DEV)  # NR_LOSS_SLOTS partial sums
     gd = ops.distortion_loss(c_full, w_full, 31, 1.0, loss)
     assert_close(cpu(loss).sum(), g["distortion"], rtol=1e-4, atol_scale=1e-6, what="distortion")
     assert_close(cpu(gd[:, :31]), g["g_dist_w2"], rtol=1e-4, atol_scale=1e-5, what="distortion grad")
