@@ -1,4 +1,6 @@
 // Proposal-field head (Linear(L*F,1,bias=False) + trunc_exp), SH degree-4 encoding, dense Adam.
+#include <stdlib.h>
+
 #include "nr_common.h"
 #include "sh4.h"
 
@@ -158,34 +160,58 @@ __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict_
 // counter) and cleared in the table; rows that do not fit `cap` stay where they are and `count` exceeds
 // `cap` (the caller then falls back to the dense all-reduce).  apply: table[row] += values, one list
 // at a time in rank order with plain adds -> every rank computes bit-identical sums.
+// Each WAVE owns a contiguous range of rows: pass A counts its non-zero rows, ONE returning atomic per block
+// reserves the block's span of the list (the waves' spans follow one another inside it), pass B re-reads the
+// range and writes the rows in ascending order -- no barrier inside either pass.  (A returning atomic per wave
+// and iteration -- 70 k of them on one address -- took 650 us: same-address atomics are applied one by one.)
 template <int F>
 __global__ void __launch_bounds__(256)
 grad_compact_kernel(float* __restrict__ grad, int64_t rows, int64_t cap, int* __restrict__ idx, float* __restrict__ val,
                     int* __restrict__ count) {
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < rows; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = base + threadIdx.x;
-    float v[F];
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int lane = nr_lane(), wave = threadIdx.x >> 6;
+  const int64_t per_wave = nr_cdiv_dev(nr_cdiv_dev(rows, (int64_t)gridDim.x * 4), NR_WAVE) * NR_WAVE;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * per_wave, r1 = r0 + per_wave < rows ? r0 + per_wave : rows;
+  auto nonzero = [&](int64_t r, float (&v)[F]) {
     bool nz = false;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      v[f] = r < rows ? grad[r * F + f] : 0.0f;
+      v[f] = r < r1 ? grad[r * F + f] : 0.0f;
       nz |= v[f] != 0.0f;
     }
+    return nz;
+  };
+  int mine = 0;  // wave-uniform
+  for (int64_t base = r0; base < r1; base += NR_WAVE) {
+    float v[F];
+    mine += __popcll(__ballot(nonzero(base + lane, v)));
+  }
+  if (lane == 0) s_wave[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = total > 0 ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
+  int64_t pos = s_base;
+  for (int k = 0; k < wave; ++k) pos += s_wave[k];
+  if (mine == 0) return;
+  for (int64_t base = r0; base < r1; base += NR_WAVE) {
+    const int64_t r = base + lane;
+    float v[F];
+    const bool nz = nonzero(r, v);
     const unsigned long long m = __ballot(nz);
-    if (m == 0) continue;
-    const int lane = nr_lane();
-    int start = 0;
-    if (lane == 0) start = atomicAdd(count, __popcll(m));
-    start = __shfl(start, 0, NR_WAVE);
-    const int64_t pos = start + __popcll(m & ((1ull << lane) - 1ull));
-    if (nz && pos < cap) {
-      idx[pos] = (int)r;
+    const int64_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
+    if (nz && at < cap) {
+      idx[at] = (int)r;
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        val[pos * F + f] = v[f];
+        val[at * F + f] = v[f];
         grad[r * F + f] = 0.0f;
       }
     }
+    pos += __popcll(m);
   }
 }
 
@@ -207,7 +233,7 @@ extern "C" int nr_grad_compact(float* grad, int64_t rows, int F, int64_t cap, in
                                nr_stream_t stream) {
   if (rows == 0) return 0;
   if (!grad || !idx || !val || !count || rows < 0 || rows > 0x7fffffff || cap < 1) return NR_EINVAL;
-  const unsigned blocks = (unsigned)(nr_cdiv(rows, 256) < 2048 ? nr_cdiv(rows, 256) : 2048);
+  const unsigned blocks = (unsigned)(nr_cdiv(rows, 256) < 1024 ? nr_cdiv(rows, 256) : 1024);
 #define CALL(FF) hipLaunchKernelGGL(grad_compact_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), grad, rows, cap, idx, val, count)
   switch (F) {
     case 1: CALL(1); break;
@@ -266,7 +292,10 @@ extern "C" int nr_prop_density_bwd(const float* feats, int64_t sn, int64_t sl, i
   if (n == 0) return 0;
   if (!feats || !w || !g_density || !g_feats || !g_w || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
   if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples))) return NR_EINVAL;
-  const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < 1024 ? nr_cdiv(n, 256) : 1024);
+  // every block ends with ONE atomic request onto the same line (grad_w): keep the queue short
+  int cap_blocks = 256;
+  if (const char* e = getenv("NR_PDBWD_BLOCKS")) cap_blocks = atoi(e) > 0 ? atoi(e) : cap_blocks;  // tuning knob
+  const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < cap_blocks ? nr_cdiv(n, 256) : cap_blocks);
 #define CALL(IN)                                                                                                       \
   hipLaunchKernelGGL(prop_density_bwd_kernel<IN>, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n, \
                      n_samples, rows_sample_major, g_density, g_feats, g_w)
