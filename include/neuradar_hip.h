@@ -172,6 +172,12 @@ int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t stream);
 int nr_prop_density_fwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
                         const float* w, int in_dim, int64_t n, int n_samples, int rows_sample_major,
                         float* density, nr_stream_t stream);
+/* nr_hash_encode_fwd (sample rows walked as stored, level-major or any strides) followed by
+ * nr_prop_density_fwd in ONE launch: feats (kept for the backward) and density [n_rays, n_samples]. */
+int nr_prop_field_fwd(const float* x, const float* std, const float* table, const float* scalings,
+                      int num_levels, int features_per_level, int log2_hashmap_size, const float* w,
+                      float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int64_t n, int n_samples,
+                      int rows_sample_major, float* density, nr_stream_t stream);
 int nr_prop_density_bwd(const float* feats, int64_t feat_stride_n, int64_t feat_stride_l, int feat_f,
                         const float* w, int in_dim, int64_t n, int n_samples, int rows_sample_major,
                         const float* density, const float* grad_density, float* grad_feats, float* grad_w,

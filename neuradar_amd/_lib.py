@@ -52,6 +52,7 @@ PROTOTYPES = {
     "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
     "nr_sh4_fwd": [P, L, P, P],
     "nr_prop_density_fwd": [P, L, L, I, P, I, L, I, I, P, P],
+    "nr_prop_field_fwd": [P, P, P, P, I, I, I, P, P, L, L, L, I, I, P, P],
     "nr_prop_density_bwd": [P, L, L, I, P, I, L, I, I, P, P, P, P, P],
     "nr_power_bins": [P, P, P, L, I, F, F, P, P, P],
     "nr_power_bins_contract": [P, P, P, P, P, P, L, I, F, F, F, I, P, P, P, P, P],

@@ -64,6 +64,61 @@ __device__ __forceinline__ Corner make_corner(const float* x, int64_t idx, float
   return c;
 }
 
+// one level of one sample: 8 gathers, trilinear interpolation in the reference's order, per-level rescale
+template <int F>
+__device__ __forceinline__ void encode_level(const float* __restrict__ x, const float* __restrict__ std,
+                                             const float* __restrict__ table, float scale, int level, int log2T, int64_t idx,
+                                             float (&feat)[F]) {
+  const Corner c = make_corner(x, idx, scale);
+  const uint32_t mask = (1u << log2T) - 1u;
+  const float* base = table + (((int64_t)level << log2T) * F);
+  float acc_z[2][F];
+#pragma unroll
+  for (int zs = 0; zs < 2; ++zs) {  // zs = 0: ceil z, 1: floor z
+    const int iz = zs == 0 ? c.hi[2] : c.lo[2];
+    float acc_y[2][F];
+#pragma unroll
+    for (int ys = 0; ys < 2; ++ys) {
+      const int iy = ys == 0 ? c.hi[1] : c.lo[1];
+      float vh[F], vl[F];
+      load_entry<F>(base + (int64_t)nr_hash3(c.hi[0], iy, iz, mask) * F, vh);
+      load_entry<F>(base + (int64_t)nr_hash3(c.lo[0], iy, iz, mask) * F, vl);
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc_y[ys][f] = vh[f] * c.w[0] + vl[f] * (1.0f - c.w[0]);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc_z[zs][f] = acc_y[0][f] * c.w[1] + acc_y[1][f] * (1.0f - c.w[1]);
+  }
+  float r = 1.0f;
+  if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);  // neurad_encoding.py:314
+#pragma unroll
+  for (int f = 0; f < F; ++f) feat[f] = (acc_z[0][f] * c.w[2] + acc_z[1][f] * (1.0f - c.w[2])) * r;
+}
+
+// Proposal field forward in one launch (NeuRADProposalField.get_density, neurad_field.py:208-213): all levels of
+// a sample in one thread, features stored for the backward, density = trunc_exp(feats . w) written [B,S].
+template <int F>
+__global__ void __launch_bounds__(256)
+prop_field_fwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ table,
+                      const float* __restrict__ scalings, int L, int log2T, const float* __restrict__ w,
+                      float* __restrict__ out, int64_t sn, int64_t sl, int64_t n, int n_samples, int sm_rays,
+                      float* __restrict__ density) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float xs = 0.0f;
+  for (int level = 0; level < L; ++level) {
+    float feat[F];
+    encode_level<F>(x, std, table, scalings[level], level, log2T, i, feat);
+    float* o = out + i * sn + (int64_t)level * sl;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      o[f] = feat[f];
+      xs += feat[f] * w[level * F + f];
+    }
+  }
+  density[nr_row_map(i, n, n_samples, sm_rays).out] = expf(xs);
+}
+
 template <int F>
 __global__ void __launch_bounds__(256)
 hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ table,
@@ -460,6 +515,26 @@ extern "C" int nr_hash_encode_fwd(const float* x, const float* std, const float*
     case 8: hipLaunchKernelGGL(hash_encode_fwd_kernel<8>, grid, block, 0, nr_s(stream), x, std, table, scalings, log2T, out, sn, sl, n, sample_major); break;
     default: return NR_EINVAL;
   }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_prop_field_fwd(const float* x, const float* std, const float* table, const float* scalings, int L, int F,
+                                 int log2T, const float* w, float* feats, int64_t sn, int64_t sl, int64_t n, int n_samples,
+                                 int rows_sample_major, float* density, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !table || !scalings || !w || !feats || !density || L < 1 || log2T < 1 || log2T > 30 || n < 0 || n_samples < 1 ||
+      n % n_samples != 0 || rows_sample_major < 0 || rows_sample_major > n / n_samples)
+    return NR_EINVAL;
+  dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
+#define CALL(FF) hipLaunchKernelGGL(prop_field_fwd_kernel<FF>, grid, block, 0, nr_s(stream), x, std, table, scalings, L, log2T, w, feats, sn, sl, n, n_samples, rows_sample_major, density)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
   NR_LAUNCH_CHECK();
   return 0;
 }

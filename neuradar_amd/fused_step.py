@@ -50,6 +50,7 @@ class FusedTrainStep:
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
         self.sm = n_rays if coherent_rays is None else int(coherent_rays)
+        self.fuse_prop_fwd = os.environ.get("NR_FUSE_PROP_FWD", "1") != "0"  # grid + density head in one launch (+1.6 %)
         self.lib = _lib.lib()
         dev = next(model.parameters()).device
         self.dev = dev
@@ -187,11 +188,18 @@ class FusedTrainStep:
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
             S, n = self.S[lvl], B * self.S[lvl]
-            check(self._timed(f"hash_encode_fwd[prop_s{S}]", lambda: lib.nr_hash_encode_fwd(
-                p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
-                pg.log2_hashmap_size, p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, 0, st)), "hash_fwd")
-            check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
-                                          pg.features_per_level, p(w_dec), w_dec.numel(), n, S, self.sm, p(self.dens[lvl]), st), "prop_density")
+            if self.fuse_prop_fwd:  # grid + density head in one launch
+                check(self._timed(f"hash_encode_fwd[prop_s{S}]", lambda: lib.nr_prop_field_fwd(
+                    p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
+                    pg.log2_hashmap_size, p(w_dec), p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, S,
+                    self.sm, p(self.dens[lvl]), st)), "prop_field_fwd")
+            else:
+                check(self._timed(f"hash_encode_fwd[prop_s{S}]", lambda: lib.nr_hash_encode_fwd(
+                    p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
+                    pg.log2_hashmap_size, p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, 0, st)), "hash_fwd")
+                check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
+                                              pg.features_per_level, p(w_dec), w_dec.numel(), n, S, self.sm, p(self.dens[lvl]), st),
+                      "prop_density")
             check(lib.nr_proposal_round(p(self.dens[lvl]), p(self.eu[lvl]), p(self.sp[lvl]), p(jit[lvl]), nears, far, o, d, area,
                                         B, S, self.S[lvl + 1], lam, scal, SKY_DISTANCE if lvl == 1 else 0.0, scale, self.sm,
                                         p(self.w[lvl]), p(self.prop_depth[lvl]), p(self.sp[lvl + 1]), p(self.eu[lvl + 1]),

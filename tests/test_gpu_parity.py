@@ -685,6 +685,34 @@ def test_reference_pinned_vectors_on_the_hip_path():
     assert torch.allclose(b.directions.norm(dim=-1), torch.ones(3, device=DEV), atol=1e-6)
 
 
+@pytest.mark.parametrize("sm_frac", [1.0, 0.0, 0.37])
+def test_prop_field_fwd_matches_two_launches(sm_frac):
+    """nr_prop_field_fwd == nr_hash_encode_fwd -> nr_prop_density_fwd (features and densities), and the reference."""
+    from neuradar_amd import _lib, ops
+
+    lib, p, st = _lib.lib(), ops._p, ops._stream
+    g = load_golden("field_neurad")
+    pf = make_prop(g)
+    rs = samples_from_edges(g, g["edges"])
+    B, S = rs.shape
+    sm = int(sm_frac * B)
+    grid = pf.hashgrid.static_grid
+    L, F, n = grid.num_levels, grid.features_per_level, B * S
+    x01, std = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, pf.hashgrid.static_scale, sample_major_rows=sm)
+    table = grid.hash_table.detach()
+    w = pf.density_decoder.weight.detach().reshape(-1).contiguous()
+    f1, d1 = torch.empty(L, n, F, device=DEV), torch.empty(n, device=DEV)
+    _lib.check(lib.nr_hash_encode_fwd(p(x01), p(std), p(table), p(grid.scalings), L, F, grid.log2_hashmap_size, p(f1), F, n * F, n, 0,
+                                      st()), "hash")
+    _lib.check(lib.nr_prop_density_fwd(p(f1), F, n * F, F, p(w), w.numel(), n, S, sm, p(d1), st()), "density")
+    f2, d2 = torch.empty_like(f1), torch.empty_like(d1)
+    _lib.check(lib.nr_prop_field_fwd(p(x01), p(std), p(table), p(grid.scalings), L, F, grid.log2_hashmap_size, p(w), p(f2), F, n * F, n,
+                                     S, sm, p(d2), st()), "fused")
+    assert torch.equal(f2, f1)
+    assert_close(cpu(d2), cpu(d1), rtol=1e-6, atol_scale=1e-7, what="density")
+    assert_close(cpu(d2.view(B, S, 1)), g["prop_density"], rtol=1e-4, atol_scale=1e-5, what="density vs reference")
+
+
 def test_row_orders_are_permutations_of_one_result():
     """Sample-major / hybrid / ray-major row storage (nr_contract_gaussians' sample_major_rows) only permutes
     rows: grid features, densities and the table gradient agree exactly."""
