@@ -157,16 +157,6 @@ class FusedTrainStep:
         assert target_features.shape[1] == self.C and self.C <= 32
         main = torch.cuda.current_stream()
         side = self._side_streams() if self.overlap else [main, main]
-        # bookkeeping nothing on the sampling rounds depends on runs beside them: loss slots, the field's
-        # weight image, the optimizers' schedule kernels
-        if side[0] is not main:
-            side[0].wait_stream(main)
-        with torch.cuda.stream(side[0]):
-            self.loss.zero_()
-            check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), ops._stream()), "field_pack")
-            if optimizers is not None:
-                for o_ in optimizers:
-                    o_.advance()
         lam, scal = c.power_lambda, c.power_scaling
         o, d, area = p(origins), p(directions), p(pixel_area)
         if fars is None:  # camera rays: fars = 1e6 (cameras.py:948), clamped to the sky distance (neuradar.py:573)
@@ -184,6 +174,16 @@ class FusedTrainStep:
         # nr_contract_gaussians); per-ray arrays stay [B,S].
         check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, self.sm, p(self.sp[0]),
                                          p(self.eu[0]), p(self.x01[0]), p(self.std[0]), st), "power_bins")
+        # bookkeeping nothing on the sampling rounds depends on runs beside them (forked AFTER the first launch of
+        # the critical path: a fork costs it ~10 us): loss slots, the field's weight image, the optimizers' schedule kernels
+        if side[0] is not main:
+            side[0].wait_stream(main)
+        with torch.cuda.stream(side[0]):
+            self.loss.zero_()
+            check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), ops._stream()), "field_pack")
+            if optimizers is not None:
+                for o_ in optimizers:
+                    o_.advance()
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
