@@ -184,8 +184,15 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
 // the 64 KB static LDS of a block).  Tuned on the bench's camera patches AND on incoherent lidar rays
 // (tools/scatter_real.py, tools/probe_incoherent.py).
 template <int F> struct BwdCfg;
-template <> struct BwdCfg<1> { static constexpr int CHUNK = 512, CAP = 256, W = 4; };
-template <> struct BwdCfg<2> { static constexpr int CHUNK = 512, CAP = 128, W = 4; };
+#ifndef NR_BWD_F1
+#define NR_BWD_F1 512, 256, 4
+#endif
+#ifndef NR_BWD_F2
+#define NR_BWD_F2 512, 128, 4
+#endif
+template <int C, int P, int WV> struct BwdCfgT { static constexpr int CHUNK = C, CAP = P, W = WV; };
+template <> struct BwdCfg<1> : BwdCfgT<NR_BWD_F1> {};
+template <> struct BwdCfg<2> : BwdCfgT<NR_BWD_F2> {};
 template <> struct BwdCfg<4> { static constexpr int CHUNK = 256, CAP = 128, W = 2; };
 template <> struct BwdCfg<8> { static constexpr int CHUNK = 256, CAP = 64, W = 2; };
 constexpr unsigned long long kEmptyKey = ~0ull;
