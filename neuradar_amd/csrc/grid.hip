@@ -128,34 +128,11 @@ hash_encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ st
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t idx = sample_of_thread(i, n, S);
-  const float scale = scalings[level];
-  const Corner c = make_corner(x, idx, scale);
-  const uint32_t mask = (1u << log2T) - 1u;
-  const float* base = table + (((int64_t)level << log2T) * F);
-
-  // x-pairs for the four (y,z) selections, reduced x -> y -> z exactly like the reference
-  float acc_z[2][F];
-#pragma unroll
-  for (int zs = 0; zs < 2; ++zs) {  // zs = 0: ceil z, 1: floor z
-    const int iz = zs == 0 ? c.hi[2] : c.lo[2];
-    float acc_y[2][F];
-#pragma unroll
-    for (int ys = 0; ys < 2; ++ys) {
-      const int iy = ys == 0 ? c.hi[1] : c.lo[1];
-      float vh[F], vl[F];
-      load_entry<F>(base + (int64_t)nr_hash3(c.hi[0], iy, iz, mask) * F, vh);
-      load_entry<F>(base + (int64_t)nr_hash3(c.lo[0], iy, iz, mask) * F, vl);
-#pragma unroll
-      for (int f = 0; f < F; ++f) acc_y[ys][f] = vh[f] * c.w[0] + vl[f] * (1.0f - c.w[0]);
-    }
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc_z[zs][f] = acc_y[0][f] * c.w[1] + acc_y[1][f] * (1.0f - c.w[1]);
-  }
-  float r = 1.0f;
-  if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * std[idx], 1.0f);  // neurad_encoding.py:314
+  float feat[F];
+  encode_level<F>(x, std, table, scalings[level], level, log2T, idx, feat);
   float* o = out + idx * sn + (int64_t)level * sl;
 #pragma unroll
-  for (int f = 0; f < F; ++f) o[f] = (acc_z[0][f] * c.w[2] + acc_z[1][f] * (1.0f - c.w[2])) * r;
+  for (int f = 0; f < F; ++f) o[f] = feat[f];
 }
 
 // Backward scatter-add.  Memory-side float atomics are the scarce resource here (about 20 G
