@@ -175,17 +175,47 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
                                             after_sampling=lambda: hip_ops.uniform_fill(r, seed, epoch))
 
+        # camera-only workloads are software-pipelined across steps: as soon as step k's sampling rounds have read
+        # the uniform buffer it is refilled, and the rays + first launch (bins, contraction) of step k+1 run on the
+        # same side stream into the other buffer set, beside step k's field / backward.  Same numbers in the same
+        # order as the unpipelined step (NR_PIPELINE=0), which generates them at the top of step k+1.
+        pipelined = mixed is None and os.environ.get("NR_PIPELINE", "1") != "0"
+        bundles = [None, None]
+        state = {"k": 0}
+
+        def gen_rays(slot):
+            bundles[slot], _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
+                                                                 scene.H, scene.W, area_scale=9.0,  # _scale_pixel_area
+                                                                 out=bundles[slot])
+            return bundles[slot]
+
+        def next_step_head(slot):
+            hip_ops.uniform_fill(r, seed, epoch)
+            b = gen_rays(slot)
+            # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
+            stepper.prepare(slot, b.origins, b.directions, b.pixel_area[:, 0], None, r[:n_t].view(n_rays, S0 + 1))
+
         def fwd_bwd():
             if mixed is not None:
                 return fwd_bwd_mixed()
-            bundle, _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
-                                                          scene.H, scene.W, area_scale=9.0)  # _scale_pixel_area
-            # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
+            k = state["k"]
+            if pipelined:
+                if bundles[k] is None:  # very first step: nothing prepared it
+                    b = gen_rays(k)
+                    stepper.prepare(k, b.origins, b.directions, b.pixel_area[:, 0], None, r[:n_t].view(n_rays, S0 + 1))
+                state["k"] = 1 - k
+                tail = lambda: next_step_head(1 - k)  # noqa: E731
+            else:
+                gen_rays(0)
+                k, tail = 0, (lambda: hip_ops.uniform_fill(r, seed, epoch))
+            bundle = bundles[k]
             return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], None, tgt_f, tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
-                                            after_sampling=lambda: hip_ops.uniform_fill(r, seed, epoch))
+                                            after_sampling=tail, slot=k, prepared=pipelined)
+
+        fwd_bwd.state = state if pipelined else None
     else:
         def fwd_bwd():
             bundle = scene.cameras.generate_rays(scene.sample_ray_indices(n_rays))
@@ -377,13 +407,18 @@ def main():
                     optim()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-            graphs = [g1]
+            # a pipelined step alternates between two buffer sets: one graph per set, replayed in turn
+            slots = getattr(fwd_bwd, "state", None)
+            for _ in range(2 if slots is not None else 1):
+                k = slots["k"] if slots is not None else 0
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                graphs.append((k, g1))
+            graphs = dict(graphs)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            use_graph, graphs = False, []
+            use_graph, graphs = False, {}
             torch.cuda.synchronize()
 
     if use_graph:
@@ -399,7 +434,12 @@ def main():
                 torch.cuda.synchronize()
 
         def step():
-            graphs[0].replay()
+            if slots is not None:
+                k = slots["k"]
+                slots["k"] = 1 - k
+                graphs[k].replay()
+            else:
+                graphs[0].replay()
             if g_opt is not None:
                 g_opt.replay()
             elif not fuse_opt:

@@ -61,7 +61,6 @@ class FusedTrainStep:
         self.pgrid, self.mgrid = self.prop.hashgrid.static_grid, model.field.hashgrid.static_grid
         self.nears = torch.zeros(B, **f32)
         self.fars = torch.empty(B, **f32)
-        self._fars_is_sky = False
         self.sp, self.eu, self.x01, self.std, self.feats, self.g_feats = [], [], [], [], [], []
         for lvl, S in enumerate(self.S):
             grid = self.pgrid if lvl < 2 else self.mgrid
@@ -71,6 +70,12 @@ class FusedTrainStep:
             self.std.append(torch.empty(B * S, **f32))
             self.feats.append(torch.empty(grid.num_levels, B * S, grid.features_per_level, **f32))
             self.g_feats.append(torch.empty_like(self.feats[-1]))
+        # level-0 bins / contracted samples and the clamped far planes exist twice: `prepare` may fill the other
+        # slot for the NEXT step while this step is still running (its scatter reads x01[0] at the very end)
+        S0 = self.S[0]
+        self._slots = [dict(sp=self.sp[0], eu=self.eu[0], x01=self.x01[0], std=self.std[0], fars=self.fars, fars_is_sky=False),
+                       dict(sp=torch.empty(B, S0 + 1, **f32), eu=torch.empty(B, S0 + 1, **f32), x01=torch.empty(B * S0, 3, **f32),
+                            std=torch.empty(B * S0, **f32), fars=torch.empty(B, **f32), fars_is_sky=False)]
         self.dens = [torch.empty(B, S, **f32) for S in self.S[:2]]
         self.g_dens = [torch.empty(B, S, **f32) for S in self.S[:2]]
         self.w = [torch.empty(B, S, **f32) for S in self.S]       # proposal weights x2, final weights
@@ -133,9 +138,28 @@ class FusedTrainStep:
         self.field_grads.beta = fld.sdf_to_density.beta.grad.data_ptr()
 
     # -------------------------------------------------------------------------------------------
+    def prepare(self, slot: int, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Optional[Tensor],
+                t_rand: Tensor) -> None:
+        """First launch of a step, split off so that a caller can run it EARLY (for the next step, on a side
+        stream, while the current step's backward runs): far-plane clamp (neuradar.py:573) + initial bins +
+        contracted Gaussians into buffer set `slot`.  forward_backward(..., slot=slot, prepared=True) consumes it."""
+        lib, p, c, B = self.lib, ops._p, self.cfg, self.B
+        sl = self._slots[slot]
+        if fars is None:  # camera rays: fars = 1e6 (cameras.py:948), clamped to the sky distance: a constant
+            if not sl["fars_is_sky"]:
+                sl["fars"].fill_(SKY_DISTANCE)
+                sl["fars_is_sky"] = True
+        else:
+            torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=sl["fars"])
+            sl["fars_is_sky"] = False
+        check(lib.nr_power_bins_contract(p(self.nears), p(sl["fars"]), p(t_rand), p(origins), p(directions), p(pixel_area), B,
+                                         self.S[0], c.power_lambda, c.power_scaling, self.model.field.hashgrid.static_scale,
+                                         self.sm, p(sl["sp"]), p(sl["eu"]), p(sl["x01"]), p(sl["std"]), ops._stream()), "power_bins")
+
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
-                         jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None) -> Tensor:
+                         jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None, slot: int = 0,
+                         prepared: bool = False) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
@@ -143,6 +167,10 @@ class FusedTrainStep:
         optimizers = (table_opt, field_opt) (FlatAdam) fuses the optimizer into the step: each table is stepped on
         the stream of its own chain as soon as its scatter (and, with several ranks, its gradient exchange) is
         done; the small parameters follow when every chain has finished.
+
+        slot / prepared: which of the two level-0 buffer sets the step uses, and whether `prepare(slot, ...)` has
+        already filled it (then origins/directions/pixel_area must be the tensors given to prepare; fars and
+        t_rand are ignored).
 
         after_sampling: optional callable run on a side stream once the sampling rounds have consumed the
         step's random numbers (t_rand, jitters) -- the caller refills them there for the NEXT step, off the
@@ -159,21 +187,16 @@ class FusedTrainStep:
         side = self._side_streams() if self.overlap else [main, main]
         lam, scal = c.power_lambda, c.power_scaling
         o, d, area = p(origins), p(directions), p(pixel_area)
-        if fars is None:  # camera rays: fars = 1e6 (cameras.py:948), clamped to the sky distance (neuradar.py:573)
-            if not self._fars_is_sky:
-                self.fars.fill_(SKY_DISTANCE)
-                self._fars_is_sky = True
-        else:
-            torch.clamp(fars.reshape(-1), max=SKY_DISTANCE, out=self.fars)  # neuradar.py:573
-            self._fars_is_sky = False
+        sl = self._slots[slot]
+        self.sp[0], self.eu[0], self.x01[0], self.std[0], self.fars = sl["sp"], sl["eu"], sl["x01"], sl["std"], sl["fars"]
+        if not prepared:
+            self.prepare(slot, origins, directions, pixel_area, fars, t_rand)
         nears, far = p(self.nears), p(self.fars)
         scale = self.model.field.hashgrid.static_scale
-        # launches of the sampling part: bins+contraction, then per round hash grid -> density -> [weights, depth,
-        # resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
+        # launches of the sampling part: bins+contraction (prepare), then per round hash grid + density -> [weights,
+        # depth, resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
         # gradients) of the first self.sm rays are kept SAMPLE-major, row s*sm+b (include/neuradar_hip.h,
         # nr_contract_gaussians); per-ray arrays stay [B,S].
-        check(lib.nr_power_bins_contract(nears, far, p(t_rand), o, d, area, B, self.S[0], lam, scal, scale, self.sm, p(self.sp[0]),
-                                         p(self.eu[0]), p(self.x01[0]), p(self.std[0]), st), "power_bins")
         # bookkeeping nothing on the sampling rounds depends on runs beside them (forked AFTER the first launch of
         # the critical path: a fork costs it ~10 us): loss slots, the field's weight image, the optimizers' schedule kernels
         if side[0] is not main:

@@ -56,13 +56,19 @@ class Cameras:
 
 
     def generate_patch_rays(self, u: Tensor, patch: int, stride: int, height: int, width: int,
-                            area_scale: float = 1.0, return_indices: bool = False):
+                            area_scale: float = 1.0, return_indices: bool = False, out: Optional[RayBundle] = None):
         """On-device batch assembly: u [n_patches,3] uniform -> rays of random
-        patch x patch blocks at pixel stride `stride`, one kernel.  Returns (RayBundle, ray_indices|None)."""
+        patch x patch blocks at pixel stride `stride`, one kernel.  Returns (RayBundle, ray_indices|None).
+        out: a bundle returned by an earlier call of the same size, overwritten in place (callers that prefetch
+        the next batch into fixed buffers)."""
         n_p, dev = u.shape[0], u.device
         n = n_p * patch * patch
-        o, d = _new(n, 3, device=dev), _new(n, 3, device=dev)
-        area, t = _new(n, device=dev), _new(n, device=dev)
+        if out is not None:
+            assert out.origins.shape[0] == n
+            o, d, area, t = out.origins, out.directions, out.pixel_area.view(-1), out.times.view(-1)
+        else:
+            o, d = _new(n, 3, device=dev), _new(n, 3, device=dev)
+            area, t = _new(n, device=dev), _new(n, device=dev)
         idx = _new(n, 3, device=dev, dtype=torch.int64) if return_indices else None
         rs = self.velocities is not None and self.rolling_shutter_offsets is not None
         p = ops._p
@@ -75,6 +81,8 @@ class Cameras:
             "nr_gen_rays_camera_patches")
         if self._far_cache is None or self._far_cache.shape[0] != n or self._far_cache.device != o.device:
             self._far_cache = torch.full((n, 1), FAR, device=dev)  # constant (cameras.py:948): one fill, not one per step
+        if out is not None:
+            return out, idx
         return RayBundle(o, d, area[:, None], fars=self._far_cache, times=t[:, None]), idx
 
 

@@ -815,6 +815,17 @@ def test_fused_step_matches_autograd_path(coherent):
     t = model.field.hashgrid.static_grid.hash_table
     rg = ref_grads[names.index("field.hashgrid.static_grid.hash_table")]
     assert_close(cpu(t.grad), 2 * cpu(rg), rtol=1e-3, atol_scale=1e-4, what="accumulated grad")
+    # the split step (prepare() early into the second buffer set, then forward_backward(prepared=True)): what the
+    # cross-step pipelining of bench.py runs; bit-identical outputs, and slot 0 is left untouched by it
+    x0 = fused._slots[0]["x01"].clone()
+    fo = {k_: v_.clone() for k_, v_ in fo.items()}  # outputs() are views of the step's buffers
+    fused.prepare(1, o, d, area[:, 0].contiguous(), fars[:, 0].contiguous(), t_rand)
+    fused.forward_backward(o, d, area[:, 0].contiguous(), None, tf, td[:, 0].contiguous(), None, j1[:, 0].contiguous(),
+                           j2[:, 0].contiguous(), slot=1, prepared=True)
+    fo2 = fused.outputs()
+    for k_ in ("features", "depth", "accumulation", "final_euclid"):
+        assert torch.equal(fo2[k_], fo[k_]), k_
+    assert torch.equal(fused._slots[0]["x01"], x0) and torch.equal(fused._slots[1]["x01"], x0)
 
 
 def test_flat_adam_flattening_keeps_parameters_and_matches_torch():
