@@ -379,8 +379,10 @@ def main():
     groups = model.get_param_groups()
     # configs/method_configs.py:384-409: hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
     unused = list(model.proposal_fields[0].parameters())  # never evaluated (reference quirk) -> never stepped
-    opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, lr_final=1e-3, max_steps=20001, warmup_steps=500, skip=unused),
-            FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3,
+    lr_scale = float(os.environ.get("NR_BENCH_LR_SCALE", "1"))  # 1e-12 ~ frozen parameters (drift experiments)
+    opts = [FlatAdam(groups["hashgrids"], lr=1e-2 * lr_scale, eps=1e-15, lr_final=1e-3 * lr_scale, max_steps=20001, warmup_steps=500,
+                     skip=unused),
+            FlatAdam(groups["fields"], lr=1e-2 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3 * lr_scale,
                      max_steps=20001, warmup_steps=500, skip=unused)]
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None,

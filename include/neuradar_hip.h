@@ -157,6 +157,11 @@ int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_strid
                  int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,
                  const float* grad_feature, const float* grad_alpha, const float* grad_sdf,
                  float* grad_feats, const nr_field_grads_t* grads, float* workspace, nr_stream_t stream);
+/* grads may be NULL: the per-block weight-gradient slabs then stay in `workspace`, and the caller adds them
+ * into the gradients later -- on any stream ordered after nr_field_bwd, e.g. beside the grid scatter that only
+ * needs grad_feats -- with nr_field_grad_reduce(field, workspace, n, grads) (same field, workspace and n). */
+int nr_field_grad_reduce(const nr_field_t* field, const float* workspace, int64_t n, const nr_field_grads_t* grads,
+                         nr_stream_t stream);
 
 /* Degree-4 real spherical harmonics, 16 components: SHEncoding.forward torch path
  * (encodings.py:797-805).  in [n,3] -> out [n,16].  (The caller applies (d+1)/2.) */

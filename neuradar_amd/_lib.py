@@ -50,6 +50,7 @@ PROTOTYPES = {
     "nr_field_pack": [POINTER(NrField), P, P],
     "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P],
     "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
+    "nr_field_grad_reduce": [POINTER(NrField), P, L, POINTER(NrFieldGrads), P],
     "nr_sh4_fwd": [P, L, P, P],
     "nr_prop_density_fwd": [P, L, L, I, P, I, L, I, I, P, P],
     "nr_prop_field_fwd": [P, P, P, P, I, I, I, P, P, L, L, L, I, I, P, P],

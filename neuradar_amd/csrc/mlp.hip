@@ -607,6 +607,18 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
   return 0;
 }
 
+namespace {
+unsigned field_bwd_blocks(int64_t n) {
+  const int64_t tiles = nr_cdiv(n, 32);
+  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+  }
+  return blocks;
+}
+}  // namespace
+
 extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
                             const float* dirs, int S, int rows_sample_major, int64_t n, const float* g_feature,
                             const float* g_alpha, const float* g_sdf, float* g_feats, const nr_field_grads_t* grads,
@@ -614,18 +626,15 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   if (n == 0) return 0;
   int hid = 0;
   if (((uintptr_t)workspace & 15u) != 0) return NR_EINVAL;
-  if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !grads || !workspace ||
-      S < 0 || F < 1 || n < 0)
+  if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !workspace || S < 0 ||
+      F < 1 || n < 0)
     return NR_EINVAL;
   if (rows_sample_major < 0 || (rows_sample_major && (S < 1 || n % S != 0 || rows_sample_major > n / S))) return NR_EINVAL;
-  for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
-  for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
-  const int64_t tiles = nr_cdiv(n, 32);
-  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
-  if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+  if (grads) {  // NULL: the per-block gradient slabs stay in the workspace for a later nr_field_grad_reduce
+    for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
+    for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   }
+  const unsigned blocks = field_bwd_blocks(n);
   float* slab = workspace + n * (kC + 1);  // [blocks][G_TOTAL] after the d_e / d_sdf rows
 #define LAUNCH_BWD(HIDC, FWC)                                                                                          \
   {                                                                                                                     \
@@ -634,8 +643,9 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
                        sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);               \
     hipLaunchKernelGGL((field_bwd_geo_kernel<32, HIDC, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn,  \
                        sl, F, n, workspace, g_feats, slab);                                                             \
-    hipLaunchKernelGGL((field_grad_reduce_kernel<32, HIDC>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0,     \
-                       nr_s(stream), slab, (int)blocks, *grads);                                                        \
+    if (grads)                                                                                                          \
+      hipLaunchKernelGGL((field_grad_reduce_kernel<32, HIDC>), dim3((unsigned)nr_cdiv(I::G_TOTAL, 64)), dim3(1024), 0,   \
+                         nr_s(stream), slab, (int)blocks, *grads);                                                      \
   }
   if (hid == 32) {
     if (F == 2) LAUNCH_BWD(32, 2) else if (F == 4) LAUNCH_BWD(32, 4) else LAUNCH_BWD(32, 0)
@@ -643,6 +653,25 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     if (F == 2) LAUNCH_BWD(64, 2) else if (F == 4) LAUNCH_BWD(64, 4) else LAUNCH_BWD(64, 0)
   }
 #undef LAUNCH_BWD
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_field_grad_reduce(const nr_field_t* field, const float* workspace, int64_t n, const nr_field_grads_t* grads,
+                                    nr_stream_t stream) {
+  if (n == 0) return 0;
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || !workspace || !grads || n < 0) return NR_EINVAL;
+  for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
+  for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
+  const unsigned blocks = field_bwd_blocks(n);
+  const float* slab = workspace + n * (kC + 1);
+  if (hid == 32)
+    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(FieldImage<32, 32>::G_TOTAL, 64)), dim3(1024), 0,
+                       nr_s(stream), slab, (int)blocks, *grads);
+  else
+    hipLaunchKernelGGL((field_grad_reduce_kernel<32, 64>), dim3((unsigned)nr_cdiv(FieldImage<32, 64>::G_TOTAL, 64)), dim3(1024), 0,
+                       nr_s(stream), slab, (int)blocks, *grads);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -50,6 +50,7 @@ class FusedTrainStep:
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
         self.sm = n_rays if coherent_rays is None else int(coherent_rays)
+        self.early_fork = int(os.environ.get("NR_EARLY_FORK", "4"))
         self.fuse_prop_fwd = os.environ.get("NR_FUSE_PROP_FWD", "1") != "0"  # grid + density head in one launch (+1.6 %)
         self.lib = _lib.lib()
         dev = next(model.parameters()).device
@@ -253,25 +254,56 @@ class FusedTrainStep:
         #      three independent chains (main grid scatter + Adam / proposal round 1 / proposal round 0), each on
         #      its own stream, that only meet again in the optimizer. ----
         Fp = pg.features_per_level
+        # Schedule (measured on the bench, tools/timeline.py; NR_EARLY_FORK selects the others for A/B runs):
+        # round 0's chain (side[1]) starts before field_bwd and shares the chip with it (-1.5 %); round 1's chain
+        # waits for field_bwd -- even its two small kernels in front cost +18 % when started early; the field's
+        # weight-gradient slabs are summed on round 1's stream instead of in front of the main scatter (-3 %).
+        early = self.early_fork  # 0: nothing before field_bwd, 1: both chains, 2: round 0, 3: round 0 + round 1's head, 4: default
+        split_reduce = early in (3, 4)  # 4: schedule 2 + the reduce on side[0]
+
+        def chain_head(lvl):
+            sp_ = ops._stream()
+            S, nl = self.S[lvl], B * self.S[lvl]
+            check(lib.nr_interlevel_loss_to_density(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]),
+                                                    p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
+                                                    losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
+                                                    p(self.loss), sp_), "interlevel_loss")
+            check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
+                                          p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
+
+        def chain_scatter(lvl):
+            sp_ = ops._stream()
+            S, nl = self.S[lvl], B * self.S[lvl]
+            check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
+                p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,
+                p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
+
+        chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
+        before = {0: (), 1: (0, 1), 2: (1,), 3: (0, 1), 4: (1,)}[early]  # side indices forked before field_bwd
+        for i_ in before:
+            if side[i_] is not main:
+                side[i_].wait_stream(main)
+        for i_ in before:
+            with torch.cuda.stream(side[i_]):
+                chain_head(chains[i_][0])
+                if not (early == 3 and i_ == 0):
+                    chain_scatter(chains[i_][0])
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
             byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
-            p(self.g_feats[2]), byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
-        for s_ in side:
-            if s_ is not main:
-                s_.wait_stream(main)
-        for lvl, stream in zip((1, 0), side):
+            p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
+        for i_, (lvl, stream) in enumerate(chains):
+            whole = i_ not in before
+            if not (whole or (early == 3 and i_ == 0)):
+                continue
+            if stream is not main:
+                stream.wait_stream(main)
             with torch.cuda.stream(stream):
-                sp_ = ops._stream()
-                S, nl = self.S[lvl], B * self.S[lvl]
-                check(lib.nr_interlevel_loss_to_density(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]),
-                                                        p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
-                                                        losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
-                                                        p(self.loss), sp_), "interlevel_loss")
-                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
-                                              p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
-                check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
-                    p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,
-                    p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
+                if whole:
+                    chain_head(lvl)
+                elif split_reduce:
+                    check(lib.nr_field_grad_reduce(byref(self.field_struct), p(self.field_ws), n, byref(self.field_grads),
+                                                   ops._stream()), "field_grad_reduce")
+                chain_scatter(lvl)
         check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
             p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
             p(mg.hash_table.grad), n, 0, st)), "hash_bwd")

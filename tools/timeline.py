@@ -1,5 +1,5 @@
 """Print the kernel timeline (start, duration, queue) of the second-to-last bench step from a
-rocprofv3 kernel_trace.csv (steps are delimited by the patch ray-generation kernel)."""
+rocprofv3 kernel_trace.csv (a step starts at the first proposal-grid launch, the one with the larger grid)."""
 import csv
 import re
 import sys
@@ -7,7 +7,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(anonymous namespace\)::|at::native::|void ", "", r["Kernel_Name"])[:60]  # noqa: E731
-idx = [i for i, r in enumerate(rows) if "gen_rays_camera_patches" in r["Kernel_Name"]]
+gsz = lambda r: int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)  # noqa: E731
+props = [i for i, r in enumerate(rows) if "prop_field_fwd" in r["Kernel_Name"]]
+idx = [i for i in props if gsz(rows[i]) == max(gsz(rows[j]) for j in props)]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
