@@ -293,16 +293,16 @@ class FusedTrainStep:
             p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
         for i_, (lvl, stream) in enumerate(chains):
             whole = i_ not in before
-            if not (whole or (early == 3 and i_ == 0)):
+            if not (whole or (early == 3 and i_ == 0) or (split_reduce and i_ == 0)):
                 continue
             if stream is not main:
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
-                if whole:
-                    chain_head(lvl)
-                elif split_reduce:
+                if split_reduce and i_ == 0:
                     check(lib.nr_field_grad_reduce(byref(self.field_struct), p(self.field_ws), n, byref(self.field_grads),
                                                    ops._stream()), "field_grad_reduce")
+                if whole:
+                    chain_head(lvl)
                 chain_scatter(lvl)
         check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
             p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
