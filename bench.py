@@ -462,6 +462,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_elapsed = time.perf_counter() - t0  # launch loop only: how far the CPU runs ahead of the GPU
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -531,7 +532,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
-                       "graph": bool(use_graph), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
+                       "graph": bool(use_graph), "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                                            if reducer.last_sparse.get("mode") == "sparse" else 0))
                        if world > 1 else 0,

@@ -50,7 +50,7 @@ class FusedTrainStep:
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
         self.sm = n_rays if coherent_rays is None else int(coherent_rays)
-        self.early_fork = int(os.environ.get("NR_EARLY_FORK", "4"))
+        self.early_fork = os.environ.get("NR_EARLY_FORK")  # schedule override for A/B runs, see forward_backward
         self.fuse_prop_fwd = os.environ.get("NR_FUSE_PROP_FWD", "1") != "0"  # grid + density head in one launch (+1.6 %)
         self.lib = _lib.lib()
         dev = next(model.parameters()).device
@@ -258,7 +258,12 @@ class FusedTrainStep:
         # round 0's chain (side[1]) starts before field_bwd and shares the chip with it (-1.5 %); round 1's chain
         # waits for field_bwd -- even its two small kernels in front cost +18 % when started early; the field's
         # weight-gradient slabs are summed on round 1's stream instead of in front of the main scatter (-3 %).
-        early = self.early_fork  # 0: nothing before field_bwd, 1: both chains, 2: round 0, 3: round 0 + round 1's head, 4: default
+        # Data-parallel steps start BOTH proposal chains before field_bwd: the proposal table's dense all-reduce
+        # (25 MB over xGMI, a few hundred us) can then begin ~150 us earlier and hide behind field_bwd, the main
+        # scatter and the main table's Adam.  That choice is reasoned from the single-GPU timeline, not measured:
+        # this round had no multi-GPU box.
+        # 0: nothing before field_bwd, 1: both chains, 2: round 0, 3: round 0 + round 1's head, 4: single-GPU default
+        early = int(self.early_fork) if self.early_fork is not None else (1 if reducer is not None else 4)
         split_reduce = early in (3, 4)  # 4: schedule 2 + the reduce on side[0]
 
         def chain_head(lvl):
