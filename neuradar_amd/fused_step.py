@@ -248,23 +248,23 @@ class FusedTrainStep:
                                   p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
                                   p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
                                   p(self.g_feature), p(self.loss), st), "render_train")
-        # ---- backward.  The field's MFMA backward runs first, by itself: its workgroups need 1 wave/SIMD worth of
-        #      registers and ~127 KB of LDS, so anything sharing the CUs with it (and it with them) crawls -- measured
-        #      0.73 vs 0.78 ms per step against forking right after the render launch.  Then the step forks into
-        #      three independent chains (main grid scatter + Adam / proposal round 1 / proposal round 0), each on
-        #      its own stream, that only meet again in the optimizer. ----
+        # ---- backward.  The field's MFMA backward needs 1 wave/SIMD worth of registers and ~127 KB of LDS per
+        #      workgroup, so LDS-heavy kernels sharing the CUs with it (and it with them) crawl: forking all three
+        #      chains (main grid scatter + Adam / proposal round 1 / proposal round 0) right after the render launch
+        #      measured 0.78 ms per step against 0.73 with field_bwd by itself.  The chains meet again in the optimizer. ----
         Fp = pg.features_per_level
         # Schedule (measured on the bench, tools/timeline.py; NR_EARLY_FORK selects the others for A/B runs):
         # round 0's chain (side[1]) starts before field_bwd and shares the chip with it (-1.5 %); round 1's chain
-        # waits for field_bwd -- even its two small kernels in front cost +18 % when started early; the field's
-        # weight-gradient slabs are summed on round 1's stream instead of in front of the main scatter (-3 %).
+        # waits for field_bwd -- started early, whole or only its two small kernels in front, or queued behind round
+        # 0's chain, it cost +1...+18 %; the field's weight-gradient slabs are summed on round 1's stream instead of
+        # in front of the main scatter (-1 %).
         # Data-parallel steps start BOTH proposal chains before field_bwd: the proposal table's dense all-reduce
         # (25 MB over xGMI, a few hundred us) can then begin ~150 us earlier and hide behind field_bwd, the main
         # scatter and the main table's Adam.  That choice is reasoned from the single-GPU timeline, not measured:
         # this round had no multi-GPU box.
-        # 0: nothing before field_bwd, 1: both chains, 2: round 0, 3: round 0 + round 1's head, 4: single-GPU default
+        # 0: nothing before field_bwd, 1: both chains, 2: round 0's chain, 4: 2 + reduce on the side stream (single-GPU default)
         early = int(self.early_fork) if self.early_fork is not None else (1 if reducer is not None else 4)
-        split_reduce = early in (3, 4)  # 4: schedule 2 + the reduce on side[0]
+        split_reduce = early == 4  # schedule 2 + the reduce on side[0]
 
         def chain_head(lvl):
             sp_ = ops._stream()
@@ -284,21 +284,20 @@ class FusedTrainStep:
                 p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
 
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
-        before = {0: (), 1: (0, 1), 2: (1,), 3: (0, 1), 4: (1,)}[early]  # side indices forked before field_bwd
+        before = {0: (), 1: (0, 1), 2: (1,), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
         for i_ in before:
             if side[i_] is not main:
                 side[i_].wait_stream(main)
         for i_ in before:
             with torch.cuda.stream(side[i_]):
                 chain_head(chains[i_][0])
-                if not (early == 3 and i_ == 0):
-                    chain_scatter(chains[i_][0])
+                chain_scatter(chains[i_][0])
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
             byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
             p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
         for i_, (lvl, stream) in enumerate(chains):
-            whole = i_ not in before
-            if not (whole or (early == 3 and i_ == 0) or (split_reduce and i_ == 0)):
+            late = i_ not in before
+            if not (late or (split_reduce and i_ == 0)):
                 continue
             if stream is not main:
                 stream.wait_stream(main)
@@ -306,9 +305,9 @@ class FusedTrainStep:
                 if split_reduce and i_ == 0:
                     check(lib.nr_field_grad_reduce(byref(self.field_struct), p(self.field_ws), n, byref(self.field_grads),
                                                    ops._stream()), "field_grad_reduce")
-                if whole:
+                if late:
                     chain_head(lvl)
-                chain_scatter(lvl)
+                    chain_scatter(lvl)
         check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
             p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
             p(mg.hash_table.grad), n, 0, st)), "hash_bwd")
