@@ -14,7 +14,7 @@ dur = collections.defaultdict(list)
 for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
-        if not (k.startswith("hash_encode") or k.startswith("field_")):
+        if not (k.startswith("hash_encode") or k.startswith("field_") or k.startswith("prop_field_fwd")):
             continue
         res[(k, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob(prefix + "*/out_kernel_trace.csv")):
@@ -26,6 +26,10 @@ for f in sorted(glob.glob(prefix + "*/out_kernel_trace.csv")):
 
 
 def tag(k, g):
+    if k.startswith("prop_field_fwd"):  # proposal grid + density head in one launch: one thread per sample
+        for S in (128, 64):
+            if g == -(-B * S // 256) * 256:
+                return f"{k} prop_s{S}"
     if not k.startswith("hash_encode"):
         return k
     # fwd: grid = N*L threads; bwd: grid = ceil(N / (W*CHUNK)) * L * W*64 threads  (N = B*S; BwdCfg in grid.hip)
@@ -59,5 +63,26 @@ doc = {
              "(x2 for those); 4-8 B/lane gathers are uncalibrated, Infinity-Cache hits are counted.  WRITE_SIZE is exact for float atomics.",
     "kernels": kernels,
 }
+
+
+def find(sub):
+    return next((v for k, v in kernels.items() if sub in k), {})
+
+
+s128, s64, main = find("bwd_kernel<1, 512, 256, 4> prop_s128"), find("bwd_kernel<1, 512, 256, 4> prop_s64"), find("bwd_kernel<2")
+if s128 and s64 and main:
+    req = [x.get("TCC_EA0_ATOMIC_sum", 0) / 1e6 for x in (s128, s64, main)]
+    doc["reading"] = [
+        f"Scatter (hash_encode_bwd) with the step's REAL gradients, freshly initialised model: {req[0]:.2f} M / {req[1]:.2f} M / {req[2]:.2f} M "
+        f"64-B atomic requests for prop_s128 / prop_s64 / main_s32 ({req[0]:.2f} M in {s128.get('avg_us_serialised', 0):.0f} us = "
+        f"{req[0] / max(s128.get('avg_us_serialised', 1), 1) * 1e3:.0f} G requests/s against the 20.7 G/s the memory side applies, "
+        "tools/atomic_lab.hip): after the on-chip dedup the kernels are bound by per-wave latency and VALU issue.  After a few thousand "
+        "training steps the request counts are 1.9 / 1.4 / 1.4 M (tools/pmc_atomics.sh) and the three concurrent scatters run AT that rate "
+        "(DESIGN.md section 5).  HBM-side traffic (FETCH+WRITE) of the prop_s128 scatter: "
+        f"{(s128.get('FETCH_SIZE', 0) + s128.get('WRITE_SIZE', 0)) * 1024 / 1e6:.1f} MB against 201 MB of algorithmic read-modify-write bytes.",
+        "Gathers (hash_encode_fwd / prop_field_fwd): L2 hit rates and FETCH_SIZE per launch are in the rows above; the 67 MB / 25 MB tables "
+        "are served from L2 / Infinity Cache.",
+        "Field MLP kernels: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES over all SIMD cycles of the launch (v_mfma_f32_32x32x2_f32).",
+    ]
 json.dump(doc, open(out_path, "w"), indent=1)
 print(json.dumps(doc, indent=1)[:6000])
