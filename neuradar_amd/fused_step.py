@@ -253,18 +253,23 @@ class FusedTrainStep:
         #      chains (main grid scatter + Adam / proposal round 1 / proposal round 0) right after the render launch
         #      measured 0.78 ms per step against 0.73 with field_bwd by itself.  The chains meet again in the optimizer. ----
         Fp = pg.features_per_level
-        # Schedule (measured on the bench, tools/timeline.py; NR_EARLY_FORK selects the others for A/B runs):
-        # round 0's chain (side[1]) starts before field_bwd and shares the chip with it (-1.5 %); round 1's chain
-        # waits for field_bwd -- started early, whole or only its two small kernels in front, or queued behind round
-        # 0's chain, it cost +1...+18 %; the field's weight-gradient slabs are summed on round 1's stream instead of
-        # in front of the main scatter (-1 %).
-        # Data-parallel steps start BOTH proposal chains before field_bwd: the proposal table's dense all-reduce
-        # (25 MB over xGMI, a few hundred us) can then begin ~150 us earlier and hide behind field_bwd, the main
-        # scatter and the main table's Adam.  That choice is reasoned from the single-GPU timeline, not measured:
-        # this round had no multi-GPU box.
-        # 0: nothing before field_bwd, 1: both chains, 2: round 0's chain, 4: 2 + reduce on the side stream (single-GPU default)
-        early = int(self.early_fork) if self.early_fork is not None else (1 if reducer is not None else 4)
-        split_reduce = early == 4  # schedule 2 + the reduce on side[0]
+        # Schedule, measured on five bench workloads (tools/timeline.py; NR_EARLY_FORK selects one for A/B runs):
+        #   0  nothing starts before field_bwd; 3 = 0 with the field's weight-gradient slabs summed on round 1's stream
+        #      instead of in front of the main scatter (-1 %): best for every workload but the headline one
+        #      (NeuRadar field at 4 096 / 16 384 rays, mixed batch, 64-wide field at 16 384 rays: 1...6 % ahead of 4)
+        #   2  round 0's chain (side[1]) starts before field_bwd and shares the chip with it; 4 = 2 with the reduce moved
+        #      as in 3: best for the 64-wide field at 4 096 rays, where the backward leaves the chip under-filled (-1.5 %)
+        #   1  both proposal chains before field_bwd (+1...+18 % on one GPU, like every other way of starting round 1
+        #      early).  Data-parallel steps use it nevertheless: the proposal table's dense all-reduce (25 MB over xGMI,
+        #      a few hundred us) can then begin ~150 us earlier and hide behind field_bwd, the main scatter and the main
+        #      table's Adam.  That choice is reasoned from the single-GPU timeline, not measured: no multi-GPU box this round.
+        if self.early_fork is not None:
+            early = int(self.early_fork)
+        elif reducer is not None:
+            early = 1
+        else:
+            early = 4 if (self.model.field.config.geo_hidden_dim >= 64 and B <= 4096) else 3
+        split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
 
         def chain_head(lvl):
             sp_ = ops._stream()
@@ -284,7 +289,7 @@ class FusedTrainStep:
                 p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
 
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
-        before = {0: (), 1: (0, 1), 2: (1,), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
+        before = {0: (), 1: (0, 1), 2: (1,), 3: (), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
         for i_ in before:
             if side[i_] is not main:
                 side[i_].wait_stream(main)
