@@ -828,6 +828,36 @@ def test_fused_step_matches_autograd_path(coherent):
     assert torch.equal(fused._slots[0]["x01"], x0) and torch.equal(fused._slots[1]["x01"], x0)
 
 
+@pytest.mark.parametrize("schedule", ["0", "1", "2", "3", "4"])
+def test_fused_step_schedules_agree(schedule, monkeypatch):
+    """Every backward schedule of the fused step (NR_EARLY_FORK: which chains start beside nr_field_bwd, where the
+    weight-gradient slabs are reduced -- nr_field_bwd(grads=NULL) + nr_field_grad_reduce) yields the same outputs and
+    parameter gradients as the serial, single-stream step."""
+    from neuradar_amd.fused_step import FusedTrainStep
+
+    g = load_golden("pipeline")
+    o, d, area, fars = dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(g["fars"])
+    t_rand, j1, j2 = dev(g["t_rand"]), dev(g["jitter1"]), dev(g["jitter2"])
+    tf, td = dev(g["target_features"]), dev(g["target_depth"])
+
+    def run(overlap):
+        model = build_hot_path(g).train()
+        fused = FusedTrainStep(model, o.shape[0], overlap=overlap)
+        loss = fused.forward_backward(o, d, area[:, 0].contiguous(), fars[:, 0].contiguous(), tf, td[:, 0].contiguous(), t_rand,
+                                      j1[:, 0].contiguous(), j2[:, 0].contiguous())
+        torch.cuda.synchronize()
+        return float(loss.sum()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv("NR_EARLY_FORK", "0")
+    ref_loss, ref = run(False)
+    monkeypatch.setenv("NR_EARLY_FORK", schedule)
+    loss, grads = run(True)
+    assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss)
+    assert grads.keys() == ref.keys()
+    for n in ref:  # scatter-adds and loss slots are summed in a different order: float noise only
+        assert_close(cpu(grads[n]), cpu(ref[n]), rtol=1e-4, atol_scale=1e-5, what=f"schedule {schedule}: {n}")
+
+
 def test_flat_adam_flattening_keeps_parameters_and_matches_torch():
     from neuradar_amd.step import FlatAdam
 
