@@ -133,6 +133,80 @@ def test_hash_encode_module_is_dropin_and_linear_in_table():
     assert enc(torch.empty(0, 3, device=DEV)).shape == (0, 32)  # empty input
 
 
+@pytest.mark.parametrize("cfg", [("prop", 6, 1, 20, 16, 512, 4096 * 128), ("l16f2", 16, 2, 19, 16, 1024, 4096 * 32),
+                                 ("l8f4", 8, 4, 22, 32, 8192, 16384 * 32)])
+def test_scatter_checksums_and_linearity_at_baseline_sizes(cfg):
+    """Size-independent properties of the table gradient at BASELINE.json's table and batch sizes, where the
+    oracle is too slow to be the checker: (1) checksum of checksums -- the trilinear weights of a sample sum to
+    one, so per level and feature sum_rows grad_table == sum_samples rescale * grad_out; (2) linearity in
+    grad_out; (3) every touched row is one of the 8 corners of some sample (nothing lands elsewhere: rows the
+    forward never reads stay exactly zero).  Clustered positions, so the on-chip dedup path is the one running."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    tag, L, F, log2t, rmin, rmax, n = cfg
+    torch.manual_seed(L * F)
+    sc = dev(hashgrid.level_scalings(L, rmin, rmax))
+    centres = torch.rand(2000, 3, device=DEV)
+    x = (centres[torch.randint(0, 2000, (n,), device=DEV)] + 0.01 * torch.randn(n, 3, device=DEV)).clamp(0, 1)
+    std = 0.002 * torch.rand(n, device=DEV)
+    table = (torch.rand(L << log2t, F, device=DEV) * 2e-3 - 1e-3).requires_grad_(True)
+
+    def grad_of(gout):
+        out = ops.hash_encode(x, table, sc, log2t, std=std, level_major=True)  # [L, n, F]
+        (gt,) = torch.autograd.grad(out, table, gout)
+        return gt
+
+    g1, g2 = torch.randn(L, n, F, device=DEV), torch.randn(L, n, F, device=DEV)
+    gt1, gt2 = grad_of(g1), grad_of(g2)
+    resc = 1.0 / torch.clamp(2.0 * sc[:, None] * std[None, :], min=1.0)  # neurad_encoding.py:309-316
+    want = (g1.double() * resc[:, :, None].double()).sum(1)  # [L, F]
+    got = gt1.view(L, 1 << log2t, F).double().sum(1)
+    scale = (g1.double().abs() * resc[:, :, None].double()).sum(1)  # magnitude the float sums ran over
+    assert float(((got - want).abs() / scale).max()) < 1e-5, f"{tag}: checksum of checksums"
+    gt12 = grad_of(2.0 * g1 - 0.5 * g2)
+    ref = 2.0 * gt1 - 0.5 * gt2
+    assert_close(cpu(gt12), cpu(ref), rtol=1e-4, atol_scale=1e-5, what=f"{tag}: linearity in grad_out")
+    # rows written == rows the forward reads: perturbing ONLY untouched rows must not change the encoding
+    touched = (gt1 != 0).any(1) | (gt2 != 0).any(1)
+    assert 0 < int(touched.sum()) < touched.numel()
+    with torch.no_grad():
+        out0 = ops.hash_encode(x, table, sc, log2t, std=std, level_major=True)
+        t2 = table.detach().clone()
+        t2[~touched] += 1.0
+        out1 = ops.hash_encode(x, t2, sc, log2t, std=std, level_major=True)
+    assert torch.equal(out0, out1), f"{tag}: the forward read a row the backward never wrote"
+
+
+def test_sampling_chain_properties_at_baseline_sizes():
+    """16 384 rays (configs[2] per-GPU size): power bins and both PDF resampling rounds are sorted and stay
+    inside [near, far]; get_weights and the alpha compositing conserve probability mass (w >= 0, sum <= 1;
+    after the sky fix-up the weights of a ray sum to one)."""
+    from neuradar_amd import ops
+
+    torch.manual_seed(3)
+    B = 16384
+    nears, fars = torch.zeros(B, device=DEV), torch.full((B,), 20000.0, device=DEV)
+    sp, eu = ops.power_bins(nears, fars, 128, t_rand=torch.rand(B, 129, device=DEV))
+    for S_in, S_out in ((128, 64), (64, 32)):
+        assert bool((eu[:, 1:] >= eu[:, :-1]).all()) and bool((sp[:, 1:] >= sp[:, :-1]).all())
+        assert float(eu.min()) >= 0.0 and float(eu.max()) <= 20000.0 * (1 + 1e-6)
+        dens = torch.exp(2.0 * torch.randn(B, S_in, device=DEV))
+        w = ops.weights_from_density(dens, eu)
+        assert bool((w >= 0).all()) and float(w.sum(1).max()) <= 1.0 + 1e-5
+        sp, eu = ops.pdf_resample(w, sp, nears, fars, S_out, jitter=torch.rand(B, device=DEV))
+    assert bool((eu[:, 1:] >= eu[:, :-1]).all())
+    alpha = torch.rand(B, 32, device=DEV) ** 4
+    feat = torch.randn(B, 32, 32, device=DEV)
+    w, acc, feats, depth = ops.composite(alpha, feat, eu)
+    assert float(w.min()) >= -1e-6  # the fix-up `w_last += 1 - acc` may round a hair below zero, as in the reference
+    # sky fix-up (neuradar.py:505-508): the last weight takes the remaining 1 - accumulation
+    torch.testing.assert_close(w.sum(1), torch.ones(B, device=DEV), rtol=0, atol=4e-6)
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-6
+    torch.testing.assert_close(feats, (w[:, :, None] * feat).sum(1), rtol=1e-4, atol=1e-5)
+    assert bool(torch.isfinite(depth).all()) and float(depth.min()) >= 0.0
+
+
 # ------------------------------------------------------------------------------------------------ a6 a7 a9
 def test_contraction_and_rescaled_grid_features():
     from neuradar_amd import ops
