@@ -178,6 +178,44 @@ def test_scatter_checksums_and_linearity_at_baseline_sizes(cfg):
     assert torch.equal(out0, out1), f"{tag}: the forward read a row the backward never wrote"
 
 
+def test_empty_and_single_inputs_through_the_abi():
+    """Empty batches are legal everywhere on the path (a sensor without rays in a mixed batch, an actor nobody hits)
+    and return empty results without touching memory; a single ray / single sample works too."""
+    from neuradar_amd import ops
+    from neuradar_amd.sensors import Cameras, Lidars
+    from oracle import hashgrid
+
+    e = lambda *shape: torch.empty(*shape, device=DEV)  # noqa: E731
+    sc = dev(hashgrid.level_scalings(4, 16, 128))
+    table = (torch.rand(4 << 12, 2, device=DEV) - 0.5).requires_grad_(True)
+    out = ops.hash_encode(e(0, 3), table, sc, 12)
+    assert out.shape == (0, 8)
+    (gt,) = torch.autograd.grad(out.sum(), table)
+    assert float(gt.abs().max()) == 0.0
+    x01, std = ops.contract_gaussians(e(0, 3), e(0, 3), e(0, 1), e(0, 33), 100.0)
+    assert x01.shape[0] == 0 and std.shape[0] == 0
+    sp, eu = ops.power_bins(e(0), e(0), 16)
+    assert sp.shape == (0, 17) and eu.shape == (0, 17)
+    assert ops.weights_from_density(e(0, 16), e(0, 17)).shape == (0, 16)
+    sp2, eu2 = ops.pdf_resample(e(0, 16), e(0, 17), e(0), e(0), 8)
+    assert sp2.shape == (0, 9)
+    w, acc, f, dep = ops.composite(e(0, 8), e(0, 8, 4), e(0, 9))
+    assert w.shape == (0, 8) and f.shape == (0, 4) and dep.shape[0] == 0
+    assert ops.sh4(e(0, 3)).shape == (0, 16)
+    cams = Cameras(torch.eye(3, 4, device=DEV)[None], *(torch.tensor([v], device=DEV) for v in (500.0, 500.0, 320.0, 240.0, 480.0, 0.0)))
+    rb = cams.generate_rays(torch.empty(0, 3, dtype=torch.int64, device=DEV))
+    assert rb.origins.shape == (0, 3)
+    lid = Lidars(torch.eye(3, 4, device=DEV)[None], torch.zeros(1, device=DEV))
+    assert lid.generate_rays(torch.empty(0, dtype=torch.int64, device=DEV), e(0, 5)).origins.shape == (0, 3)
+    # one ray, one sample
+    one = ops.hash_encode(torch.full((1, 3), 0.3, device=DEV), table, sc, 12)
+    ref = hashgrid.encode(torch.full((1, 3), 0.3), cpu(table.detach()), cpu(sc), 1 << 12)
+    assert_close(cpu(one.detach()), ref, rtol=1e-5, atol_scale=1e-6, what="single sample")
+    w1, acc1, _, _ = ops.composite(torch.full((1, 1), 0.25, device=DEV), torch.ones(1, 1, 3, device=DEV),
+                                   torch.tensor([[1.0, 2.0]], device=DEV))
+    assert abs(float(w1.sum()) - 1.0) < 1e-6 and abs(float(acc1.reshape(-1)[0]) - 0.25) < 1e-6
+
+
 def test_sampling_chain_properties_at_baseline_sizes():
     """16 384 rays (configs[2] per-GPU size): power bins and both PDF resampling rounds are sorted and stay
     inside [near, far]; get_weights and the alpha compositing conserve probability mass (w >= 0, sum <= 1;
