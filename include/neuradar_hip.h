@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 4
+#define NR_ABI_VERSION 5
 #define NR_LOSS_SLOTS 1024 /* loss kernels add into loss[0..1023]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;

@@ -110,7 +110,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 4:
+        if handle.nr_abi_version() != 5:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib
