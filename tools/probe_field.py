@@ -23,6 +23,14 @@ st.g_feature.normal_()
 st.g_alpha.normal_()
 from ctypes import byref  # noqa: E402
 lib, p, s = st.lib, ops._p, ops._stream
+only = os.environ.get("PROBE_N")  # PROBE_N=<samples>: just that size, 50 calls (for a rocprofv3 --kernel-trace run)
+if only:
+    nn = int(only)
+    for _ in range(50):
+        lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 0, nn, p(st.feature), p(st.sdf), p(st.alpha), s())
+        lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 0, nn, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s())
+    torch.cuda.synchronize()
+    sys.exit(0)
 for fb in os.environ.get("FWD_BLOCKS", "256,512").split(","):
     os.environ["NR_FIELD_FWD_BLOCKS"] = fb
     t = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, B, n, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
