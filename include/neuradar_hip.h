@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 5
+#define NR_ABI_VERSION 6
 #define NR_LOSS_SLOTS 1024 /* loss kernels add into loss[0..1023]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
@@ -133,6 +133,10 @@ typedef struct nr_field {
   const float* beta;   /* SigmoidDensity.beta, 1 float */
   const float* packed; /* NULL, or the weight image written by nr_field_pack for these weights:
                           lets every block load the weights with one 16-byte-wide copy */
+  float* stash;        /* NULL, or nr_field_stash_floats(field, n) floats of caller-owned scratch: nr_field_fwd
+                          then leaves the activations the backward needs there (e, mlp_feature's two hidden
+                          layers, sdf: 392 B / 648 B per sample at width 32 / 64) and nr_field_bwd, called with the
+                          same field, n and inputs, reads them instead of recomputing the forward */
 } nr_field_t;
 
 typedef struct nr_field_grads {
@@ -152,6 +156,7 @@ int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_t n);
 /* Weight image for nr_field_t.packed: nr_field_image_floats(field) floats, 16-byte aligned; rebuild it
  * (nr_field_pack) whenever the weights change, i.e. once per optimizer step. */
 int64_t nr_field_image_floats(const nr_field_t* field);
+int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n);
 int nr_field_pack(const nr_field_t* field, float* image, nr_stream_t stream);
 int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
                  int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,

@@ -26,7 +26,7 @@ class NrMlpGrads(Structure):
 
 
 class NrField(Structure):
-    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p)]
+    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p)]
 
 
 class NrFieldGrads(Structure):
@@ -46,6 +46,7 @@ PROTOTYPES = {
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
     "nr_field_bwd_workspace_floats": [POINTER(NrField), L],
+    "nr_field_stash_floats": [POINTER(NrField), L],
     "nr_field_image_floats": [POINTER(NrField)],
     "nr_field_pack": [POINTER(NrField), P, P],
     "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P],
@@ -79,7 +80,8 @@ PROTOTYPES = {
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
-_RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64}
+_RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
+             "nr_field_stash_floats": c_int64}
 
 _lib = None
 
@@ -110,7 +112,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 5:
+        if handle.nr_abi_version() != 6:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -108,7 +108,31 @@ __device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], co
 #define NR_MLP_BWD_WAVES 1
 #endif
 
-template <int IN, int HID, int FW>  // FW: feature width F as a compile-time constant (0: runtime)
+// Activation stash (nr_field_t.stash): what the feature half of the backward would otherwise recompute -- e,
+// the two hidden activations of mlp_feature (after their ReLU) and sdf -- kept per 32-sample tile in the
+// registers' own layout: float (reg * 64 + lane) of the tile's block, so every store / load is one coalesced
+// 256-byte access.  The backward walks the same tiles (tile t = samples 32t..32t+31), any grid size.
+template <int HID> struct Stash {
+  static constexpr int HT = (HID + 31) / 32;
+  static constexpr int oE = 0, oF1 = 16, oF2 = 16 + 16 * HT, oSdf = 16 + 32 * HT, REGS = oSdf + 1;
+  static constexpr int64_t kTile = (int64_t)REGS * 64;
+};
+template <int NT>
+__device__ __forceinline__ void stash_put(float* __restrict__ p, const f32x16 (&t)[NT], int lane) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[(k * 16 + r) * 64 + lane] = t[k][r];
+}
+template <int NT>
+__device__ __forceinline__ void stash_get(const float* __restrict__ p, f32x16 (&t)[NT], int lane) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[k][r] = p[(k * 16 + r) * 64 + lane];
+}
+
+template <int IN, int HID, int FW, bool STASH>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_FWD_WAVES)
 field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                  const float* __restrict__ dirs, int S, int rows_sm, int64_t n, float* __restrict__ feature,
@@ -134,6 +158,14 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     dense_fwd<HID, kC, false>(f2, o, lw + I::oF3, i, h);
+    if (STASH) {
+      using St = Stash<HID>;
+      float* sp = fld.stash + tile * St::kTile;
+      stash_put<1>(sp + St::oE * 64, e, lane);
+      stash_put<I::HT>(sp + St::oF1 * 64, f1, lane);
+      stash_put<I::HT>(sp + St::oF2 * 64, f2, lane);
+      sp[St::oSdf * 64 + lane] = sdf;
+    }
     if (valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // rows 8q+4h .. +3 are registers 4q..4q+3
@@ -165,7 +197,7 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f
 //     (the sdf row via per-lane partial products); writes grad_feats.
 constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
 
-template <int IN, int HID, int FW>  // FW: feature width F as a compile-time constant (0: runtime)
+template <int IN, int HID, int FW, bool STASH>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
 field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                       const float* __restrict__ dirs, int S, int rows_sm, int64_t n, const float* __restrict__ g_feature,
@@ -195,19 +227,31 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
     const bool valid = smp < n;
     f32x16 cat[2], f1[I::HT], f2[I::HT];
     float sdf;
-    {
-      f32x16 x0[I::IT], h1[I::HT], e[1];
-      load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
-                    [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); });
-      dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
-      dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
-      sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
-      cat[0] = e[0];
-    }
     const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
-    cat[1] = sh_tile(dirs, rm.ray, h);
-    dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
-    dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
+    if (STASH) {  // the forward left e, f1, f2, sdf of this tile in the stash: 81 loads instead of 176 MFMAs
+      using St = Stash<HID>;
+      const float* sp = fld.stash + tile * St::kTile;
+      f32x16 e[1];
+      stash_get<1>(sp + St::oE * 64, e, lane);
+      cat[0] = e[0];
+      stash_get<I::HT>(sp + St::oF1 * 64, f1, lane);
+      stash_get<I::HT>(sp + St::oF2 * 64, f2, lane);
+      sdf = sp[St::oSdf * 64 + lane];
+      cat[1] = sh_tile(dirs, rm.ray, h);
+    } else {
+      {
+        f32x16 x0[I::IT], h1[I::HT], e[1];
+        load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
+                      [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); });
+        dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
+        dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
+        sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
+        cat[0] = e[0];
+      }
+      cat[1] = sh_tile(dirs, rm.ray, h);
+      dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
+      dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
+    }
     f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2];
     load_rows<kC>(d_o, g_feature + rm.out * kC, valid, h, [](int k) { return (int64_t)k; });
     dense_bwd_dw_reg<HID, kC>(d_o, f2, aF3, bF3, scr, i, h);          // layers[2]: o = V3 f2 + b
@@ -592,17 +636,20 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
     const int v = atoi(e);
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
+#define LAUNCH_FWD2(HIDC, FWC, ST)                                                                                    \
+  hipLaunchKernelGGL((field_fwd_kernel<32, HIDC, FWC, ST>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
+                     F, dirs, S, rows_sample_major, n, feature, sdf, alpha)
 #define LAUNCH_FWD(FWC)                                                                                               \
   {                                                                                                                    \
-    if (hid == 32)                                                                                                     \
-      hipLaunchKernelGGL((field_fwd_kernel<32, 32, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
-                         F, dirs, S, rows_sample_major, n, feature, sdf, alpha);                                       \
-    else                                                                                                               \
-      hipLaunchKernelGGL((field_fwd_kernel<32, 64, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
-                         F, dirs, S, rows_sample_major, n, feature, sdf, alpha);                                       \
+    if (hid == 32) {                                                                                                   \
+      if (field->stash) LAUNCH_FWD2(32, FWC, true); else LAUNCH_FWD2(32, FWC, false);                                  \
+    } else {                                                                                                           \
+      if (field->stash) LAUNCH_FWD2(64, FWC, true); else LAUNCH_FWD2(64, FWC, false);                                  \
+    }                                                                                                                  \
   }
   if (F == 2) LAUNCH_FWD(2) else if (F == 4) LAUNCH_FWD(4) else LAUNCH_FWD(0)
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD2
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -639,8 +686,12 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
 #define LAUNCH_BWD(HIDC, FWC)                                                                                          \
   {                                                                                                                     \
     using I = FieldImage<32, HIDC>;                                                                                     \
-    hipLaunchKernelGGL((field_bwd_feat_kernel<32, HIDC, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, \
-                       sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);               \
+    if (field->stash)                                                                                                   \
+      hipLaunchKernelGGL((field_bwd_feat_kernel<32, HIDC, FWC, true>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, \
+                         sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);         \
+    else                                                                                                                \
+      hipLaunchKernelGGL((field_bwd_feat_kernel<32, HIDC, FWC, false>), dim3(blocks), dim3(256), 0, nr_s(stream), *field,   \
+                         feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, workspace, slab);  \
     hipLaunchKernelGGL((field_bwd_geo_kernel<32, HIDC, FWC>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn,  \
                        sl, F, n, workspace, g_feats, slab);                                                             \
     if (grads)                                                                                                          \
@@ -681,6 +732,12 @@ extern "C" int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_
   if (check_field(field, &hid) != 0 || n < 0) return -1;
   const int64_t g_total = hid == 32 ? FieldImage<32, 32>::G_TOTAL : FieldImage<32, 64>::G_TOTAL;
   return n * (kC + 1) + 256 * g_total;  // d_e / d_sdf rows + one gradient slab per block (<= 256 blocks)
+}
+
+extern "C" int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n) {
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || n < 0) return -1;
+  return nr_cdiv(n, 32) * (hid == 32 ? Stash<32>::kTile : Stash<64>::kTile);
 }
 
 extern "C" int64_t nr_field_image_floats(const nr_field_t* field) {

@@ -133,6 +133,12 @@ class FusedTrainStep:
         # weight image every block of the field kernels copies into LDS; rebuilt at the start of each step
         self.field_image = torch.empty(self.lib.nr_field_image_floats(byref(self.field_struct)), device=self.dev)
         self.field_struct.packed = self.field_image.data_ptr()
+        # activation stash: field_fwd leaves e / hidden activations / sdf there, the backward's feature half reads
+        # them instead of recomputing the forward (648 B per sample at width 64)
+        if os.environ.get("NR_FIELD_STASH", "1") != "0":
+            n_main = self.B * self.S[2]
+            self.field_stash = torch.empty(self.lib.nr_field_stash_floats(byref(self.field_struct), n_main), device=self.dev)
+            self.field_struct.stash = self.field_stash.data_ptr()
         self.field_grads = NrFieldGrads()
         self.field_grads.geo = ops._mlp_grads_struct([w.grad for w in gw], [b.grad for b in gb])
         self.field_grads.feat = ops._mlp_grads_struct([w.grad for w in fw], [b.grad for b in fb])
