@@ -158,8 +158,14 @@ class _Field(torch.autograd.Function):
         sdf = torch.empty((n,), device=feats.device, dtype=torch.float32)
         alpha = torch.empty((n,), device=feats.device, dtype=torch.float32)
         sn, sl = strides
+        # a backward will follow: let the forward leave its activations for it (nr_field_t.stash)
+        stash = None
+        if n > 0 and (feats.requires_grad or any(p.requires_grad for p in params)):
+            stash = torch.empty(_lib.lib().nr_field_stash_floats(byref(fld), n), device=feats.device, dtype=torch.float32)
+            fld.stash = stash.data_ptr()
         check(_lib.lib().nr_field_fwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(feature), _p(sdf), _p(alpha), _stream()), "nr_field_fwd")
+        ctx.stash = stash
         ctx.save_for_backward(feats, directions, beta, *params)
         ctx.meta = (strides, feat_f, n_samples, rows_sm, n, n_geo, n_feat)
         return feature, sdf, alpha
@@ -172,6 +178,8 @@ class _Field(torch.autograd.Function):
         feat_w, feat_b = params[2 * n_geo:2 * n_geo + n_feat], params[2 * n_geo + n_feat:]
         fld = NrField()
         fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
+        if ctx.stash is not None:
+            fld.stash = ctx.stash.data_ptr()
         grads = [torch.zeros_like(p) for p in params]
         g_beta = torch.zeros_like(beta)
         gs = NrFieldGrads()
