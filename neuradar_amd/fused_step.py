@@ -259,22 +259,22 @@ class FusedTrainStep:
         #      chains (main grid scatter + Adam / proposal round 1 / proposal round 0) right after the render launch
         #      measured 0.78 ms per step against 0.73 with field_bwd by itself.  The chains meet again in the optimizer. ----
         Fp = pg.features_per_level
-        # Schedule, measured on five bench workloads (tools/timeline.py; NR_EARLY_FORK selects one for A/B runs):
-        #   0  nothing starts before field_bwd; 3 = 0 with the field's weight-gradient slabs summed on round 1's stream
-        #      instead of in front of the main scatter (-1 %): best for every workload but the headline one
-        #      (NeuRadar field at 4 096 / 16 384 rays, mixed batch, 64-wide field at 16 384 rays: 1...6 % ahead of 4)
-        #   2  round 0's chain (side[1]) starts before field_bwd and shares the chip with it; 4 = 2 with the reduce moved
-        #      as in 3: best for the 64-wide field at 4 096 rays, where the backward leaves the chip under-filled (-1.5 %)
-        #   1  both proposal chains before field_bwd (+1...+18 % on one GPU, like every other way of starting round 1
-        #      early).  Data-parallel steps use it nevertheless: the proposal table's dense all-reduce (25 MB over xGMI,
-        #      a few hundred us) can then begin ~150 us earlier and hide behind field_bwd, the main scatter and the main
-        #      table's Adam.  That choice is reasoned from the single-GPU timeline, not measured: no multi-GPU box this round.
+        # Schedule (NR_EARLY_FORK selects one for A/B runs; tools/timeline.py shows the result).  With the activation
+        # stash the feature half of field_bwd is short enough that the plain order wins or ties on all five bench
+        # workloads (graph replay, one box: headline 0.63 / 0.66 / 0.65 ms for 0 / 3 / 4; NeuRadar field and mixed
+        # batches: 0 = 3 < 4; only the 64-wide field at 16 384 rays prefers 4, by 1 %):
+        #   0  nothing starts before field_bwd (default); 3 = 0 with the field's weight-gradient slabs summed on
+        #      round 1's stream (nr_field_grad_reduce) instead of in front of the main scatter
+        #   2  round 0's chain (side[1]) starts before field_bwd and shares the chip with it; 4 = 2 with the reduce
+        #      moved as in 3 (was the best for the headline batch, by 1.5 %, while the backward still recomputed the forward)
+        #   1  both proposal chains before field_bwd (+5...+18 % on one GPU).  Data-parallel steps use it nevertheless:
+        #      the proposal table's dense all-reduce (25 MB over xGMI, a few hundred us) can then begin ~150 us earlier
+        #      and hide behind field_bwd, the main scatter and the main table's Adam.  That choice is reasoned from
+        #      the single-GPU timeline, not measured: no multi-GPU box this round.
         if self.early_fork is not None:
             early = int(self.early_fork)
-        elif reducer is not None:
-            early = 1
         else:
-            early = 4 if (self.model.field.config.geo_hidden_dim >= 64 and B <= 4096) else 3
+            early = 1 if reducer is not None else 0
         split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
 
         def chain_head(lvl):
