@@ -196,6 +196,10 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f
 //   B (geometry half): recompute h1; backward through mlp_geo from the workspace; accumulates dW1, dW2
 //     (the sdf row via per-lane partial products); writes grad_feats.
 constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
+// d_e / d_sdf handed from the feature half to the geometry half: per 32-sample tile 17 registers x 64 lanes in the
+// registers' own layout (float reg * 64 + lane), one coalesced 256-byte access per register on either side
+constexpr int64_t kWsTile = 17 * 64;
+__host__ __device__ constexpr int64_t ws_floats(int64_t n) { return (n + 31) / 32 * kWsTile; }
 
 template <int IN, int HID, int FW, bool STASH>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
@@ -269,11 +273,11 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
     float d_sdf = dsig * (-beta);
     if (g_sdf != nullptr && valid) d_sdf += g_sdf[rm.out];
     if (h == 0) d_beta += dsig * (-sdf) * (beta_raw >= 0.0f ? 1.0f : -1.0f);
-    if (valid) {  // d_e = d_o + d_cat[0] (residual; SH carries no gradient) and d_sdf -> workspace
-      float* w = ws + smp * (kC + 1);
+    {  // d_e = d_o + d_cat[0] (residual; SH carries no gradient) and d_sdf -> workspace (zeros for rows >= n)
+      float* w = ws + tile * kWsTile;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) w[rowmap(r, 0) + 4 * h] = d_o[0][r] + d_cat[0][r];
-      if (h == 0) w[kC] = d_sdf;
+      for (int r = 0; r < 16; ++r) w[r * 64 + lane] = valid ? d_o[0][r] + d_cat[0][r] : 0.0f;
+      w[16 * 64 + lane] = valid ? d_sdf : 0.0f;
     }
   }
   d_beta = nr_wave_sum(d_beta);
@@ -333,8 +337,10 @@ field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn
     auto foff = [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); };
     load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
     dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
-    load_rows<kC>(d_e, ws + (valid ? smp * (kC + 1) : 0), valid, h, [](int k) { return (int64_t)k; });
-    const float d_sdf = valid ? ws[smp * (kC + 1) + kC] : 0.0f;
+    const float* wt = ws + tile * kWsTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d_e[0][r] = wt[r * 64 + lane];
+    const float d_sdf = wt[16 * 64 + lane];
     if (h == 0) bSdf += d_sdf;
     // mlp_geo.layers[1]: rows 1..C -> e (MFMA), row 0 -> sdf (per-lane partial products, reduced at the end)
     dense_bwd_dw_reg<HID, kC>(d_e, h1, aG2, bG2, scr, i, h);
@@ -682,7 +688,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   }
   const unsigned blocks = field_bwd_blocks(n);
-  float* slab = workspace + n * (kC + 1);  // [blocks][G_TOTAL] after the d_e / d_sdf rows
+  float* slab = workspace + ws_floats(n);  // [blocks][G_TOTAL] after the d_e / d_sdf tiles
 #define LAUNCH_BWD(HIDC, FWC)                                                                                          \
   {                                                                                                                     \
     using I = FieldImage<32, HIDC>;                                                                                     \
@@ -716,7 +722,7 @@ extern "C" int nr_field_grad_reduce(const nr_field_t* field, const float* worksp
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   const unsigned blocks = field_bwd_blocks(n);
-  const float* slab = workspace + n * (kC + 1);
+  const float* slab = workspace + ws_floats(n);
   if (hid == 32)
     hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(FieldImage<32, 32>::G_TOTAL, 64)), dim3(1024), 0,
                        nr_s(stream), slab, (int)blocks, *grads);
@@ -731,7 +737,7 @@ extern "C" int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_
   int hid = 0;
   if (check_field(field, &hid) != 0 || n < 0) return -1;
   const int64_t g_total = hid == 32 ? FieldImage<32, 32>::G_TOTAL : FieldImage<32, 64>::G_TOTAL;
-  return n * (kC + 1) + 256 * g_total;  // d_e / d_sdf rows + one gradient slab per block (<= 256 blocks)
+  return ws_floats(n) + 256 * g_total;  // d_e / d_sdf tiles + one gradient slab per block (<= 256 blocks)
 }
 
 extern "C" int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n) {
