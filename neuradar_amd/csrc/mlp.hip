@@ -257,7 +257,11 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
       dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     }
     f32x16 d_o[1], d_f2[I::HT], d_f1[I::HT], d_cat[2];
-    load_rows<kC>(d_o, g_feature + rm.out * kC, valid, h, [](int k) { return (int64_t)k; });
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // rows 8q+4h .. +3 of the sample's [C] row are registers 4q..4q+3: 16-byte loads
+      const float4 v = valid ? *reinterpret_cast<const float4*>(g_feature + rm.out * kC + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
+      d_o[0][4 * q] = v.x; d_o[0][4 * q + 1] = v.y; d_o[0][4 * q + 2] = v.z; d_o[0][4 * q + 3] = v.w;
+    }
     dense_bwd_dw_reg<HID, kC>(d_o, f2, aF3, bF3, scr, i, h);          // layers[2]: o = V3 f2 + b
     dense_bwd_dx<HID, kC>(d_o, d_f2, lw + I::oF3, i, h);
     relu_mask<HID>(d_f2, f2);
@@ -678,7 +682,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
                             float* workspace, nr_stream_t stream) {
   if (n == 0) return 0;
   int hid = 0;
-  if (((uintptr_t)workspace & 15u) != 0) return NR_EINVAL;
+  if ((((uintptr_t)workspace | (uintptr_t)g_feature) & 15u) != 0) return NR_EINVAL;  // read / written with 16-byte accesses
   if (check_field(field, &hid) != 0 || !feats || !dirs || !g_feature || !g_alpha || !g_feats || !workspace || S < 0 ||
       F < 1 || n < 0)
     return NR_EINVAL;
