@@ -48,6 +48,13 @@ class HotPathConfig:
     depth_mult: float = 0.01
     interlevel_loss_mult: float = 0.001
     distortion_loss_mult: float = 0.002
+    # lidar decoder (K7) and its losses (neuradar.py:89-110)
+    lidar_decoder: bool = False
+    intensity_mult: float = 0.1
+    ray_drop_loss_mult: float = 0.01
+    non_return_lidar_distance: float = 150.0
+    non_return_loss_mult: float = 0.1
+    quantile_threshold: float = 0.95
 
 
 class NeuRadarHotPath(nn.Module):
@@ -71,6 +78,11 @@ class NeuRadarHotPath(nn.Module):
         if c.appearance_dim > 0:
             self._num_embeds_per_sensor = math.ceil(c.duration * c.temporal_appearance_freq)
             self.appearance_embedding = nn.Embedding(c.num_sensors * self._num_embeds_per_sensor, c.appearance_dim)
+        if c.lidar_decoder:  # neuradar.py:241-248: per-ray MLP on the rendered features (+ appearance embedding)
+            from .mlp import MLP
+
+            self.lidar_decoder = MLP(in_dim=c.field.nff_out_dim + c.appearance_dim, layer_width=32, out_dim=2, num_layers=3,
+                                     implementation="hip", out_activation=None)
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
         groups: Dict[str, List[nn.Parameter]] = {"hashgrids": [], "fields": []}
@@ -78,6 +90,8 @@ class NeuRadarHotPath(nn.Module):
             f.get_param_groups(groups)
         if self.config.appearance_dim > 0:
             groups["fields"] += list(self.appearance_embedding.parameters())
+        if self.config.lidar_decoder:
+            groups["fields"] += list(self.lidar_decoder.parameters())  # neuradar.py:343
         return groups
 
     def _get_ray_samples(self, bundle: RayBundle, t_rand=None, jitters=(None, None)):
@@ -155,6 +169,33 @@ class NeuRadarHotPath(nn.Module):
         return out
 
     forward = get_nff_outputs
+
+    def decode_lidar(self, features: Tensor, is_lidar: Tensor):
+        """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the
+        decoder MLP (MFMA kernels) -> (intensity in (0,1) [n_lidar,1], ray_drop_logit [n_lidar,1]); (None, None)
+        when the batch holds no lidar ray."""
+        lidar_features = features[is_lidar[..., 0]]
+        if lidar_features.numel() == 0:
+            return None, None
+        intensity, ray_drop_logit = self.lidar_decoder(lidar_features).split(1, dim=-1)
+        return intensity.sigmoid(), ray_drop_logit
+
+    def lidar_losses(self, pred_depth: Tensor, intensity: Tensor, ray_drop_logits: Tensor, termination_depth: Tensor,
+                     did_return: Tensor, points_intensities: Tensor) -> Dict[str, Tensor]:
+        """Training losses of the lidar rays (neuradar.py:612-636) with the multipliers of :690-700 applied:
+        quantile-masked depth L1 (non-returning rays pulled beyond 150 m), intensity MSE, ray-drop BCE."""
+        c = self.config
+        target = termination_depth.clone()
+        far = torch.tensor(c.non_return_lidar_distance, device=pred_depth.device)
+        target[~did_return] = pred_depth.detach()[~did_return].maximum(far)
+        unreduced = (target - pred_depth).abs()
+        unreduced[~did_return] = unreduced[~did_return] * c.non_return_loss_mult
+        mask = (unreduced < torch.quantile(unreduced, c.quantile_threshold)).squeeze(-1)
+        qr = mask & did_return
+        return {"depth_loss": c.depth_mult * unreduced[mask].mean(),
+                "intensity_loss": c.intensity_mult * ((points_intensities[qr] - intensity[qr]) ** 2).mean(),
+                "ray_drop_loss": c.ray_drop_loss_mult * torch.nn.functional.binary_cross_entropy_with_logits(
+                    ray_drop_logits, (~did_return).unsqueeze(-1).to(ray_drop_logits))}
 
     def bench_loss(self, out: Dict[str, Tensor], target_features: Tensor, target_depth: Tensor) -> Tensor:
         """rgb_mult*MSE(features) + depth_mult*L1(depth) + inter-level + distortion (neuradar.py:672-704

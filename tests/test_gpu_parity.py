@@ -1048,6 +1048,61 @@ def test_fused_training_matches_torch_training():
         assert float(diff.max()) <= 3 * lr * 1.0001, n  # nothing can differ by more than the three steps themselves
 
 
+def test_lidar_decoder_and_losses_vs_oracle():
+    """SURVEY 8f-2, first item: the per-ray lidar decoder (neuradar.py:241-248, 432-452) on the MFMA MLP kernels and
+    the lidar losses (:612-636, multipliers :690-700) against the oracle restatement, forward and parameter /
+    feature gradients; the decoder MLP itself is pinned by the reference-generated sh_mlp golden."""
+    from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
+    from oracle import decoders
+
+    g = load_golden("sh_mlp")
+    cfg = HotPathConfig(appearance_dim=16, lidar_decoder=True, num_sensors=2)
+    cfg.field.grid.static.log2_hashmap_size = 12
+    cfg.proposal_field_1.grid.static.log2_hashmap_size = 12
+    cfg.proposal_field_2.grid.static.log2_hashmap_size = 12
+    model = NeuRadarHotPath(cfg).to(DEV).train()
+    with torch.no_grad():
+        for i, layer in enumerate(model.lidar_decoder.layers):
+            layer.weight.copy_(dev(g[f"mlp_w{i}"]))
+            layer.bias.copy_(dev(g[f"mlp_b{i}"]))
+    assert any(p is model.lidar_decoder.layers[0].weight for p in model.get_param_groups()["fields"])
+    # the reference's own vector first: all rows are lidar rays
+    x = dev(g["mlp_x"])
+    inten, drop = model.decode_lidar(x, torch.ones(x.shape[0], 1, dtype=torch.bool, device=DEV))
+    y = torch.as_tensor(g["mlp_y"])
+    assert_close(cpu(inten), torch.sigmoid(y[:, :1]), rtol=1e-4, atol_scale=1e-5, what="intensity vs reference MLP")
+    assert_close(cpu(drop), y[:, 1:], rtol=1e-4, atol_scale=1e-5, what="ray drop logit vs reference MLP")
+    # a mixed batch: 4 661 lidar rays among camera rays, 10 % non-returns
+    torch.manual_seed(5)
+    B, n_l = 8192, 4661
+    feats = torch.randn(B, 48)
+    is_lidar = torch.zeros(B, 1, dtype=torch.bool)
+    is_lidar[torch.randperm(B)[:n_l]] = True
+    depth = 2.0 + 148.0 * torch.rand(n_l, 1)
+    term = depth + 0.5 * torch.randn(n_l, 1)
+    did_return = torch.rand(n_l) > 0.1
+    pts_int = torch.rand(n_l, 1)
+    ws = [cpu(l.weight.detach()) for l in model.lidar_decoder.layers]
+    bs = [cpu(l.bias.detach()) for l in model.lidar_decoder.layers]
+    fr, dr = feats.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+    wr, br = [w.clone().requires_grad_(True) for w in ws], [b.clone().requires_grad_(True) for b in bs]
+    i_ref, l_ref = decoders.lidar_decode(fr, is_lidar, wr, br)
+    ref = decoders.lidar_losses(dr, i_ref, l_ref, term, did_return, pts_int)
+    ref_total = 0.01 * ref["depth_loss"] + 0.1 * ref["intensity_loss"] + 0.01 * ref["ray_drop_loss"]
+    ref_g = torch.autograd.grad(ref_total, [fr, dr, *wr, *br])
+    fd, dd = dev(feats).requires_grad_(True), dev(depth).requires_grad_(True)
+    i_hip, l_hip = model.decode_lidar(fd, dev(is_lidar))
+    out = model.lidar_losses(dd, i_hip, l_hip, dev(term), dev(did_return), dev(pts_int))
+    assert_close(cpu(i_hip.detach()), i_ref.detach(), rtol=1e-4, atol_scale=1e-5, what="intensity")
+    for k, mult in (("depth_loss", 0.01), ("intensity_loss", 0.1), ("ray_drop_loss", 0.01)):
+        assert abs(float(out[k].detach()) - mult * float(ref[k].detach())) <= 1e-4 * abs(mult * float(ref[k].detach())) + 1e-9, k
+    params = [l.weight for l in model.lidar_decoder.layers] + [l.bias for l in model.lidar_decoder.layers]
+    got = torch.autograd.grad(sum(out.values()), [fd, dd, *params])
+    for a_, b_, n_ in zip(got, ref_g, ["features", "depth", "w0", "w1", "w2", "b0", "b1", "b2"]):
+        assert_close(cpu(a_), b_, rtol=1e-3, atol_scale=1e-5, what="lidar loss grad " + n_)
+    assert model.decode_lidar(fd, torch.zeros(B, 1, dtype=torch.bool, device=DEV)) == (None, None)
+
+
 def test_flat_adam_flattening_keeps_parameters_and_matches_torch():
     from neuradar_amd.step import FlatAdam
 

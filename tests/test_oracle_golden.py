@@ -55,6 +55,17 @@ def test_sh_and_mlp():
     assert_close(field.direction_encoding(g["dirs"]), g["sh_01"], rtol=1e-6, atol_scale=1e-7)
     layers = [(g[f"mlp_w{i}"], g[f"mlp_b{i}"]) for i in range(3)]
     assert_close(field.mlp(g["mlp_x"], layers), g["mlp_y"], rtol=1e-5, atol_scale=1e-6)
+    # the lidar decoder (K7) is this MLP + split + sigmoid (neuradar.py:432-452)
+    from oracle import decoders
+
+    x = torch.as_tensor(g["mlp_x"])
+    is_lidar = torch.zeros(x.shape[0], 1, dtype=torch.bool)
+    is_lidar[::2] = True
+    inten, drop = decoders.lidar_decode(x, is_lidar, [torch.as_tensor(w) for w, _ in layers], [torch.as_tensor(b) for _, b in layers])
+    y = torch.as_tensor(g["mlp_y"])[::2]
+    assert_close(inten, torch.sigmoid(y[:, :1]), rtol=1e-5, atol_scale=1e-6)
+    assert_close(drop, y[:, 1:], rtol=1e-5, atol_scale=1e-6)
+    assert decoders.lidar_decode(x, torch.zeros(x.shape[0], 1, dtype=torch.bool), [], []) == (None, None)
 
 
 def _check_field(tag):
