@@ -120,10 +120,13 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
                       mm.z != 0.0f || mm.w != 0.0f || vv.x != 0.0f || vv.y != 0.0f || vv.z != 0.0f || vv.w != 0.0f;
     if (can_skip && !__syncthreads_or(live)) continue;  // whole chunk is a fixed point
     if (!in) continue;
+    if (can_skip && !live) continue;  // so are this lane's four parameters: no parameter read, no stores -- pays
+                                      // where neighbouring lanes skip too (never-touched rows of a coarse level)
     float4 p = p4[i];
+    const bool had_grad = g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f;
     upd(p.x, g.x, mm.x, vv.x); upd(p.y, g.y, mm.y, vv.y); upd(p.z, g.z, mm.z, vv.z); upd(p.w, g.w, mm.w, vv.w);
     p4[i] = p; m4[i] = mm; v4[i] = vv;
-    if (zero_grad) g4[i] = g;
+    if (zero_grad && had_grad) g4[i] = g;  // most of a hash table's gradient is already zero: 28 instead of 32 B/param
   }
   if (blockIdx.x == 0)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) upd(param[i], grad[i], m[i], v[i]);
