@@ -77,11 +77,14 @@ sh4_kernel(const float* __restrict__ dirs, int64_t n, float* __restrict__ out) {
 // Dense Adam / AdamW, torch.optim semantics (single tensor, no amsgrad/maximize), grad zeroed in
 // the same pass: 4 reads + 4 writes of 4 B per parameter, pure HBM streaming (float4 per lane).
 //
-// Exact shortcut for hash tables: an entry with grad == 0, exp_avg == 0 and exp_avg_sq == 0 is a fixed
-// point of Adam without weight decay (update = lr * 0 / (0 + eps) = 0, moments stay 0), so a workgroup
-// whose whole 4 KiB chunk of (g, m, v) is zero writes nothing and never reads the parameters: 12 instead
-// of 32 bytes per parameter.  Multiresolution hash tables are overwhelmingly untouched (a 131k-sample
-// batch reaches ~1e5 of 1.7e7 entries), so this is most of the table; results are bit-identical.
+// Exact shortcuts for hash tables: an entry with grad == 0, exp_avg == 0 and exp_avg_sq == 0 is a fixed
+// point of Adam without weight decay (update = lr * 0 / (0 + eps) = 0, moments stay 0).  A lane whose four
+// entries are all at that point reads (g, m, v) only -- no parameter read, no stores: 12 instead of 32 bytes per
+// parameter wherever neighbouring lanes skip together, i.e. in the never-touched rows of the coarse levels (a level
+// of resolution R has (R+1)^3 vertices for T rows: for R < ~80 at T = 2^19 most rows stay untouched for the whole
+// training) and in most of every level early on; a workgroup whose whole 4 KiB chunk is at the fixed point skips as
+// one.  A gradient that is already zero is not zeroed again (28 B).  Results are bit-identical to the dense update.
+// Measured on the 537 MB NeuRadar table: step 1.22 -> 1.04 ms; headline step -4 %.
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
             int64_t n, float lr, float beta1, float beta2, float eps, float wd, int adamw, float bc1, float bc2_sqrt,
