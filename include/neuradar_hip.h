@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 6
+#define NR_ABI_VERSION 7
 #define NR_LOSS_SLOTS 1024 /* loss kernels add into loss[0..1023]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
@@ -345,7 +345,11 @@ int nr_interlevel_loss_to_density(const float* c, int c_stride, const float* w, 
  * ---------------------------------------------------------------------------------------------- */
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
-                 int step, float grad_scale, int zero_grad, const float* dev_hyper, nr_stream_t stream);
+                 int step, float grad_scale, int zero_grad, const float* dev_hyper, uint8_t* seen_grad,
+                 nr_stream_t stream);
+/* seen_grad: NULL, or n/4 bytes owned by the caller, zeroed when exp_avg / exp_avg_sq are zeroed.  Byte i is set
+ * the first time parameters 4i..4i+3 receive a non-zero gradient; while it is 0 their moments are known to be
+ * zero, and (weight_decay == 0) a zero gradient leaves them untouched without reading the moments.  Exact. */
 
 /* Advance the optimizer step counter step_t[0] (device float, 0-based scheduler step) and refresh
  * dev_hyper = {lr(step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))} with the reference's

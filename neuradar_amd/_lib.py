@@ -69,7 +69,7 @@ PROTOTYPES = {
     "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
     "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
-    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P],
+    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P],
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
@@ -112,7 +112,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 6:
+        if handle.nr_abi_version() != 7:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -574,6 +574,44 @@ def test_fused_adam_matches_torch_optim():
         torch.testing.assert_close(p, ref.data, rtol=1e-5, atol=1e-7)
 
 
+def test_adam_sparse_gradients_are_exact():
+    """Hash-table gradients are sparse: the kernel leaves entries at Adam's fixed point (g = m = v = 0) alone and, with
+    the caller's seen_grad bytes, does so without reading the moments.  Both variants give bit-identical parameters and
+    moments, match torch.optim.Adam, and never-touched entries keep their initial bits -- across steps whose touched
+    rows move and a step with no gradient at all (entries with momentum still move)."""
+    from neuradar_amd import ops
+
+    torch.manual_seed(9)
+    n = 1 << 18
+    p0 = torch.randn(n, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
+    runs = [dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV), seen=None),
+            dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
+                 seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV))]
+    ever = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for step in range(1, 7):
+        g = torch.zeros(n, device=DEV)
+        if step != 4:
+            rows = torch.randint(0, n // 8, (3000,), device=DEV) + (step % 3) * (n // 8)  # clustered, moving window
+            g[rows] = torch.randn(rows.numel(), device=DEV)
+        ever |= g != 0
+        ref.grad = g.clone()
+        opt.step()
+        for r in runs:
+            gbuf = g.clone()
+            ops.adam_step(r["p"], gbuf, r["m"], r["v"], 1e-2, step, eps=1e-15, seen_grad=r["seen"])
+            assert float(gbuf.abs().max()) == 0.0
+    a_, b_ = runs
+    assert torch.equal(a_["p"], b_["p"]) and torch.equal(a_["m"], b_["m"]) and torch.equal(a_["v"], b_["v"])
+    st = opt.state[ref]
+    torch.testing.assert_close(a_["p"], ref.data, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(a_["m"], st["exp_avg"], rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(a_["v"], st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    assert torch.equal(a_["p"][~ever], p0[~ever]) and float(a_["m"][~ever].abs().max()) == 0.0
+    assert torch.equal(b_["seen"].bool(), ever.view(-1, 4).any(1))
+
+
 # ------------------------------------------------------------------------------------------------ f-3 loss kernels
 def test_loss_kernels_vs_reference_golden_and_oracle():
     from neuradar_amd import ops
