@@ -411,17 +411,19 @@ def main():
             torch.cuda.synchronize()
             # a pipelined step alternates between two buffer sets: one graph per set, replayed in turn
             slots = getattr(fwd_bwd, "state", None)
-            # both buffer sets' steps in ONE graph, one replay per two steps (-1.2 %: one replay boundary per two steps;
-            # NR_GRAPH_UNROLL=1 or an odd --steps / --warmup: one graph per buffer set, replayed in turn)
-            pair = slots is not None and fuse_opt and os.environ.get("NR_GRAPH_UNROLL", "2") == "2" and args.steps % 2 == 0 \
-                and args.warmup % 2 == 0
+            # the two buffer sets' steps in ONE graph, one replay per `unroll` (even) steps: fewer replay boundaries
+            # (2: -1.2 %).  NR_GRAPH_UNROLL=1, or --steps / --warmup not multiples of it: one graph per set, in turn
+            unroll = int(os.environ.get("NR_GRAPH_UNROLL", "2"))
+            pair = slots is not None and fuse_opt and unroll >= 2 and unroll % 2 == 0 and args.steps % unroll == 0 \
+                and args.warmup % unroll == 0
             if pair:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
-                    fwd_bwd()
-                    fwd_bwd()
+                    for _ in range(unroll):
+                        fwd_bwd()
                 graphs.append(("pair", g1))
             else:
+                unroll = 1
                 for _ in range(2 if slots is not None else 1):
                     k = slots["k"] if slots is not None else 0
                     g1 = torch.cuda.CUDAGraph()
@@ -449,10 +451,10 @@ def main():
         pair_phase = [0]
 
         def step():
-            if "pair" in graphs:  # one replay runs two steps: launch on every other call
+            if "pair" in graphs:  # one replay runs `unroll` steps: launch on every unroll-th call
                 if pair_phase[0] == 0:
                     graphs["pair"].replay()
-                pair_phase[0] ^= 1
+                pair_phase[0] = (pair_phase[0] + 1) % unroll
                 return
             if slots is not None:
                 k = slots["k"]
@@ -550,7 +552,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
-                       "graph": bool(use_graph), "steps_per_graph_replay": (2 if use_graph and "pair" in graphs else 1), "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
+                       "graph": bool(use_graph), "steps_per_graph_replay": (unroll if use_graph else 1), "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                                            if reducer.last_sparse.get("mode") == "sparse" else 0))
                        if world > 1 else 0,
