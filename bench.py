@@ -134,8 +134,14 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
     if fused:
         from neuradar_amd.fused_step import FusedTrainStep
 
-        # camera patches are coherent (sample-major rows), lidar / radar rays are not (ray-major rows)
-        stepper = FusedTrainStep(model, n_rays, coherent_rays=mixed["cam_rays"] if mixed is not None else None)
+        # camera patches are coherent (sample-major rows), lidar rays are not (ray-major rows)
+        # a radar scan is a regular azimuth x elevation grid from one origin: coherent like a camera patch at the coarse
+        # levels, so its rays join the sample-major block (batch order camera, radar, lidar): 3.42 -> 3.19 ms per step
+        radar_coherent = mixed is not None and os.environ.get("NR_RADAR_COHERENT", "1") == "1"
+        n_coh = None
+        if mixed is not None:
+            n_coh = mixed["cam_rays"] + (n_rays - mixed["cam_rays"] - mixed["lidar_rays"] if radar_coherent else 0)
+        stepper = FusedTrainStep(model, n_rays, coherent_rays=n_coh)
         S0 = model.config.num_proposal_samples[0]
         dev = tgt_f.device
 
@@ -168,7 +174,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             lid = scene.lidars.generate_rays(scene.lidar_owner[pick], scene.lidar_points[pick])
             scans = (u[n_u + n_lidar:n_u + n_lidar + n_scans] * scene.n_cams).long().clamp_(max=scene.n_cams - 1)
             rad = scene.radars.generate_rays(scans)
-            b = merge_bundles(cam, lid, rad)
+            b = merge_bundles(cam, rad, lid) if radar_coherent else merge_bundles(cam, lid, rad)
             return stepper.forward_backward(b.origins, b.directions, b.pixel_area[:, 0], b.fars[:, 0], tgt_f, tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
