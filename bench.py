@@ -173,66 +173,75 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         seed = 0x5EED0000 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)  # seed + rank
         epoch = opts[0].step_t  # device-resident step counter (advanced by the optimizer's schedule kernel)
 
-        def fwd_bwd_mixed():
+        # Batches are software-pipelined across steps: as soon as step k's sampling rounds have read the uniform
+        # buffer it is refilled, and the batch assembly (patch rays; for mixed batches also lidar picks, radar scans and
+        # the merge -- some fifty tiny launches) + first launch (bins, contraction) of step k+1 run on the same side
+        # stream into the other buffer set, beside step k's field / backward.  Same numbers in the same order as the
+        # unpipelined step (NR_PIPELINE=0), which does all that at the top of step k+1.
+        pipelined = os.environ.get("NR_PIPELINE", "1") != "0"
+        state = {"k": 0}
+        f32 = dict(device=dev, dtype=torch.float32)
+        # per buffer set: the merged batch the step reads (camera-only: the generator writes it directly)
+        batch = [None, None] if mixed is None else [
+            dict(o=torch.empty(n_rays, 3, **f32), d=torch.empty(n_rays, 3, **f32), area=torch.empty(n_rays, **f32),
+                 fars=torch.empty(n_rays, **f32)) for _ in range(2)]
+        cam_out = [None, None]
+        ready = [False, False]
+
+        def assemble(slot):
+            """This step's rays into buffer set `slot` (on the current stream); returns (origins, directions, area, fars)."""
+            u = r[n_t + 2 * n_rays:]
+            cam_out[slot], _ = scene.cameras.generate_patch_rays(u[:n_u].view(n_p, 3), scene.PATCH, scene.STRIDE, scene.H, scene.W,
+                                                                 area_scale=9.0, out=cam_out[slot])  # _scale_pixel_area
+            cam = cam_out[slot]
+            if mixed is None:
+                # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
+                return cam.origins, cam.directions, cam.pixel_area[:, 0], None
             # camera patches + lidar points + one radar scan, merged like _merge_img_lidar_radar
             # (image_lidar_radar_datamanager.py:335-409); sensor indices come from the same uniform buffer
-            from neuradar_amd.sensors import merge_bundles
-
-            u = r[n_t + 2 * n_rays:]
-            cam, _ = scene.cameras.generate_patch_rays(u[:n_u].view(n_p, 3), scene.PATCH, scene.STRIDE, scene.H, scene.W,
-                                                       area_scale=9.0)
             pick = (u[n_u:n_u + n_lidar] * scene.lidar_points.shape[0]).long().clamp_(max=scene.lidar_points.shape[0] - 1)
             if lidar_sorted:
                 pick = torch.sort(pick).values
             lid = scene.lidars.generate_rays(scene.lidar_owner[pick], scene.lidar_points[pick])
             scans = (u[n_u + n_lidar:n_u + n_lidar + n_scans] * scene.n_cams).long().clamp_(max=scene.n_cams - 1)
             rad = scene.radars.generate_rays(scans)
-            b = merge_bundles(cam, rad, lid) if radar_coherent else merge_bundles(cam, lid, rad)
-            return stepper.forward_backward(b.origins, b.directions, b.pixel_area[:, 0], b.fars[:, 0], tgt_f, tgt_d[:, 0],
-                                            r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
-                                            optimizers=opts if fuse_optimizer else None,
-                                            reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
-                                            after_sampling=lambda: hip_ops.uniform_fill(r, seed, epoch))
+            mb, off = batch[slot], 0
+            for part in ((cam, rad, lid) if radar_coherent else (cam, lid, rad)):
+                m_ = part.origins.shape[0]
+                mb["o"][off:off + m_].copy_(part.origins)
+                mb["d"][off:off + m_].copy_(part.directions)
+                mb["area"][off:off + m_].copy_(part.pixel_area[:, 0])
+                mb["fars"][off:off + m_].copy_(part.fars[:, 0])
+                off += m_
+            return mb["o"], mb["d"], mb["area"], mb["fars"]
 
-        # camera-only workloads are software-pipelined across steps: as soon as step k's sampling rounds have read
-        # the uniform buffer it is refilled, and the rays + first launch (bins, contraction) of step k+1 run on the
-        # same side stream into the other buffer set, beside step k's field / backward.  Same numbers in the same
-        # order as the unpipelined step (NR_PIPELINE=0), which generates them at the top of step k+1.
-        pipelined = mixed is None and os.environ.get("NR_PIPELINE", "1") != "0"
-        bundles = [None, None]
-        state = {"k": 0}
+        rays = [None, None]
 
-        def gen_rays(slot):
-            bundles[slot], _ = scene.cameras.generate_patch_rays(r[n_t + 2 * n_rays:].view(n_p, 3), scene.PATCH, scene.STRIDE,
-                                                                 scene.H, scene.W, area_scale=9.0,  # _scale_pixel_area
-                                                                 out=bundles[slot])
-            return bundles[slot]
+        def head(slot):
+            rays[slot] = assemble(slot)
+            o_, d_, a_, f_ = rays[slot]
+            stepper.prepare(slot, o_, d_, a_, f_, r[:n_t].view(n_rays, S0 + 1))
+            ready[slot] = True
 
         def next_step_head(slot):
             hip_ops.uniform_fill(r, seed, epoch)
-            b = gen_rays(slot)
-            # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
-            stepper.prepare(slot, b.origins, b.directions, b.pixel_area[:, 0], None, r[:n_t].view(n_rays, S0 + 1))
+            head(slot)
 
         def fwd_bwd():
-            if mixed is not None:
-                return fwd_bwd_mixed()
-            k = state["k"]
+            k = state["k"] if pipelined else 0
+            if not (pipelined and ready[k]):  # unpipelined, or the very first step: nothing prepared it
+                head(k)
             if pipelined:
-                if bundles[k] is None:  # very first step: nothing prepared it
-                    b = gen_rays(k)
-                    stepper.prepare(k, b.origins, b.directions, b.pixel_area[:, 0], None, r[:n_t].view(n_rays, S0 + 1))
                 state["k"] = 1 - k
                 tail = lambda: next_step_head(1 - k)  # noqa: E731
             else:
-                gen_rays(0)
-                k, tail = 0, (lambda: hip_ops.uniform_fill(r, seed, epoch))
-            bundle = bundles[k]
-            return stepper.forward_backward(bundle.origins, bundle.directions, bundle.pixel_area[:, 0], None, tgt_f, tgt_d[:, 0],
+                tail = lambda: hip_ops.uniform_fill(r, seed, epoch)  # noqa: E731
+            o_, d_, a_, f_ = rays[k]
+            return stepper.forward_backward(o_, d_, a_, f_, tgt_f, tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
-                                            after_sampling=tail, slot=k, prepared=pipelined)
+                                            after_sampling=tail, slot=k, prepared=True)
 
         fwd_bwd.state = state if pipelined else None
     else:
