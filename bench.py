@@ -47,13 +47,14 @@ WORKLOADS = {
 }
 
 
-def build_model(wl, device):
+def build_model(wl, device, mlp_dtype="float32", grad_scale=1.0):
     from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
     from neuradar_amd.neurad_field import NeuRADFieldConfig
     from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
 
     cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(**wl["grid"])),
-                                                geo_hidden_dim=wl["hidden"], nff_hidden_dim=wl["hidden"]))
+                                                geo_hidden_dim=wl["hidden"], nff_hidden_dim=wl["hidden"],
+                                                mlp_dtype=mlp_dtype, mlp_grad_scale=grad_scale))
     torch.manual_seed(0)  # identical replicas on every rank
     return NeuRadarHotPath(cfg).to(device).train()
 
@@ -371,6 +372,10 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cam4096_l16f2_w64", choices=sorted(WORKLOADS))
+    ap.add_argument("--mlp-dtype", default="float32", choices=["float32", "bfloat16", "float16"],
+                    help="MFMA operand type of the field MLP stack (fp32 accumulation in every case)")
+    ap.add_argument("--mlp-grad-scale", type=float, default=None, help="static loss scale of the 16-bit MLP backward "
+                    "(default: 1 for float32 / bfloat16, 8192 for float16)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--autograd", action="store_true", help="time the modular torch.autograd path instead of the fused step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -402,7 +407,8 @@ def main():
     wl = WORKLOADS[args.workload]
     n_rays = wl["rays"]
 
-    model = build_model(wl, device)
+    grad_scale = args.mlp_grad_scale if args.mlp_grad_scale is not None else (8192.0 if args.mlp_dtype == "float16" else 1.0)
+    model = build_model(wl, device, args.mlp_dtype, grad_scale)
     broadcast_parameters(model)
     groups = model.get_param_groups()
     # configs/method_configs.py:384-409: hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
@@ -577,7 +583,7 @@ def main():
         line = {
             "metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.mlp_dtype], "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_gpu_per_step": n_rays, "samples_per_ray": "128/64/32",
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
                        "graph": bool(use_graph), "steps_per_graph_replay": (unroll if use_graph else 1), "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4), "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",

@@ -26,7 +26,10 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 7
+#define NR_ABI_VERSION 8
+#define NR_DTYPE_F32 0
+#define NR_DTYPE_BF16 1
+#define NR_DTYPE_F16 2
 #define NR_LOSS_SLOTS 1024 /* loss kernels add into loss[0..1023]; the loss value is the sum of the slots */
 
 typedef void* nr_stream_t;
@@ -137,6 +140,14 @@ typedef struct nr_field {
                           then leaves the activations the backward needs there (e, mlp_feature's two hidden
                           layers, sdf: 392 B / 648 B per sample at width 32 / 64) and nr_field_bwd, called with the
                           same field, n and inputs, reads them instead of recomputing the forward */
+  int dtype;           /* NR_DTYPE_F32 (0): v_mfma_f32_32x32x2_f32, the 1e-4 parity path.  NR_DTYPE_BF16 / NR_DTYPE_F16:
+                          16-bit operands on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation (what the reference
+                          trains with: torch.autocast + tcnn FullyFusedMLP, engine/trainer.py:189-200,564,
+                          field_components/mlp.py:109-127).  Inputs, outputs, parameters and gradients stay fp32 tensors;
+                          `packed` is then REQUIRED (nr_field_pack converts the weights) and `stash` is ignored. */
+  float grad_scale;    /* reduced precision only: gradients are multiplied by this factor where they enter the 16-bit
+                          domain and divided back where they leave it (a static GradScaler, trainer.py:200,585-595);
+                          <= 0 means 1.  bf16 needs none; fp16 gradients underflow without it. */
 } nr_field_t;
 
 typedef struct nr_field_grads {

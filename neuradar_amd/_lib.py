@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
+NR_ABI_VERSION = 8
+NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
 class NrMlp(Structure):
@@ -26,7 +28,8 @@ class NrMlpGrads(Structure):
 
 
 class NrField(Structure):
-    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p)]
+    _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p),
+                ("dtype", c_int), ("grad_scale", c_float)]
 
 
 class NrFieldGrads(Structure):
@@ -112,7 +115,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch, fail loudly
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
-        if handle.nr_abi_version() != 7:
+        if handle.nr_abi_version() != NR_ABI_VERSION:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -3,37 +3,12 @@
 // See mlp_tiles.h for the register/LDS layout.  Persistent 4-wave workgroups, one 32-sample tile per
 // wave per iteration; weights are loaded into LDS once per workgroup, weight gradients are summed in
 // LDS (ds_add_f32) over all tiles of the workgroup and flushed once with contiguous global atomics.
-#include <stdlib.h>
-
-#include "nr_common.h"
-#include "mlp_tiles.h"
-#include "sh4.h"
+#include "field_common.h"
 
 using namespace nrmlp;
+using namespace nrfield;
 
 namespace {
-
-constexpr int kC = 32;         // geo_feat_dim == nff_out_dim (fields/neurad_field.py:64,97)
-constexpr int kSH = 16;        // SHEncoding(levels=4)
-constexpr float kBetaMin = 1e-4f;  // model_components/utils.py:24
-
-template <int IN, int HID>
-struct FieldImage {
-  using G1 = Layer<IN, HID>;       // mlp_geo.layers[0]
-  using G2 = Layer<HID, kC>;       // mlp_geo.layers[1], embedding rows 1..C
-  using F1 = Layer<kC + kSH, HID>; // mlp_feature.layers[0]
-  using F2 = Layer<HID, HID>;
-  using F3 = Layer<HID, kC>;
-  static constexpr int SDF = (HID + 1 + 3) / 4 * 4;  // row 0 of mlp_geo.layers[1] + its bias (padded to 16 bytes)
-  // weight image offsets
-  static constexpr int oG1 = 0, oG2 = oG1 + G1::SIZE, oSdf = oG2 + G2::SIZE, oF1 = oSdf + SDF,
-                       oF2 = oF1 + F1::SIZE, oF3 = oF2 + F2::SIZE, W_TOTAL = oF3 + F3::SIZE;
-  // gradient image offsets
-  static constexpr int gG1 = 0, gG2 = gG1 + G1::G_SIZE, gSdf = gG2 + G2::G_SIZE, gF1 = gSdf + SDF,
-                       gF2 = gF1 + F1::G_SIZE, gF3 = gF2 + F2::G_SIZE, gBeta = gF3 + F3::G_SIZE,
-                       G_TOTAL = gBeta + 2;
-  static constexpr int HT = (HID + 31) / 32, IT = (IN + 31) / 32;
-};
 
 // Every block of the three field kernels needs the whole weight image in LDS.  Building it from the
 // torch-layout matrices costs five zero-fill + gather passes and barriers PER BLOCK (measured: ~20 us
@@ -65,41 +40,6 @@ __device__ __forceinline__ void load_field_weights(float* lw, const nr_field_t& 
   __syncthreads();
 }
 
-// load a [rows x 32 samples] block given per-sample element addressing elem(k) -> offset
-template <int ROWS, typename OffFn>
-__device__ __forceinline__ void load_rows(f32x16 (&t)[(ROWS + 31) / 32], const float* __restrict__ base, bool valid,
-                                          int h, OffFn off) {
-#pragma unroll
-  for (int kt = 0; kt < (ROWS + 31) / 32; ++kt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = kt * 32 + rowmap(r, 0) + 4 * h;
-      t[kt][r] = (valid && k < ROWS) ? base[off(k)] : 0.0f;
-    }
-}
-
-__device__ __forceinline__ f32x16 sh_tile(const float* __restrict__ dirs, int64_t ray, int h) {
-  // SH of the [0,1]-mapped direction (fields/base_field.py:135-141 + encodings.py:797-800)
-  float sh[16];
-  nr_sh4((dirs[ray * 3 + 0] + 1.0f) / 2.0f, (dirs[ray * 3 + 1] + 1.0f) / 2.0f, (dirs[ray * 3 + 2] + 1.0f) / 2.0f, sh);
-  f32x16 t;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = r < 8 ? (h ? sh[rowmap(r, 0) + 4] : sh[rowmap(r, 0)]) : 0.0f;
-  return t;
-}
-
-template <int HID>
-__device__ __forceinline__ float sdf_row(const f32x16 (&h1)[(HID + 31) / 32], const float* wsdf, int h) {
-  float part = 0.0f;
-#pragma unroll
-  for (int t = 0; t < (HID + 31) / 32; ++t)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int k = t * 32 + rowmap(s, 0) + 4 * h;
-      if (k < HID) part += wsdf[k] * h1[t][s];
-    }
-  return part + __shfl_xor(part, 32, NR_WAVE) + wsdf[HID];
-}
 
 #ifndef NR_MLP_FWD_WAVES
 #define NR_MLP_FWD_WAVES 1
@@ -195,11 +135,6 @@ __device__ __forceinline__ void relu_mask(f32x16 (&g)[(ROWS + 31) / 32], const f
 //     sigmoid; writes d_e [n,C] and d_sdf [n] to the workspace; accumulates dV1..dV3, d_beta.
 //   B (geometry half): recompute h1; backward through mlp_geo from the workspace; accumulates dW1, dW2
 //     (the sdf row via per-lane partial products); writes grad_feats.
-constexpr int kBwdScrTiles = 4;  // KT + MT <= 4 staged tiles per layer
-// d_e / d_sdf handed from the feature half to the geometry half: per 32-sample tile 17 registers x 64 lanes in the
-// registers' own layout (float reg * 64 + lane), one coalesced 256-byte access per register on either side
-constexpr int64_t kWsTile = 17 * 64;
-__host__ __device__ constexpr int64_t ws_floats(int64_t n) { return (n + 31) / 32 * kWsTile; }
 
 template <int IN, int HID, int FW, bool STASH>  // FW: feature width F as a compile-time constant (0: runtime)
 __global__ void __launch_bounds__(256, NR_MLP_BWD_WAVES)
@@ -619,18 +554,6 @@ int check_mlp(const nr_mlp_t* m) {
     }                                                                                                        \
   } while (0)
 
-int check_field(const nr_field_t* f, int* hid) {
-  if (!f || !f->beta) return NR_EINVAL;
-  const nr_mlp_t &g = f->geo, &m = f->feat;
-  if (g.num_layers != 2 || m.num_layers != 3) return NR_EINVAL;
-  if (g.in_dim != 32 || g.out_dim != kC + 1 || m.in_dim != kC + kSH || m.out_dim != kC || g.width != m.width) return NR_EINVAL;
-  if (g.width != 32 && g.width != 64) return NR_EINVAL;
-  for (int l = 0; l < 2; ++l) if (!g.weight[l] || !g.bias[l]) return NR_EINVAL;
-  for (int l = 0; l < 3; ++l) if (!m.weight[l] || !m.bias[l]) return NR_EINVAL;
-  *hid = g.width;
-  return 0;
-}
-
 }  // namespace
 
 extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
@@ -646,6 +569,8 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
     const int v = atoi(e);
     if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   }
+  if (field->dtype != NR_DTYPE_F32)  // bf16 / fp16 operands (mlp_lp.hip)
+    return field_fwd_lp(field, hid, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha, blocks, nr_s(stream));
 #define LAUNCH_FWD2(HIDC, FWC, ST)                                                                                    \
   hipLaunchKernelGGL((field_fwd_kernel<32, HIDC, FWC, ST>), dim3(blocks), dim3(256), 0, nr_s(stream), *field, feats, sn, sl, \
                      F, dirs, S, rows_sample_major, n, feature, sdf, alpha)
@@ -664,17 +589,6 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
   return 0;
 }
 
-namespace {
-unsigned field_bwd_blocks(int64_t n) {
-  const int64_t tiles = nr_cdiv(n, 32);
-  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
-  if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
-  }
-  return blocks;
-}
-}  // namespace
 
 extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
                             const float* dirs, int S, int rows_sample_major, int64_t n, const float* g_feature,
@@ -693,6 +607,21 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
   }
   const unsigned blocks = field_bwd_blocks(n);
   float* slab = workspace + ws_floats(n);  // [blocks][G_TOTAL] after the d_e / d_sdf tiles
+  if (field->dtype != NR_DTYPE_F32) {  // bf16 / fp16 operands (mlp_lp.hip); same workspace / slab layout, same reduce
+    const int rc = field_bwd_lp(field, hid, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, g_feats,
+                                workspace, slab, blocks, nr_s(stream));
+    if (rc != 0) return rc;
+    if (grads) {
+      if (hid == 32)
+        hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(FieldImage<32, 32>::G_TOTAL, 64)), dim3(1024),
+                           0, nr_s(stream), slab, (int)blocks, *grads);
+      else
+        hipLaunchKernelGGL((field_grad_reduce_kernel<32, 64>), dim3((unsigned)nr_cdiv(FieldImage<32, 64>::G_TOTAL, 64)), dim3(1024),
+                           0, nr_s(stream), slab, (int)blocks, *grads);
+      NR_LAUNCH_CHECK();
+    }
+    return 0;
+  }
 #define LAUNCH_BWD(HIDC, FWC)                                                                                          \
   {                                                                                                                     \
     using I = FieldImage<32, HIDC>;                                                                                     \
@@ -747,18 +676,33 @@ extern "C" int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_
 extern "C" int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n) {
   int hid = 0;
   if (check_field(field, &hid) != 0 || n < 0) return -1;
+  if (field->dtype != NR_DTYPE_F32) return 0;  // the reduced-precision backward recomputes the forward
   return nr_cdiv(n, 32) * (hid == 32 ? Stash<32>::kTile : Stash<64>::kTile);
 }
 
 extern "C" int64_t nr_field_image_floats(const nr_field_t* field) {
   int hid = 0;
+  if (field && field->dtype != NR_DTYPE_F32 && field->packed == nullptr) {  // size query before the image exists
+    nr_field_t probe = *field;
+    probe.packed = reinterpret_cast<const float*>(&probe);
+    if (check_field(&probe, &hid) != 0) return -1;
+    return field_image_bytes_lp(hid) / 4;
+  }
   if (check_field(field, &hid) != 0) return -1;
+  if (field->dtype != NR_DTYPE_F32) return field_image_bytes_lp(hid) / 4;
   return hid == 32 ? FieldImage<32, 32>::W_TOTAL : FieldImage<32, 64>::W_TOTAL;
 }
 
 extern "C" int nr_field_pack(const nr_field_t* field, float* image, nr_stream_t stream) {
   int hid = 0;
-  if (check_field(field, &hid) != 0 || !image || ((uintptr_t)image & 15u) != 0) return NR_EINVAL;
+  if (!field || !image || ((uintptr_t)image & 15u) != 0) return NR_EINVAL;
+  if (field->dtype != NR_DTYPE_F32) {
+    nr_field_t probe = *field;
+    probe.packed = image;
+    if (check_field(&probe, &hid) != 0) return NR_EINVAL;
+    return field_pack_lp(field, hid, image, nr_s(stream));
+  }
+  if (check_field(field, &hid) != 0) return NR_EINVAL;
   if (hid == 32)
     hipLaunchKernelGGL((field_pack_kernel<32, 32>), dim3(1), dim3(1024), 0, nr_s(stream), *field, image);
   else

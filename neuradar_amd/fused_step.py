@@ -130,19 +130,24 @@ class FusedTrainStep:
         self.field_struct = NrField()
         self.field_struct.geo, self.field_struct.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
         self.field_struct.beta = fld.sdf_to_density.beta.data_ptr()
+        self.field_struct.dtype = _lib.NR_DTYPES[fld.config.mlp_dtype]
+        self.field_struct.grad_scale = float(fld.config.mlp_grad_scale)
         # weight image every block of the field kernels copies into LDS; rebuilt at the start of each step
         self.field_image = torch.empty(self.lib.nr_field_image_floats(byref(self.field_struct)), device=self.dev)
         self.field_struct.packed = self.field_image.data_ptr()
         # activation stash: field_fwd leaves e / hidden activations / sdf there, the backward's feature half reads
         # them instead of recomputing the forward (648 B per sample at width 64)
-        if os.environ.get("NR_FIELD_STASH", "1") != "0":
+        if os.environ.get("NR_FIELD_STASH", "1") != "0" and self.field_struct.dtype == 0:
             n_main = self.B * self.S[2]
             self.field_stash = torch.empty(self.lib.nr_field_stash_floats(byref(self.field_struct), n_main), device=self.dev)
             self.field_struct.stash = self.field_stash.data_ptr()
         self.field_grads = NrFieldGrads()
         self.field_grads.geo = ops._mlp_grads_struct([w.grad for w in gw], [b.grad for b in gb])
         self.field_grads.feat = ops._mlp_grads_struct([w.grad for w in fw], [b.grad for b in fb])
-        self.field_grads.beta = fld.sdf_to_density.beta.grad.data_ptr()
+        beta = fld.sdf_to_density.beta
+        if beta.grad is None:  # learnable_beta=False: the kernels still write d_beta somewhere
+            self._beta_grad_sink = torch.zeros_like(beta)
+        self.field_grads.beta = (beta.grad if beta.grad is not None else self._beta_grad_sink).data_ptr()
 
     # -------------------------------------------------------------------------------------------
     def prepare(self, slot: int, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Optional[Tensor],
@@ -326,17 +331,22 @@ class FusedTrainStep:
             table_opt, field_opt = optimizers
             scale = 1.0 if reducer is None else 1.0 / reducer.world
             i_prop, i_main = table_opt.buffer_of(pg.hash_table), table_opt.buffer_of(mg.hash_table)
+            shared = i_prop == i_main  # tiny tables (<= 65536 elements) live in ONE flat buffer: reduce and step it once,
+            #                            after both tables' scatters (below, on side[0])
             # main table first: its list exchange holds the step's only host read, and issuing it before the
             # proposal table's all-reduce keeps the CPU from parking behind the proposal chains
-            if reducer is not None:
-                if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
-                    reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
-                else:
-                    reducer.start(table_opt.buffers[i_main][1])
-                    reducer.wait_all()
-            table_opt.step_buffer(i_main, scale)
+            if not shared:
+                if reducer is not None:
+                    if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
+                        reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
+                    else:
+                        reducer.start(table_opt.buffers[i_main][1])
+                        reducer.wait_all()
+                table_opt.step_buffer(i_main, scale)
             if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
                 side[0].wait_stream(side[1])
+                if shared:
+                    side[0].wait_stream(main)
             with torch.cuda.stream(side[0]):
                 if reducer is not None:
                     reducer.start(table_opt.buffers[i_prop][1])

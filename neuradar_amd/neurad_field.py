@@ -42,6 +42,12 @@ class NeuRADFieldConfig:  # neurad_field.py:44-75
     use_sdf: bool = True
     sdf_beta: float = 20.0
     learnable_beta: bool = True
+    # precision of the MLP stack's MFMA operands (this build; the reference reaches the same thing through
+    # torch.autocast + tcnn's fp16 FullyFusedMLP, engine/trainer.py:189-200,564): "float32" is the 1e-4 parity path,
+    # "bfloat16" / "float16" run on v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  mlp_grad_scale: static loss
+    # scale applied where gradients enter the 16-bit domain (the role of trainer.py's GradScaler; fp16 needs one).
+    mlp_dtype: str = "float32"
+    mlp_grad_scale: float = 1.0
 
     def setup(self, **kwargs) -> "NeuRADField":
         return NeuRADField(self, **kwargs)
@@ -78,7 +84,8 @@ class NeuRADField(nn.Module):
         feature, sdf, alpha = ops.field_mlp(buf, strides, self.hashgrid.static_grid.features_per_level,
                                             ray_samples.directions if dirs is None else dirs, S if dirs is None else 0,
                                             B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
-                                            self.sdf_to_density.beta, rows_sample_major=rows_sm)
+                                            self.sdf_to_density.beta, rows_sample_major=rows_sm,
+                                            dtype=self.config.mlp_dtype, grad_scale=self.config.mlp_grad_scale)
         return {FieldHeadNames.FEATURE: feature.view(B, S, -1), FieldHeadNames.SDF: sdf.view(B, S, 1),
                 FieldHeadNames.ALPHA: alpha.view(B, S, 1)}
 

@@ -146,13 +146,20 @@ class _Field(torch.autograd.Function):
     """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
 
     @staticmethod
-    def forward(ctx, feats, strides, feat_f, directions, n_samples, rows_sm, n, beta, n_geo, *params):
+    def forward(ctx, feats, strides, feat_f, directions, n_samples, rows_sm, n, beta, precision, n_geo, *params):
         geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
         rest = params[2 * n_geo:]
         n_feat = len(rest) // 2
         feat_w, feat_b = rest[:n_feat], rest[n_feat:]
         fld = NrField()
         fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
+        dtype, grad_scale = precision
+        fld.dtype, fld.grad_scale = _lib.NR_DTYPES[dtype], float(grad_scale)
+        image = None
+        if fld.dtype != 0:  # bf16 / fp16 operands: the kernels read the weights from the converted image only
+            image = torch.empty(_lib.lib().nr_field_image_floats(byref(fld)), device=feats.device, dtype=torch.float32)
+            check(_lib.lib().nr_field_pack(byref(fld), _p(image), _stream()), "nr_field_pack")
+            fld.packed = image.data_ptr()
         C = feat_w[-1].shape[0]
         feature = torch.empty((n, C), device=feats.device, dtype=torch.float32)
         sdf = torch.empty((n,), device=feats.device, dtype=torch.float32)
@@ -160,26 +167,29 @@ class _Field(torch.autograd.Function):
         sn, sl = strides
         # a backward will follow: let the forward leave its activations for it (nr_field_t.stash)
         stash = None
-        if n > 0 and (feats.requires_grad or any(p.requires_grad for p in params)):
+        if n > 0 and fld.dtype == 0 and (feats.requires_grad or any(p.requires_grad for p in params)):
             stash = torch.empty(_lib.lib().nr_field_stash_floats(byref(fld), n), device=feats.device, dtype=torch.float32)
             fld.stash = stash.data_ptr()
         check(_lib.lib().nr_field_fwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(feature), _p(sdf), _p(alpha), _stream()), "nr_field_fwd")
-        ctx.stash = stash
+        ctx.stash, ctx.image = stash, image
         ctx.save_for_backward(feats, directions, beta, *params)
-        ctx.meta = (strides, feat_f, n_samples, rows_sm, n, n_geo, n_feat)
+        ctx.meta = (strides, feat_f, n_samples, rows_sm, n, n_geo, n_feat, fld.dtype, fld.grad_scale)
         return feature, sdf, alpha
 
     @staticmethod
     def backward(ctx, g_feature, g_sdf, g_alpha):
         feats, directions, beta, *params = ctx.saved_tensors
-        (sn, sl), feat_f, n_samples, rows_sm, n, n_geo, n_feat = ctx.meta
+        (sn, sl), feat_f, n_samples, rows_sm, n, n_geo, n_feat, dtype, grad_scale = ctx.meta
         geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
         feat_w, feat_b = params[2 * n_geo:2 * n_geo + n_feat], params[2 * n_geo + n_feat:]
         fld = NrField()
         fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
+        fld.dtype, fld.grad_scale = dtype, grad_scale
         if ctx.stash is not None:
             fld.stash = ctx.stash.data_ptr()
+        if ctx.image is not None:
+            fld.packed = ctx.image.data_ptr()
         grads = [torch.zeros_like(p) for p in params]
         g_beta = torch.zeros_like(beta)
         gs = NrFieldGrads()
@@ -194,17 +204,19 @@ class _Field(torch.autograd.Function):
         check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(g_feature), _p(g_alpha), _p(g_sdf), _p(g_feats), byref(gs), _p(ws), _stream()),
               "nr_field_bwd")
-        return (g_feats, None, None, None, None, None, None, g_beta, None, *grads)
+        return (g_feats, None, None, None, None, None, None, g_beta, None, None, *grads)
 
 
 def field_mlp(feats: Tensor, strides: Tuple[int, int], feat_f: int, directions: Tensor, n_samples: int, n: int,
               geo: Tuple[List[Tensor], List[Tensor]], feat: Tuple[List[Tensor], List[Tensor]], beta: Tensor,
-              rows_sample_major: bool = False):
+              rows_sample_major: bool = False, dtype: str = "float32", grad_scale: float = 1.0):
     """NeuRADField after the grid (neurad_field.py:137-148).  feats is the raw buffer written by
     hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]
-    (always in [B,S] order; rows_sample_major: feats rows are s*B+b)."""
+    (always in [B,S] order; rows_sample_major: feats rows are s*B+b).
+    dtype: "float32" (fp32 MFMA, the parity path), "bfloat16" or "float16": 16-bit MFMA operands with fp32 accumulation
+    (nr_field_t.dtype); grad_scale: static loss scale of the 16-bit backward (fp16 needs one)."""
     sm = _sm_rays(rows_sample_major, n // n_samples if n_samples else 0)
-    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, sm, n, beta, len(geo[0]),
+    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, sm, n, beta, (dtype, grad_scale), len(geo[0]),
                         *geo[0], *geo[1], *feat[0], *feat[1])
 
 
@@ -397,14 +409,20 @@ def interlevel_loss(spacing: Tensor, weights: Tensor, n_used: int, prop_spacing:
 def grad_compact(grad: Tensor, row_width: int, idx: Tensor, val: Tensor, count: Tensor) -> None:
     """Move the non-zero rows of grad [rows*row_width] into (idx, val), zero them in grad; count += rows found."""
     g = _f32(grad, "grad")
+    if g.data_ptr() != grad.data_ptr():
+        raise RuntimeError("grad_compact works in place: grad must be a contiguous float32 tensor")
     check(_lib.lib().nr_grad_compact(_p(g), g.numel() // row_width, row_width, idx.numel(), _p(idx), _p(val), _p(count),
                                      _stream()), "nr_grad_compact")
 
 
 def grad_apply(idx: Tensor, val: Tensor, count: Tensor, row_width: int, grad: Tensor) -> None:
     """grad[idx[i]] += val[i] for i < min(count, len(idx))."""
-    check(_lib.lib().nr_grad_apply(_p(idx), _p(val), _p(count), idx.numel(), row_width, _p(_f32(grad, "grad")), _stream()),
-          "nr_grad_apply")
+    g = _f32(grad, "grad")
+    if g.data_ptr() != grad.data_ptr():
+        raise RuntimeError("grad_apply works in place: grad must be a contiguous float32 tensor")
+    if idx.numel() == 0:
+        return
+    check(_lib.lib().nr_grad_apply(_p(idx), _p(val), _p(count), idx.numel(), row_width, _p(g), _stream()), "nr_grad_apply")
 
 
 def uniform_fill(out: Tensor, seed: int, epoch: Optional[Tensor] = None) -> Tensor:

@@ -47,20 +47,20 @@ class GradAllReducer:
     """Mean all-reduce of `.grad` over the world: big tensors in place, small ones via one flat bucket."""
 
     def __init__(self, params: Optional[Iterable[nn.Parameter]], group=None, table_dtype: Optional[torch.dtype] = None,
-                 buffers: Optional[List[torch.Tensor]] = None, sparse_tables: bool = True):
+                 buffers: Optional[List[torch.Tensor]] = None, sparse_tables: bool = True, separate_sparse_group: bool = False):
         """`params`: parameters whose .grad is reduced; or `buffers`: ready-made flat gradient buffers
         (FlatAdam.grad_buffers(): one per hash table + one holding every small parameter).
         sparse_tables: the fused step exchanges the main table's gradient as (row, value) lists
-        (reduce_sparse) instead of all-reducing the dense table."""
+        (reduce_sparse) instead of all-reducing the dense table.
+        separate_sparse_group: give the list exchange a communicator of its own.  Off by default: two communicators
+        with collectives in flight at the same time on different streams is the documented NCCL/RCCL deadlock hazard
+        (each rank may launch them in a different order); with ONE communicator the collectives execute in issue
+        order, and the fused step issues the main table's exchange first."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sparse_tables = sparse_tables
         self.last_sparse: dict = {}
-        # the list exchange gets a communicator of its own: collectives of ONE communicator execute in issue
-        # order, and the main table's lists must not queue behind the proposal table's dense all-reduce
-        # (which waits for the proposal chains on another stream)
-        self.sparse_group = dist.new_group() if (self.world > 1 and sparse_tables) else group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.sparse_group = dist.new_group() if (self.world > 1 and sparse_tables and separate_sparse_group) else group
         self.table_dtype = table_dtype
         self._flat: Optional[torch.Tensor] = None
         if buffers is not None:
@@ -122,8 +122,11 @@ class GradAllReducer:
         compact(grad, row_width, idx, val, count)
         counts = [st["counts"][r:r + 1] for r in range(self.world)]
         dist.all_gather(counts, count, group=self.sparse_group)
-        n_rows = st["counts"].cpu()
+        n_rows = st["counts"].cpu()  # the step's one host read: sizes the list exchange (all ranks read the same numbers)
         max_rows = int(n_rows.max())
+        if max_rows == 0:  # nobody touched the table: nothing to exchange, nothing to apply
+            self.last_sparse = {"mode": "sparse", "rows": n_rows.tolist(), "bytes": 0}
+            return self.last_sparse
         if max_rows > cap:  # a rank's list does not fit: put the local rows back, reduce densely
             apply(idx, val, count, row_width, grad)
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.sparse_group)
@@ -151,8 +154,10 @@ class GradAllReducer:
             return
         works = []
         for p in self.big:
+            if p.grad is None:  # e.g. proposal_fields[0].hash_table (never evaluated): every rank must still issue the
+                p.grad = torch.zeros_like(p)  # matching collective -- all-reduced as zeros
             g = p.grad
-            if self.table_dtype is not None:
+            if self.table_dtype is not None and g.numel() > SMALL_PARAM_NUMEL:
                 low = g.to(self.table_dtype)
                 dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group)
                 g.copy_(low).div_(self.world)

@@ -278,6 +278,33 @@ class FlatAdam:
         ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
                       zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i])
 
+    def state_dict(self) -> Dict[str, object]:
+        """Moments, the device-side step counter / schedule triple and the `seen` flags (what the reference's
+        trainer checkpoints as optimizer + scheduler state, engine/trainer.py:514-548)."""
+        return {"exp_avg": [m.clone() for m, _ in self.state], "exp_avg_sq": [v.clone() for _, v in self.state],
+                "step_t": self.step_t.clone(), "hyper": self.hyper.clone()}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        for (m, v), m_, v_ in zip(self.state, sd["exp_avg"], sd["exp_avg_sq"]):
+            m.copy_(m_)
+            v.copy_(v_)
+        self.step_t.copy_(sd["step_t"])
+        self.hyper.copy_(sd["hyper"])
+        for s, (m, v) in zip(self.seen, self.state):  # "has had a gradient" = any moment non-zero, per group of four
+            if s is not None:
+                nz = ((m != 0) | (v != 0)).view(-1)[: s.numel() * 4].view(-1, 4).any(dim=1)
+                s.copy_(nz.to(torch.uint8))
+
+    def check_views(self) -> None:
+        """The flat buffers are only the parameters' storage while nobody re-homes them (zero_grad(set_to_none=True),
+        module.to(), load_state_dict(assign=True) do): raise instead of silently stepping detached buffers."""
+        for p in self.params:
+            i = self.buffer_of(p)
+            g = self.buffers[i][1]
+            if p.grad is None or not (g.data_ptr() <= p.grad.data_ptr() < g.data_ptr() + g.numel() * 4):
+                raise RuntimeError("FlatAdam: a parameter's .grad no longer lives in the optimizer's flat buffer "
+                                   "(re-homed by zero_grad(set_to_none=True) / .to() / assign=True?)")
+
     def buffer_of(self, param: nn.Parameter) -> int:
         """Index of the buffer that holds `param` (its own for tables, the flat one for small parameters)."""
         ptr = param.data_ptr()

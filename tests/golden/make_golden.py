@@ -205,6 +205,40 @@ def golden_field():
         save(f"field_{tag}", **arrays)
 
 
+def golden_field_autocast():
+    """N2: the reference's own NeuRADField under torch.autocast (engine/trainer.py:564 wraps the whole forward in it) on
+    the inputs and parameters of field_{neurad,l16f2w64}.npz -- only the outputs and gradients are stored here, the
+    inputs live in those files.  CPU autocast runs every nn.Linear with 16-bit inputs, weights AND outputs."""
+    arrays = {}
+    for tag, kw in {"neurad": {}, "l16f2w64": dict(
+            static=StaticSettings(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024, log2_hashmap_size=12),
+            hidden=64)}.items():
+        fld, _ = _make_fields(**kw)
+        g = torch.Generator().manual_seed(31)
+        B, S = 40, 12
+        o, d, area, times = synth_rays(B, g)
+        edges = torch.sort(torch.rand(B, S + 1, generator=g) ** 2 * 300.0, dim=-1).values + 0.05
+        bundle = RayBundle(origins=o, directions=d, pixel_area=area, nears=torch.zeros(B, 1),
+                           fars=torch.full((B, 1), 1e6), times=times, metadata={})
+        rs = bundle.get_ray_samples(bin_starts=edges[:, :-1, None], bin_ends=edges[:, 1:, None])
+        g_feat, g_alpha = torch.randn(B, S, 32, generator=g), torch.randn(B, S, 1, generator=g)  # same draws as golden_field
+        for dtype in (torch.bfloat16, torch.float16):
+            with torch.autocast("cpu", dtype=dtype):
+                out = fld(rs)
+            feat, sdf, alpha = (out[k].float() for k in (FieldHeadNames.FEATURE, FieldHeadNames.SDF, FieldHeadNames.ALPHA))
+            names = [n for n, _ in fld.named_parameters()]
+            grads = torch.autograd.grad((feat * g_feat).sum() + (alpha * g_alpha).sum(), list(fld.parameters()), allow_unused=True)
+            gmap = dict(zip(names, grads))
+            pre = f"{tag}_{str(dtype).split('.')[-1]}_"
+            arrays.update({pre + "feature": feat, pre + "sdf": sdf, pre + "alpha": alpha,
+                           pre + "grad_table": gmap["hashgrid.static_grid.hash_table"]})
+            for i in range(2):
+                arrays[pre + f"grad_geo_w{i}"] = gmap[f"mlp_geo.layers.{i}.weight"]
+            for i in range(3):
+                arrays[pre + f"grad_feat_w{i}"] = gmap[f"mlp_feature.layers.{i}.weight"]
+    save("field_autocast", **arrays)
+
+
 def golden_sh_mlp():
     """SHEncoding torch path (a15) and a bare MLP."""
     g = torch.Generator().manual_seed(41)
@@ -551,6 +585,6 @@ def golden_actors():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors"]
+    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors"]
     for w in which:
         globals()["golden_" + w]()

@@ -47,3 +47,16 @@ def assert_close(actual, expected, rtol=1e-4, atol_scale=1e-5, what=""):
     expected = expected.to(actual.dtype)
     scale = float(expected.abs().max()) if expected.numel() else 1.0
     torch.testing.assert_close(actual, expected, rtol=rtol, atol=atol_scale * max(scale, 1e-30), msg=lambda m: f"{what}: {m}")
+
+
+def assert_close_but_few(actual, expected, rtol, atol_scale, max_outlier_frac, what=""):
+    """assert_close for results that contain DISCRETE decisions (ReLU masks, round-to-nearest ties) which a change in
+    accumulation order may flip for isolated elements: every element within tolerance except at most
+    `max_outlier_frac` of them, and those few must still be finite."""
+    expected = expected.to(actual.dtype).reshape(actual.shape)
+    scale = float(expected.abs().max()) if expected.numel() else 1.0
+    bad = (actual - expected).abs() > (atol_scale * max(scale, 1e-30) + rtol * expected.abs())
+    frac = float(bad.float().mean()) if bad.numel() else 0.0
+    assert bool(torch.isfinite(actual).all()), f"{what}: non-finite values"
+    assert frac <= max_outlier_frac, (f"{what}: {int(bad.sum())} of {bad.numel()} elements ({frac:.2e}) outside rtol={rtol:.1e} / "
+                                      f"atol={atol_scale:.1e}*scale; worst |d| = {float((actual - expected).abs().max()):.3e}")

@@ -38,7 +38,7 @@ def _worker(rank, world, port, bf16):
     assert all(torch.equal(g, gathered[0]) for g in gathered), "broadcast did not synchronise the replicas"
 
     table.grad = torch.full_like(table, float(rank + 1))
-    unused.grad = torch.zeros_like(unused)
+    unused.grad = None  # never evaluated -> no gradient at all; the reducer must still issue the collective (as zeros)
     small[0].grad = torch.full_like(small[0], 10.0 * (rank + 1))
     small[1].grad = None  # e.g. a bias that did not take part
     red = GradAllReducer(list(mod), table_dtype=torch.bfloat16 if bf16 else None)

@@ -1,0 +1,177 @@
+"""GPU parity of the reduced-precision (bf16 / fp16 MFMA) NeuRADField MLP stack, through the C ABI.
+
+Three bars, tolerances stated and justified where they are used:
+  1. against oracle/field_lp.py, which restates the SAME rounding points in torch on the CPU: only the fp32
+     accumulation order (and a rare flipped round-to-nearest tie that it causes) may differ;
+  2. against goldens generated from the reference itself under torch.autocast (tests/golden/make_golden.py,
+     field_autocast.npz): a different choice of rounding points of the same precision class;
+  3. against the fp32 path: the price of 16-bit operands, as a relative L2 error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_but_few, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPS = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}  # unit roundoff of the operand type
+
+
+def _params(hidden, gen, scale=1.0):
+    def lin(o, i):
+        k = 1 / np.sqrt(i)
+        return ((torch.rand(o, i, generator=gen) * 2 - 1) * k * scale, (torch.rand(o, generator=gen) * 2 - 1) * k)
+
+    return [lin(hidden, 32), lin(33, hidden)], [lin(hidden, 48), lin(hidden, hidden), lin(32, hidden)]
+
+
+def _run_hip(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, grad_scale, layout):
+    """ops.field_mlp on per-sample directions (n_samples = 0); layout 'rows' = [n, 32], 'levels' = level-major [L, n, F]."""
+    from neuradar_amd import ops
+
+    n = feats.shape[0]
+    F = 4
+    L = 32 // F
+    if layout == "levels":
+        buf = feats.view(n, L, F).permute(1, 0, 2).contiguous().to(DEV).requires_grad_(True)
+        strides = (F, n * F)
+    else:
+        buf = feats.clone().to(DEV).requires_grad_(True)
+        strides = (32, F)
+    gp = [[w.to(DEV).requires_grad_(True) for w, _ in geo], [b.to(DEV).requires_grad_(True) for _, b in geo]]
+    fp = [[w.to(DEV).requires_grad_(True) for w, _ in feat], [b.to(DEV).requires_grad_(True) for _, b in feat]]
+    bt = beta.clone().to(DEV).requires_grad_(True)
+    feature, sdf, alpha = ops.field_mlp(buf, strides, F, dirs.to(DEV), 0, n, gp, fp, bt, dtype=dtype, grad_scale=grad_scale)
+    out = {"feature": feature.detach().cpu(), "sdf": sdf.detach().cpu(), "alpha": alpha.detach().cpu()}
+    loss = (feature * g_feature.to(DEV)).sum() + (alpha * g_alpha.to(DEV)).sum()
+    grads = torch.autograd.grad(loss, [buf, *gp[0], *gp[1], *fp[0], *fp[1], bt])
+    gf = grads[0].detach().cpu()
+    out["g_feats"] = gf.permute(1, 0, 2).reshape(n, 32) if layout == "levels" else gf
+    names = ["g_geo_w0", "g_geo_w1", "g_geo_b0", "g_geo_b1", "g_feat_w0", "g_feat_w1", "g_feat_w2", "g_feat_b0", "g_feat_b1",
+             "g_feat_b2", "g_beta"]
+    for k, g in zip(names, grads[1:]):
+        out[k] = g.detach().cpu()
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("hidden", [32, 64])
+@pytest.mark.parametrize("n,layout", [(1000, "rows"), (4096 + 17, "levels")])
+def test_field_lp_matches_rounding_oracle(dtype, hidden, n, layout):
+    """Bar 1.  Same operands, same rounding points; what may differ is the order of the fp32 accumulation
+    (relative 1e-6) and, through it, a round-to-nearest tie of some 16-bit activation (one unit roundoff u of ONE of a
+    unit's <= 64 inputs) or the ReLU mask of a unit whose pre-activation is ~0.  Tolerance: 2u relative with an absolute
+    floor of u/4 of the tensor's scale, on all but 1e-4 of the elements (the flips; measured: 1 element of 131 616) -- a
+    wrong fragment layout, a transposed weight or a dropped k-step shows up as O(1) errors everywhere."""
+    from oracle import field_lp
+
+    gen = torch.Generator().manual_seed(1234 + hidden + n)
+    geo, feat = _params(hidden, gen)
+    feats = torch.randn(n, 32, generator=gen) * 0.5
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    beta = torch.tensor([3.0])
+    g_feature, g_alpha = torch.randn(n, 32, generator=gen), torch.randn(n, generator=gen)
+    gs = 64.0 if dtype == "float16" else 1.0
+    want = field_lp.field_mlp_lp(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, gs)
+    got = _run_hip(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, gs, layout)
+    u = EPS[dtype]
+    for k in want:
+        assert_close_but_few(got[k], want[k], rtol=2 * u, atol_scale=u / 4, max_outlier_frac=1e-4, what=f"{dtype} h{hidden} {k}")
+
+
+def _bounds(dtype):
+    """Bars 2 and 3 compare DIFFERENT rounding schemes.  Forward values then differ by a few unit roundoffs u (five
+    chained layers: <= 5u of the tensor's scale).  Gradients differ by more, for a reason that has nothing to do with
+    the kernels: a hidden unit whose pre-activation is within ~u of zero gets its ReLU mask flipped, which changes that
+    (sample, unit) term by O(1); a fraction ~u of the terms flips, and with the incoherent (random) upstream gradients
+    of these tests a sum of N terms of which uN are replaced moves by sqrt(u) of its norm -- 6 % in bf16, 2 % in fp16.
+    The reference's own autocast gradients sit exactly there against its fp32 gradients (field_autocast.npz vs
+    field_*.npz: 2-5 % bf16, 0.3-2.8 % fp16).  Bounds: 5u forward, 2*sqrt(u) gradients."""
+    u = EPS[dtype]
+    return 5 * u, 2 * u ** 0.5
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("hidden", [32, 64])
+def test_field_lp_vs_fp32_path(dtype, hidden):
+    """Bar 3: the price of 16-bit operands against the fp32 MFMA path, as relative L2 errors (bounds: _bounds)."""
+    gen = torch.Generator().manual_seed(99 + hidden)
+    n = 8192
+    geo, feat = _params(hidden, gen)
+    feats = torch.randn(n, 32, generator=gen) * 0.5
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    beta = torch.tensor([3.0])
+    g_feature, g_alpha = torch.randn(n, 32, generator=gen), torch.randn(n, generator=gen)
+    ref = _run_hip(feats, dirs, geo, feat, beta, "float32", g_feature, g_alpha, 1.0, "levels")
+    got = _run_hip(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, 256.0 if dtype == "float16" else 1.0, "levels")
+    fwd_bound, grad_bound = _bounds(dtype)
+    for k in ref:
+        err = float((got[k] - ref[k]).norm() / ref[k].norm().clamp_min(1e-30))
+        bound = fwd_bound if k in ("feature", "sdf", "alpha") else grad_bound
+        assert err < bound, f"{dtype} h{hidden} {k}: relative L2 error {err:.3e} >= {bound:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_field_lp_grad_scale_is_transparent(dtype):
+    """The static loss scale only moves gradients inside the 16-bit domain: powers of two change nothing in bf16
+    (same exponent range as fp32 -> bit-identical results); in fp16 a scale rescues gradients that would flush."""
+    gen = torch.Generator().manual_seed(5)
+    n, hidden = 2048, 64
+    geo, feat = _params(hidden, gen)
+    feats = torch.randn(n, 32, generator=gen) * 0.5
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    beta = torch.tensor([3.0])
+    g_feature, g_alpha = 1e-6 * torch.randn(n, 32, generator=gen), 1e-6 * torch.randn(n, generator=gen)
+    a = _run_hip(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, 1.0, "rows")
+    b = _run_hip(feats, dirs, geo, feat, beta, dtype, g_feature, g_alpha, 4096.0, "rows")
+    ref = _run_hip(feats, dirs, geo, feat, beta, "float32", g_feature, g_alpha, 1.0, "rows")
+    for k in ("g_feat_w1", "g_geo_w0", "g_feats"):
+        ea = float((a[k] - ref[k]).norm() / ref[k].norm())
+        eb = float((b[k] - ref[k]).norm() / ref[k].norm())
+        if dtype == "bfloat16":
+            assert torch.equal(a[k], b[k]), f"bf16 {k}: a power-of-two scale changed the result"
+        else:
+            assert eb < 3e-3, f"fp16 {k}: scaled gradients off by {eb:.3e}"
+            assert ea > 10 * eb, f"fp16 {k}: unscaled 1e-6 gradients should underflow (err {ea:.3e} vs {eb:.3e})"
+
+
+@pytest.mark.parametrize("tag,hidden", [("field_neurad", 32), ("field_l16f2w64", 64)])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_field_lp_vs_reference_autocast_golden(tag, hidden, dtype):
+    """Bar 2.  The reference's own field under torch.autocast(dtype) on the golden inputs (hash grid fp32, Linear
+    layers 16-bit with 16-bit OUTPUTS, sigmoid in 16 bit).  It rounds in more places than the HIP kernels do (layer
+    outputs, sdf, alpha), so forward values agree to a few unit roundoffs of the tensor's scale: 4u relative, floor
+    4u*scale.  Parameter gradients: relative L2 error < 2*sqrt(u) (ReLU-mask flips, see _bounds), AND the HIP path must
+    not sit further from the reference's fp32 gradients than 3x what the reference's own autocast gradients do."""
+    from neuradar_amd.field_heads import FieldHeadNames
+    from neuradar_amd.neurad_encoding import StaticSettings
+    from test_gpu_parity import make_field, samples_from_edges
+
+    g = load_golden(tag)
+    ga = load_golden("field_autocast")
+    pre = f"{tag[len('field_'):]}_{dtype}_"
+    static = None
+    if hidden == 64:
+        static = StaticSettings(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024, log2_hashmap_size=int(g["log2t"]))
+    fld = make_field(g, hidden=hidden, static=static)
+    fld.config.mlp_dtype = dtype
+    fld.config.mlp_grad_scale = 1024.0 if dtype == "float16" else 1.0
+    out = fld(samples_from_edges(g, g["edges"]))
+    u = EPS[dtype]
+    for head, key in ((FieldHeadNames.FEATURE, "feature"), (FieldHeadNames.SDF, "sdf"), (FieldHeadNames.ALPHA, "alpha")):
+        assert_close(out[head].detach().cpu(), ga[pre + key], rtol=4 * u, atol_scale=4 * u, what=f"{tag} {dtype} {key}")
+    loss = (out[FieldHeadNames.FEATURE] * g["g_feature"].to(DEV)).sum() + (out[FieldHeadNames.ALPHA] * g["g_alpha"].to(DEV)).sum()
+    named = dict(fld.named_parameters())
+    keys = ["hashgrid.static_grid.hash_table"] + [f"mlp_geo.layers.{i}.weight" for i in range(2)] + \
+           [f"mlp_feature.layers.{i}.weight" for i in range(3)]
+    gold = ["grad_table"] + [f"grad_geo_w{i}" for i in range(2)] + [f"grad_feat_w{i}" for i in range(3)]
+    grads = torch.autograd.grad(loss, [named[k] for k in keys])
+    _, grad_bound = _bounds(dtype)
+    for k, gk, gr in zip(keys, gold, grads):
+        want, fp32 = ga[pre + gk], g[gk]
+        got = gr.detach().cpu()
+        err = float((got - want).norm() / want.norm())
+        assert err < grad_bound, f"{tag} {dtype} grad {k}: relative L2 error {err:.3e} vs the autocast reference"
+        ours, theirs = float((got - fp32).norm() / fp32.norm()), float((want - fp32).norm() / fp32.norm())
+        assert ours < 3 * theirs + u, f"{tag} {dtype} grad {k}: {ours:.3e} from fp32, the reference's autocast {theirs:.3e}"
