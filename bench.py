@@ -104,15 +104,13 @@ class SyntheticScene:
         pts = torch.stack([rng * torch.cos(el) * torch.cos(az), rng * torch.cos(el) * torch.sin(az), rng * torch.sin(el),
                            torch.rand(n_pts, generator=g), 0.1 * torch.rand(n_pts, generator=g)], dim=1)
         owner = torch.randint(0, n, (n_pts,), generator=g)
-        if os.environ.get("NR_LIDAR_SORTED", "1") == "1":
-            # stored the way a sweep is recorded: by scan, then by direction (azimuth sector, beam).  A batch's random
-            # picks, sorted by index, are then neighbours in space -- rays of one batch may come in any order
-            key = (owner.long() * 4096 + (az / (2 * math.pi) * 64).long().clamp_(0, 63) * 64
-                   + ((el - el.min()) / (el.max() - el.min() + 1e-9) * 63).long())
-            order = torch.argsort(key)
-            pts, owner = pts[order], owner[order]
+        # stored the way sweeps are recorded: scan after scan (points_per_lidar), inside a scan by direction
+        key = (owner.long() * 4096 + (az / (2 * math.pi) * 64).long().clamp_(0, 63) * 64
+               + ((el - el.min()) / (el.max() - el.min() + 1e-9) * 63).long())
+        order = torch.argsort(key)
+        pts, owner = pts[order], owner[order]
         self.lidar_points = pts.to(device)
-        self.lidar_owner = owner.to(device)
+        self.points_per_lidar = torch.bincount(owner, minlength=n)
         r2w = l2w.clone()
         r2w[:, 2, 3] = 0.5
         self.radars = Radars(r2w.to(device), t.to(device), radar_azimuth_ray_divergence=0.015,  # zod_dataparser.py:138-140
@@ -147,7 +145,6 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         # a radar scan is a regular azimuth x elevation grid from one origin: coherent like a camera patch at the coarse
         # levels, so its rays join the sample-major block (batch order camera, radar, lidar): 3.42 -> 3.19 ms per step
         radar_coherent = mixed is not None and os.environ.get("NR_RADAR_COHERENT", "1") == "1"
-        lidar_sorted = os.environ.get("NR_LIDAR_SORTED", "1") == "1"
         n_coh = None
         if mixed is not None:
             n_coh = mixed["cam_rays"] + (n_rays - mixed["cam_rays"] - mixed["lidar_rays"] if radar_coherent else 0)
@@ -160,61 +157,41 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         n_cam = mixed["cam_rays"] if mixed is not None else n_rays
         n_lidar, n_scans = (mixed["lidar_rays"], mixed["radar_scans"]) if mixed is not None else (0, 0)
         n_p = n_cam // (scene.PATCH * scene.PATCH)
-        n_t, n_u = n_rays * (S0 + 1), 3 * n_p
-        if mixed is not None:
-            n_az, n_el = scene.radars.grid_shape()
-            assert n_cam + n_lidar + n_scans * n_az * n_el == n_rays, "mixed workload: ray counts must add up"
+        n_t = n_rays * (S0 + 1)
+        # batch assembly on the device (neuradar_amd/batch_assembly.py: the reference's samplers + merge as four launches
+        # that write straight into the merged buffers); segment order camera, radar, lidar = coherent rays first
+        from neuradar_amd.batch_assembly import SensorBatchAssembler
+
+        asm = SensorBatchAssembler(scene.cameras, scene.H, scene.W, scene.PATCH, scene.STRIDE, n_p,
+                                   lidars=scene.lidars if n_lidar else None, lidar_points=scene.lidar_points,
+                                   points_per_lidar=scene.points_per_lidar, n_lidar_rays=n_lidar,
+                                   radars=scene.radars if n_scans else None, n_radar_scans=n_scans,
+                                   order=("camera", "radar", "lidar") if radar_coherent or mixed is None else ("camera", "lidar", "radar"))
+        assert asm.n == n_rays, "workload: ray counts must add up"
+        n_u = asm.uniform_count()
 
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
-        # per-ray jitter for the two rounds (:326) and the patch positions of the on-device batch assembly.
+        # per-ray jitter for the two rounds (:326) and the random numbers of the batch assembly.
         # The buffer is refilled for the NEXT step on a side stream as soon as the sampling rounds have read it.
         from neuradar_amd import ops as hip_ops
 
-        r = torch.rand(n_t + 2 * n_rays + n_u + n_lidar + n_scans, device=dev)
+        r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
         seed = 0x5EED0000 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)  # seed + rank
         epoch = opts[0].step_t  # device-resident step counter (advanced by the optimizer's schedule kernel)
 
         # Batches are software-pipelined across steps: as soon as step k's sampling rounds have read the uniform
-        # buffer it is refilled, and the batch assembly (patch rays; for mixed batches also lidar picks, radar scans and
-        # the merge -- some fifty tiny launches) + first launch (bins, contraction) of step k+1 run on the same side
-        # stream into the other buffer set, beside step k's field / backward.  Same numbers in the same order as the
-        # unpipelined step (NR_PIPELINE=0), which does all that at the top of step k+1.
+        # buffer it is refilled, and the batch assembly + first launch (bins, contraction) of step k+1 run on the same
+        # side stream into the other buffer set, beside step k's field / backward.  Same numbers in the same order as
+        # the unpipelined step (NR_PIPELINE=0), which does all that at the top of step k+1.
         pipelined = os.environ.get("NR_PIPELINE", "1") != "0"
         state = {"k": 0}
-        f32 = dict(device=dev, dtype=torch.float32)
-        # per buffer set: the merged batch the step reads (camera-only: the generator writes it directly)
-        batch = [None, None] if mixed is None else [
-            dict(o=torch.empty(n_rays, 3, **f32), d=torch.empty(n_rays, 3, **f32), area=torch.empty(n_rays, **f32),
-                 fars=torch.empty(n_rays, **f32)) for _ in range(2)]
-        cam_out = [None, None]
         ready = [False, False]
 
         def assemble(slot):
             """This step's rays into buffer set `slot` (on the current stream); returns (origins, directions, area, fars)."""
-            u = r[n_t + 2 * n_rays:]
-            cam_out[slot], _ = scene.cameras.generate_patch_rays(u[:n_u].view(n_p, 3), scene.PATCH, scene.STRIDE, scene.H, scene.W,
-                                                                 area_scale=9.0, out=cam_out[slot])  # _scale_pixel_area
-            cam = cam_out[slot]
-            if mixed is None:
-                # fars=None: camera rays all carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
-                return cam.origins, cam.directions, cam.pixel_area[:, 0], None
-            # camera patches + lidar points + one radar scan, merged like _merge_img_lidar_radar
-            # (image_lidar_radar_datamanager.py:335-409); sensor indices come from the same uniform buffer
-            pick = (u[n_u:n_u + n_lidar] * scene.lidar_points.shape[0]).long().clamp_(max=scene.lidar_points.shape[0] - 1)
-            if lidar_sorted:
-                pick = torch.sort(pick).values
-            lid = scene.lidars.generate_rays(scene.lidar_owner[pick], scene.lidar_points[pick])
-            scans = (u[n_u + n_lidar:n_u + n_lidar + n_scans] * scene.n_cams).long().clamp_(max=scene.n_cams - 1)
-            rad = scene.radars.generate_rays(scans)
-            mb, off = batch[slot], 0
-            for part in ((cam, rad, lid) if radar_coherent else (cam, lid, rad)):
-                m_ = part.origins.shape[0]
-                mb["o"][off:off + m_].copy_(part.origins)
-                mb["d"][off:off + m_].copy_(part.directions)
-                mb["area"][off:off + m_].copy_(part.pixel_area[:, 0])
-                mb["fars"][off:off + m_].copy_(part.fars[:, 0])
-                off += m_
-            return mb["o"], mb["d"], mb["area"], mb["fars"]
+            s_ = asm.assemble(r[n_t + 2 * n_rays:], slot)
+            # fars=None: every sensor's rays carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
+            return s_["origins"], s_["directions"], s_["pixel_area"], None
 
         rays = [None, None]
 

@@ -70,6 +70,20 @@ int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings,
                        const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                        float* grad_table, int64_t n, int sample_major, nr_stream_t stream);
 
+/* The same scatter-add for INCOHERENT rows (lidar rays: neighbouring rows share no fine-level cell, the on-chip
+ * merging of nr_hash_encode_bwd finds nothing and the launch runs at the memory side's rate for single-entry float
+ * atomics).  Two passes: contributions are binned by 128-KB table slice into queues in `workspace`, then one workgroup
+ * per slice accumulates its queue in LDS and adds the slice to grad_table with contiguous atomics.  Rows are walked as
+ * stored; results equal nr_hash_encode_bwd's up to summation order.  Supported when a level's table is at most 32
+ * slices (T * F <= 2^20 floats: the NeuRadar proposal grids, the L16/F2/T=2^19 main grid);
+ * nr_hash_encode_bwd_binned_workspace_bytes returns -1 otherwise (use nr_hash_encode_bwd).  workspace: that many bytes,
+ * 16-byte aligned, caller-owned; no initialisation needed. */
+int64_t nr_hash_encode_bwd_binned_workspace_bytes(int num_levels, int features_per_level, int log2_hashmap_size, int64_t n);
+int nr_hash_encode_bwd_binned(const float* x, const float* std, const float* scalings,
+                              int num_levels, int features_per_level, int log2_hashmap_size,
+                              const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
+                              float* grad_table, int64_t n, void* workspace, nr_stream_t stream);
+
 /* grad_x [n,3] = d(sum out*grad_out)/dx (overwritten).  Only needed where positions depend on
  * parameters: samples inside dynamic-actor boxes, whose box-frame coordinates follow the learnable
  * trajectories (require_actor_grad, field_components/neurad_encoding.py:83,176). */
@@ -307,6 +321,27 @@ int nr_gen_rays_lidar(const int64_t* lidar_indices, const float* points, int poi
                       const float* scan_times, const float* velocities, int64_t n,
                       float* origins, float* directions, float* pixel_area, float* times,
                       float* directions_norm, uint8_t* did_return, nr_stream_t stream);
+/* LidarPointSampler.collate_image_dataset_batch (data/pixel_samplers.py:538-577) followed by nr_gen_rays_lidar, one
+ * launch (the reference samples on CPU workers and generates rays there).  Ray i belongs to
+ * lidar lidar_order[i / rays_per_lidar] (the reference's randperm shuffle, supplied by the caller; rays_per_lidar =
+ * ceil(num_rays / num_lidars)) and looks at point floor(u[i] * points_per_lidar[lidar]) of that lidar's scan (u in
+ * [0,1); the product is formed in double like the reference's float64 draw).  points [sum points_per_lidar, point_dim]
+ * holds the scans back to back, cum_points[l] = first row of lidar l.  indices [n,2] int64 (nullable) receives
+ * (lidar, point).  Outputs as nr_gen_rays_lidar. */
+int nr_gen_rays_lidar_sampled(const float* u, int64_t n, int rays_per_lidar, const int64_t* lidar_order,
+                              const int64_t* points_per_lidar, const int64_t* cum_points, const float* points, int point_dim,
+                              const float* l2w, const float* scan_times, const float* velocities, float* origins,
+                              float* directions, float* pixel_area, float* times, float* directions_norm,
+                              uint8_t* did_return, int64_t* indices, nr_stream_t stream);
+/* order [n] int64 <- the permutation that sorts u [n] (ties by index): a uniformly random permutation of n sensors
+ * from n uniform numbers, standing in for torch.randperm in LidarPointSampler (data/pixel_samplers.py:550,560-563)
+ * without leaving the device or the captured graph.  n <= 65536 (one workgroup; n is a sensor count). */
+int nr_permutation_from_uniform(const float* u, int n, int64_t* order, nr_stream_t stream);
+/* RadarPointSampler's choice of scans (data/pixel_samplers.py:640-649): scan_indices [n_scans] = 0..num_radars-1 padded
+ * with 0 when num_radars <= n_scans, else floor(u[k] * (num_radars - 1)) -- like the reference's randint(0,
+ * num_radars - 1) the LAST scan is never drawn.  Feed the result to nr_gen_rays_radar. */
+int nr_sample_radar_scans(const float* u, int n_scans, int64_t num_radars, int64_t* scan_indices, nr_stream_t stream);
+
 /* Radars._generate_rays_from_fov (cameras/radars.py:268-358).  scan_indices [n_scans] int64;
  * the FOV grid is n_az x n_el (azimuth-major) with az_i = (float)(min_az + i*d_az) evaluated in
  * double like torch.arange.  r2w [n_radars,3,4]; scan_times [n_radars].

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "nr_target_arch": [],
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
+    "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
+    "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
     "nr_contract_gaussians": [P, P, P, P, L, I, F, I, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
@@ -71,6 +73,9 @@ PROTOTYPES = {
     "nr_depth_from_weights": [P, P, L, I, P, P],
     "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
     "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
+    "nr_gen_rays_lidar_sampled": [P, L, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P],
+    "nr_sample_radar_scans": [P, I, L, P, P],
+    "nr_permutation_from_uniform": [P, I, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
     "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P],
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
@@ -84,7 +89,7 @@ PROTOTYPES = {
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
-             "nr_field_stash_floats": c_int64}
+             "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -179,6 +179,72 @@ gen_rays_lidar_kernel(const int64_t* __restrict__ lidar_indices, const float* __
   did_return[i] = dist < kLidarValid ? 1 : 0;
 }
 
+// LidarPointSampler.collate_image_dataset_batch (data/pixel_samplers.py:538-577) + LidarRayGenerator in one launch:
+// ray i belongs to slot i / rays_per_lidar of the shuffled lidar order, its point is floor(u_i * n_points[lidar]).
+__global__ void __launch_bounds__(256)
+gen_rays_lidar_sampled_kernel(const float* __restrict__ u, int64_t n, int rays_per_lidar, const int64_t* __restrict__ order,
+                              const int64_t* __restrict__ points_per_lidar, const int64_t* __restrict__ cum_points,
+                              const float* __restrict__ points, int point_dim, const float* __restrict__ l2w,
+                              const float* __restrict__ scan_times, const float* __restrict__ velocities,
+                              float* __restrict__ origins, float* __restrict__ directions, float* __restrict__ pixel_area,
+                              float* __restrict__ times, float* __restrict__ directions_norm, uint8_t* __restrict__ did_return,
+                              int64_t* __restrict__ indices) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t li = order[i / rays_per_lidar];
+  const int64_t np = points_per_lidar[li];
+  int64_t pt = (int64_t)floor((double)u[i] * (double)np);  // the reference draws float64 rands (:553-554)
+  pt = pt < np - 1 ? pt : np - 1;
+  if (indices != nullptr) { indices[i * 2] = li; indices[i * 2 + 1] = pt; }
+  const float* pose = l2w + li * 12;
+  const float* p = points + (cum_points[li] + pt) * point_dim;
+  const float dt = p[4];
+  float v[3], o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float world = (p[0] * pose[r * 4 + 0] + p[1] * pose[r * 4 + 1] + p[2] * pose[r * 4 + 2]) + pose[r * 4 + 3];
+    o[r] = pose[r * 4 + 3];
+    if (velocities != nullptr) o[r] = o[r] + dt * velocities[li * 3 + r];  // lidars.py:378-380
+    v[r] = world - o[r];
+  }
+  const float dist = normalize3(v);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    origins[i * 3 + r] = o[r];
+    directions[i * 3 + r] = v[r];
+  }
+  pixel_area[i] = kLidarHDiv * kLidarVDiv;
+  times[i] = scan_times[li] + dt;
+  directions_norm[i] = dist;
+  did_return[i] = dist < kLidarValid ? 1 : 0;
+}
+
+// RadarPointSampler's scan choice (data/pixel_samplers.py:640-649): every radar once when there are at most n_scans of
+// them (padded with scan 0), else n_scans draws of randint(0, num_radars - 1) -- the last scan is never drawn.
+__global__ void sample_radar_scans_kernel(const float* __restrict__ u, int n_scans, int64_t num_radars, int64_t* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_scans) return;
+  if (num_radars <= n_scans) {
+    out[k] = k < num_radars ? k : 0;
+  } else {
+    const int64_t hi = num_radars - 1;
+    int64_t s = (int64_t)floor((double)u[k] * (double)hi);
+    out[k] = s < hi - 1 ? s : hi - 1;
+  }
+}
+
+// order <- the permutation that sorts u (ties by index): torch.randperm's role in LidarPointSampler
+// (data/pixel_samplers.py:550,560-563), by counting ranks -- n is a number of sensors (hundreds), O(n^2 / threads).
+__global__ void __launch_bounds__(256)
+permutation_kernel(const float* __restrict__ u, int n, int64_t* __restrict__ order) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float ui = u[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (u[j] < ui || (u[j] == ui && j < i)) ? 1 : 0;
+    order[rank] = i;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 gen_rays_radar_kernel(const int64_t* __restrict__ scan_indices, int64_t n_scans, const float* __restrict__ r2w,
                       const float* __restrict__ scan_times, float min_az, float d_az, int n_az, float min_el,
@@ -291,6 +357,39 @@ extern "C" int nr_gen_rays_lidar(const int64_t* lidar_indices, const float* poin
   hipLaunchKernelGGL(gen_rays_lidar_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), lidar_indices,
                      points, point_dim, l2w, scan_times, velocities, n, origins, directions, pixel_area, times,
                      directions_norm, did_return);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_gen_rays_lidar_sampled(const float* u, int64_t n, int rays_per_lidar, const int64_t* lidar_order,
+                                         const int64_t* points_per_lidar, const int64_t* cum_points, const float* points,
+                                         int point_dim, const float* l2w, const float* scan_times, const float* velocities,
+                                         float* origins, float* directions, float* pixel_area, float* times,
+                                         float* directions_norm, uint8_t* did_return, int64_t* indices, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!u || !lidar_order || !points_per_lidar || !cum_points || !points || point_dim < 5 || rays_per_lidar < 1 || !l2w ||
+      !scan_times || !origins || !directions || !pixel_area || !times || !directions_norm || !did_return || n < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(gen_rays_lidar_sampled_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), u, n,
+                     rays_per_lidar, lidar_order, points_per_lidar, cum_points, points, point_dim, l2w, scan_times, velocities,
+                     origins, directions, pixel_area, times, directions_norm, did_return, indices);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_permutation_from_uniform(const float* u, int n, int64_t* order, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!u || !order || n < 0 || n > 65536) return NR_EINVAL;
+  hipLaunchKernelGGL(permutation_kernel, dim3(1), dim3(256), 0, nr_s(stream), u, n, order);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_sample_radar_scans(const float* u, int n_scans, int64_t num_radars, int64_t* scan_indices, nr_stream_t stream) {
+  if (n_scans == 0) return 0;
+  if (!scan_indices || n_scans < 0 || num_radars < 1 || (num_radars > n_scans && (!u || num_radars < 2))) return NR_EINVAL;
+  hipLaunchKernelGGL(sample_radar_scans_kernel, dim3((unsigned)nr_cdiv(n_scans, 64)), dim3(64), 0, nr_s(stream), u, n_scans,
+                     num_radars, scan_indices);
   NR_LAUNCH_CHECK();
   return 0;
 }

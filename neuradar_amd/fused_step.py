@@ -99,6 +99,17 @@ class FusedTrainStep:
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
         self._structs()
+        # Incoherent rows (the lidar rays behind the first self.sm rays) go through the two-pass binned scatter where the
+        # table allows it (nr_hash_encode_bwd_binned: the proposal grids; a main grid of <= 32 slices per level): the
+        # merging kernel finds nothing to merge there and runs at the memory side's single-entry atomic rate.
+        self.binned_ws = [None, None, None]
+        if os.environ.get("NR_BINNED", "1") != "0" and self.sm < B:
+            for lvl, S in enumerate(self.S):
+                grid = self.pgrid if lvl < 2 else self.mgrid
+                need = self.lib.nr_hash_encode_bwd_binned_workspace_bytes(grid.num_levels, grid.features_per_level,
+                                                                          grid.log2_hashmap_size, (B - self.sm) * S)
+                if need > 0:
+                    self.binned_ws[lvl] = torch.empty(need, device=dev, dtype=torch.uint8)
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
 
     def _timed(self, name: str, launch):
@@ -292,12 +303,28 @@ class FusedTrainStep:
             check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                           p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 
-        def chain_scatter(lvl):
+        def scatter(lvl, grid, tag):
+            """grad_table += scatter of g_feats[lvl] on the current stream: the merging kernel on the coherent rows, the
+            binned one on the rows behind them (when a workspace was set up for this level)."""
             sp_ = ops._stream()
-            S, nl = self.S[lvl], B * self.S[lvl]
-            check(self._timed(f"hash_encode_bwd[prop_s{S}]", lambda: lib.nr_hash_encode_bwd(
-                p(self.x01[lvl]), p(self.std[lvl]), p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size,
-                p(self.g_feats[lvl]), Fp, nl * Fp, p(pg.hash_table.grad), nl, 0, sp_)), "hash_bwd")
+            S, nl, Fg = self.S[lvl], B * self.S[lvl], grid.features_per_level
+            n_coh = nl if self.binned_ws[lvl] is None else self.sm * S
+
+            def launch():
+                rc = lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                            grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
+                                            n_coh, 0, sp_) if n_coh > 0 else 0
+                if rc == 0 and n_coh < nl:
+                    rc = lib.nr_hash_encode_bwd_binned(p(self.x01[lvl][n_coh:]), p(self.std[lvl][n_coh:]), p(grid.scalings),
+                                                       grid.num_levels, Fg, grid.log2_hashmap_size,
+                                                       p(self.g_feats[lvl][:, n_coh:, :]), Fg, nl * Fg, p(grid.hash_table.grad),
+                                                       nl - n_coh, p(self.binned_ws[lvl]), sp_)
+                return rc
+
+            check(self._timed(f"hash_encode_bwd[{tag}_s{S}]", launch), "hash_bwd")
+
+        def chain_scatter(lvl):
+            scatter(lvl, pg, "prop")
 
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
         before = {0: (), 1: (0, 1), 2: (1,), 3: (), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
@@ -324,9 +351,7 @@ class FusedTrainStep:
                 if late:
                     chain_head(lvl)
                     chain_scatter(lvl)
-        check(self._timed(f"hash_encode_bwd[main_s{Sm}]", lambda: lib.nr_hash_encode_bwd(
-            p(self.x01[2]), p(self.std[2]), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size, p(self.g_feats[2]), F, n * F,
-            p(mg.hash_table.grad), n, 0, st)), "hash_bwd")
+        scatter(2, mg, "main")
         if optimizers is not None:
             table_opt, field_opt = optimizers
             scale = 1.0 if reducer is None else 1.0 / reducer.world

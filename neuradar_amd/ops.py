@@ -73,6 +73,23 @@ def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
     return _HashEncode.apply(x, std, table, scalings, log2_hashmap_size, level_major, sample_major)
 
 
+def hash_encode_bwd_binned(x: Tensor, std: Optional[Tensor], scalings: Tensor, log2_hashmap_size: int, grad_out: Tensor,
+                           strides: Tuple[int, int], features_per_level: int, grad_table: Tensor,
+                           workspace: Optional[Tensor] = None) -> Tensor:
+    """grad_table += scatter of grad_out (element (i,l,f) at i*strides[0] + l*strides[1] + f) through the two-pass binned
+    kernels (nr_hash_encode_bwd_binned: for incoherent rows).  Returns the workspace (reusable for the same sizes)."""
+    n, L = x.shape[0], scalings.numel()
+    need = _lib.lib().nr_hash_encode_bwd_binned_workspace_bytes(L, features_per_level, log2_hashmap_size, n)
+    if need < 0:
+        raise RuntimeError("nr_hash_encode_bwd_binned: a level of this table has more than 32 slices of 128 KB")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().nr_hash_encode_bwd_binned(_p(x), _p(std), _p(scalings), L, features_per_level, log2_hashmap_size,
+                                               _p(grad_out), strides[0], strides[1], _p(grad_table), n, _p(workspace),
+                                               _stream()), "nr_hash_encode_bwd_binned")
+    return workspace
+
+
 def _sm_rays(flag, n_rays: int) -> int:
     """Row-order argument of the ABI: number of leading rays stored sample-major (True = all)."""
     return n_rays if flag is True else int(flag)

@@ -1,0 +1,104 @@
+"""GPU parity of the two-pass binned scatter-add (nr_hash_encode_bwd_binned, for incoherent rows) against the oracle at
+small sizes and against the merging kernel (nr_hash_encode_bwd) at BASELINE sizes; bit-exact work: the set of rows
+written."""
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _binned(x, std, sc, log2t, gout_rows, F, rows):
+    """gout_rows [n, L*F] -> grad_table [rows, F] through the binned kernels."""
+    from neuradar_amd import ops
+
+    gt = torch.zeros(rows, F, device=DEV)
+    L = sc.numel()
+    ops.hash_encode_bwd_binned(x, std, sc, log2t, gout_rows.contiguous(), (L * F, F), F, gt)
+    return gt
+
+
+@pytest.mark.parametrize("F", [1, 2, 4])
+@pytest.mark.parametrize("case", ["uniform", "one_cell", "ragged_tiny_table"])
+def test_binned_scatter_vs_oracle(F, case):
+    """uniform: every bucket of every level in use; one_cell: all rows in ONE cell (bins and queue regions overflow ->
+    the direct-atomic fallback carries most of the sum); ragged_tiny_table: n not a multiple of 64 / 1024, table smaller
+    than one slice."""
+    from oracle import hashgrid
+
+    torch.manual_seed(10 * F + len(case))
+    L, log2t, n = (3, 17, 30_000) if case != "ragged_tiny_table" else (2, 9, 1025 + 37)
+    sc = hashgrid.level_scalings(L, 16, 2048)
+    x = torch.rand(n, 3)
+    if case == "one_cell":
+        x = (torch.tensor([0.3137, 0.7211, 0.5003]) + 1e-6 * torch.rand(n, 3)).clamp(0, 1)
+    x[:5] = torch.tensor([0.0, 0.25, 0.5])  # exact grid planes
+    std = 0.01 * torch.rand(n)
+    gout = torch.randn(n, L * F)
+    gout[::7] = 0.0  # zero gradients are skipped, not binned
+    table = hashgrid.init_table(L, log2t, F, scale=1.0).requires_grad_(True)
+    resc = 1.0 / torch.clamp(2.0 * sc[None, :] * std[:, None], min=1.0)  # neurad_encoding.py:309-316
+    ref = hashgrid.encode(x, table, sc, 2**log2t).view(n, L, F) * resc[:, :, None]
+    (gref,) = torch.autograd.grad(ref, table, gout.view(n, L, F))
+    gt = _binned(x.to(DEV), std.to(DEV), sc.to(DEV), log2t, gout.to(DEV), F, table.shape[0])
+    assert_close(gt.cpu(), gref, rtol=1e-4, atol_scale=2e-6, what=f"binned F={F} {case}")
+    assert torch.equal(gt.cpu() != 0, gref != 0) or case == "one_cell", "rows written differ from the oracle's"
+
+
+@pytest.mark.parametrize("cfg", [("prop", 6, 1, 20, 128, 4096, 4661 * 128), ("l16f2", 16, 2, 19, 16, 1024, 4661 * 32)])
+def test_binned_scatter_equals_merging_kernel_at_baseline_sizes(cfg):
+    """At BASELINE table sizes and the lidar share of the configs[2] batch (4 661 rays), on incoherent rows: the two
+    scatter implementations agree (rtol 1e-4 of the gradient's scale) and write the same set of rows."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    tag, L, F, log2t, rmin, rmax, n = cfg
+    torch.manual_seed(L + F)
+    sc = hashgrid.level_scalings(L, rmin, rmax).to(DEV)
+    x = torch.rand(n, 3, device=DEV)
+    std = 0.002 * torch.rand(n, device=DEV)
+    gout = torch.randn(n, L * F, device=DEV)
+    rows = L << log2t
+    want = torch.zeros(rows, F, device=DEV)
+    lib, p, st = ops._lib.lib(), ops._p, ops._stream
+    ops.check(lib.nr_hash_encode_bwd(p(x), p(std), p(sc), L, F, log2t, p(gout), L * F, F, p(want), n, 0, st()), "bwd")
+    got = _binned(x, std, sc, log2t, gout, F, rows)
+    assert_close(got.cpu(), want.cpu(), rtol=1e-4, atol_scale=1e-5, what=tag)
+    assert torch.equal(got != 0, want != 0), f"{tag}: different rows written"
+
+
+def test_binned_scatter_rejects_tables_with_too_many_slices():
+    from neuradar_amd import _lib
+
+    assert _lib.lib().nr_hash_encode_bwd_binned_workspace_bytes(8, 4, 22, 1000) == -1  # NeuRadar main grid: 512 slices per level
+    assert _lib.lib().nr_hash_encode_bwd_binned_workspace_bytes(6, 1, 20, 1000) > 0
+
+
+@pytest.mark.parametrize("F", [1, 2])
+@pytest.mark.parametrize("run", [3, 17, 40, 64, 200])
+def test_scatters_sum_long_runs_of_one_cell(F, run):
+    """Rows come in runs of `run` consecutive rows inside one cell (samples of a ray in a coarse cell; camera pixels at a
+    coarse level): both scatter kernels sum such runs across the wave's lanes before anything leaves the wave -- runs
+    shorter than, equal to and longer than a row of 16 lanes, a half wave and a wave."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    torch.manual_seed(run + F)
+    L, log2t = 2, 14
+    n = run * 97 + 5
+    sc = hashgrid.level_scalings(L, 16, 64)
+    cells = torch.rand(n // run + 1, 3)
+    x = (cells.repeat_interleave(run, dim=0)[:n] + 1e-5 * torch.rand(n, 3)).clamp(0, 1)
+    gout = torch.randn(n, L * F)
+    table = hashgrid.init_table(L, log2t, F, scale=1.0).requires_grad_(True)
+    ref = hashgrid.encode(x, table, sc, 2**log2t)
+    (gref,) = torch.autograd.grad(ref, table, gout)
+    xd, scd, gd = x.to(DEV), sc.to(DEV), gout.to(DEV)
+    got_binned = _binned(xd, None, scd, log2t, gd, F, table.shape[0])
+    got_merge = torch.zeros_like(got_binned)
+    lib, p, st = ops._lib.lib(), ops._p, ops._stream
+    ops.check(lib.nr_hash_encode_bwd(p(xd), None, p(scd), L, F, log2t, p(gd), L * F, F, p(got_merge), n, 0, st()), "bwd")
+    assert_close(got_merge.cpu(), gref, rtol=1e-4, atol_scale=1e-5, what=f"merging kernel, runs of {run}")
+    assert_close(got_binned.cpu(), gref, rtol=1e-4, atol_scale=1e-5, what=f"binned kernel, runs of {run}")

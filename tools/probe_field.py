@@ -11,7 +11,7 @@ from neuradar_amd.fused_step import FusedTrainStep  # noqa: E402
 
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cam4096_l16f2_w64"]
 dev = torch.device("cuda")
-model = bench.build_model(wl, dev)
+model = bench.build_model(wl, dev, os.environ.get("PROBE_DTYPE", "float32"), float(os.environ.get("PROBE_GRAD_SCALE", "1")))
 B = wl["rays"]
 st = FusedTrainStep(model, B)
 n = B * 32
@@ -23,6 +23,7 @@ st.g_feature.normal_()
 st.g_alpha.normal_()
 from ctypes import byref  # noqa: E402
 lib, p, s = st.lib, ops._p, ops._stream
+lib.nr_field_pack(byref(st.field_struct), p(st.field_image), s())  # the weight image the kernels read
 only = os.environ.get("PROBE_N")  # PROBE_N=<samples>: just that size, 50 calls (for a rocprofv3 --kernel-trace run)
 if only:
     nn = int(only)
