@@ -1,0 +1,178 @@
+"""Per-ray decoders behind the rendered features: `decode_features` of the reference
+(models/neuradar.py:410-493) with the same parameter names, so a reference state_dict loads unchanged.
+
+  * lidar decoder   MLP 48->32->32->2 on the MFMA MLP kernels (neuradar.py:241-248,432-452)
+  * radar decoder   DETR-style encoder, one pre-norm layer, ONE head of width d_model = 48, feed-forward 64
+                    (detr/models/transformer.py:32-70,143-205), sine position embedding of the rendered 3-D points
+                    (detr/models/position_encoding_3d.py:56-103), then three width-16 heads (:251-278,463-491).
+                    Feed-forward block and heads run on the MFMA MLP kernels (nr_mlp_fwd/bwd); layer norms, the q/k/v and
+                    output projections and the n x n attention of one scan (n = 3 531 ZOD / 4 545 VoD rays) are torch-ROCm
+                    ops -- per RAY, once per step, 0.1 % of the step's FLOPs (SURVEY section 2 lists them as standard ops).
+  * RGB decoder     the 7x7 residual CNN on 32x32 feature patches (:225-240,455-461; model_components/cnns.py:21-47):
+                    torch-ROCm convolutions (MIOpen), same module tree as the reference's nn.Sequential.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .mlp import MLP
+
+
+def sine_position_embedding(xyz: Tensor, num_channels: int, temperature: float = 10000.0) -> Tensor:
+    """PositionEmbeddingCoordsSine(pos_type="sine").forward (position_encoding_3d.py:56-103): xyz [N, n, 3] ->
+    [N, n, num_channels] (the reference returns [N, C, n] and permutes back inside the transformer)."""
+    d_in = xyz.shape[2]
+    ndim = num_channels // d_in
+    ndim -= ndim % 2
+    rems = num_channels - ndim * d_in
+    parts = []
+    for d in range(d_in):
+        cdim = ndim
+        if rems > 0:
+            cdim += 2
+            rems -= 2
+        dim_t = torch.arange(cdim, dtype=torch.float32, device=xyz.device)
+        dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / cdim)
+        pos = (xyz[:, :, d] * (2 * math.pi))[:, :, None] / dim_t
+        parts.append(torch.stack((pos[:, :, 0::2].sin(), pos[:, :, 1::2].cos()), dim=3).flatten(2))
+    return torch.cat(parts, dim=2)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float) -> None:
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, 1, dropout=dropout)  # parameter container (names, init)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.p_drop = dropout
+
+    def forward(self, x: Tensor, pos: Tensor) -> Tensor:
+        """forward_pre (transformer.py:176-189).  x, pos [N, n, C]; attention runs inside a scan (N = scans)."""
+        from . import ops
+
+        C = x.shape[-1]
+        x2 = self.norm1(x)
+        qk = x2 + pos
+        w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        q, k, v = F.linear(qk, w[:C], b[:C]), F.linear(qk, w[C:2 * C], b[C:2 * C]), F.linear(x2, w[2 * C:], b[2 * C:])
+        att = F.scaled_dot_product_attention(q, k, v, dropout_p=self.p_drop if self.training else 0.0)
+        x = x + F.dropout(self.self_attn.out_proj(att), self.p_drop, self.training)
+        x2 = self.norm2(x)
+        if self.training and self.p_drop > 0:  # dropout sits between the two linears: plain torch ops
+            ff = self.linear2(F.dropout(torch.relu(self.linear1(x2)), self.p_drop, True))
+        else:  # 48 -> 64 -> 48 on the MFMA MLP kernels
+            ff = ops.mlp(x2.reshape(-1, C), [self.linear1.weight, self.linear2.weight], [self.linear1.bias, self.linear2.bias]).view_as(x)
+        return x + F.dropout(ff, self.p_drop, self.training)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(d_model, dim_feedforward, dropout)])
+        self.norm = nn.LayerNorm(d_model)
+
+
+class Transformer(nn.Module):
+    """detr.models.transformer.Transformer(d_model, nhead=1, num_encoder_layers=1, dim_feedforward=64, dropout=0.1,
+    normalize_before=True): same parameter names (`encoder.layers.0.self_attn.in_proj_weight`, ..., `encoder.norm.*`)."""
+
+    def __init__(self, d_model: int = 48, dim_feedforward: int = 64, dropout: float = 0.1) -> None:
+        super().__init__()
+        self.encoder = _Encoder(d_model, dim_feedforward, dropout)
+        for p in self.parameters():  # transformer.py:52-55
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model = d_model
+
+    def forward(self, src: Tensor, pos: Tensor) -> Tensor:
+        """src, pos [N, n, C] -> [N, n, C]."""
+        return self.encoder.norm(self.encoder.layers[0](src, pos))
+
+
+class BasicBlock(nn.Module):
+    """model_components/cnns.py:21-47 (in_dim == dim, batch norm)."""
+
+    def __init__(self, dim: int, kernel_size: int = 7, padding: int = 3) -> None:
+        super().__init__()
+        self.res_branch = nn.Identity()
+        self.main_branch = nn.Sequential(nn.Conv2d(dim, dim, kernel_size, padding=padding), nn.BatchNorm2d(dim), nn.ReLU(inplace=True),
+                                         nn.Conv2d(dim, dim, kernel_size, padding=padding), nn.BatchNorm2d(dim))
+        self.final_activation = nn.ReLU(inplace=True)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.final_activation(self.res_branch(x) + self.main_branch(x))
+
+
+def make_rgb_decoder(in_dim: int, hidden_dim: int = 32, upsample: int = 3) -> nn.Sequential:
+    """neuradar.py:225-240."""
+    return nn.Sequential(nn.Conv2d(in_dim, hidden_dim, 1), nn.ReLU(inplace=True), BasicBlock(hidden_dim), BasicBlock(hidden_dim),
+                         nn.ConvTranspose2d(hidden_dim, hidden_dim, upsample, stride=upsample), BasicBlock(hidden_dim),
+                         BasicBlock(hidden_dim), nn.Conv2d(hidden_dim, 3, 1), nn.Sigmoid())
+
+
+class Decoders(nn.Module):
+    """The decoder attributes of NeuRadarModel (neuradar.py:225-278) and its decode_features (:410-493)."""
+
+    def __init__(self, n_features: int = 48, rgb_hidden_dim: int = 32, rgb_upsample_factor: int = 3) -> None:
+        super().__init__()
+        self.n_features = n_features
+        self.rgb_decoder = make_rgb_decoder(n_features, rgb_hidden_dim, rgb_upsample_factor)
+        self.lidar_decoder = MLP(in_dim=n_features, layer_width=32, out_dim=2, num_layers=3, implementation="hip")
+        self.radar_decoder = Transformer(d_model=n_features)
+        mk = lambda out, act: MLP(in_dim=n_features, layer_width=16, out_dim=out, num_layers=3, out_activation=act)  # noqa: E731
+        self.offset_head = mk(3, nn.Tanh())
+        self.radar_angle_head = mk(2, nn.Tanh())  # built and checkpointed by the reference, never evaluated
+        self.radar_uncertainty_head = mk(3, nn.Softplus())
+        self.existence_probability_head = mk(1, nn.Sigmoid())
+
+    def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int) -> Tensor:
+        """neuradar.py:463-491: features / depth / (azimuth, elevation) of the radar rays, scan after scan ->
+        radar_output [scans, n, 7] = (existence probability, x, y, z, three Laplace scales)."""
+        C = radar_features.shape[-1]
+        depth = depth.reshape(num_radar_scans, -1, 1)
+        sph = directions_spher.reshape(num_radar_scans, -1, 2)
+        theta, phi = sph[..., 1:2], sph[..., 0:1]
+        xyz = torch.cat((depth * torch.cos(phi) * torch.cos(theta), depth * torch.sin(phi) * torch.cos(theta), depth * torch.sin(theta)), dim=2)
+        with torch.no_grad():
+            pos = sine_position_embedding(xyz.detach(), C)
+        out = self.radar_decoder(radar_features.reshape(num_radar_scans, -1, C), pos)
+        offset = 1.5 * self.offset_head(out)
+        ep = self.existence_probability_head(out)
+        unc = self.radar_uncertainty_head(out)
+        return torch.cat((ep, xyz + offset, unc), dim=-1).float()
+
+    def forward(self, features: Tensor, patch_size: Tuple[int, int], depth: Tensor, directions_spher: Tensor,
+                is_lidar: Optional[Tensor] = None, is_radar: Optional[Tensor] = None, num_radar_scans: Optional[int] = None):
+        """decode_features: (rgb, intensity, ray_drop_logit, radar_output); entries are None where the batch holds no
+        ray of that sensor."""
+        n = features.shape[0]
+        lid = is_lidar[..., 0] if is_lidar is not None else torch.zeros(n, dtype=torch.bool, device=features.device)
+        rad = is_radar[..., 0] if is_radar is not None else torch.zeros(n, dtype=torch.bool, device=features.device)
+        cam = ~(lid | rad)
+        intensity = ray_drop_logit = rgb = radar_output = None
+        lf = features[lid]
+        if lf.numel() > 0:
+            intensity, ray_drop_logit = self.lidar_decoder(lf).split(1, dim=-1)
+            intensity = intensity.sigmoid()
+        cf = features[cam]
+        if cf.numel() > 0:
+            patches = cf.view(-1, *patch_size, cf.shape[-1]).permute(0, 3, 1, 2)
+            rgb = self.rgb_decoder(patches).permute(0, 2, 3, 1)
+        rf = features[rad]
+        if rf.numel() > 0:
+            radar_output = self.decode_radar(rf, depth[rad], directions_spher[rad], num_radar_scans or 1)
+        return rgb, intensity, ray_drop_logit, radar_output
+
+
+def sample_radar_points(radar_output: Tensor, threshold: float = 0.5, max_detections: int = 1000):
+    """model_components/radar_utils.py:170-229, "euclidean" branch (the deterministic head of BASELINE configs[2]): the
+    last scan's predictions by descending existence probability, kept above the threshold."""
+    pred = radar_output[-1]
+    ep = pred[..., 0].clamp(min=1e-6, max=1 - 1e-6).flatten()
+    order = torch.argsort(ep, descending=True)[:max_detections]
+    keep = ep[order] > threshold
+    return pred[..., 1:4].reshape(-1, 3)[order][keep], order[keep]

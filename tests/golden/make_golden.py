@@ -584,7 +584,134 @@ def golden_actors():
     save("actors", **out)
 
 
+def _build_reference_model(seed=11):
+    """The reference NeuRadarModel itself, small tables, VGG loss patched out (needs torchvision weights)."""
+    import nerfstudio.models.neuradar as nm
+    from nerfstudio.data.scene_box import SceneBox
+
+    class _NoVGG(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            return torch.zeros(())
+
+    nm.VGGPerceptualLossPix2Pix = _NoVGG
+    cfg = nm.NeuRadarModelConfig()
+    cfg.implementation = "torch"
+    cfg.loss.radar_loss_type = "euclidean"  # configs[2]'s "deterministic" head
+    cfg.field.grid.static.log2_hashmap_size = 12
+    cfg.field.grid.actor.log2_hashmap_size = 10
+    for s in (cfg.sampling.proposal_field_1, cfg.sampling.proposal_field_2):
+        s.grid.static.log2_hashmap_size = 12
+        s.grid.actor.log2_hashmap_size = 10
+    torch.manual_seed(seed)
+    model = cfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-100.0, -100, -10], [100, 100, 30]])), num_train_data=10,
+                      metadata={"duration": 20.0, "sensor_idx_to_name": {0: "cam", 1: "lidar", 2: "radar"}, "trajectories": []})
+    return nm, model
+
+
+def golden_model():
+    """Rows a19, a20, f-2 and the lidar losses, pinned by calling the reference NeuRadarModel's OWN methods:
+    _get_appearance_embedding (neuradar.py:550-568), _compute_is_close_to_lidar (:971-994), decode_features (:410-493:
+    lidar MLP, RGB CNN, radar transformer + heads), get_metrics_dict / get_loss_dict (:588-704: lidar losses, radar
+    loss incl. the Hungarian association), sample_radar_points + chamfer_distance (radar_utils.py:170-229,380-420)."""
+    from nerfstudio.model_components import radar_utils as ru
+
+    nm, model = _build_reference_model()
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    # ---- a19: temporal appearance embedding
+    B = 64
+    times = torch.rand(B, 1, generator=g) * 20.0
+    times[0], times[1] = 0.0, 20.0  # clamp edges
+    sensor = torch.randint(0, 3, (B, 1), generator=g)
+    bundle = RayBundle(origins=torch.zeros(B, 3), directions=torch.zeros(B, 3), pixel_area=torch.ones(B, 1), times=times,
+                       metadata={"sensor_idxs": sensor})
+    out.update(app_times=times, app_sensor=sensor, app_table=model.appearance_embedding.weight,
+               app_embed=model._get_appearance_embedding(bundle, torch.zeros(B, 32)))
+    # ---- a20: is_close_to_lidar on ray samples of a mixed batch
+    S = 12
+    edges = torch.sort(torch.rand(B, S + 1, generator=g) * 200.0, dim=-1).values
+    is_lidar = torch.rand(B, 1, generator=g) < 0.5
+    did_return = torch.rand(B, 1, generator=g) < 0.8
+    dist = torch.rand(B, 1, generator=g) * 180.0
+    mid = (edges[:, :-1] + edges[:, 1:]) / 2
+    dist[is_lidar[:, 0]][:5] = mid[is_lidar[:, 0]][:5, 3:4]  # some samples exactly on the measured range
+    rb = RayBundle(origins=torch.zeros(B, 3), directions=torch.ones(B, 3), pixel_area=torch.ones(B, 1), times=times,
+                   metadata={"is_lidar": is_lidar, "did_return": did_return, "directions_norm": dist})
+    rs = rb.get_ray_samples(bin_starts=edges[:, :-1, None], bin_ends=edges[:, 1:, None])
+    model._compute_is_close_to_lidar(rs)
+    out.update(close_edges=edges, close_is_lidar=is_lidar, close_did_return=did_return, close_dist=dist,
+               close_mask=rs.metadata["is_close_to_lidar"])
+    # ---- f-2: decode_features of a mixed batch (1 camera patch of 8x8, 40 lidar rays, 2 radar scans of 90 rays), eval mode
+    model.eval()
+    n_cam, n_lid, n_scan, nr = 64, 40, 2, 90
+    n = n_cam + n_lid + n_scan * nr
+    feats = torch.randn(n, 48, generator=g) * 0.5
+    is_l = torch.zeros(n, 1, dtype=torch.bool)
+    is_l[n_cam:n_cam + n_lid] = True
+    is_r = torch.zeros(n, 1, dtype=torch.bool)
+    is_r[n_cam + n_lid:] = True
+    depth = torch.rand(n, 1, generator=g) * 80.0 + 1.0
+    spher = torch.stack([torch.rand(n, generator=g) * 1.6 - 0.8, torch.rand(n, generator=g) * 0.48 - 0.08], dim=-1)
+    params = {k: v for k, v in model.named_parameters() if k.split(".")[0] in (
+        "rgb_decoder", "lidar_decoder", "radar_decoder", "offset_head", "radar_angle_head", "radar_uncertainty_head",
+        "existence_probability_head")}
+    buffers = {k: v for k, v in model.named_buffers() if k.startswith("rgb_decoder")}
+    rgb, intensity, drop, radar_output = model.decode_features(feats, (8, 8), depth, spher, is_lidar=is_l, is_radar=is_r,
+                                                               num_radar_scans=n_scan)
+    out.update(dec_features=feats, dec_is_lidar=is_l, dec_is_radar=is_r, dec_depth=depth, dec_spher=spher, dec_rgb=rgb,
+               dec_intensity=intensity, dec_ray_drop_logit=drop, dec_radar_output=radar_output)
+    g_ro = torch.randn(radar_output.shape, generator=g)
+    keys = ["radar_decoder.encoder.layers.0.self_attn.in_proj_weight", "radar_decoder.encoder.layers.0.linear1.weight",
+            "radar_decoder.encoder.norm.weight", "offset_head.layers.0.weight", "existence_probability_head.layers.2.bias"]
+    named = dict(model.named_parameters())
+    grads = torch.autograd.grad((radar_output * g_ro).sum(), [named[k] for k in keys])
+    out["dec_g_radar_output"] = g_ro
+    for k, gr in zip(keys, grads):
+        out["dec_grad." + k] = gr
+    for k, v in {**params, **buffers}.items():
+        out["param." + k] = v
+    # ---- radar loss (Hungarian association, euclidean) + sampled points + Chamfer against synthetic detections
+    n_det = 25
+    gt_pts = torch.cat([torch.randn(n_det, 3, generator=g) * 20.0 + torch.tensor([30.0, 0.0, 0.0]), torch.rand(n_det, 6, generator=g)], dim=1)
+    gt2 = torch.cat([torch.randn(n_det + 7, 3, generator=g) * 20.0 + torch.tensor([30.0, 0.0, 0.0]), torch.rand(n_det + 7, 6, generator=g)], dim=1)
+    radar_batch = torch.cat([gt_pts, gt2])
+    indices = torch.cat([torch.stack([torch.zeros(n_det), torch.arange(n_det)], 1), torch.stack([torch.ones(n_det + 7), torch.arange(n_det + 7)], 1)]).long()
+    loss, assoc, _ = ru.calculate_radar_loss(radar_batch, radar_output.detach(), indices, loss_type="euclidean", training=True)
+    ro = radar_output.detach().clone()
+    ro[..., 0] = torch.rand(ro.shape[:-1], generator=g)  # spread existence probabilities around the 0.5 threshold
+    pts, ber = ru.sample_radar_points(ro, loss_type="euclidean", threshold=0.5)
+    cd = ru.chamfer_distance(pts[:, :3].numpy(), gt2[:, :3].numpy())
+    out.update(radar_batch=radar_batch, radar_indices=indices, radar_loss=loss, radar_assoc_last=assoc, cd_radar_output=ro,
+               cd_points=pts, cd_ber=ber, cd_gt=gt2[:, :3], cd_value=float(cd))
+    # ---- lidar losses through get_metrics_dict / get_loss_dict (training branch)
+    model.train()
+    nl = 200
+    is_lb = torch.zeros(nl + 30, 1, dtype=torch.bool)
+    is_lb[:nl] = True
+    did = torch.rand(nl + 30, 1, generator=g) < 0.85
+    lidar_pts = torch.cat([torch.randn(nl, 3, generator=g), torch.rand(nl, 1, generator=g), torch.rand(nl, 1, generator=g) * 0.1], dim=1)
+    dist_l = torch.rand(nl, 1, generator=g) * 100.0 + 2.0
+    outputs = {"depth": torch.rand(nl + 30, 1, generator=g) * 100.0, "ray_drop_logits": torch.randn(nl, 1, generator=g),
+               "intensity": torch.rand(nl, 1, generator=g), "non_nearby_weights": torch.rand(500, generator=g),
+               "prop_depth_0": torch.rand(nl + 30, 1, generator=g) * 100.0, "prop_depth_1": torch.rand(nl + 30, 1, generator=g) * 100.0,
+               "prop_weights_loss_0": torch.tensor(3.0), "prop_weights_loss_1": torch.tensor(1.5)}
+    batch = {"lidar": lidar_pts, "is_lidar": is_lb, "did_return": did, "distance": dist_l}
+    metrics, _ = model.get_metrics_dict(dict(outputs), dict(batch))
+    losses = model.get_loss_dict(dict(outputs), dict(batch), metrics)
+    out.update(ll_depth=outputs["depth"], ll_ray_drop_logits=outputs["ray_drop_logits"], ll_intensity=outputs["intensity"],
+               ll_non_nearby=outputs["non_nearby_weights"], ll_prop_depth_0=outputs["prop_depth_0"], ll_prop_depth_1=outputs["prop_depth_1"],
+               ll_is_lidar=is_lb, ll_did_return=did, ll_points=lidar_pts, ll_distance=dist_l)
+    for k in ("depth_loss", "intensity_loss", "ray_drop_loss", "carving_loss", "depth_loss_0", "depth_loss_1", "carving_loss_0", "carving_loss_1"):
+        out["ll_metric." + k] = metrics[k]
+        if k in losses:  # the proposal-level entries need "weights_list" in outputs (:679-688)
+            out["ll_loss." + k] = losses[k]
+    save("model", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors"]
+    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors", "model"]
     for w in which:
         globals()["golden_" + w]()
