@@ -103,11 +103,12 @@ class FusedTrainStep:
         # table allows it (nr_hash_encode_bwd_binned: the proposal grids; a main grid of <= 32 slices per level): the
         # merging kernel finds nothing to merge there and runs at the memory side's single-entry atomic rate.
         self.binned_ws = [None, None, None]
-        if os.environ.get("NR_BINNED", "1") != "0" and self.sm < B:
+        self.binned_from = 0 if os.environ.get("NR_BINNED") == "all" else self.sm  # first ray whose rows go through the binned kernels
+        if os.environ.get("NR_BINNED", "1") != "0" and self.binned_from < B:
             for lvl, S in enumerate(self.S):
                 grid = self.pgrid if lvl < 2 else self.mgrid
                 need = self.lib.nr_hash_encode_bwd_binned_workspace_bytes(grid.num_levels, grid.features_per_level,
-                                                                          grid.log2_hashmap_size, (B - self.sm) * S)
+                                                                          grid.log2_hashmap_size, (B - self.binned_from) * S)
                 if need > 0:
                     self.binned_ws[lvl] = torch.empty(need, device=dev, dtype=torch.uint8)
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
@@ -308,7 +309,7 @@ class FusedTrainStep:
             binned one on the rows behind them (when a workspace was set up for this level)."""
             sp_ = ops._stream()
             S, nl, Fg = self.S[lvl], B * self.S[lvl], grid.features_per_level
-            n_coh = nl if self.binned_ws[lvl] is None else self.sm * S
+            n_coh = nl if self.binned_ws[lvl] is None else self.binned_from * S
 
             def launch():
                 rc = lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,

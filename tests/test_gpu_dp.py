@@ -1,0 +1,57 @@
+"""The data-parallel fused step exercised on a GPU (round 1 only reasoned about it): two ranks share ONE device, gloo
+carries the collectives, each rank renders half of a fixed global batch.  Checked: (1) the replicas stay bit-identical
+over three optimizer steps; (2) after the first step Adam's first moment -- (1 - beta1) x the reduced mean gradient --
+equals the single-process run on the whole batch, for every parameter buffer; (3) both exchange paths of the main table
+are hit: (row, value) lists, and the dense fallback when a step touches more than rows / 16."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(tmp, tag, world, extra):
+    out = os.path.join(tmp, tag)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        cmd = [sys.executable, WORKER, "--out", out, *extra]
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), WORKER, "--out", out, *extra]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{tag}: rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    return [torch.load(f"{out}.rank{k}", weights_only=False) for k in range(world)]
+
+
+@pytest.mark.parametrize("path,extra", [("sparse", ["--log2t", "20", "--rays", "256"]), ("dense_fallback", ["--log2t", "14", "--rays", "512"]),
+                                        ("dense", ["--log2t", "16", "--rays", "512", "--dense"])])
+def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
+    dp = _run(str(tmp_path), "dp", 2, extra)
+    single = _run(str(tmp_path), "single", 1, extra + ["--steps", "1"])[0]
+    first = _run(str(tmp_path), "dp1", 2, extra + ["--steps", "1"])
+    # (1) replicas bit-identical after three steps
+    for n, p in dp[0]["params"].items():
+        assert torch.equal(p, dp[1]["params"][n]), f"{path}: parameter {n} differs between the ranks after 3 steps"
+    # (3) the exchange path that was meant to run did run
+    modes = {e.get("mode") for e in dp[0]["exchange"]}
+    want = {"sparse": {"sparse"}, "dense_fallback": {"dense"}, "dense": {None}}[path]
+    assert modes == want, f"{path}: main-table exchange modes {modes}"
+    # (2) the reduced gradient of step 1 == the single-process gradient on the whole batch
+    for i, (a, b) in enumerate(zip(first[0]["exp_avg"], single["exp_avg"])):
+        err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert err < 1e-4, f"{path}: Adam first moment of buffer {i}: relative L2 error {err:.3e} against the single-process run"
+        assert torch.equal(a, first[1]["exp_avg"][i])
