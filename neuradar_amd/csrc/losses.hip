@@ -63,6 +63,17 @@ distortion_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
 // losses.py:626-705 for ONE proposal level.  Final level: c [.., n_used+1 edges], w [.., n_used]
 // (detached); proposal level: cp [n_rays, Sp+1], wp [n_rays, Sp].  n_used <= 31 so that the 2*(n_used+1)
 // blur knots fit one wavefront.  Outputs g_wp [n_rays, Sp] (overwritten) and loss +=.
+// inclusive prefix sum over lanes 0..n-1 in lane order, one rounding per addition (what a sequential cumsum does)
+__device__ __forceinline__ float seq_incl_sum(float v, int n) {
+  float acc = 0.0f, out = 0.0f;
+  const int lane = nr_lane();
+  for (int j = 0; j < n; ++j) {
+    acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+    out = lane == j ? acc : out;
+  }
+  return lane >= n ? acc : out;
+}
+
 constexpr int kMaxKnots = 66;
 constexpr int kMaxProp = 256;
 
@@ -148,14 +159,17 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   const float sj = lane < K ? val[1 + lane] : 0.0f;
   const float x_next = __shfl_down(xj, 1, NR_WAVE);
   // y2 is defined on the first K-1 sorted knots (:632); slope after knot j = cumsum(y2)[j]
-  const float slope = nr_wave_incl_sum(lane < K - 1 ? sj : 0.0f);
+  // The three running sums below are SEQUENTIAL (lane 0's term first), like torch.cumsum on the reference's side: the
+  // slope jumps are O(w / dc / pulse) ~ 1e5 with alternating signs, and a tree scan's different rounding order moved the
+  // gradient of the fine pulse by up to 3e-2 of its value on near-empty proposal bins.  <= 64 knots: ~400 VALU per ray.
+  const float slope = seq_incl_sum(lane < K - 1 ? sj : 0.0f, K);
   const float seg = lane < K - 1 ? (x_next - xj) * slope : 0.0f;
-  float yr = fmaxf(nr_wave_incl_sum(seg), 0.0f);        // value at knot j+1 (:633)
+  float yr = fmaxf(seq_incl_sum(seg, K), 0.0f);        // value at knot j+1 (:633)
   float y_at = __shfl_up(yr, 1, NR_WAVE);               // value at knot j
   if (lane == 0) y_at = 0.0f;
   const float y_next = lane < K - 1 ? yr : 0.0f;        // value at knot j+1 (only used for j < K-1)
   const float area = lane < K - 1 ? 0.5f * (y_next + y_at) * (x_next - xj) : 0.0f;  // :685
-  const float cdf_incl = nr_wave_incl_sum(area);        // cdf at knot j+1
+  const float cdf_incl = seq_incl_sum(area, K);         // cdf at knot j+1
   float cdf_at = __shfl_up(cdf_incl, 1, NR_WAVE);
   if (lane == 0) cdf_at = 0.0f;
   if (lane < K) {

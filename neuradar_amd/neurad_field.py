@@ -57,8 +57,8 @@ class NeuRADField(nn.Module):
     def __init__(self, config: NeuRADFieldConfig, actors=None, static_scale: float = 1.0,
                  implementation: Literal["hip"] = "hip") -> None:
         super().__init__()
-        if not config.use_sdf or config.num_multisamples != 1:
-            raise NotImplementedError("the HIP path implements NeuRadar's defaults: use_sdf=True, num_multisamples=1")
+        if config.num_multisamples != 1:
+            raise NotImplementedError("the HIP path implements NeuRadar's default num_multisamples=1")
         self.config = config
         self.implementation = implementation
         self.hashgrid: NeuRADHashEncoding = config.grid.setup(dynamic_actors=actors, static_scale=static_scale,
@@ -68,12 +68,17 @@ class NeuRADField(nn.Module):
                            layer_width=config.geo_hidden_dim, out_dim=self.geo_feat_dim + 1, implementation=implementation)
         self.mlp_feature = MLP(in_dim=16 + self.geo_feat_dim, num_layers=config.nff_num_layers,
                                layer_width=config.nff_hidden_dim, out_dim=config.nff_out_dim, implementation=implementation)
-        self.sdf_to_density = SigmoidDensity(config.sdf_beta, learnable_beta=config.learnable_beta)
+        if config.use_sdf:
+            self.sdf_to_density = SigmoidDensity(config.sdf_beta, learnable_beta=config.learnable_beta)
+        else:  # neurad_field.py:149-150: density = trunc_exp(geo_out).  The fused kernels still want a beta; it takes
+            # no part in the density outputs and is not a parameter of the module (the reference builds none either)
+            self.register_buffer("_unused_beta", torch.ones(1), persistent=False)
 
     def get_param_groups(self, param_groups: Dict):
         self.hashgrid.get_param_groups(param_groups)
         param_groups["fields"] += list(self.mlp_geo.parameters()) + list(self.mlp_feature.parameters())
-        param_groups["fields"] += list(self.sdf_to_density.parameters())
+        if self.config.use_sdf:
+            param_groups["fields"] += list(self.sdf_to_density.parameters())
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False, flip: Optional[Tensor] = None
                 ) -> Dict[FieldHeadNames, Tensor]:
@@ -84,8 +89,15 @@ class NeuRADField(nn.Module):
         feature, sdf, alpha = ops.field_mlp(buf, strides, self.hashgrid.static_grid.features_per_level,
                                             ray_samples.directions if dirs is None else dirs, S if dirs is None else 0,
                                             B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
-                                            self.sdf_to_density.beta, rows_sample_major=rows_sm,
-                                            dtype=self.config.mlp_dtype, grad_scale=self.config.mlp_grad_scale)
+                                            self.sdf_to_density.beta if self.config.use_sdf else self._unused_beta,
+                                            rows_sample_major=rows_sm, dtype=self.config.mlp_dtype,
+                                            grad_scale=self.config.mlp_grad_scale)
+        if not self.config.use_sdf:
+            # geo_out is the kernels' `sdf` output (row 0 of mlp_geo); density = trunc_exp(geo_out) on the proposal head's
+            # kernel (trunc_exp of a 1-feature "grid" times the weight 1: nr_prop_density_fwd/bwd, activations.py:28-54)
+            one = torch.ones(1, 1, device=sdf.device)
+            density = ops.prop_density(sdf.view(-1, 1), (1, 1), 1, one, B * S)
+            return {FieldHeadNames.FEATURE: feature.view(B, S, -1), FieldHeadNames.DENSITY: density.view(B, S, 1)}
         return {FieldHeadNames.FEATURE: feature.view(B, S, -1), FieldHeadNames.SDF: sdf.view(B, S, 1),
                 FieldHeadNames.ALPHA: alpha.view(B, S, 1)}
 

@@ -142,8 +142,12 @@ class NeuRadarHotPath(nn.Module):
         (sensors.scale_pixel_area = _scale_pixel_area)."""
         rs, prop_rs, prop_w = self._get_ray_samples(bundle, t_rand, jitters)
         outputs = self.field(rs)
-        weights, accumulation, features, depth = composite(outputs[FieldHeadNames.ALPHA],
-                                                           outputs[FieldHeadNames.FEATURE], rs)
+        if FieldHeadNames.ALPHA in outputs:
+            alpha = outputs[FieldHeadNames.ALPHA]
+        else:  # use_sdf=False (_render_weights, neuradar.py:1018-1022): nerfacc.render_weight_from_density is alpha
+            # compositing of alpha_i = 1 - exp(-sigma_i * (t_end_i - t_start_i)) -- one elementwise op in front of the same kernel
+            alpha = 1.0 - torch.exp(-outputs[FieldHeadNames.DENSITY] * rs.deltas)
+        weights, accumulation, features, depth = composite(alpha, outputs[FieldHeadNames.FEATURE], rs)
         if self.config.appearance_dim > 0:
             features = torch.cat([features, self._get_appearance_embedding(bundle)], dim=-1)
         out = {"features": features, "depth": depth, "accumulation": accumulation}

@@ -179,10 +179,11 @@ trunc_exp = _TruncExp.apply
 
 
 def field_forward(p: FieldParams, origins, directions, starts, ends, pixel_area,
-                  actor_ctx: Optional[dict] = None):
-    """NeuRADField.forward (use_sdf=True).  neurad_field.py:128-152.
+                  actor_ctx: Optional[dict] = None, use_sdf: bool = True):
+    """NeuRADField.forward.  neurad_field.py:128-152.
 
-    Returns feature [B,S,C], sdf [B,S,1], alpha [B,S,1].
+    Returns feature [B,S,C], sdf [B,S,1], alpha [B,S,1]; with use_sdf=False (:149-150) feature and
+    density = trunc_exp(geo_out) [B,S,1].
     """
     B, S = starts.shape
     mean, std = isotropic_gaussian(origins, directions, starts, ends, pixel_area)
@@ -199,6 +200,8 @@ def field_forward(p: FieldParams, origins, directions, starts, ends, pixel_area,
     sh = direction_encoding(dirs.reshape(-1, 3))
     feature = geo_embedding + mlp(torch.cat([geo_embedding, sh], dim=-1), p.feat)
     sdf = sdf.view(B, S, 1)
+    if not use_sdf:
+        return feature.view(B, S, -1), trunc_exp(sdf)
     return feature.view(B, S, -1), sdf, sigmoid_density(sdf, p.beta)
 
 

@@ -19,6 +19,14 @@ def render_weight_from_alpha(alphas):
     return alphas * trans, trans
 
 
+def render_weight_from_density(t_starts, t_ends, sigmas):
+    """nerfacc batched branch (call site models/neuradar.py:1018-1022, use_sdf=False): alpha_i = 1 - exp(-sigma_i *
+    (t_end_i - t_start_i)), then render_weight_from_alpha.  Returns (weights, transmittance, alphas)."""
+    alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+    w, trans = render_weight_from_alpha(alphas)
+    return w, trans, alphas
+
+
 def accumulate_along_rays(weights, values=None):
     """nerfacc batched branch: sum_s w[...,s,None] * values[...,s,:]."""
     src = weights[..., None] if values is None else weights[..., None] * values

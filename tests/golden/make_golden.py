@@ -239,6 +239,40 @@ def golden_field_autocast():
     save("field_autocast", **arrays)
 
 
+def golden_field_density():
+    """a16, use_sdf=False branch: NeuRADField emits DENSITY = trunc_exp(geo_out) (fields/neurad_field.py:149-150)."""
+    actors = DynamicActorsConfig().setup(trajectories=[])
+    torch.manual_seed(17)
+    fld = NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=10), actor=ActorSettings(flip_prob=0.25)),
+                            use_sdf=False).setup(actors=actors, static_scale=STATIC_SCALE, implementation="torch")
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.mul_(300.0)
+    g = torch.Generator().manual_seed(33)
+    B, S = 24, 10
+    o, d, area, times = synth_rays(B, g)
+    edges = torch.sort(torch.rand(B, S + 1, generator=g) ** 2 * 300.0, dim=-1).values + 0.05
+    bundle = RayBundle(origins=o, directions=d, pixel_area=area, nears=torch.zeros(B, 1), fars=torch.full((B, 1), 1e6), times=times, metadata={})
+    rs = bundle.get_ray_samples(bin_starts=edges[:, :-1, None], bin_ends=edges[:, 1:, None])
+    out = fld(rs)
+    assert FieldHeadNames.SDF not in out and FieldHeadNames.ALPHA not in out
+    feat, dens = out[FieldHeadNames.FEATURE], out[FieldHeadNames.DENSITY]
+    g_feat, g_dens = torch.randn(feat.shape, generator=g), torch.randn(dens.shape, generator=g)
+    names = [n for n, _ in fld.named_parameters()]
+    grads = torch.autograd.grad((feat * g_feat).sum() + (dens * g_dens).sum(), list(fld.parameters()), allow_unused=True)
+    gmap = dict(zip(names, grads))
+    arrays = dict(origins=o, directions=d, pixel_area=area, edges=edges, feature=feat, density=dens, g_feature=g_feat, g_density=g_dens,
+                  log2t=10)
+    arrays.update({"table": fld.hashgrid.static_grid.hash_table, "scalings": fld.hashgrid.static_grid.scalings})
+    for i, lyr in enumerate(fld.mlp_geo.layers):
+        arrays[f"geo_w{i}"], arrays[f"geo_b{i}"] = lyr.weight, lyr.bias
+        arrays[f"grad_geo_w{i}"], arrays[f"grad_geo_b{i}"] = gmap[f"mlp_geo.layers.{i}.weight"], gmap[f"mlp_geo.layers.{i}.bias"]
+    for i, lyr in enumerate(fld.mlp_feature.layers):
+        arrays[f"feat_w{i}"], arrays[f"feat_b{i}"] = lyr.weight, lyr.bias
+        arrays[f"grad_feat_w{i}"] = gmap[f"mlp_feature.layers.{i}.weight"]
+    arrays["grad_table"] = gmap["hashgrid.static_grid.hash_table"]
+    save("field_density", **arrays)
+
+
 def golden_sh_mlp():
     """SHEncoding torch path (a15) and a bare MLP."""
     g = torch.Generator().manual_seed(41)
@@ -712,6 +746,6 @@ def golden_model():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors", "model"]
+    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "field_density", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors", "model"]
     for w in which:
         globals()["golden_" + w]()

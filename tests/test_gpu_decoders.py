@@ -57,3 +57,47 @@ def test_radar_point_set_chamfer_within_1e3_of_reference():
     loss, assoc = orad.radar_loss_euclidean(g["radar_batch"], dec.decode_radar(d("dec_features")[is_r], d("dec_depth")[is_r],
                                                                                d("dec_spher")[is_r], 2).detach().cpu(), g["radar_indices"])
     assert abs(float(loss) - g["radar_loss"]) <= 1e-3 * g["radar_loss"] and torch.equal(assoc, g["radar_assoc_last"])
+
+
+def test_field_density_branch_vs_reference_golden():
+    """a16, use_sdf=False (fields/neurad_field.py:149-150, models/neuradar.py:1018-1022): DENSITY head on the HIP kernels
+    against the reference's own field, then density -> weights against the oracle's render_weight_from_density."""
+    from neuradar_amd.field_heads import FieldHeadNames
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.rays import RaySamples
+    from oracle import render as orender
+
+    g = load_golden("field_density")
+    fld = NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=int(g["log2t"]))), use_sdf=False
+                            ).setup(actors=None, static_scale=100.0).to(DEV)
+    assert "sdf_to_density.beta" not in dict(fld.named_parameters())  # the reference builds none in this branch either
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(g["table"])
+        fld.hashgrid.static_grid.scalings.copy_(g["scalings"])
+        for i, l in enumerate(fld.mlp_geo.layers):
+            l.weight.copy_(g[f"geo_w{i}"]); l.bias.copy_(g[f"geo_b{i}"])
+        for i, l in enumerate(fld.mlp_feature.layers):
+            l.weight.copy_(g[f"feat_w{i}"]); l.bias.copy_(g[f"feat_b{i}"])
+    e = g["edges"].to(DEV)
+    B = e.shape[0]
+    rs = RaySamples(g["origins"].to(DEV), g["directions"].to(DEV), g["pixel_area"].to(DEV), torch.zeros_like(e), e,
+                    torch.zeros(B, 1, device=DEV), torch.full((B, 1), 1e6, device=DEV))
+    out = fld(rs)
+    assert FieldHeadNames.SDF not in out and FieldHeadNames.ALPHA not in out
+    assert_close(out[FieldHeadNames.FEATURE].detach().cpu(), g["feature"], rtol=1e-4, atol_scale=1e-5, what="feature")
+    assert_close(out[FieldHeadNames.DENSITY].detach().cpu(), g["density"], rtol=1e-4, atol_scale=1e-5, what="density")
+    loss = (out[FieldHeadNames.FEATURE] * g["g_feature"].to(DEV)).sum() + (out[FieldHeadNames.DENSITY] * g["g_density"].to(DEV)).sum()
+    named = dict(fld.named_parameters())
+    keys = {"hashgrid.static_grid.hash_table": "grad_table", "mlp_geo.layers.0.weight": "grad_geo_w0", "mlp_geo.layers.1.weight": "grad_geo_w1",
+            "mlp_geo.layers.1.bias": "grad_geo_b1", "mlp_feature.layers.0.weight": "grad_feat_w0"}
+    grads = torch.autograd.grad(loss, [named[k] for k in keys])
+    for (k, gk), gr in zip(keys.items(), grads):
+        assert_close(gr.cpu(), g[gk], rtol=2e-4, atol_scale=2e-5, what="grad " + k)
+    # density -> alpha -> weights: the elementwise step in front of the compositing kernel (step.py) == nerfacc's formula
+    dens = out[FieldHeadNames.DENSITY].detach()
+    alpha = 1.0 - torch.exp(-dens * rs.deltas)
+    from neuradar_amd.renderers import render_weight_from_alpha
+    w, _ = render_weight_from_alpha(alpha[..., 0])
+    want, _, _ = orender.render_weight_from_density(g["edges"][:, :-1], g["edges"][:, 1:], g["density"][..., 0])
+    assert_close(w.cpu(), want, rtol=1e-4, atol_scale=1e-5, what="weights from density")

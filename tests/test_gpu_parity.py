@@ -473,10 +473,7 @@ def test_pipeline_end_to_end_vs_reference_golden():
     grads = torch.autograd.grad(loss, list(names.values()) + [p0], allow_unused=True)
     assert grads[-1] is None
     for (n, _), gr in zip(names.items(), grads):
-        # the proposal parameters are trained by the inter-level loss alone, now the one-launch HIP kernel: its
-        # fine-pulse gradient carries summation-order noise of ~1e-4 of the largest entry (see
-        # test_loss_kernels_vs_reference_golden_and_oracle), hence the wider floor for them
-        assert_close(cpu(gr), g["grad_" + n], rtol=1e-3, atol_scale=3e-4 if n.startswith("prop1") else 1e-4, what="grad " + n)
+        assert_close(cpu(gr), g["grad_" + n], rtol=1e-3, atol_scale=1e-4, what="grad " + n)
 
 
 def test_regularisers_product_vs_reference_golden():
@@ -487,7 +484,7 @@ def test_regularisers_product_vs_reference_golden():
     g = load_golden("losses")
     cs = [dev(g[f"c{i}"]) for i in range(3)]
     for inter_fn, dist_fn, tol1 in ((losses.zipnerf_interlevel_loss_torch, losses.distortion_loss_torch, 1e-3),
-                                    (losses.zipnerf_interlevel_loss, losses.distortion_loss, 3e-2)):
+                                    (losses.zipnerf_interlevel_loss, losses.distortion_loss, 1.001e-3)):
         ws = [dev(g[f"w{i}"]).requires_grad_(True) for i in range(3)]
         inter = inter_fn(cs, ws)
         dist = dist_fn(cs[-1], ws[-1])
@@ -632,12 +629,9 @@ def test_loss_kernels_vs_reference_golden_and_oracle():
     for i, pulse in enumerate((0.03, 0.003)):
         loss.zero_()
         gi = ops.interlevel_loss(c_full, w_full, 31, dev(g[f"c{i}"]), dev(g[f"w{i}"]), pulse, 1.0, loss)
-        # the blurred-histogram slopes are O(w/dc/pulse) ~ 1e5 with alternating signs: their running sums
-        # carry ~1e-5 absolute noise that depends on summation order (tree scan here, sequential cumsum
-        # on the CPU reference), and d/dwp amplifies it by 1/(wp+1e-5)^2 on near-empty proposal bins.
-        assert_close(cpu(gi), g[f"g_inter_w{i}"], rtol=3e-2 if i else 1e-3, atol_scale=1e-4, what=f"interlevel grad {i}")
-        close = torch.isclose(cpu(gi), g[f"g_inter_w{i}"], rtol=1e-3, atol=1e-4 * float(g[f"g_inter_w{i}"].abs().max()))
-        assert close.float().mean() > 0.995
+        # the blurred-histogram slopes are O(w/dc/pulse) ~ 1e5 with alternating signs; the kernel's running sums are
+        # sequential like the reference's torch.cumsum (a tree scan differed by up to 3e-2 on the fine pulse)
+        assert_close(cpu(gi), g[f"g_inter_w{i}"], rtol=1e-3, atol_scale=1e-4, what=f"interlevel grad {i}")
         total += float(loss.sum())
     assert abs(total - float(g["interlevel"])) <= 1e-4 * abs(float(g["interlevel"]))
     # supervision loss vs plain torch

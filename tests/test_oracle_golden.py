@@ -285,3 +285,21 @@ def test_reference_pinhole_camera_origin():
                              torch.tensor([400.0]), torch.zeros(1))
     assert torch.allclose(out["origins"], torch.zeros(3, 3))
     assert torch.allclose(out["directions"].norm(dim=-1), torch.ones(3), atol=1e-6)
+
+
+def test_field_density_branch_vs_reference_golden():
+    """a16, use_sdf=False: DENSITY = trunc_exp(geo_out) (fields/neurad_field.py:149-150), forward and parameter gradients."""
+    from oracle import field as of
+
+    g = load_golden("field_density")
+    req = lambda k: g[k].clone().requires_grad_(True)  # noqa: E731
+    p = of.FieldParams(of.GridParams(req("table"), g["scalings"], int(g["log2t"])), [(req(f"geo_w{i}"), req(f"geo_b{i}")) for i in range(2)],
+                       [(req(f"feat_w{i}"), req(f"feat_b{i}")) for i in range(3)], torch.ones(1))
+    e = g["edges"]
+    feature, density = of.field_forward(p, g["origins"], g["directions"], e[:, :-1], e[:, 1:], g["pixel_area"], use_sdf=False)
+    torch.testing.assert_close(feature, g["feature"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(density, g["density"], rtol=1e-5, atol=1e-6)
+    loss = (feature * g["g_feature"]).sum() + (density * g["g_density"]).sum()
+    grads = torch.autograd.grad(loss, [p.grid.table, p.geo[0][0], p.geo[1][0], p.geo[1][1], p.feat[0][0]])
+    for got, k in zip(grads, ("grad_table", "grad_geo_w0", "grad_geo_w1", "grad_geo_b1", "grad_feat_w0")):
+        torch.testing.assert_close(got, g[k], rtol=1e-4, atol=1e-5 * float(g[k].abs().max()))
