@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 8
+#define NR_ABI_VERSION 9
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -91,6 +91,46 @@ int nr_hash_encode_bwd_input(const float* x, const float* std, const float* tabl
                              int num_levels, int features_per_level, int log2_hashmap_size,
                              const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                              float* grad_x, int64_t n, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic actors without host synchronisation (reference: two `nonzero`s and a Python loop over
+ * actors, field_components/neurad_encoding.py:231-275,295-307).  Fixed-shape launches:
+ *   nr_actor_candidates  cand [n_rays,K] int32 <- ascending ids of the actors whose bounding sphere (radius = |bounds|) the
+ *                        ray's first->last-sample line passes and that exist at the ray's time (:237-246), -1 padded; actors
+ *                        beyond K are dropped and *overflow (device int, caller-zeroed) receives max(count).  left/right [n_rays]
+ *                        int64 and frac [n_rays] are the keyframe interval of the ray's time (utils/poses.py:117-131), positions
+ *                        [T,A,3], present [T,A] uint8, bounds [A,3] = sizes/2 + padding (dynamic_actors.py:95-96).
+ *   nr_actor_assign      per sample row (row order as nr_contract_gaussians: sample_major_rows): sphere test (:254-258) and
+ *                        exact box test (:263-267) against the ray's candidates with w2b [n_rays,K,3,4] (world->box, e.g. from
+ *                        torch so that autograd reaches the trajectories) and centres [n_rays,K,3]; slot_of_row [n] <- index into
+ *                        cand (-1: static sample; the LAST matching candidate wins).  For actor samples: box-frame position,
+ *                        x *= flip[ray] (+-1 or NULL, :218-225), ScaledSceneContraction(actor_scale) -> x01a [n,3], std01a [n];
+ *                        dirs_sample [n_rays*S,3] (ray-major, nullable) <- the view direction of every sample: rotated into the
+ *                        box, normalised and flipped for actor samples (:210-215), the ray's direction otherwise.
+ *   nr_actor_encode_fwd  feats rows of actor samples <- the actor's grid (tables [A][L*T,F], shared scalings [L]) with the
+ *                        per-level rescale, levels L..static_levels-1 zeroed (:186-187); F must equal the static grid's F.
+ *   nr_actor_encode_bwd  g_tables += scatter of those rows of g_feats, which are then ZEROED (the static grid was overwritten
+ *                        there); with g_w2b [n_rays,K,3,4] (caller-zeroed, nullable) += d loss / d w2b through the grid's input
+ *                        gradient, the contraction and the flip (require_actor_grad, :83,176).
+ * ---------------------------------------------------------------------------------------------- */
+int nr_actor_candidates(const float* origins, const float* directions, const float* euclid, int64_t n_rays, int n_samples,
+                        const int64_t* left, const int64_t* right, const float* frac, const float* positions,
+                        const uint8_t* present, const float* bounds, int n_actors, int K, int* cand, int* overflow,
+                        nr_stream_t stream);
+int nr_actor_assign(const float* origins, const float* directions, const float* pixel_area, const float* euclid,
+                    int64_t n_rays, int n_samples, int sample_major_rows, const int* cand, int K, const float* w2b,
+                    const float* centres, const float* bounds, float actor_scale, const float* flip, int* slot_of_row,
+                    float* x01a, float* std01a, float* dirs_sample, nr_stream_t stream);
+int nr_actor_encode_fwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
+                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const float* scalings,
+                        int num_levels, int features_per_level, int log2_hashmap_size, float* feats, int64_t feat_stride_n,
+                        int64_t feat_stride_l, int static_levels, nr_stream_t stream);
+int nr_actor_encode_bwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
+                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const float* scalings,
+                        int num_levels, int features_per_level, int log2_hashmap_size, float* grad_feats, int64_t feat_stride_n,
+                        int64_t feat_stride_l, int static_levels, float* grad_tables, const float* origins,
+                        const float* directions, const float* pixel_area, const float* euclid, const float* w2b,
+                        float actor_scale, const float* flip, float* grad_w2b, nr_stream_t stream);
 
 /* Frustums.get_fast_isotropic_gaussian(1) (cameras/rays.py:109-124) followed by
  * ScaledSceneContraction(order=inf, scale) on the GaussiansStd
@@ -159,6 +199,9 @@ typedef struct nr_field {
                           trains with: torch.autocast + tcnn FullyFusedMLP, engine/trainer.py:189-200,564,
                           field_components/mlp.py:109-127).  Inputs, outputs, parameters and gradients stay fp32 tensors;
                           `packed` is then REQUIRED (nr_field_pack converts the weights) and `stash` is ignored. */
+  const float* sample_dirs; /* NULL, or view directions per SAMPLE [n,3] indexed by the ray-major sample index b*S+s (they
+                          replace `directions`): dynamic actors rotate the view direction of the samples inside their boxes
+                          (nr_actor_assign writes this array); row order of feats is unaffected */
   float grad_scale;    /* reduced precision only: gradients are multiplied by this factor where they enter the 16-bit
                           domain and divided back where they leave it (a static GradScaler, trainer.py:200,585-595);
                           <= 0 means 1.  bf16 needs none; fp16 gradients underflow without it. */

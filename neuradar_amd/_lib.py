@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 8
+NR_ABI_VERSION = 9
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -29,7 +29,7 @@ class NrMlpGrads(Structure):
 
 class NrField(Structure):
     _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p),
-                ("dtype", c_int), ("grad_scale", c_float)]
+                ("dtype", c_int), ("sample_dirs", c_void_p), ("grad_scale", c_float)]
 
 
 class NrFieldGrads(Structure):
@@ -47,6 +47,10 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
+    "nr_actor_candidates": [P, P, P, L, I, P, P, P, P, P, P, I, I, P, P, P],
+    "nr_actor_assign": [P, P, P, P, L, I, I, P, I, P, P, P, F, P, P, P, P, P, P],
+    "nr_actor_encode_fwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P],
+    "nr_actor_encode_bwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P, P, P, P, P, P, F, P, P, P],
     "nr_contract_gaussians": [P, P, P, P, L, I, F, I, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],

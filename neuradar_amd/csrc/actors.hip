@@ -1,0 +1,374 @@
+// Dynamic actors on the device, without host synchronisation.
+//
+// The reference finds the samples inside actor boxes with two `nonzero`s (host syncs) and loops over the actors in
+// Python (field_components/neurad_encoding.py:231-275,295-307).  Here every step is a fixed-shape launch:
+//   nr_actor_candidates   per ray: the actors whose bounding sphere the ray's sample line passes (:237-246), at most K
+//   (torch, fixed shape)  world->box transforms of those (ray, actor) pairs from the learnable trajectories
+//                         (model_components/dynamic_actors.py:183-197, utils/poses.py:90-149): tiny tensors, autograd
+//   nr_actor_assign       per sample: sphere test (:254-258), exact box test (:263-267) -> the actor it belongs to,
+//                         box-frame position through the actor contraction, box-frame view direction, per-ray flip
+//   nr_actor_encode_fwd   the actor's 3-D hash grid written over the static features of those samples (:186-187)
+//   nr_actor_encode_bwd   gradients: actor tables (+=), zero for the overwritten static features, and -- for the
+//                         trajectory optimisation -- d loss / d (world->box transform) per (ray, candidate)
+// Samples outside every box cost one 4-byte read in the last two kernels.
+#include "grid_dev.h"
+
+using namespace nrgrid;
+
+namespace {
+
+constexpr float kEps = 1.0e-7f;  // neurad_encoding.py:33
+
+__global__ void __launch_bounds__(256)
+actor_candidates_kernel(const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ euclid,
+                        int S, const int64_t* __restrict__ left, const int64_t* __restrict__ right, const float* __restrict__ frac,
+                        const float* __restrict__ positions, const uint8_t* __restrict__ present, const float* __restrict__ bounds,
+                        int n_actors, int64_t n_rays, int K, int* __restrict__ cand, int* __restrict__ overflow) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_rays) return;
+  const float* e = euclid + b * (S + 1);
+  const float t0 = e[0] + (e[1] - e[0]) / 2.0f, t1 = e[S - 1] + (e[S] - e[S - 1]) / 2.0f;
+  float o[3], line[3], p0[3], len = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    o[a] = origins[b * 3 + a];
+    const float d = directions[b * 3 + a];
+    p0[a] = o[a] + d * t0;
+    line[a] = (o[a] + d * t1) - p0[a];  // first -> last sample (:239-240)
+    len += line[a] * line[a];
+  }
+  len = sqrtf(len) + kEps;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) line[a] /= len;
+  const int64_t l = left[b], r = right[b];
+  const float f = frac[b];
+  int n = 0;
+  for (int a = 0; a < n_actors; ++a) {
+    const bool valid = present[l * n_actors + a] || present[r * n_actors + a];
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float pl = positions[(l * n_actors + a) * 3 + k], pr = positions[(r * n_actors + a) * 3 + k];
+      c[k] = (pl + (pr - pl) * f) - p0[k];
+    }
+    const float cx = c[1] * line[2] - c[2] * line[1], cy = c[2] * line[0] - c[0] * line[2], cz = c[0] * line[1] - c[1] * line[0];
+    const float dist = sqrtf(cx * cx + cy * cy + cz * cz);
+    const float radius = sqrtf(bounds[a * 3] * bounds[a * 3] + bounds[a * 3 + 1] * bounds[a * 3 + 1] + bounds[a * 3 + 2] * bounds[a * 3 + 2]);
+    if (valid && dist < radius) {
+      if (n < K) cand[b * K + n] = a;
+      ++n;
+    }
+  }
+  for (int k = n < K ? n : K; k < K; ++k) cand[b * K + k] = -1;
+  if (n > K) atomicMax(overflow, n);
+}
+
+// ScaledSceneContraction(order = inf, scale) on (position, std): spatial_distortions.py:103-113,126-136
+__device__ __forceinline__ void contract_actor(const float (&p)[3], float sd, float scale, float (&x01)[3], float& std01) {
+  float m[3], mag = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    m[a] = p[a] / scale;
+    mag = fmaxf(mag, fabsf(m[a]));
+  }
+  sd = sd / scale;
+  if (!(mag < 1.0f)) {
+    const float cm = fmaxf(mag, 1.0f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) m[a] = (2.0f - (1.0f / cm)) * (m[a] / cm);
+    const float k = powf(2.0f * cm - 1.0f, 1.0f / 3.0f) / cm;
+    sd = sd * (k * k);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x01[a] = (m[a] + 2.0f) / 4.0f;
+  std01 = sd / 4.0f;
+}
+
+struct SampleGeom {
+  int64_t ray;
+  int64_t out;   // ray-major sample index b * S + s
+  float pos[3];  // world position of the sample's centre
+  float sd;      // isotropic std (cameras/rays.py:109-124)
+};
+
+__device__ __forceinline__ SampleGeom sample_geom(int64_t row, int64_t n, int S, int sm, const float* __restrict__ origins,
+                                                  const float* __restrict__ directions, const float* __restrict__ pixel_area,
+                                                  const float* __restrict__ euclid) {
+  const NrRowMap rm = nr_row_map(row, n, S, sm);
+  SampleGeom g;
+  g.ray = rm.ray;
+  g.out = rm.out;
+  const int s = (int)(rm.out - rm.ray * S);
+  const float e0 = euclid[rm.ray * (S + 1) + s], e1 = euclid[rm.ray * (S + 1) + s + 1];
+  const float half = (e1 - e0) / 2.0f;
+  const float t = e0 + 1.0f * half;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g.pos[a] = origins[rm.ray * 3 + a] + directions[rm.ray * 3 + a] * t;
+  g.sd = powf(pixel_area[rm.ray] * (t * t) * half, 1.0f / 3.0f);
+  return g;
+}
+
+__global__ void __launch_bounds__(256)
+actor_assign_kernel(const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ pixel_area,
+                    const float* __restrict__ euclid, int64_t n_rays, int S, int sm, const int* __restrict__ cand, int K,
+                    const float* __restrict__ w2b, const float* __restrict__ centres, const float* __restrict__ bounds,
+                    float actor_scale, const float* __restrict__ flip, int* __restrict__ slot_of_row,
+                    float* __restrict__ x01a, float* __restrict__ std01a, float* __restrict__ dirs_sample) {
+  const int64_t n = n_rays * S;
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const SampleGeom g = sample_geom(row, n, S, sm, origins, directions, pixel_area, euclid);
+  int slot = -1;
+  for (int k = 0; k < K; ++k) {
+    const int a = cand[g.ray * K + k];
+    if (a < 0) break;
+    const float* c = centres + (g.ray * K + k) * 3;
+    const float dx = g.pos[0] - c[0], dy = g.pos[1] - c[1], dz = g.pos[2] - c[2];
+    const float* bd = bounds + a * 3;
+    const float radius = sqrtf(bd[0] * bd[0] + bd[1] * bd[1] + bd[2] * bd[2]);
+    if (!(sqrtf(dx * dx + dy * dy + dz * dz) < radius)) continue;  // :254-258
+    const float* w = w2b + (g.ray * K + k) * 12;
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float pb = (g.pos[0] * w[i * 4] + g.pos[1] * w[i * 4 + 1] + g.pos[2] * w[i * 4 + 2]) + w[i * 4 + 3];
+      inside = inside && fabsf(pb) < bd[i];
+    }
+    if (inside) slot = k;  // candidates ascend by actor: the last match wins, like the reference's index_put order
+  }
+  slot_of_row[row] = slot;
+  float dvec[3] = {directions[g.ray * 3], directions[g.ray * 3 + 1], directions[g.ray * 3 + 2]};
+  if (slot >= 0) {
+    const float* w = w2b + (g.ray * K + slot) * 12;
+    const float sign = flip != nullptr ? flip[g.ray] : 1.0f;
+    float pb[3], db[3], dn = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      pb[i] = (g.pos[0] * w[i * 4] + g.pos[1] * w[i * 4 + 1] + g.pos[2] * w[i * 4 + 2]) + w[i * 4 + 3];
+      db[i] = dvec[0] * w[i * 4] + dvec[1] * w[i * 4 + 1] + dvec[2] * w[i * 4 + 2];
+      dn += db[i] * db[i];
+    }
+    dn = sqrtf(dn) + kEps;
+    pb[0] *= sign;  // per-ray random flip around the x axis (:218-225)
+    float x01[3], s01;
+    contract_actor(pb, g.sd, actor_scale, x01, s01);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      x01a[row * 3 + i] = x01[i];
+      dvec[i] = db[i] / dn;
+    }
+    dvec[0] *= sign;
+    std01a[row] = s01;
+  }
+  if (dirs_sample != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dirs_sample[g.out * 3 + i] = dvec[i];
+  }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+actor_encode_fwd_kernel(const float* __restrict__ x01a, const float* __restrict__ std01a, const int* __restrict__ slot_of_row,
+                        const int* __restrict__ cand, int K, int S, int sm, int64_t n, const float* __restrict__ tables,
+                        const float* __restrict__ scalings, int L, int log2T, float* __restrict__ feats, int64_t sn, int64_t sl,
+                        int static_levels) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int slot = slot_of_row[row];
+  if (slot < 0) return;
+  const NrRowMap rm = nr_row_map(row, n, S, sm);
+  const int a = cand[rm.ray * K + slot];
+  const float* table = tables + (((int64_t)a * L) << log2T) * F;
+  for (int level = 0; level < static_levels; ++level) {
+    float feat[F];
+    if (level < L) {
+      encode_level<F>(x01a, std01a, table, scalings[level], level, log2T, row, feat);
+    } else {  // actor features are zero-padded to the static width (:186)
+#pragma unroll
+      for (int f = 0; f < F; ++f) feat[f] = 0.0f;
+    }
+    float* o = feats + row * sn + (int64_t)level * sl;
+#pragma unroll
+    for (int f = 0; f < F; ++f) o[f] = feat[f];
+  }
+}
+
+// backward of contract_actor's position path (the std path carries no gradient: the grid's rescale weight is treated as
+// a constant of the sample, as in ops._HashEncode): g wrt x01 -> g wrt the box-frame position
+__device__ __forceinline__ void contract_actor_bwd(const float (&p)[3], float scale, const float (&g01)[3], float (&gp)[3]) {
+  float x[3], mag = 0.0f;
+  int jmax = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    x[a] = p[a] / scale;
+    if (fabsf(x[a]) > mag) { mag = fabsf(x[a]); jmax = a; }
+  }
+  float gx[3];
+  if (mag < 1.0f) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gx[a] = g01[a] / 4.0f;
+  } else {  // x' = (2 - 1/m) x / m, m = |x_jmax|
+    const float m = mag, k = (2.0f - 1.0f / m) / m;
+    float gm = 0.0f;  // d loss / d m
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      gx[a] = (g01[a] / 4.0f) * k;
+      gm += (g01[a] / 4.0f) * x[a] * (-2.0f / (m * m) + 2.0f / (m * m * m));
+    }
+    gx[jmax] += gm * (x[jmax] >= 0.0f ? 1.0f : -1.0f);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gp[a] = gx[a] / scale;
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+actor_encode_bwd_kernel(const float* __restrict__ x01a, const float* __restrict__ std01a, const int* __restrict__ slot_of_row,
+                        const int* __restrict__ cand, int K, int S, int sm, int64_t n, const float* __restrict__ tables,
+                        const float* __restrict__ scalings, int L, int log2T, float* __restrict__ g_feats, int64_t sn, int64_t sl,
+                        int static_levels, float* __restrict__ g_tables, const float* __restrict__ origins,
+                        const float* __restrict__ directions, const float* __restrict__ pixel_area, const float* __restrict__ euclid,
+                        const float* __restrict__ w2b, float actor_scale, const float* __restrict__ flip, float* __restrict__ g_w2b) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int slot = slot_of_row[row];
+  if (slot < 0) return;
+  const NrRowMap rm = nr_row_map(row, n, S, sm);
+  const int a = cand[rm.ray * K + slot];
+  const uint32_t mask = (1u << log2T) - 1u;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int level = 0; level < L; ++level) {
+    const float scale = scalings[level];
+    const Corner c = make_corner(x01a, row, scale);
+    const int64_t base = ((((int64_t)a * L + level) << log2T)) * F;
+    float r = 1.0f / fmaxf(scale * 2.0f * std01a[row], 1.0f);
+    float g[F];
+    float* gi = g_feats + row * sn + (int64_t)level * sl;
+#pragma unroll
+    for (int f = 0; f < F; ++f) g[f] = gi[f] * r;
+    float t[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
+      const int64_t e = base + (int64_t)nr_hash3(hx ? c.hi[0] : c.lo[0], hy ? c.hi[1] : c.lo[1], hz ? c.hi[2] : c.lo[2], mask) * F;
+      const float w = (hx ? c.w[0] : 1.0f - c.w[0]) * (hy ? c.w[1] : 1.0f - c.w[1]) * (hz ? c.w[2] : 1.0f - c.w[2]);
+      float d = 0.0f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (g[f] != 0.0f) unsafeAtomicAdd(g_tables + e + f, g[f] * w);
+        if (g_w2b != nullptr) d += tables[e + f] * g[f];
+      }
+      t[corner] = d;
+    }
+    if (g_w2b != nullptr) {  // d interp / d position, as hash_encode_bwd_input_kernel
+      const float wx = c.w[0], wy = c.w[1], wz = c.w[2];
+      acc[0] += scale * (((t[7] - t[6]) * wy + (t[5] - t[4]) * (1.0f - wy)) * wz + ((t[3] - t[2]) * wy + (t[1] - t[0]) * (1.0f - wy)) * (1.0f - wz));
+      acc[1] += scale * (((t[7] - t[5]) * wx + (t[6] - t[4]) * (1.0f - wx)) * wz + ((t[3] - t[1]) * wx + (t[2] - t[0]) * (1.0f - wx)) * (1.0f - wz));
+      acc[2] += scale * (((t[7] - t[3]) * wx + (t[6] - t[2]) * (1.0f - wx)) * wy + ((t[5] - t[1]) * wx + (t[4] - t[0]) * (1.0f - wx)) * (1.0f - wy));
+    }
+  }
+  // the static grid was overwritten at this sample: it receives no gradient (:186-187)
+  for (int level = 0; level < static_levels; ++level) {
+    float* gi = g_feats + row * sn + (int64_t)level * sl;
+#pragma unroll
+    for (int f = 0; f < F; ++f) gi[f] = 0.0f;
+  }
+  if (g_w2b != nullptr) {
+    const SampleGeom gm = sample_geom(row, n, S, sm, origins, directions, pixel_area, euclid);
+    const float* w = w2b + (rm.ray * K + slot) * 12;
+    const float sign = flip != nullptr ? flip[rm.ray] : 1.0f;
+    float pb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pb[i] = (gm.pos[0] * w[i * 4] + gm.pos[1] * w[i * 4 + 1] + gm.pos[2] * w[i * 4 + 2]) + w[i * 4 + 3];
+    pb[0] *= sign;
+    float gp[3];
+    contract_actor_bwd(pb, actor_scale, acc, gp);
+    gp[0] *= sign;
+    float* gw = g_w2b + (rm.ray * K + slot) * 12;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) unsafeAtomicAdd(gw + i * 4 + j, gp[i] * gm.pos[j]);
+      unsafeAtomicAdd(gw + i * 4 + 3, gp[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int nr_actor_candidates(const float* origins, const float* directions, const float* euclid, int64_t n_rays, int S,
+                                   const int64_t* left, const int64_t* right, const float* frac, const float* positions,
+                                   const uint8_t* present, const float* bounds, int n_actors, int K, int* cand, int* overflow,
+                                   nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!origins || !directions || !euclid || !left || !right || !frac || !positions || !present || !bounds || !cand || !overflow ||
+      S < 1 || n_actors < 1 || K < 1 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(actor_candidates_kernel, dim3((unsigned)nr_cdiv(n_rays, 256)), dim3(256), 0, nr_s(stream), origins, directions,
+                     euclid, S, left, right, frac, positions, present, bounds, n_actors, n_rays, K, cand, overflow);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_actor_assign(const float* origins, const float* directions, const float* pixel_area, const float* euclid,
+                               int64_t n_rays, int S, int sample_major_rows, const int* cand, int K, const float* w2b,
+                               const float* centres, const float* bounds, float actor_scale, const float* flip, int* slot_of_row,
+                               float* x01a, float* std01a, float* dirs_sample, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!origins || !directions || !pixel_area || !euclid || !cand || !w2b || !centres || !bounds || !slot_of_row || !x01a ||
+      !std01a || S < 1 || K < 1 || n_rays < 0 || !(actor_scale > 0) || sample_major_rows < 0 || sample_major_rows > n_rays)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(actor_assign_kernel, dim3((unsigned)nr_cdiv(n_rays * S, 256)), dim3(256), 0, nr_s(stream), origins, directions,
+                     pixel_area, euclid, n_rays, S, sample_major_rows, cand, K, w2b, centres, bounds, actor_scale, flip, slot_of_row,
+                     x01a, std01a, dirs_sample);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_actor_encode_fwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
+                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const float* scalings, int L,
+                                   int F, int log2T, float* feats, int64_t sn, int64_t sl, int static_levels, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!x01a || !std01a || !slot_of_row || !cand || !tables || !scalings || !feats || L < 1 || static_levels < L || log2T < 1 ||
+      log2T > 30 || S < 1 || K < 1 || n_rays < 0)
+    return NR_EINVAL;
+  const int64_t n = n_rays * S;
+  dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
+#define CALL(FF) hipLaunchKernelGGL(actor_encode_fwd_kernel<FF>, grid, block, 0, nr_s(stream), x01a, std01a, slot_of_row, cand, K, S, \
+                                    sample_major_rows, n, tables, scalings, L, log2T, feats, sn, sl, static_levels)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_actor_encode_bwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
+                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const float* scalings, int L,
+                                   int F, int log2T, float* g_feats, int64_t sn, int64_t sl, int static_levels, float* g_tables,
+                                   const float* origins, const float* directions, const float* pixel_area, const float* euclid,
+                                   const float* w2b, float actor_scale, const float* flip, float* g_w2b, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!x01a || !std01a || !slot_of_row || !cand || !tables || !scalings || !g_feats || !g_tables || L < 1 || static_levels < L ||
+      log2T < 1 || log2T > 30 || S < 1 || K < 1 || n_rays < 0)
+    return NR_EINVAL;
+  if (g_w2b != nullptr && (!origins || !directions || !pixel_area || !euclid || !w2b || !(actor_scale > 0))) return NR_EINVAL;
+  const int64_t n = n_rays * S;
+  dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
+#define CALL(FF) hipLaunchKernelGGL(actor_encode_bwd_kernel<FF>, grid, block, 0, nr_s(stream), x01a, std01a, slot_of_row, cand, K, S, \
+                                    sample_major_rows, n, tables, scalings, L, log2T, g_feats, sn, sl, static_levels, g_tables,         \
+                                    origins, directions, pixel_area, euclid, w2b, actor_scale, flip, g_w2b)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}

@@ -159,17 +159,28 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   const float sj = lane < K ? val[1 + lane] : 0.0f;
   const float x_next = __shfl_down(xj, 1, NR_WAVE);
   // y2 is defined on the first K-1 sorted knots (:632); slope after knot j = cumsum(y2)[j]
-  // The three running sums below are SEQUENTIAL (lane 0's term first), like torch.cumsum on the reference's side: the
-  // slope jumps are O(w / dc / pulse) ~ 1e5 with alternating signs, and a tree scan's different rounding order moved the
-  // gradient of the fine pulse by up to 3e-2 of its value on near-empty proposal bins.  <= 64 knots: ~400 VALU per ray.
-  const float slope = seq_incl_sum(lane < K - 1 ? sj : 0.0f, K);
-  const float seg = lane < K - 1 ? (x_next - xj) * slope : 0.0f;
-  float yr = fmaxf(seq_incl_sum(seg, K), 0.0f);        // value at knot j+1 (:633)
-  float y_at = __shfl_up(yr, 1, NR_WAVE);               // value at knot j
-  if (lane == 0) y_at = 0.0f;
-  const float y_next = lane < K - 1 ? yr : 0.0f;        // value at knot j+1 (only used for j < K-1)
-  const float area = lane < K - 1 ? 0.5f * (y_next + y_at) * (x_next - xj) : 0.0f;  // :685
-  const float cdf_incl = seq_incl_sum(area, K);         // cdf at knot j+1
+  // The three running sums (slope, value, cdf) are SEQUENTIAL in lane order, like torch.cumsum on the reference's side:
+  // the slope jumps are O(w / dc / pulse) ~ 1e5 with alternating signs, and a tree scan's different rounding order moved
+  // the gradient of the fine pulse by up to 3e-2 of its value on near-empty proposal bins.  One loop of <= 64 steps carries
+  // all three sums as wave-uniform values (every lane computes them from the broadcast inputs; lane j keeps step j's).
+  const float s_in = lane < K - 1 ? sj : 0.0f;
+  const float dx_in = lane < K - 1 ? x_next - xj : 0.0f;
+  float slope_run = 0.0f, y_run = 0.0f, cdf_run = 0.0f, y_prev_c = 0.0f;
+  float yr = 0.0f, y_at = 0.0f, cdf_incl = 0.0f;
+#pragma unroll 4
+  for (int j = 0; j < K; ++j) {
+    const float sj_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s_in), j));
+    const float dx_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dx_in), j));
+    slope_run += sj_b;                         // cumsum(y2)[j]                      (:632)
+    y_run += dx_b * slope_run;                 // cumsum((x[1:] - x[:-1]) * slope)[j] (:633)
+    const float y_c = fmaxf(y_run, 0.0f);      // clamped value at knot j+1
+    cdf_run += 0.5f * (y_c + y_prev_c) * dx_b; // integral up to knot j+1            (:685)
+    const bool me = lane == j;
+    yr = me ? y_c : yr;
+    y_at = me ? y_prev_c : y_at;
+    cdf_incl = me ? cdf_run : cdf_incl;
+    y_prev_c = y_c;
+  }
   float cdf_at = __shfl_up(cdf_incl, 1, NR_WAVE);
   if (lane == 0) cdf_at = 0.0f;
   if (lane < K) {

@@ -94,7 +94,7 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
     const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
     cat[0] = e[0];
     const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
-    cat[1] = sh_tile(dirs, rm.ray, h);
+    cat[1] = (fld.sample_dirs != nullptr ? sh_tile(fld.sample_dirs, rm.out, h) : sh_tile(dirs, rm.ray, h));
     dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
     dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     dense_fwd<HID, kC, false>(f2, o, lw + I::oF3, i, h);
@@ -176,7 +176,7 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
       stash_get<I::HT>(sp + St::oF1 * 64, f1, lane);
       stash_get<I::HT>(sp + St::oF2 * 64, f2, lane);
       sdf = sp[St::oSdf * 64 + lane];
-      cat[1] = sh_tile(dirs, rm.ray, h);
+      cat[1] = (fld.sample_dirs != nullptr ? sh_tile(fld.sample_dirs, rm.out, h) : sh_tile(dirs, rm.ray, h));
     } else {
       {
         f32x16 x0[I::IT], h1[I::HT], e[1];
@@ -187,7 +187,7 @@ field_bwd_feat_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t s
         sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
         cat[0] = e[0];
       }
-      cat[1] = sh_tile(dirs, rm.ray, h);
+      cat[1] = (fld.sample_dirs != nullptr ? sh_tile(fld.sample_dirs, rm.out, h) : sh_tile(dirs, rm.ray, h));
       dense_fwd<kC + kSH, HID, true>(cat, f1, lw + I::oF1, i, h);
       dense_fwd<HID, HID, true>(f1, f2, lw + I::oF2, i, h);
     }

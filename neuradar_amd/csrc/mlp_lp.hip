@@ -277,7 +277,7 @@ field_fwd_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn,
     const float sdf = sdf_row_lp<HID>(h1, fb + I::wSdf, h);
     dense_lp<T, HS, 1>(h1p, e, lds + I::oG2f, fb + I::bG2, lane, h);
     const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
-    PTile cat[2] = {to_ptile<T>(e[0]), sh_ptile<T>(dirs, rm.ray, h)};
+    PTile cat[2] = {to_ptile<T>(e[0]), (fld.sample_dirs != nullptr ? sh_ptile<T>(fld.sample_dirs, rm.out, h) : sh_ptile<T>(dirs, rm.ray, h))};
     dense_lp<T, 3, HT>(cat, f1, lds + I::oF1f, fb + I::bF1, lane, h);
     PTile f1p[HT], f2p[HT];
 #pragma unroll
@@ -355,7 +355,7 @@ field_bwd_feat_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_
       sdf = sdf_row_lp<HID>(h1, fb + I::wSdf, h);
       dense_lp<T, HS, 1>(h1p, e, lds + I::oG2f, fb + I::bG2, lane, h);
       cat[0] = to_ptile<T>(e[0]);
-      cat[1] = sh_ptile<T>(dirs, rm.ray, h);
+      cat[1] = (fld.sample_dirs != nullptr ? sh_ptile<T>(fld.sample_dirs, rm.out, h) : sh_ptile<T>(dirs, rm.ray, h));
       dense_lp<T, 3, HT>(cat, f1, lds + I::oF1f, fb + I::bF1, lane, h);
 #pragma unroll
       for (int t = 0; t < HT; ++t) { relu_tile(f1[t]); f1p[t] = to_ptile<T>(f1[t]); }

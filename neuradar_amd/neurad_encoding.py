@@ -1,8 +1,9 @@
-"""`NeuRADHashEncoding` (reference: field_components/neurad_encoding.py:36-316), static branch.
+"""`NeuRADHashEncoding` (reference: field_components/neurad_encoding.py:36-316).
 
 forward = contraction kernel (isotropic Gaussian already folded in by the caller) + hash gather with
-the per-level rescale fused.  Dynamic actors (neurad_encoding.py:191-307) are the second phase of the
-build and are rejected loudly here rather than silently ignored.
+the per-level rescale fused; with dynamic actors (neurad_encoding.py:191-307) the samples inside actor boxes are then
+found and re-encoded on the device by fixed-shape launches (csrc/actors.hip: no `nonzero`, no host read, no Python loop
+over actors).
 """
 from dataclasses import dataclass, field
 from typing import Dict, Literal, Optional, Tuple
@@ -12,7 +13,6 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import ops
-from .dynamic_actors import pose_inverse
 from .encodings import HashEncoding
 
 EPS = 1.0e-7
@@ -89,7 +89,7 @@ class NeuRADHashEncoding(nn.Module):
         features written over the static ones (:175-187)."""
         g = self.static_grid
         B, S = ray_samples.shape
-        rows_sm = rows_sample_major and self.n_actors == 0
+        rows_sm = bool(rows_sample_major)
         x01, std01 = ops.contract_gaussians(ray_samples.origins, ray_samples.directions, ray_samples.pixel_area,
                                             ray_samples.euclid, self.static_scale, sample_major_rows=rows_sm)
         buf = ops.hash_encode(x01, g.hash_table, g.scalings, g.log2_hashmap_size, std=std01,
@@ -98,7 +98,8 @@ class NeuRADHashEncoding(nn.Module):
         strides = (F_, n * F_) if level_major else (g.get_out_dim(), F_)
         dirs = None
         if self.n_actors > 0:
-            dirs = self._overwrite_actor_features(buf, level_major, ray_samples, directions, flip)
+            dirs = self._overwrite_actor_features(buf, level_major, ray_samples, directions, flip,
+                                                  sample_major_rows=B if rows_sm else 0)
         return buf, strides, dirs, rows_sm
 
     def forward(self, ray_samples, times: Optional[Tensor] = None, directions: Optional[Tensor] = None
@@ -108,86 +109,121 @@ class NeuRADHashEncoding(nn.Module):
         return buf, (dirs if dirs is not None else directions)
 
     # ------------------------------------------------------------------------------------------ actors
-    @torch.no_grad()
-    def _get_actor_indices(self, pos: Tensor, b2w: Tensor, valid: Tensor, w2b: Tensor):
-        """neurad_encoding.py:231-275: rays are culled by the distance of the box centre to the
-        first->last-sample line, samples by their distance to the centre, then the exact box test."""
-        bounds = self.actors.actor_bounds()
-        radii = bounds.norm(dim=-1)
-        p0 = pos[:, 0, :]
-        line = pos[:, -1, :] - p0
-        line = (line / (torch.linalg.norm(line, dim=-1, keepdim=True) + EPS)).unsqueeze(-2)
-        from_line = b2w[..., :3, 3] - p0.unsqueeze(-2)
-        dist = torch.linalg.norm(torch.cross(from_line, line.expand_as(from_line), dim=-1), dim=-1)
-        ray_idx, actor_idx = ((dist < radii) & valid).nonzero(as_tuple=False).T
-        if ray_idx.shape[0] == 0:
-            return None
-        centre = b2w[ray_idx, actor_idx, :3, 3].unsqueeze(-2)
-        within = (torch.linalg.norm(pos[ray_idx] - centre, dim=-1) < radii[actor_idx].unsqueeze(-1)).nonzero(as_tuple=False)
-        idx = torch.stack([ray_idx[within[:, 0]], within[:, 1], actor_idx[within[:, 0]]], dim=-1)
-        sel = w2b[idx[:, 0], idx[:, 2]]
-        in_box = (pos[idx[:, 0], idx[:, 1]].unsqueeze(-2) @ sel[..., :3, :3].swapaxes(-2, -1)).squeeze(-2) + sel[..., :3, 3]
-        idx = idx[(in_box.abs() < bounds[idx[:, 2]]).all(dim=-1)]
-        return (idx[:, 0], idx[:, 1], idx[:, 2]) if idx.shape[0] else None
+    MAX_CANDIDATES = 8  # actors whose bounding sphere one ray may cross; further ones are dropped (actor_overflow records it)
 
-    def _overwrite_actor_features(self, buf: Tensor, level_major: bool, rs, want_dirs: bool, flip: Optional[Tensor]):
-        """neurad_encoding.py:175-229,295-307.  Returns per-sample directions [B*S,3] (or None)."""
+    def _actor_tables(self) -> Tensor:
+        """The actor grids' tables as ONE buffer [A, L*T, F] the kernels index by actor id; the per-actor
+        `hash_table` parameters (state_dict keys unchanged) are views of it.  Re-homed lazily: `.to(device)` and
+        `load_state_dict(assign=True)` give every parameter storage of its own again."""
+        grids = list(self.actor_grids)
+        rows, flat = grids[0].hash_table.shape[0], getattr(self, "_actor_flat", None)
+        ok = flat is not None and flat.device == grids[0].hash_table.device and all(
+            g.hash_table.data_ptr() == flat.data_ptr() + a * rows * flat.shape[-1] * 4 for a, g in enumerate(grids))
+        if not ok:
+            flat = torch.stack([g.hash_table.data for g in grids]).contiguous()
+            for a, g in enumerate(grids):
+                g.hash_table.data = flat[a]
+            self._actor_flat = flat
+        return flat
+
+    def actor_geometry(self, rs, flip: Optional[Tensor] = None):
+        """Per-RAY part of the actor lookup, shared by every sampling level of a step (fixed shapes, no host read):
+        keyframe interval of each ray's time, candidate actors (nr_actor_candidates) and -- in torch, so that autograd
+        reaches the trajectories -- the world->box transforms of the (ray, candidate) pairs
+        (dynamic_actors.py:183-197, utils/poses.py:90-149)."""
+        from .dynamic_actors import pose_inverse, rotation_6d_to_matrix
+
+        act, K = self.actors, self.MAX_CANDIDATES
+        B = rs.origins.shape[0]
+        dev = rs.origins.device
+        times = rs.times[:, 0].contiguous()
+        ts = act.unique_timestamps
+        right = torch.searchsorted(ts, times)
+        left = (right - 1).clamp(min=0)
+        right = right.clamp(max=len(ts) - 1)
+        frac = ((times - ts[left]) / (ts[right] - ts[left] + 1e-6)).clamp(0.0, 1.0)
+        bounds = act.actor_bounds().contiguous()
+        cand = torch.empty((B, K), device=dev, dtype=torch.int32)
+        if not hasattr(self, "actor_overflow") or self.actor_overflow.device != dev:
+            self.actor_overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+        lib, p = ops._lib.lib(), ops._p
+        euclid = rs.euclid.contiguous()
+        ops.check(lib.nr_actor_candidates(p(rs.origins.contiguous()), p(rs.directions.contiguous()), p(euclid), B, euclid.shape[1] - 1,
+                                          p(left), p(right), p(frac.contiguous()), p(act.actor_positions.detach().contiguous()),
+                                          p(act.actor_present_at_time.to(torch.uint8).contiguous()), p(bounds), act.n_actors, K,
+                                          p(cand), p(self.actor_overflow), ops._stream()), "nr_actor_candidates")
+        with torch.enable_grad() if self.config.require_actor_grad else torch.no_grad():
+            poses = torch.cat([act.actor_rotations_6d, act.actor_positions], dim=-1)  # [T,A,9]
+            a1 = F.normalize(poses[..., :3], dim=-1)
+            a2 = poses[..., 3:6]
+            a2 = F.normalize(a2 - (a1 * a2).sum(-1, keepdim=True) * a1, dim=-1)
+            poses = torch.cat([a1, a2, poses[..., 6:9]], dim=-1)
+            c = cand.clamp(min=0).long()
+            pl, pr = poses[left[:, None], c], poses[right[:, None], c]  # [B,K,9]
+            interp = pl + (pr - pl) * frac[:, None, None]
+            b2w = torch.cat([rotation_6d_to_matrix(interp[..., :6]), interp[..., 6:].unsqueeze(-1)], dim=-1)  # [B,K,3,4]
+            w2b = pose_inverse(b2w).contiguous()
+        if flip is None and self.training and self.config.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
+            flip = torch.bernoulli(torch.full((B,), self.config.actor.flip_prob, device=dev)) * -2 + 1
+        if not self.training:
+            flip = None
+        return dict(cand=cand, w2b=w2b, centres=b2w[..., :3, 3].detach().contiguous(), bounds=bounds, flip=flip)
+
+    def _overwrite_actor_features(self, buf: Tensor, level_major: bool, rs, want_dirs: bool, flip: Optional[Tensor],
+                                  sample_major_rows: int = 0):
+        """neurad_encoding.py:175-229,295-307 on the device: nr_actor_assign + nr_actor_encode_fwd (backward:
+        nr_actor_encode_bwd).  Returns per-sample directions [B*S,3] (or None)."""
         B, S = rs.shape
-        # sample centres and isotropic std (cameras/rays.py:109-124); cheap torch ops, only the culling
-        # needs all of them
-        e0, e1 = rs.euclid[:, :-1], rs.euclid[:, 1:]
-        half = (e1 - e0) / 2
-        t = e0 + half
-        mean = rs.origins[:, None, :] + rs.directions[:, None, :] * t[..., None]
-        std = (rs.pixel_area[:, None, :] * t[..., None] ** 2 * half[..., None]).pow(1 / 3)
-        cfg = self.config
-        with torch.enable_grad() if cfg.require_actor_grad else torch.no_grad():
-            b2w, valid = self.actors.get_boxes2world(rs.times[:, 0])
-            w2b = pose_inverse(b2w)
-            found = self._get_actor_indices(mean, b2w, valid, w2b)
-            dirs_full = rs.directions[:, None, :].expand(B, S, 3).reshape(B * S, 3) if want_dirs else None
-            if found is None:
-                return dirs_full
-            ray_idx, sample_idx, actor_idx = found
-            sel = w2b[ray_idx, actor_idx]
-            rot, trans = sel[..., :3, :3], sel[..., :3, 3]
-            pos = (mean[ray_idx, sample_idx].unsqueeze(-2) @ rot.swapaxes(-2, -1)).squeeze(-2) + trans
-            flat = ray_idx * S + sample_idx
-            sign = None
-            if self.training and cfg.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
-                if flip is None:
-                    flip = torch.bernoulli(torch.full((B,), cfg.actor.flip_prob, device=pos.device)) * -2 + 1
-                sign = flip[ray_idx]
-                pos = torch.cat([pos[:, :1] * sign[:, None], pos[:, 1:]], dim=-1)
-            if want_dirs:
-                d = (rs.directions[ray_idx].unsqueeze(-2) @ rot.swapaxes(-2, -1)).squeeze(-2)
-                d = d / (torch.linalg.norm(d, dim=-1, keepdim=True) + EPS)
-                if sign is not None:
-                    d = torch.cat([d[:, :1] * sign[:, None], d[:, 1:]], dim=-1)
-                dirs_full = dirs_full.clone()
-                dirs_full[flat] = d
-        # actor_contraction (ScaledSceneContraction, scale = actor_scale) in torch: the positions carry
-        # the trajectory gradient (spatial_distortions.py:103-136)
-        x = pos / cfg.actor.actor_scale
-        s = std[ray_idx, sample_idx] / cfg.actor.actor_scale
-        mag = x.abs().amax(dim=-1, keepdim=True)
-        m = mag.clamp_min(1.0)
-        x = torch.where(mag < 1, x, (2 - (1 / m)) * (x / m))
-        s = torch.where(mag < 1, s, s * ((2 * m - 1).pow(1 / 3) / m) ** 2)
-        x01, s01 = (x + 2.0) / 4.0, (s / 4.0)[:, 0]
-        out = None
-        for a in actor_idx.unique().tolist():  # one 3-D grid per actor (_get_actor_features_slow)
-            grid: HashEncoding = self.actor_grids[int(self.actors.actor_to_id[a])]
-            mask = actor_idx == a
-            feats = ops.hash_encode(x01[mask].contiguous(), grid.hash_table, grid.scalings, grid.log2_hashmap_size,
-                                    std=s01[mask].contiguous())
-            if out is None:
-                out = torch.zeros((actor_idx.shape[0], feats.shape[-1]), device=feats.device)
-            out = out.index_put((mask.nonzero(as_tuple=True)[0],), feats)
-        padded = F.pad(out, (0, self.scene_repr_dim - out.shape[-1]))
+        geom = self.actor_geometry(rs, flip)
         g = self.static_grid
-        if level_major:  # buf is [L, N, F]: write through its [N, L, F] view
-            buf.permute(1, 0, 2)[flat] = padded.view(-1, g.num_levels, g.features_per_level)
-        else:
-            buf[flat] = padded
-        return dirs_full
+        ag = self.actor_grids[0]
+        n = B * S
+        dev = buf.device
+        slot = torch.empty(n, device=dev, dtype=torch.int32)
+        x01a, std01a = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
+        dirs = torch.empty(n, 3, device=dev) if want_dirs else None
+        lib, p = ops._lib.lib(), ops._p
+        euclid, area = rs.euclid.contiguous(), rs.pixel_area.reshape(-1).contiguous()
+        o, d = rs.origins.contiguous(), rs.directions.contiguous()
+        K = self.MAX_CANDIDATES
+        ops.check(lib.nr_actor_assign(p(o), p(d), p(area), p(euclid), B, S, sample_major_rows, p(geom["cand"]), K,
+                                      p(geom["w2b"].detach()), p(geom["centres"]), p(geom["bounds"]), self.config.actor.actor_scale,
+                                      p(geom["flip"]), p(slot), p(x01a), p(std01a), p(dirs), ops._stream()), "nr_actor_assign")
+        F_, L_s = g.features_per_level, g.num_levels
+        strides = (F_, n * F_) if level_major else (g.get_out_dim(), F_)
+        meta = dict(slot=slot, x01a=x01a, std01a=std01a, cand=geom["cand"], K=K, B=B, S=S, sm=sample_major_rows, strides=strides,
+                    static_levels=L_s, L=ag.num_levels, F=ag.features_per_level, log2t=ag.log2_hashmap_size, scalings=ag.scalings,
+                    o=o, d=d, area=area, euclid=euclid, flip=geom["flip"], actor_scale=self.config.actor.actor_scale)
+        assert ag.features_per_level == F_, "actor grids must have the static grid's features per level"
+        _ActorEncode.apply(buf, geom["w2b"], self._actor_tables(), meta, *[gr.hash_table for gr in self.actor_grids])
+        return dirs
+
+
+class _ActorEncode(torch.autograd.Function):
+    """nr_actor_encode_fwd / nr_actor_encode_bwd: writes the actor features over rows of `buf` IN PLACE."""
+
+    @staticmethod
+    def forward(ctx, buf, w2b, flat, meta, *tables):
+        m = meta
+        lib, p = ops._lib.lib(), ops._p
+        ops.check(lib.nr_actor_encode_fwd(p(m["x01a"]), p(m["std01a"]), p(m["slot"]), p(m["cand"]), m["K"], m["B"], m["S"], m["sm"],
+                                          p(flat), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(buf), m["strides"][0], m["strides"][1],
+                                          m["static_levels"], ops._stream()), "nr_actor_encode_fwd")
+        ctx.mark_dirty(buf)
+        ctx.meta, ctx.flat, ctx.w2b = m, flat, w2b.detach()
+        ctx.want_pose = w2b.requires_grad
+        return buf
+
+    @staticmethod
+    def backward(ctx, g_buf):
+        m, flat = ctx.meta, ctx.flat
+        lib, p = ops._lib.lib(), ops._p
+        g_buf = g_buf.contiguous().clone()  # rows of actor samples are zeroed for the static grid's scatter
+        g_flat = torch.zeros_like(flat)
+        g_w2b = torch.zeros_like(ctx.w2b) if ctx.want_pose else None
+        ops.check(lib.nr_actor_encode_bwd(p(m["x01a"]), p(m["std01a"]), p(m["slot"]), p(m["cand"]), m["K"], m["B"], m["S"], m["sm"],
+                                          p(flat), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(g_buf), m["strides"][0],
+                                          m["strides"][1], m["static_levels"], p(g_flat), p(m["o"]), p(m["d"]), p(m["area"]),
+                                          p(m["euclid"]), p(ctx.w2b), m["actor_scale"], p(m["flip"]), p(g_w2b), ops._stream()),
+                  "nr_actor_encode_bwd")
+        return (g_buf, g_w2b, None, None, *[g_flat[a] for a in range(g_flat.shape[0])])

@@ -85,13 +85,12 @@ class NeuRADField(nn.Module):
         B, S = ray_samples.shape
         buf, strides, dirs, rows_sm = self.hashgrid.encode_samples(ray_samples, directions=True, flip=flip,
                                                                    rows_sample_major=True)
-        # per-ray directions, or per-sample ones (n_samples = 0) when dynamic actors rotated some of them
+        # per-ray directions, or per-sample ones (nr_field_t.sample_dirs) when dynamic actors rotated some of them
         feature, sdf, alpha = ops.field_mlp(buf, strides, self.hashgrid.static_grid.features_per_level,
-                                            ray_samples.directions if dirs is None else dirs, S if dirs is None else 0,
-                                            B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
+                                            ray_samples.directions, S, B * S, self.mlp_geo.weights(), self.mlp_feature.weights(),
                                             self.sdf_to_density.beta if self.config.use_sdf else self._unused_beta,
                                             rows_sample_major=rows_sm, dtype=self.config.mlp_dtype,
-                                            grad_scale=self.config.mlp_grad_scale)
+                                            grad_scale=self.config.mlp_grad_scale, sample_dirs=dirs)
         if not self.config.use_sdf:
             # geo_out is the kernels' `sdf` output (row 0 of mlp_geo); density = trunc_exp(geo_out) on the proposal head's
             # kernel (trunc_exp of a 1-feature "grid" times the weight 1: nr_prop_density_fwd/bwd, activations.py:28-54)

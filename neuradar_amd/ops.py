@@ -163,7 +163,7 @@ class _Field(torch.autograd.Function):
     """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
 
     @staticmethod
-    def forward(ctx, feats, strides, feat_f, directions, n_samples, rows_sm, n, beta, precision, n_geo, *params):
+    def forward(ctx, feats, strides, feat_f, directions, n_samples, rows_sm, n, beta, precision, sample_dirs, n_geo, *params):
         geo_w, geo_b = params[:n_geo], params[n_geo:2 * n_geo]
         rest = params[2 * n_geo:]
         n_feat = len(rest) // 2
@@ -172,6 +172,8 @@ class _Field(torch.autograd.Function):
         fld.geo, fld.feat, fld.beta = _mlp_struct(geo_w, geo_b), _mlp_struct(feat_w, feat_b), beta.data_ptr()
         dtype, grad_scale = precision
         fld.dtype, fld.grad_scale = _lib.NR_DTYPES[dtype], float(grad_scale)
+        if sample_dirs is not None:
+            fld.sample_dirs = sample_dirs.data_ptr()
         image = None
         if fld.dtype != 0:  # bf16 / fp16 operands: the kernels read the weights from the converted image only
             image = torch.empty(_lib.lib().nr_field_image_floats(byref(fld)), device=feats.device, dtype=torch.float32)
@@ -191,6 +193,7 @@ class _Field(torch.autograd.Function):
                                       _p(feature), _p(sdf), _p(alpha), _stream()), "nr_field_fwd")
         ctx.stash, ctx.image = stash, image
         ctx.save_for_backward(feats, directions, beta, *params)
+        ctx.sample_dirs = sample_dirs
         ctx.meta = (strides, feat_f, n_samples, rows_sm, n, n_geo, n_feat, fld.dtype, fld.grad_scale)
         return feature, sdf, alpha
 
@@ -207,6 +210,8 @@ class _Field(torch.autograd.Function):
             fld.stash = ctx.stash.data_ptr()
         if ctx.image is not None:
             fld.packed = ctx.image.data_ptr()
+        if ctx.sample_dirs is not None:
+            fld.sample_dirs = ctx.sample_dirs.data_ptr()
         grads = [torch.zeros_like(p) for p in params]
         g_beta = torch.zeros_like(beta)
         gs = NrFieldGrads()
@@ -221,19 +226,24 @@ class _Field(torch.autograd.Function):
         check(_lib.lib().nr_field_bwd(byref(fld), _p(feats), sn, sl, feat_f, _p(directions), n_samples, rows_sm, n,
                                       _p(g_feature), _p(g_alpha), _p(g_sdf), _p(g_feats), byref(gs), _p(ws), _stream()),
               "nr_field_bwd")
-        return (g_feats, None, None, None, None, None, None, g_beta, None, None, *grads)
+        return (g_feats, None, None, None, None, None, None, g_beta, None, None, None, *grads)
 
 
 def field_mlp(feats: Tensor, strides: Tuple[int, int], feat_f: int, directions: Tensor, n_samples: int, n: int,
               geo: Tuple[List[Tensor], List[Tensor]], feat: Tuple[List[Tensor], List[Tensor]], beta: Tensor,
-              rows_sample_major: bool = False, dtype: str = "float32", grad_scale: float = 1.0):
+              rows_sample_major: bool = False, dtype: str = "float32", grad_scale: float = 1.0,
+              sample_dirs: Optional[Tensor] = None):
     """NeuRADField after the grid (neurad_field.py:137-148).  feats is the raw buffer written by
     hash_encode; `strides` = (stride_n, stride_l) in floats.  Returns feature [n,C], sdf [n], alpha [n]
     (always in [B,S] order; rows_sample_major: feats rows are s*B+b).
     dtype: "float32" (fp32 MFMA, the parity path), "bfloat16" or "float16": 16-bit MFMA operands with fp32 accumulation
-    (nr_field_t.dtype); grad_scale: static loss scale of the 16-bit backward (fp16 needs one)."""
+    (nr_field_t.dtype); grad_scale: static loss scale of the 16-bit backward (fp16 needs one).
+    sample_dirs [n,3]: view directions per sample (ray-major index), replacing `directions` (dynamic actors)."""
     sm = _sm_rays(rows_sample_major, n // n_samples if n_samples else 0)
-    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, sm, n, beta, (dtype, grad_scale), len(geo[0]),
+    if sample_dirs is not None:
+        sample_dirs = _f32(sample_dirs, "sample_dirs")
+    return _Field.apply(feats, strides, feat_f, _f32(directions, "directions"), n_samples, sm, n, beta, (dtype, grad_scale), sample_dirs,
+                        len(geo[0]),
                         *geo[0], *geo[1], *feat[0], *feat[1])
 
 

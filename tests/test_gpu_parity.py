@@ -1241,12 +1241,26 @@ def test_dynamic_actors_vs_reference_golden():
     assert_close(cpu(out[FieldHeadNames.FEATURE]), g["eval_feature"], rtol=1e-4, atol_scale=1e-5, what="eval feature")
     assert_close(cpu(out[FieldHeadNames.ALPHA]), g["eval_alpha"], rtol=1e-4, atol_scale=1e-5, what="eval alpha")
     assert_close(cpu(prop.get_density(rs)[0]), g["eval_prop_density"], rtol=1e-4, atol_scale=1e-5, what="eval prop density")
-    found = fld.hashgrid._get_actor_indices(
-        dev(g["origins"])[:, None, :] + dev(g["directions"])[:, None, :] * ((dev(e)[:, :-1] + dev(e)[:, 1:]) / 2)[..., None],
-        *(lambda b2w, valid: (b2w, valid, __import__("neuradar_amd.dynamic_actors", fromlist=["x"]).pose_inverse(b2w)))(
-            *actors.get_boxes2world(dev(g["times"])[:, 0])))
-    assert torch.equal(cpu(found[0]), g["actor_ray_idx"]) and torch.equal(cpu(found[1]), g["actor_sample_idx"])
-    assert torch.equal(cpu(found[2]), g["actor_actor_idx"])
+    # the (ray, sample, actor) triples of the reference's culling (neurad_encoding.py:231-275), from the device-side lookup
+    from neuradar_amd import ops
+
+    hg = fld.hashgrid
+    geom = hg.actor_geometry(rs)
+    S = e.shape[1] - 1
+    slot = torch.empty(B * S, device=DEV, dtype=torch.int32)
+    xa, sa = torch.empty(B * S, 3, device=DEV), torch.empty(B * S, device=DEV)
+    lib, p = ops._lib.lib(), ops._p
+    ops.check(lib.nr_actor_assign(p(rs.origins), p(rs.directions), p(rs.pixel_area.reshape(-1).contiguous()), p(rs.euclid), B, S, 0,
+                                  p(geom["cand"]), hg.MAX_CANDIDATES, p(geom["w2b"].detach()), p(geom["centres"]), p(geom["bounds"]),
+                                  hg.config.actor.actor_scale, None, p(slot), p(xa), p(sa), None, ops._stream()), "assign")
+    assert int(hg.actor_overflow) == 0
+    hit = (slot.view(B, S) >= 0).nonzero()
+    actor = geom["cand"][hit[:, 0], slot.view(B, S)[hit[:, 0], hit[:, 1]].long()]
+    got = set(zip(cpu(hit[:, 0]).tolist(), cpu(hit[:, 1]).tolist(), cpu(actor).tolist()))
+    want = {}
+    for r, s_, a in zip(g["actor_ray_idx"].tolist(), g["actor_sample_idx"].tolist(), g["actor_actor_idx"].tolist()):
+        want[(r, s_)] = max(a, want.get((r, s_), -1))  # a sample inside two boxes: the later (higher) actor's write wins
+    assert got == {(r, s_, a) for (r, s_), a in want.items()} and len(got) > 0
     fld.train()
     out = fld(rs, flip=dev(g["flip"]))
     assert_close(cpu(out[FieldHeadNames.FEATURE]), g["train_feature"], rtol=1e-4, atol_scale=1e-5, what="train feature")
