@@ -98,6 +98,19 @@ class FusedTrainStep:
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
+        # dynamic actors: per-level assignment buffers; the per-ray candidates / transforms are rebuilt each step
+        self.hg_main, self.hg_prop = model.field.hashgrid, self.prop.hashgrid
+        self.n_actors = self.hg_main.n_actors
+        if self.n_actors:
+            i32 = dict(device=dev, dtype=torch.int32)
+            self.a_slot = [torch.empty(B * S, **i32) for S in self.S]
+            self.a_x01 = [torch.empty(B * S, 3, **f32) for S in self.S]
+            self.a_std = [torch.empty(B * S, **f32) for S in self.S]
+            self.a_dirs = torch.empty(B * Sm, 3, **f32)
+            self.g_w2b = torch.zeros(B, self.hg_main.MAX_CANDIDATES, 3, 4, **f32)
+            self.fuse_prop_fwd = False  # actor features are written over the grid's before the density head reads them
+            for hg in (self.hg_main, self.hg_prop):
+                hg.actor_table_grads()  # raises unless tables and gradients live in their flat buffers
         self._structs()
         # Incoherent rows (the lidar rays behind the first self.sm rays) go through the two-pass binned scatter where the
         # table allows it (nr_hash_encode_bwd_binned: the proposal grids; a main grid of <= 32 slices per level): the
@@ -183,7 +196,7 @@ class FusedTrainStep:
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
                          jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None, slot: int = 0,
-                         prepared: bool = False) -> Tensor:
+                         prepared: bool = False, times: Optional[Tensor] = None, flips=None) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
@@ -199,6 +212,10 @@ class FusedTrainStep:
         after_sampling: optional callable run on a side stream once the sampling rounds have consumed the
         step's random numbers (t_rand, jitters) -- the caller refills them there for the NEXT step, off the
         critical path.
+
+        times [B] / flips: with dynamic actors, the rays' times and the per-ray random x-flips (+-1 [B] each) of the three
+        field evaluations (proposal round 0, round 1, main field; neurad_encoding.py:218-225), None = no flip.  optimizers may
+        then carry a third entry, the trajectory optimizer.
 
         reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The main table's
         gradient is exchanged as (row, value) lists right after its scatter (reduce_sparse), the proposal table's
@@ -217,6 +234,47 @@ class FusedTrainStep:
             self.prepare(slot, origins, directions, pixel_area, fars, t_rand)
         nears, far = p(self.nears), p(self.fars)
         scale = self.model.field.hashgrid.static_scale
+        geom = None
+        if self.n_actors:  # per-ray candidates + (autograd) world->box transforms, shared by the three levels
+            from types import SimpleNamespace
+
+            assert times is not None, "dynamic actors need the rays' times"
+            geom = self.hg_main.actor_geometry(SimpleNamespace(origins=origins, directions=directions, times=times.reshape(B, 1),
+                                                               euclid=self.eu[0]), flip=None, draw_flip=False)
+            geom["w2b_d"] = geom["w2b"].detach()
+            flips = flips if flips is not None else (None, None, None)
+            self.field_struct.sample_dirs = self.a_dirs.data_ptr()
+
+        def actor_overwrite(lvl, grid):
+            """Samples inside actor boxes: feats rows re-encoded from the actor's grid (after the static gather)."""
+            hg = self.hg_prop if lvl < 2 else self.hg_main
+            ag, S_, K_ = hg.actor_grids[0], self.S[lvl], hg.MAX_CANDIDATES
+            st_ = ops._stream()
+            check(lib.nr_actor_assign(o, d, area, p(self.eu[lvl]), B, S_, self.sm, p(geom["cand"]), K_, p(geom["w2b_d"]),
+                                      p(geom["centres"]), p(geom["bounds"]), hg.config.actor.actor_scale, p(flips[lvl]),
+                                      p(self.a_slot[lvl]), p(self.a_x01[lvl]), p(self.a_std[lvl]),
+                                      p(self.a_dirs) if lvl == 2 else None, st_), "actor_assign")
+            Fg = grid.features_per_level
+            check(lib.nr_actor_encode_fwd(p(self.a_x01[lvl]), p(self.a_std[lvl]), p(self.a_slot[lvl]), p(geom["cand"]), K_, B, S_,
+                                          self.sm, p(hg._actor_tables()), p(ag.scalings), ag.num_levels, ag.features_per_level,
+                                          ag.log2_hashmap_size, p(self.feats[lvl]), Fg, B * S_ * Fg, grid.num_levels, st_),
+                  "actor_encode_fwd")
+
+        def actor_backward(lvl, grid):
+            """Before the static scatter of a level: actor tables' gradients, zero rows for the static grid, pose gradients."""
+            hg = self.hg_prop if lvl < 2 else self.hg_main
+            ag, S_, K_ = hg.actor_grids[0], self.S[lvl], hg.MAX_CANDIDATES
+            Fg = grid.features_per_level
+            want_pose = lvl == 2 and hg.config.require_actor_grad and geom["w2b"].requires_grad
+            check(lib.nr_actor_encode_bwd(p(self.a_x01[lvl]), p(self.a_std[lvl]), p(self.a_slot[lvl]), p(geom["cand"]), K_, B, S_,
+                                          self.sm, p(hg._actor_tables()), p(ag.scalings), ag.num_levels, ag.features_per_level,
+                                          ag.log2_hashmap_size, p(self.g_feats[lvl]), Fg, B * S_ * Fg, grid.num_levels,
+                                          p(hg.actor_table_grads()), o, d, area, p(self.eu[lvl]), p(geom["w2b_d"]),
+                                          hg.config.actor.actor_scale, p(flips[lvl]), p(self.g_w2b) if want_pose else None,
+                                          ops._stream()), "actor_encode_bwd")
+            if want_pose:  # tiny fixed-shape autograd graph: transforms -> trajectories (positions, 6-D rotations)
+                torch.autograd.backward([geom["w2b"]], [self.g_w2b])
+
         # launches of the sampling part: bins+contraction (prepare), then per round hash grid + density -> [weights,
         # depth, resampling, contraction of the new samples].  Per-sample rows (positions, grid features, their
         # gradients) of the first self.sm rays are kept SAMPLE-major, row s*sm+b (include/neuradar_hip.h,
@@ -227,6 +285,8 @@ class FusedTrainStep:
             side[0].wait_stream(main)
         with torch.cuda.stream(side[0]):
             self.loss.zero_()
+            if self.n_actors:
+                self.g_w2b.zero_()
             check(lib.nr_field_pack(byref(self.field_struct), p(self.field_image), ops._stream()), "field_pack")
             if optimizers is not None:
                 for o_ in optimizers:
@@ -244,6 +304,8 @@ class FusedTrainStep:
                 check(self._timed(f"hash_encode_fwd[prop_s{S}]", lambda: lib.nr_hash_encode_fwd(
                     p(self.x01[lvl]), p(self.std[lvl]), p(pg.hash_table), p(pg.scalings), pg.num_levels, pg.features_per_level,
                     pg.log2_hashmap_size, p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level, n, 0, st)), "hash_fwd")
+                if self.n_actors:
+                    actor_overwrite(lvl, pg)
                 check(lib.nr_prop_density_fwd(p(self.feats[lvl]), pg.features_per_level, n * pg.features_per_level,
                                               pg.features_per_level, p(w_dec), w_dec.numel(), n, S, self.sm, p(self.dens[lvl]), st),
                       "prop_density")
@@ -257,6 +319,8 @@ class FusedTrainStep:
         check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
             p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
             p(self.feats[2]), F, n * F, n, 0, st)), "hash_fwd")
+        if self.n_actors:
+            actor_overwrite(2, mg)
         if side[0] is not main:
             main.wait_stream(side[0])
         if after_sampling is not None:
@@ -311,6 +375,9 @@ class FusedTrainStep:
             S, nl, Fg = self.S[lvl], B * self.S[lvl], grid.features_per_level
             n_coh = nl if self.binned_ws[lvl] is None else self.binned_from * S
 
+            if self.n_actors:
+                actor_backward(lvl, grid)
+
             def launch():
                 rc = lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
                                             grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
@@ -354,7 +421,7 @@ class FusedTrainStep:
                     chain_scatter(lvl)
         scatter(2, mg, "main")
         if optimizers is not None:
-            table_opt, field_opt = optimizers
+            table_opt, field_opt = optimizers[:2]
             scale = 1.0 if reducer is None else 1.0 / reducer.world
             i_prop, i_main = table_opt.buffer_of(pg.hash_table), table_opt.buffer_of(mg.hash_table)
             shared = i_prop == i_main  # tiny tables (<= 65536 elements) live in ONE flat buffer: reduce and step it once,
@@ -388,6 +455,15 @@ class FusedTrainStep:
                 reducer.wait_all()
             for i in range(len(field_opt.buffers)):
                 field_opt.step_buffer(i, scale)
+            # whatever else the table optimizer holds (per-actor grids) and the trajectory optimizer
+            others = [(table_opt, i) for i in range(len(table_opt.buffers)) if i not in (i_prop, i_main)]
+            others += [(o_, i) for o_ in optimizers[2:] for i in range(len(o_.buffers))]
+            if reducer is not None:
+                for o_, i in others:
+                    reducer.start(o_.buffers[i][1])
+                reducer.wait_all()
+            for o_, i in others:
+                o_.step_buffer(i, scale)
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:

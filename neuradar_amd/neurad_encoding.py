@@ -75,6 +75,15 @@ class NeuRADHashEncoding(nn.Module):
     def get_out_dim(self) -> int:
         return self.scene_repr_dim
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()` / `.cuda()` give every parameter storage of its own again: re-home the actor tables (and their
+        gradients) into their shared buffers right away, so that optimizers built afterwards see the final storage."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._actor_flat = None
+        if self.n_actors > 0:
+            self._actor_tables()
+        return out
+
     def get_param_groups(self, param_groups: Dict):
         param_groups["hashgrids"] += list(self.static_grid.parameters()) + list(self.actor_grids.parameters())
 
@@ -121,12 +130,26 @@ class NeuRADHashEncoding(nn.Module):
             g.hash_table.data_ptr() == flat.data_ptr() + a * rows * flat.shape[-1] * 4 for a, g in enumerate(grids))
         if not ok:
             flat = torch.stack([g.hash_table.data for g in grids]).contiguous()
+            flat_grad = torch.zeros_like(flat)
             for a, g in enumerate(grids):
+                if g.hash_table.grad is not None:
+                    flat_grad[a].copy_(g.hash_table.grad)
                 g.hash_table.data = flat[a]
-            self._actor_flat = flat
+                g.hash_table.grad = flat_grad[a]
+            self._actor_flat, self._actor_flat_grad = flat, flat_grad
         return flat
 
-    def actor_geometry(self, rs, flip: Optional[Tensor] = None):
+    def actor_table_grads(self) -> Tensor:
+        """Gradient buffer [A, L*T, F] behind the per-actor `hash_table.grad` views (see _actor_tables)."""
+        self._actor_tables()
+        grids = list(self.actor_grids)
+        fg = self._actor_flat_grad
+        if any(g.hash_table.grad is None or g.hash_table.grad.data_ptr() != fg[a].data_ptr() for a, g in enumerate(grids)):
+            raise RuntimeError("actor table gradients were re-homed (zero_grad(set_to_none=True)?): the fused step needs the "
+                               "flat buffer set up by NeuRADHashEncoding._actor_tables()")
+        return fg
+
+    def actor_geometry(self, rs, flip: Optional[Tensor] = None, draw_flip: bool = True):
         """Per-RAY part of the actor lookup, shared by every sampling level of a step (fixed shapes, no host read):
         keyframe interval of each ray's time, candidate actors (nr_actor_candidates) and -- in torch, so that autograd
         reaches the trajectories -- the world->box transforms of the (ray, candidate) pairs
@@ -163,7 +186,7 @@ class NeuRADHashEncoding(nn.Module):
             interp = pl + (pr - pl) * frac[:, None, None]
             b2w = torch.cat([rotation_6d_to_matrix(interp[..., :6]), interp[..., 6:].unsqueeze(-1)], dim=-1)  # [B,K,3,4]
             w2b = pose_inverse(b2w).contiguous()
-        if flip is None and self.training and self.config.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
+        if flip is None and draw_flip and self.training and self.config.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
             flip = torch.bernoulli(torch.full((B,), self.config.actor.flip_prob, device=dev)) * -2 + 1
         if not self.training:
             flip = None

@@ -128,9 +128,10 @@ class NeuRADProposalField(nn.Module):
         self.hashgrid.get_param_groups(param_groups)
         param_groups["fields"] += list(self.density_decoder.parameters())
 
-    def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
+    def get_density(self, ray_samples: RaySamples, flip: Optional[Tensor] = None) -> Tuple[Tensor, None]:
+        """flip [B] of +-1: the per-ray x-flip of samples inside actor boxes (drawn at random in training when None)."""
         B, S = ray_samples.shape
-        buf, strides, _, rows_sm = self.hashgrid.encode_samples(ray_samples, rows_sample_major=True)
+        buf, strides, _, rows_sm = self.hashgrid.encode_samples(ray_samples, rows_sample_major=True, flip=flip)
         density = ops.prop_density(buf, strides, self.hashgrid.static_grid.features_per_level,
                                    self.density_decoder.weight, B * S, n_samples=S, rows_sample_major=rows_sm)
         return density.view(B, S, 1), None

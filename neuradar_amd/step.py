@@ -58,19 +58,22 @@ class HotPathConfig:
 
 
 class NeuRadarHotPath(nn.Module):
-    def __init__(self, config: HotPathConfig) -> None:
+    def __init__(self, config: HotPathConfig, actors=None) -> None:
+        """actors: a `DynamicActors` module shared by the main and the proposal fields (neuradar.py:196-208,293-300)."""
         super().__init__()
         self.config = config
         c = config
-        self.field = c.field.setup(actors=None, static_scale=c.static_scale, implementation="hip")
+        self.dynamic_actors = actors
+        self.field = c.field.setup(actors=actors, static_scale=c.static_scale, implementation="hip")
         self.proposal_fields = nn.ModuleList(
-            [pc.setup(actors=None, static_scale=c.static_scale, implementation="hip")
+            [pc.setup(actors=actors, static_scale=c.static_scale, implementation="hip")
              for pc in (c.proposal_field_1, c.proposal_field_2)])
         # Reference quirk (neuradar.py:302, SURVEY Appendix B): the density_fns list is built with a
         # late-binding lambda, so BOTH proposal rounds evaluate proposal_fields[1]; proposal_fields[0]
         # exists (state_dict, optimizer, all-reduce) but never runs.  Reproduced on purpose.
         last = self.proposal_fields[-1]
-        self.density_fns = [lambda rs: last.get_density(rs)[0] for _ in self.proposal_fields]
+        self._flips = (None, None, None)  # injected per-ray actor flips of (round 0, round 1, main field); None = draw
+        self.density_fns = [lambda rs, i=i: last.get_density(rs, flip=self._flips[i])[0] for i in range(len(self.proposal_fields))]
         self.sampler = ProposalNetworkSampler(
             num_proposal_samples_per_ray=c.num_proposal_samples, num_nerf_samples_per_ray=c.num_nerf_samples,
             num_proposal_network_iterations=len(c.num_proposal_samples), single_jitter=c.single_jitter,
@@ -88,6 +91,8 @@ class NeuRadarHotPath(nn.Module):
         groups: Dict[str, List[nn.Parameter]] = {"hashgrids": [], "fields": []}
         for f in (self.field, *self.proposal_fields):
             f.get_param_groups(groups)
+        if self.dynamic_actors is not None:
+            self.dynamic_actors.get_param_groups(groups)  # "trajectory_opt" (dynamic_actors.py:203-205)
         if self.config.appearance_dim > 0:
             groups["fields"] += list(self.appearance_embedding.parameters())
         if self.config.lidar_decoder:
@@ -137,11 +142,14 @@ class NeuRadarHotPath(nn.Module):
         e1 = self.appearance_embedding(after.squeeze(-1).long())
         return e0 * (1 - ratio) + e1 * ratio
 
-    def get_nff_outputs(self, bundle: RayBundle, t_rand=None, jitters=(None, None)) -> Dict[str, Tensor]:
+    def get_nff_outputs(self, bundle: RayBundle, t_rand=None, jitters=(None, None), flips=(None, None, None)) -> Dict[str, Tensor]:
         """neuradar.py:495-548.  `bundle.pixel_area` is expected to be already scaled
-        (sensors.scale_pixel_area = _scale_pixel_area)."""
+        (sensors.scale_pixel_area = _scale_pixel_area).  flips: per-ray actor x-flips (+-1 [B]) of proposal round 0,
+        round 1 and the main field, for callers that inject the random draws (None: drawn inside, training only)."""
+        self._flips = tuple(flips)
         rs, prop_rs, prop_w = self._get_ray_samples(bundle, t_rand, jitters)
-        outputs = self.field(rs)
+        outputs = self.field(rs, flip=self._flips[2])
+        self._flips = (None, None, None)
         if FieldHeadNames.ALPHA in outputs:
             alpha = outputs[FieldHeadNames.ALPHA]
         else:  # use_sdf=False (_render_weights, neuradar.py:1018-1022): nerfacc.render_weight_from_density is alpha
