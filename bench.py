@@ -44,7 +44,32 @@ WORKLOADS = {
     # (107 x 33 = 3 531 rays) = 16 384 rays, NeuRadar's own field; fp32 (the bf16 MLP of configs[2] is not built)
     "mixed16384_neuradar": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1,
                                 grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
+    # the same batch in a scene with 12 dynamic actors (vehicles on the road ahead of the ego car, learnable trajectories,
+    # one 3-D hash grid per actor and field: neurad_encoding.py:112-133, dynamic_actors.py:98-147)
+    "mixed16384_neuradar_actors": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1, actors=12,
+                                       grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
 }
+
+
+def synthetic_actors(n_actors, seed=5):
+    """Vehicles driving along the ego lane and the neighbouring ones: keyframes at 10 Hz over the 20 s sequence, box sizes of
+    cars (w, l, h ~ 2 x 4.5 x 1.6 m), some of them present for only a part of the sequence."""
+    from neuradar_amd.dynamic_actors import DynamicActorsConfig
+
+    g = torch.Generator().manual_seed(seed)
+    ts = torch.linspace(0, 20, 201)
+    trajs = []
+    for a in range(n_actors):
+        t0, t1 = (0, 201) if a % 3 else (int(torch.randint(0, 80, (1,), generator=g)), int(torch.randint(120, 201, (1,), generator=g)))
+        tt = ts[t0:t1]
+        lane = float(torch.tensor([-3.5, 0.0, 3.5])[a % 3])
+        x0, v = -40.0 + 15.0 * a, 4.0 + 2.0 * float(torch.rand(1, generator=g))
+        yaw = 0.02 * torch.sin(0.3 * tt + a)
+        poses = torch.eye(4).repeat(len(tt), 1, 1)
+        poses[:, 0, 0], poses[:, 0, 1], poses[:, 1, 0], poses[:, 1, 1] = torch.cos(yaw), -torch.sin(yaw), torch.sin(yaw), torch.cos(yaw)
+        poses[:, 0, 3], poses[:, 1, 3], poses[:, 2, 3] = x0 + v * tt, lane + 0.2 * torch.sin(0.2 * tt), 0.8
+        trajs.append({"poses": poses, "timestamps": tt.clone(), "dims": torch.tensor([2.0, 4.5, 1.6]) + 0.3 * torch.rand(3, generator=g)})
+    return DynamicActorsConfig().setup(trajectories=trajs)
 
 
 def build_model(wl, device, mlp_dtype="float32", grad_scale=1.0):
@@ -56,7 +81,8 @@ def build_model(wl, device, mlp_dtype="float32", grad_scale=1.0):
                                                 geo_hidden_dim=wl["hidden"], nff_hidden_dim=wl["hidden"],
                                                 mlp_dtype=mlp_dtype, mlp_grad_scale=grad_scale))
     torch.manual_seed(0)  # identical replicas on every rank
-    return NeuRadarHotPath(cfg).to(device).train()
+    actors = synthetic_actors(wl["actors"]) if wl.get("actors") else None
+    return NeuRadarHotPath(cfg, actors=actors).to(device).train()
 
 
 class SyntheticScene:
@@ -175,7 +201,12 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         # The buffer is refilled for the NEXT step on a side stream as soon as the sampling rounds have read it.
         from neuradar_amd import ops as hip_ops
 
-        r = torch.rand(n_t + 2 * n_rays + n_u, device=dev)
+        has_actors = model.dynamic_actors is not None
+        n_flip = 3 * n_rays if has_actors else 0  # per-ray actor x-flips of the three field evaluations (neurad_encoding.py:218-225)
+        r = torch.rand(n_t + 2 * n_rays + n_u + n_flip, device=dev)
+        flip_p = (model.proposal_fields[1].hashgrid.config.actor.flip_prob,) * 2 + (model.field.hashgrid.config.actor.flip_prob,)
+        flip_buf = [torch.empty(3, n_rays, device=dev) for _ in range(2)] if has_actors else None
+        times_of = [None, None]
         seed = 0x5EED0000 + (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)  # seed + rank
         epoch = opts[0].step_t  # device-resident step counter (advanced by the optimizer's schedule kernel)
 
@@ -189,7 +220,12 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
 
         def assemble(slot):
             """This step's rays into buffer set `slot` (on the current stream); returns (origins, directions, area, fars)."""
-            s_ = asm.assemble(r[n_t + 2 * n_rays:], slot)
+            s_ = asm.assemble(r[n_t + 2 * n_rays:n_t + 2 * n_rays + n_u], slot)
+            if has_actors:
+                times_of[slot] = s_["times"]
+                u3 = r[n_t + 2 * n_rays + n_u:].view(3, n_rays)
+                for i_ in range(3):
+                    torch.sub(1.0, torch.lt(u3[i_], flip_p[i_]).float(), alpha=2.0, out=flip_buf[slot][i_])  # -1 with probability p
             # fars=None: every sensor's rays carry fars = 1e6 (cameras.py:948), the step's clamp to 20 km is a constant
             return s_["origins"], s_["directions"], s_["pixel_area"], None
 
@@ -219,7 +255,9 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
-                                            after_sampling=tail, slot=k, prepared=True)
+                                            after_sampling=tail, slot=k, prepared=True,
+                                            times=times_of[k] if has_actors else None,
+                                            flips=list(flip_buf[k]) if has_actors else None)
 
         fwd_bwd.state = state if pipelined else None
         fwd_bwd.last_rays = lambda: next(x for x in rays if x is not None)[:3]  # (origins, directions, pixel_area) of a slot
@@ -367,6 +405,9 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                      skip=unused),
             FlatAdam(groups["fields"], lr=1e-2 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3 * lr_scale,
                      max_steps=20001, warmup_steps=500, skip=unused)]
+    if "trajectory_opt" in groups:  # Adam lr 1e-3 -> 1e-4, 2 500 warm-up steps (method_configs.py:401-405)
+        opts.append(FlatAdam(groups["trajectory_opt"], lr=1e-3 * lr_scale, eps=1e-15, lr_final=1e-4 * lr_scale, max_steps=20001,
+                             warmup_steps=2500))
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None,
                              sparse_tables=not args.dense_allreduce and not args.autograd)

@@ -117,6 +117,16 @@ int nr_actor_candidates(const float* origins, const float* directions, const flo
                         const int64_t* left, const int64_t* right, const float* frac, const float* positions,
                         const uint8_t* present, const float* bounds, int n_actors, int K, int* cand, int* overflow,
                         nr_stream_t stream);
+/* w2b [n_rays,K,3,4], centres [n_rays,K,3] <- world->box transform and box centre of every (ray, candidate) pair from the
+ * learnable trajectories rotations_6d [T,A,6], positions [T,A,3] (dynamic_actors.py:183-197, utils/poses.py:35-49,90-149,
+ * cameras/camera_utils.py:422-443): keyframe Gram-Schmidt, linear interpolation at the ray's time, Gram-Schmidt, inverse.
+ * Backward: grad_rotations_6d / grad_positions += from grad_w2b (pairs with cand < 0 or a zero gradient are skipped). */
+int nr_actor_w2b_fwd(const int* cand, int64_t n_rays, int K, int n_actors, const int64_t* left, const int64_t* right,
+                     const float* frac, const float* rotations_6d, const float* positions, float* w2b, float* centres,
+                     nr_stream_t stream);
+int nr_actor_w2b_bwd(const int* cand, int64_t n_rays, int K, int n_actors, const int64_t* left, const int64_t* right,
+                     const float* frac, const float* rotations_6d, const float* positions, const float* grad_w2b,
+                     float* grad_rotations_6d, float* grad_positions, nr_stream_t stream);
 int nr_actor_assign(const float* origins, const float* directions, const float* pixel_area, const float* euclid,
                     int64_t n_rays, int n_samples, int sample_major_rows, const int* cand, int K, const float* w2b,
                     const float* centres, const float* bounds, float actor_scale, const float* flip, int* slot_of_row,

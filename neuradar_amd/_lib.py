@@ -48,6 +48,8 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
     "nr_actor_candidates": [P, P, P, L, I, P, P, P, P, P, P, I, I, P, P, P],
+    "nr_actor_w2b_fwd": [P, L, I, I, P, P, P, P, P, P, P, P],
+    "nr_actor_w2b_bwd": [P, L, I, I, P, P, P, P, P, P, P, P, P],
     "nr_actor_assign": [P, P, P, P, L, I, I, P, I, P, P, P, F, P, P, P, P, P, P],
     "nr_actor_encode_fwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P],
     "nr_actor_encode_bwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P, P, P, P, P, P, F, P, P, P],

@@ -294,7 +294,155 @@ actor_encode_bwd_kernel(const float* __restrict__ x01a, const float* __restrict_
   }
 }
 
+// ---- world->box transforms of the (ray, candidate) pairs from the learnable trajectories, forward and backward ----------
+// dynamic_actors.py:183-197 over interpolate_trajectories_6d (utils/poses.py:90-149), rotation_6d_to_matrix
+// (cameras/camera_utils.py:422-443) and pose_inverse (utils/poses.py:35-49): per keyframe the stored 6-D rotation is
+// orthonormalised (Gram-Schmidt), the 9-vector (b1, b2, position) is interpolated linearly at the ray's time,
+// orthonormalised again into the rotation's ROWS, and inverted.  One thread per pair, everything in registers.
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float nrm(V3 a) { return fmaxf(sqrtf(dot(a, a)), 1e-12f); }  // F.normalize's clamp
+
+struct Gs { V3 b1, b2, v; float n1, nv; };  // b1 = r1/|r1|, v = r2 - (b1.r2) b1, b2 = v/|v|
+__device__ __forceinline__ Gs gram_schmidt(V3 r1, V3 r2) {
+  Gs g;
+  g.n1 = nrm(r1);
+  g.b1 = r1 * (1.0f / g.n1);
+  g.v = r2 - g.b1 * dot(g.b1, r2);
+  g.nv = nrm(g.v);
+  g.b2 = g.v * (1.0f / g.nv);
+  return g;
+}
+// gradients wrt (r1, r2) from gradients wrt (b1, b2)
+__device__ __forceinline__ void gram_schmidt_bwd(const Gs& g, V3 r2, V3 gb1, V3 gb2, V3& gr1, V3& gr2) {
+  const V3 gv = (gb2 - g.b2 * dot(gb2, g.b2)) * (1.0f / g.nv);
+  gr2 = gv - g.b1 * dot(g.b1, gv);
+  gb1 = gb1 - r2 * dot(g.b1, gv) - gv * dot(g.b1, r2);
+  gr1 = (gb1 - g.b1 * dot(gb1, g.b1)) * (1.0f / g.n1);
+}
+
+struct PairPose { Gs kl, kr, m; V3 u1, u2, c, b3; };
+__device__ __forceinline__ PairPose pair_pose(const float* __restrict__ rot6, const float* __restrict__ pos, int64_t il, int64_t ir, float f) {
+  PairPose p;
+  p.kl = gram_schmidt(v3(rot6 + il * 6), v3(rot6 + il * 6 + 3));
+  p.kr = gram_schmidt(v3(rot6 + ir * 6), v3(rot6 + ir * 6 + 3));
+  p.u1 = p.kl.b1 + (p.kr.b1 - p.kl.b1) * f;
+  p.u2 = p.kl.b2 + (p.kr.b2 - p.kl.b2) * f;
+  const V3 pl = v3(pos + il * 3), pr = v3(pos + ir * 3);
+  p.c = pl + (pr - pl) * f;
+  p.m = gram_schmidt(p.u1, p.u2);
+  p.b3 = cross(p.m.b1, p.m.b2);
+  return p;
+}
+
+__global__ void __launch_bounds__(256)
+actor_w2b_fwd_kernel(const int* __restrict__ cand, int64_t n_pairs, int K, int n_actors, const int64_t* __restrict__ left,
+                     const int64_t* __restrict__ right, const float* __restrict__ frac, const float* __restrict__ rot6,
+                     const float* __restrict__ pos, float* __restrict__ w2b, float* __restrict__ centres) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int64_t b = i / K;
+  int a = cand[i];
+  a = a < 0 ? 0 : a;  // padding slots get actor 0's transform (never used: nr_actor_assign stops at -1)
+  const PairPose p = pair_pose(rot6, pos, left[b] * n_actors + a, right[b] * n_actors + a, frac[b]);
+  const V3 rows[3] = {p.m.b1, p.m.b2, p.b3};  // b2w rotation rows; w2b = [R^T | -R^T c]
+  float* w = w2b + i * 12;
+  const float cv[3] = {p.c.x, p.c.y, p.c.z};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {  // row r of R^T = column r of R
+    const float col[3] = {r == 0 ? rows[0].x : (r == 1 ? rows[0].y : rows[0].z), r == 0 ? rows[1].x : (r == 1 ? rows[1].y : rows[1].z),
+                          r == 0 ? rows[2].x : (r == 1 ? rows[2].y : rows[2].z)};
+    w[r * 4] = col[0]; w[r * 4 + 1] = col[1]; w[r * 4 + 2] = col[2];
+    w[r * 4 + 3] = -(col[0] * cv[0] + col[1] * cv[1] + col[2] * cv[2]);
+    centres[i * 3 + r] = cv[r];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+actor_w2b_bwd_kernel(const int* __restrict__ cand, int64_t n_pairs, int K, int n_actors, const int64_t* __restrict__ left,
+                     const int64_t* __restrict__ right, const float* __restrict__ frac, const float* __restrict__ rot6,
+                     const float* __restrict__ pos, const float* __restrict__ g_w2b, float* __restrict__ g_rot6,
+                     float* __restrict__ g_pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int a = cand[i];
+  if (a < 0) return;
+  const float* G = g_w2b + i * 12;
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) any = any || G[k] != 0.0f;
+  if (!any) return;
+  const int64_t b = i / K;
+  const float f = frac[b];
+  const int64_t il = left[b] * n_actors + a, ir = right[b] * n_actors + a;
+  const PairPose p = pair_pose(rot6, pos, il, ir, f);
+  // w2b[r][j] = R[j][r] (j < 3), w2b[r][3] = -sum_j R[j][r] c_j      (R rows b1, b2, b3)
+  const float c[3] = {p.c.x, p.c.y, p.c.z};
+  float gR[3][3], gc[3] = {0.0f, 0.0f, 0.0f};
+  const V3 rows[3] = {p.m.b1, p.m.b2, p.b3};
+  const float R[3][3] = {{rows[0].x, rows[0].y, rows[0].z}, {rows[1].x, rows[1].y, rows[1].z}, {rows[2].x, rows[2].y, rows[2].z}};
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      gR[j][r] = G[r * 4 + j] - c[j] * G[r * 4 + 3];
+      gc[j] -= R[j][r] * G[r * 4 + 3];
+    }
+  V3 gb1 = {gR[0][0], gR[0][1], gR[0][2]}, gb2 = {gR[1][0], gR[1][1], gR[1][2]};
+  const V3 gb3 = {gR[2][0], gR[2][1], gR[2][2]};
+  gb1 = gb1 + cross(p.m.b2, gb3);  // b3 = b1 x b2
+  gb2 = gb2 + cross(gb3, p.m.b1);
+  V3 gu1, gu2;
+  gram_schmidt_bwd(p.m, p.u2, gb1, gb2, gu1, gu2);
+  const float wl = 1.0f - f, wr = f;
+  V3 gr1, gr2;
+  gram_schmidt_bwd(p.kl, v3(rot6 + il * 6 + 3), gu1 * wl, gu2 * wl, gr1, gr2);
+  const float gl[6] = {gr1.x, gr1.y, gr1.z, gr2.x, gr2.y, gr2.z};
+  gram_schmidt_bwd(p.kr, v3(rot6 + ir * 6 + 3), gu1 * wr, gu2 * wr, gr1, gr2);
+  const float gr_[6] = {gr1.x, gr1.y, gr1.z, gr2.x, gr2.y, gr2.z};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (gl[k] != 0.0f) unsafeAtomicAdd(g_rot6 + il * 6 + k, gl[k]);
+    if (gr_[k] != 0.0f) unsafeAtomicAdd(g_rot6 + ir * 6 + k, gr_[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (gc[k] * wl != 0.0f) unsafeAtomicAdd(g_pos + il * 3 + k, gc[k] * wl);
+    if (gc[k] * wr != 0.0f) unsafeAtomicAdd(g_pos + ir * 3 + k, gc[k] * wr);
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_actor_w2b_fwd(const int* cand, int64_t n_rays, int K, int n_actors, const int64_t* left, const int64_t* right,
+                                const float* frac, const float* rotations_6d, const float* positions, float* w2b, float* centres,
+                                nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!cand || !left || !right || !frac || !rotations_6d || !positions || !w2b || !centres || K < 1 || n_actors < 1 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(actor_w2b_fwd_kernel, dim3((unsigned)nr_cdiv(n_rays * K, 256)), dim3(256), 0, nr_s(stream), cand, n_rays * K, K,
+                     n_actors, left, right, frac, rotations_6d, positions, w2b, centres);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_actor_w2b_bwd(const int* cand, int64_t n_rays, int K, int n_actors, const int64_t* left, const int64_t* right,
+                                const float* frac, const float* rotations_6d, const float* positions, const float* grad_w2b,
+                                float* grad_rotations_6d, float* grad_positions, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!cand || !left || !right || !frac || !rotations_6d || !positions || !grad_w2b || !grad_rotations_6d || !grad_positions ||
+      K < 1 || n_actors < 1 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(actor_w2b_bwd_kernel, dim3((unsigned)nr_cdiv(n_rays * K, 256)), dim3(256), 0, nr_s(stream), cand, n_rays * K, K,
+                     n_actors, left, right, frac, rotations_6d, positions, grad_w2b, grad_rotations_6d, grad_positions);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_actor_candidates(const float* origins, const float* directions, const float* euclid, int64_t n_rays, int S,
                                    const int64_t* left, const int64_t* right, const float* frac, const float* positions,

@@ -154,8 +154,6 @@ class NeuRADHashEncoding(nn.Module):
         keyframe interval of each ray's time, candidate actors (nr_actor_candidates) and -- in torch, so that autograd
         reaches the trajectories -- the world->box transforms of the (ray, candidate) pairs
         (dynamic_actors.py:183-197, utils/poses.py:90-149)."""
-        from .dynamic_actors import pose_inverse, rotation_6d_to_matrix
-
         act, K = self.actors, self.MAX_CANDIDATES
         B = rs.origins.shape[0]
         dev = rs.origins.device
@@ -176,21 +174,12 @@ class NeuRADHashEncoding(nn.Module):
                                           p(act.actor_present_at_time.to(torch.uint8).contiguous()), p(bounds), act.n_actors, K,
                                           p(cand), p(self.actor_overflow), ops._stream()), "nr_actor_candidates")
         with torch.enable_grad() if self.config.require_actor_grad else torch.no_grad():
-            poses = torch.cat([act.actor_rotations_6d, act.actor_positions], dim=-1)  # [T,A,9]
-            a1 = F.normalize(poses[..., :3], dim=-1)
-            a2 = poses[..., 3:6]
-            a2 = F.normalize(a2 - (a1 * a2).sum(-1, keepdim=True) * a1, dim=-1)
-            poses = torch.cat([a1, a2, poses[..., 6:9]], dim=-1)
-            c = cand.clamp(min=0).long()
-            pl, pr = poses[left[:, None], c], poses[right[:, None], c]  # [B,K,9]
-            interp = pl + (pr - pl) * frac[:, None, None]
-            b2w = torch.cat([rotation_6d_to_matrix(interp[..., :6]), interp[..., 6:].unsqueeze(-1)], dim=-1)  # [B,K,3,4]
-            w2b = pose_inverse(b2w).contiguous()
+            w2b, centres = _ActorPoses.apply(act.actor_rotations_6d, act.actor_positions, cand, left, right, frac.contiguous())
         if flip is None and draw_flip and self.training and self.config.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
             flip = torch.bernoulli(torch.full((B,), self.config.actor.flip_prob, device=dev)) * -2 + 1
         if not self.training:
             flip = None
-        return dict(cand=cand, w2b=w2b, centres=b2w[..., :3, 3].detach().contiguous(), bounds=bounds, flip=flip)
+        return dict(cand=cand, w2b=w2b, centres=centres, bounds=bounds, flip=flip)
 
     def _overwrite_actor_features(self, buf: Tensor, level_major: bool, rs, want_dirs: bool, flip: Optional[Tensor],
                                   sample_major_rows: int = 0):
@@ -220,6 +209,35 @@ class NeuRADHashEncoding(nn.Module):
         assert ag.features_per_level == F_, "actor grids must have the static grid's features per level"
         _ActorEncode.apply(buf, geom["w2b"], self._actor_tables(), meta, *[gr.hash_table for gr in self.actor_grids])
         return dirs
+
+
+class _ActorPoses(torch.autograd.Function):
+    """nr_actor_w2b_fwd / nr_actor_w2b_bwd: trajectories -> world->box transforms of the (ray, candidate) pairs.  One
+    launch each way (the same chain in torch ops -- fancy-index gathers, batched 3x3 matmuls -- cost 12 ms per step in
+    its backward alone at 16 384 rays)."""
+
+    @staticmethod
+    def forward(ctx, rot6, pos, cand, left, right, frac):
+        B, K = cand.shape
+        rot6c, posc = rot6.detach().contiguous(), pos.detach().contiguous()
+        w2b = torch.empty((B, K, 3, 4), device=cand.device, dtype=torch.float32)
+        centres = torch.empty((B, K, 3), device=cand.device, dtype=torch.float32)
+        lib, p = ops._lib.lib(), ops._p
+        ops.check(lib.nr_actor_w2b_fwd(p(cand), B, K, rot6.shape[1], p(left), p(right), p(frac), p(rot6c), p(posc), p(w2b), p(centres),
+                                       ops._stream()), "nr_actor_w2b_fwd")
+        ctx.save_for_backward(rot6c, posc, cand, left, right, frac)
+        ctx.mark_non_differentiable(centres)
+        return w2b, centres
+
+    @staticmethod
+    def backward(ctx, g_w2b, _g_centres):
+        rot6, pos, cand, left, right, frac = ctx.saved_tensors
+        B, K = cand.shape
+        g_rot6, g_pos = torch.zeros_like(rot6), torch.zeros_like(pos)
+        lib, p = ops._lib.lib(), ops._p
+        ops.check(lib.nr_actor_w2b_bwd(p(cand), B, K, rot6.shape[1], p(left), p(right), p(frac), p(rot6), p(pos),
+                                       p(g_w2b.contiguous()), p(g_rot6), p(g_pos), ops._stream()), "nr_actor_w2b_bwd")
+        return g_rot6, g_pos, None, None, None, None
 
 
 class _ActorEncode(torch.autograd.Function):
