@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 9
+#define NR_ABI_VERSION 10
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -336,6 +336,20 @@ int nr_composite_bwd(const float* alpha, const float* feature, const float* eucl
 int nr_depth_from_weights(const float* weights, const float* euclid, int64_t n_rays, int n_samples,
                           float* depth, nr_stream_t stream);
 
+/* Lidar supervision of the weights (the "carving" terms of models/neuradar.py:529-531,537-541,637-638,650 with
+ * _compute_is_close_to_lidar :971-994): for a lidar ray, a sample is "close" when |range - t_mid| < carving_epsilon (the ray
+ * returned) or t_mid < non_return_distance (it did not); the loss adds weight * sum over the ray's other samples of w_s^2,
+ * i.e. sum((w * mask)^2) * weight with mask = is_lidar & !close.  `weight` already contains the level's multiplier and
+ * 1 / (number of lidar rays in the batch).  All arrays are per ray [n_rays]. */
+typedef struct nr_lidar_sup {
+  const uint8_t* is_lidar;
+  const uint8_t* did_return;
+  const float* range;          /* RayBundle.metadata["directions_norm"]: the measured distance of a lidar ray */
+  float carving_epsilon;       /* 0.1   (LossSettings.carving_epsilon, neuradar.py:94) */
+  float non_return_distance;   /* 150 m (non_return_lidar_distance, :102) */
+  float weight;
+} nr_lidar_sup_t;
+
 /* One-launch training tail of a ray batch: nr_composite_fwd, then the bench loss
  *   rgb_mult * mean((features - target_features)^2) + depth_mult * mean(|depth - target_depth|)
  *   + distortion_mult * distortion(spacing, weights[:, :S-1])      (losses.py:137-157)
@@ -348,7 +362,11 @@ int nr_render_train(const float* alpha, const float* feature, const float* eucli
                     const float* target_features, const float* target_depth, int64_t n_rays, int n_samples,
                     int n_channels, float rgb_mult, float depth_mult, float distortion_mult,
                     float* weights, float* accumulation, float* features, float* depth,
-                    float* grad_alpha, float* grad_feature, float* loss, nr_stream_t stream);
+                    float* grad_alpha, float* grad_feature, float* loss, const float* grad_features_extra,
+                    const nr_lidar_sup_t* lidar, nr_stream_t stream);
+/* grad_features_extra [n_rays,C] (nullable): an upstream gradient on the rendered features from a consumer the launch does
+ * not contain (per-ray decoders), added to the supervision term's.  lidar (nullable): carving term on the first S-1
+ * samples (the sky sample is dropped before the reference computes non_nearby_weights, neuradar.py:515,537-541). */
 
 /* ------------------------------------------------------------------------------------------------
  * Sensor ray generation (device-side; the reference runs these on CPU workers)
@@ -432,7 +450,28 @@ int nr_interlevel_loss(const float* c, int c_stride, const float* w, int w_strid
 int nr_interlevel_loss_to_density(const float* c, int c_stride, const float* w, int w_stride, int n_used,
                                   const float* c_prop, const float* w_prop, const float* density_prop,
                                   const float* euclid_prop, int n_prop, int64_t n_rays, float pulse_width,
-                                  float mult, float* grad_density_prop, float* loss, nr_stream_t stream);
+                                  float mult, float* grad_density_prop, float* loss, const nr_lidar_sup_t* lidar,
+                                  nr_stream_t stream);
+/* lidar (nullable): + weight * sum_j (w_prop_j * mask_j)^2 over ALL samples of the proposal level (prop_weights_loss_i,
+ * neuradar.py:529-531). */
+
+/* Temporal appearance embedding (models/neuradar.py:550-568) concatenated to the rendered features of rays
+ * [row0, row0 + n_rows): out [n_rows, C + A] = [features[row] | lerp(table[sensor*E + floor(t/duration*E)], next, ratio)]
+ * -- the input rows of a per-ray decoder (:510-512).  table [n_sensors*E, A]; times [n_rays]; sensor_idx [n_rays] int64.
+ * Backward: grad_features [n_rays, C] rows [row0, row0+n_rows) <- the first C columns of grad_out; grad_table +=. */
+int nr_appearance_concat_fwd(const float* features, int n_channels, const float* table, int app_dim, const float* times,
+                             const int64_t* sensor_idx, float duration, int embeds_per_sensor, int64_t row0, int64_t n_rows,
+                             float* out, nr_stream_t stream);
+int nr_appearance_concat_bwd(const float* grad_out, int n_channels, int app_dim, const float* times, const int64_t* sensor_idx,
+                             float duration, int embeds_per_sensor, int64_t row0, int64_t n_rows, float* grad_features,
+                             float* grad_table, int64_t table_rows, nr_stream_t stream);
+/* Losses of the lidar decoder's two outputs y [n,2] (models/neuradar.py:432-452,624-636 with the multipliers of :690-700):
+ * intensity_mult * mean over RETURNING rays of (sigmoid(y0) - target_intensity)^2 (inv_n_returning: device scalar, 1 / their
+ * number) + ray_drop_mult * mean BCE-with-logits(y1, !did_return).  The reference additionally masks by the 95 % quantile of
+ * the depth residual (a sort): not part of this launch.  -> grad_y [n,2] (overwritten), loss +=. */
+int nr_lidar_head_loss(const float* y, const float* target_intensity, const uint8_t* did_return, int64_t n,
+                       const float* inv_n_returning, float intensity_mult, float ray_drop_mult, float* grad_y, float* loss,
+                       nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer: dense Adam/AdamW over a flat parameter buffer, one pass (param, grad, m, v), grad

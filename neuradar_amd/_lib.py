@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 9
+NR_ABI_VERSION = 10
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -30,6 +30,11 @@ class NrMlpGrads(Structure):
 class NrField(Structure):
     _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p),
                 ("dtype", c_int), ("sample_dirs", c_void_p), ("grad_scale", c_float)]
+
+
+class NrLidarSup(Structure):
+    _fields_ = [("is_lidar", c_void_p), ("did_return", c_void_p), ("range", c_void_p), ("carving_epsilon", c_float),
+                ("non_return_distance", c_float), ("weight", c_float)]
 
 
 class NrFieldGrads(Structure):
@@ -75,7 +80,10 @@ PROTOTYPES = {
     "nr_pdf_resample": [P, P, P, P, P, L, I, I, F, F, F, P, P, P],
     "nr_composite_fwd": [P, P, P, L, I, I, P, P, P, P, P],
     "nr_composite_bwd": [P, P, P, P, P, P, P, P, L, I, I, P, P, P],
-    "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P],
+    "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P, POINTER(NrLidarSup), P],
+    "nr_appearance_concat_fwd": [P, I, P, I, P, P, F, I, L, L, P, P],
+    "nr_appearance_concat_bwd": [P, I, I, P, P, F, I, L, L, P, P, L, P],
+    "nr_lidar_head_loss": [P, P, P, L, P, F, F, P, P, P],
     "nr_depth_from_weights": [P, P, L, I, P, P],
     "nr_gen_rays_camera": [P, P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P],
     "nr_gen_rays_lidar": [P, P, I, P, P, P, L, P, P, P, P, P, P, P],
@@ -87,7 +95,7 @@ PROTOTYPES = {
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
-    "nr_interlevel_loss_to_density": [P, I, P, I, I, P, P, P, P, I, L, F, F, P, P, P],
+    "nr_interlevel_loss_to_density": [P, I, P, I, I, P, P, P, P, I, L, F, F, P, P, POINTER(NrLidarSup), P],
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
     "nr_grad_compact": [P, L, I, L, P, P, P, P],
     "nr_grad_apply": [P, P, P, L, I, P, P],

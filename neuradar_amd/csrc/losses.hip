@@ -86,7 +86,7 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
                        const float* __restrict__ cp, const float* __restrict__ wp, int Sp, int64_t n_rays, float pulse,
                        float mult, float* __restrict__ g_wp, float* __restrict__ loss,
                        const float* __restrict__ density_p, const float* __restrict__ euclid_p,
-                       float* __restrict__ g_density_p) {
+                       float* __restrict__ g_density_p, nr_lidar_sup_t lidar) {
   __shared__ float s_knot[kWavesPerBlock][kMaxKnots];   // c_  : [0, sorted knots, 1]
   __shared__ float s_val[kWavesPerBlock][kMaxKnots];    // w_  : blurred density at the knots
   __shared__ float s_cdf[kWavesPerBlock][kMaxKnots];    // cdf : integral of the piecewise-linear density
@@ -218,7 +218,10 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // ---- loss and its gradient w.r.t. the proposal weights (:700-704) ----
   const float k = mult / (float)n_rays;
-  float l = 0.0f;
+  float l = 0.0f, lc = 0.0f;
+  const bool carve = lidar.is_lidar != nullptr && euclid_p != nullptr && lidar.is_lidar[ray] != 0;
+  const bool carve_ret = carve && lidar.did_return[ray] != 0;
+  const float carve_range = carve ? lidar.range[ray] : 0.0f;
   float gj[kPerLane];
 #pragma unroll
   for (int t = 0; t < kPerLane; ++t) {
@@ -230,11 +233,20 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
       const float ex = fmaxf(target - p, 0.0f), den = p + 1e-5f;
       l += ex * ex / den;
       gj[t] = k * (-2.0f * ex / den - ex * ex / (den * den));
+      if (carve) {  // prop_weights_loss_i = sum((w * mask)^2), neuradar.py:529-531
+        const float mid = (euclid_p[ray * (Sp + 1) + j] + euclid_p[ray * (Sp + 1) + j + 1]) * 0.5f;
+        const bool close = carve_ret ? fabsf(carve_range - mid) < lidar.carving_epsilon : mid < lidar.non_return_distance;
+        if (!close) {
+          lc += p * p;
+          gj[t] += 2.0f * lidar.weight * p;
+        }
+      }
       if (g_wp != nullptr) g_wp[ray * Sp + j] = gj[t];
     }
   }
-  l = nr_wave_sum(l);
-  if (lane == 0) unsafeAtomicAdd(loss_slot(loss), k * l);
+  l = k * nr_wave_sum(l);
+  if (carve) l += lidar.weight * nr_wave_sum(lc);
+  if (lane == 0) unsafeAtomicAdd(loss_slot(loss), l);
   if constexpr (ITEMS > 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // every lane has read its q[j], q[j+1]
@@ -251,7 +263,145 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   }
 }
 
+// Temporal appearance embedding (neuradar.py:556-565) next to the rendered features of rays [row0, row0 + n_rows)
+__device__ __forceinline__ void appearance_index(float t, int64_t sensor, float duration, int E, int64_t& before, int64_t& after,
+                                                 float& ratio) {
+  const float ti = t / duration * (float)E;
+  float b = floorf(ti);
+  b = fminf(fmaxf(b, 0.0f), (float)(E - 1));
+  const float a = fminf(fmaxf(b + 1.0f, 0.0f), (float)(E - 1));
+  ratio = ti - b;
+  before = (int64_t)b + sensor * E;
+  after = (int64_t)a + sensor * E;
+}
+
+__global__ void __launch_bounds__(256)
+appearance_concat_fwd_kernel(const float* __restrict__ features, int C, const float* __restrict__ table, int A,
+                             const float* __restrict__ times, const int64_t* __restrict__ sensor_idx, float duration, int E,
+                             int64_t row0, int64_t n_rows, float* __restrict__ out) {
+  const int W = C + A;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * W) return;
+  const int64_t r = i / W;
+  const int c = (int)(i - r * W);
+  const int64_t ray = row0 + r;
+  if (c < C) {
+    out[i] = features[ray * C + c];
+    return;
+  }
+  int64_t b, a;
+  float ratio;
+  appearance_index(times[ray], sensor_idx[ray], duration, E, b, a, ratio);
+  out[i] = table[b * A + (c - C)] * (1.0f - ratio) + table[a * A + (c - C)] * ratio;
+}
+
+constexpr int kAppLds = 4096;  // table gradients of up to this many floats are summed per block in LDS first
+__global__ void __launch_bounds__(256)
+appearance_concat_bwd_kernel(const float* __restrict__ g_out, int C, int A, const float* __restrict__ times,
+                             const int64_t* __restrict__ sensor_idx, float duration, int E, int64_t row0, int64_t n_rows,
+                             float* __restrict__ g_features, float* __restrict__ g_table, int64_t table_rows) {
+  __shared__ float acc[kAppLds];
+  const bool use_lds = table_rows * A <= kAppLds;
+  if (use_lds) {
+    for (int k = threadIdx.x; k < table_rows * A; k += blockDim.x) acc[k] = 0.0f;
+    __syncthreads();
+  }
+  const int W = C + A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * W; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / W;
+    const int c = (int)(i - r * W);
+    const int64_t ray = row0 + r;
+    const float g = g_out[i];
+    if (c < C) {
+      g_features[ray * C + c] = g;
+      continue;
+    }
+    if (g == 0.0f) continue;
+    int64_t b, a;
+    float ratio;
+    appearance_index(times[ray], sensor_idx[ray], duration, E, b, a, ratio);
+    if (use_lds) {
+      atomicAdd(&acc[b * A + (c - C)], g * (1.0f - ratio));
+      atomicAdd(&acc[a * A + (c - C)], g * ratio);
+    } else {
+      unsafeAtomicAdd(g_table + b * A + (c - C), g * (1.0f - ratio));
+      unsafeAtomicAdd(g_table + a * A + (c - C), g * ratio);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < table_rows * A; k += blockDim.x)
+      if (acc[k] != 0.0f) unsafeAtomicAdd(g_table + k, acc[k]);
+  }
+}
+
+// neuradar.py:432-452,624-636: intensity MSE on returning rays, ray-drop BCE with logits on all lidar rays
+__global__ void __launch_bounds__(256)
+lidar_head_loss_kernel(const float* __restrict__ y, const float* __restrict__ target_i, const uint8_t* __restrict__ did_return,
+                       int64_t n, const float* __restrict__ inv_n_ret, float ki, float kd, float* __restrict__ g_y,
+                       float* __restrict__ loss) {
+  float acc = 0.0f;
+  const float inv_ret = inv_n_ret[0], inv_n = 1.0f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float y0 = y[i * 2], y1 = y[i * 2 + 1];
+    const bool ret = did_return[i] != 0;
+    float g0 = 0.0f;
+    if (ret) {
+      const float s = 1.0f / (1.0f + expf(-y0));
+      const float d = s - target_i[i];
+      acc += ki * inv_ret * d * d;
+      g0 = 2.0f * ki * inv_ret * d * s * (1.0f - s);
+    }
+    // BCE with logits, target z = !did_return: max(y,0) - y z + log(1 + exp(-|y|))
+    const float z = ret ? 0.0f : 1.0f;
+    acc += kd * inv_n * (fmaxf(y1, 0.0f) - y1 * z + log1pf(expf(-fabsf(y1))));
+    const float sg = 1.0f / (1.0f + expf(-y1));
+    g_y[i * 2] = g0;
+    g_y[i * 2 + 1] = kd * inv_n * (sg - z);
+  }
+  acc = nr_wave_sum(acc);
+  if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss_slot(loss), acc);
+}
+
 }  // namespace
+
+extern "C" int nr_appearance_concat_fwd(const float* features, int C, const float* table, int A, const float* times,
+                                        const int64_t* sensor_idx, float duration, int E, int64_t row0, int64_t n_rows, float* out,
+                                        nr_stream_t stream) {
+  if (n_rows == 0) return 0;
+  if (!features || !table || !times || !sensor_idx || !out || C < 1 || A < 1 || E < 1 || !(duration > 0) || row0 < 0 || n_rows < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(appearance_concat_fwd_kernel, dim3((unsigned)nr_cdiv(n_rows * (C + A), 256)), dim3(256), 0, nr_s(stream), features,
+                     C, table, A, times, sensor_idx, duration, E, row0, n_rows, out);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_appearance_concat_bwd(const float* g_out, int C, int A, const float* times, const int64_t* sensor_idx, float duration,
+                                        int E, int64_t row0, int64_t n_rows, float* g_features, float* g_table, int64_t table_rows,
+                                        nr_stream_t stream) {
+  if (n_rows == 0) return 0;
+  if (!g_out || !times || !sensor_idx || !g_features || !g_table || C < 1 || A < 1 || E < 1 || !(duration > 0) || row0 < 0 ||
+      n_rows < 0 || table_rows < 1)
+    return NR_EINVAL;
+  const int64_t want = nr_cdiv(n_rows * (C + A), 256);
+  hipLaunchKernelGGL(appearance_concat_bwd_kernel, dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, nr_s(stream), g_out, C, A,
+                     times, sensor_idx, duration, E, row0, n_rows, g_features, g_table, table_rows);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_lidar_head_loss(const float* y, const float* target_intensity, const uint8_t* did_return, int64_t n,
+                                  const float* inv_n_returning, float intensity_mult, float ray_drop_mult, float* g_y, float* loss,
+                                  nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!y || !target_intensity || !did_return || !inv_n_returning || !g_y || !loss || n < 0) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n, 256);
+  hipLaunchKernelGGL(lidar_head_loss_kernel, dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, nr_s(stream), y, target_intensity,
+                     did_return, n, inv_n_returning, intensity_mult, ray_drop_mult, g_y, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_supervision_loss(const float* features, int feat_stride, const float* target_f, int C,
                                    const float* depth, const float* target_d, int64_t n_rays, float rgb_mult,
@@ -288,7 +438,8 @@ extern "C" int nr_interlevel_loss(const float* c, int c_stride, const float* w, 
       c_stride < n_used + 1 || Sp < 1 || Sp > kMaxProp || !(pulse > 0.0f) || n_rays < 0)
     return NR_EINVAL;
   hipLaunchKernelGGL(interlevel_loss_kernel<0>, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
-                     c, c_stride, w, w_stride, n_used, cp, wp, Sp, n_rays, pulse, mult, g_wp, loss, nullptr, nullptr, nullptr);
+                     c, c_stride, w, w_stride, n_used, cp, wp, Sp, n_rays, pulse, mult, g_wp, loss, nullptr, nullptr, nullptr,
+                     nr_lidar_sup_t{});
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -296,15 +447,21 @@ extern "C" int nr_interlevel_loss(const float* c, int c_stride, const float* w, 
 extern "C" int nr_interlevel_loss_to_density(const float* c, int c_stride, const float* w, int w_stride, int n_used,
                                              const float* cp, const float* wp, const float* density_p,
                                              const float* euclid_p, int Sp, int64_t n_rays, float pulse, float mult,
-                                             float* g_density_p, float* loss, nr_stream_t stream) {
+                                             float* g_density_p, float* loss, const nr_lidar_sup_t* lidar,
+                                             nr_stream_t stream) {
   if (n_rays == 0) return 0;
+  nr_lidar_sup_t lid = {};
+  if (lidar != nullptr) {
+    if (!lidar->is_lidar || !lidar->did_return || !lidar->range) return NR_EINVAL;
+    lid = *lidar;
+  }
   if (!c || !w || !cp || !wp || !density_p || !euclid_p || !g_density_p || !loss || n_used < 1 || n_used > 31 ||
       w_stride < n_used || c_stride < n_used + 1 || Sp < 1 || Sp > kMaxProp || !(pulse > 0.0f) || n_rays < 0)
     return NR_EINVAL;
   const dim3 grid((unsigned)nr_cdiv(n_rays, kWavesPerBlock));
 #define CALL(I)                                                                                                          \
   hipLaunchKernelGGL(interlevel_loss_kernel<I>, grid, dim3(256), 0, nr_s(stream), c, c_stride, w, w_stride, n_used, cp, wp, \
-                     Sp, n_rays, pulse, mult, nullptr, loss, density_p, euclid_p, g_density_p)
+                     Sp, n_rays, pulse, mult, nullptr, loss, density_p, euclid_p, g_density_p, lid)
   if (Sp <= 64) { CALL(1); } else if (Sp <= 128) { CALL(2); } else { CALL(4); }
 #undef CALL
   NR_LAUNCH_CHECK();

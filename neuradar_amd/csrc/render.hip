@@ -115,7 +115,8 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
                     const float* __restrict__ target_d, int64_t n_rays, int S, int C, float rgb_mult, float depth_mult,
                     float dist_mult, float* __restrict__ weights, float* __restrict__ accumulation,
                     float* __restrict__ features, float* __restrict__ depth, float* __restrict__ g_alpha,
-                    float* __restrict__ g_feature, float* __restrict__ loss) {
+                    float* __restrict__ g_feature, float* __restrict__ loss, const float* __restrict__ g_features_extra,
+                    nr_lidar_sup_t lidar) {
   const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const int lane = nr_lane();
@@ -151,7 +152,8 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
   const float kf = rgb_mult / (float)(n_rays * C), kd = depth_mult / (float)n_rays;
   const float diff = cvalid ? fsum - target_f[ray * C + c] : 0.0f;
   float lossv = sh == 0 ? kf * diff * diff : 0.0f;
-  const float gF = 2.0f * kf * diff;  // d loss / d features[c], in both halves
+  float gF = 2.0f * kf * diff;  // d loss / d features[c], in both halves
+  if (g_features_extra != nullptr && cvalid) gF += g_features_extra[ray * C + c];
   const float dd = d - target_d[ray];
   if (lane == 0) lossv += kd * fabsf(dd);
   const float gD = dd > 0.0f ? kd : (dd < 0.0f ? -kd : 0.0f);
@@ -167,7 +169,15 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
   for (int j = 0; j < n_used; ++j) inner += readlane_f(wi, j) * fabsf(mid_c - readlane_f(mid_c, j));
   const float kdist = dist_mult / (float)n_rays;
   if (on) lossv += kdist * (wi * inner + wi * wi * (c1 - c0) / 3.0f);
-  const float gW = on ? kdist * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
+  float gW = on ? kdist * (2.0f * inner + 2.0f * wi * (c1 - c0) / 3.0f) : 0.0f;
+  if (lidar.is_lidar != nullptr && lidar.is_lidar[ray]) {  // carving: the weights away from the measured return (neuradar.py:537-541)
+    const bool ret = lidar.did_return[ray] != 0;
+    const bool close = ret ? fabsf(lidar.range[ray] - mid_e) < lidar.carving_epsilon : mid_e < lidar.non_return_distance;
+    if (on && !close) {
+      lossv += lidar.weight * wi * wi;
+      gW += 2.0f * lidar.weight * wi;
+    }
+  }
   lossv = nr_wave_sum(lossv);
   if (lane == 0 && lossv != 0.0f) unsafeAtomicAdd(loss + nr_loss_slot_index(), lossv);
   // ---- composite backward ----
@@ -270,20 +280,25 @@ extern "C" int nr_render_train(const float* alpha, const float* feature, const f
                                const float* target_features, const float* target_depth, int64_t n_rays, int S, int C,
                                float rgb_mult, float depth_mult, float distortion_mult, float* weights,
                                float* accumulation, float* features, float* depth, float* g_alpha, float* g_feature,
-                               float* loss, nr_stream_t stream) {
+                               float* loss, const float* g_features_extra, const nr_lidar_sup_t* lidar, nr_stream_t stream) {
   if (n_rays == 0) return 0;
   if (!alpha || !feature || !euclid || !spacing || !target_features || !target_depth || !weights || !accumulation ||
       !features || !depth || !g_alpha || !g_feature || !loss || S < 2 || S > NR_WAVE || C < 1 || C > 32 || n_rays < 0)
     return NR_EINVAL;
+  nr_lidar_sup_t lid = {};
+  if (lidar != nullptr) {
+    if (!lidar->is_lidar || !lidar->did_return || !lidar->range) return NR_EINVAL;
+    lid = *lidar;
+  }
   const dim3 grid((unsigned)nr_cdiv(n_rays, kWavesPerBlock));
   if (S <= 32)
     hipLaunchKernelGGL(render_train_kernel<16>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
                        target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
-                       accumulation, features, depth, g_alpha, g_feature, loss);
+                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, lid);
   else
     hipLaunchKernelGGL(render_train_kernel<32>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
                        target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
-                       accumulation, features, depth, g_alpha, g_feature, loss);
+                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, lid);
   NR_LAUNCH_CHECK();
   return 0;
 }

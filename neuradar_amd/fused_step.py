@@ -46,7 +46,6 @@ class FusedTrainStep:
         self.overlap = overlap and os.environ.get("NR_STEP_OVERLAP", "1") != "0"  # tuning knob
         self._streams = None
         self.timers = None  # dict name -> [(start, end) events]: set by a caller that wants in-step kernel times (eager only)
-        assert c.appearance_dim == 0, "appearance embedding is not part of the fused step yet"
         assert len(c.num_proposal_samples) == 2
         self.model, self.cfg, self.B = model, c, n_rays
         self.sm = n_rays if coherent_rays is None else int(coherent_rays)
@@ -95,6 +94,10 @@ class FusedTrainStep:
         self.g_depth = torch.empty(B, **f32)
         self.g_alpha = torch.empty(B * Sm, **f32)
         self.g_feature = torch.empty(B * Sm, C, **f32)
+        # lidar rays of the batch (set_lidar): carving masks on the weights of all three levels; with an appearance embedding
+        # and the lidar decoder in the model, the decoder and its two losses run inside the step on the lidar rows
+        self.lidar = None
+        self.g_features_extra = None
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -125,6 +128,44 @@ class FusedTrainStep:
                 if need > 0:
                     self.binned_ws[lvl] = torch.empty(need, device=dev, dtype=torch.uint8)
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
+
+    def set_lidar(self, is_lidar: Tensor, did_return: Tensor, lidar_range: Tensor, row0: int, n_lidar: int,
+                  target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None) -> None:
+        """Describe the lidar rays of the batch (they occupy rows [row0, row0 + n_lidar) of every per-ray array; the layout is
+        fixed, the values may be rewritten in place between steps): is_lidar / did_return [B] uint8, lidar_range [B] =
+        metadata["directions_norm"].  Adds to the step's loss, for those rays,
+          * the carving terms of neuradar.py:529-531,537-541,637-638,650 (carving_mult / n_lidar on the final weights,
+            prop_lidar_loss_mult * carving_mult / n_lidar on each proposal level), inside nr_render_train and
+            nr_interlevel_loss_to_density;
+          * when the model has an appearance embedding and a lidar decoder (config.appearance_dim > 0, config.lidar_decoder):
+            decoder([rendered features | appearance(time, sensor_idx)]) -> intensity MSE on returning rays + ray-drop BCE
+            (neuradar.py:432-452,624-636,692-700), with target_intensity [B] and sensor_idx [B] int64."""
+        from ._lib import NrLidarSup
+
+        c, dev, B = self.cfg, self.dev, self.B
+        assert is_lidar.dtype == torch.uint8 and did_return.dtype == torch.uint8 and is_lidar.numel() == B
+        self.lidar = dict(is_lidar=is_lidar, did_return=did_return, range=lidar_range, row0=int(row0), n=int(n_lidar))
+
+        def sup(weight):
+            s = NrLidarSup()
+            s.is_lidar, s.did_return, s.range = is_lidar.data_ptr(), did_return.data_ptr(), lidar_range.data_ptr()
+            s.carving_epsilon, s.non_return_distance, s.weight = c.carving_epsilon, c.non_return_lidar_distance, weight
+            return s
+
+        self.lidar["main"] = sup(c.carving_mult / max(n_lidar, 1))
+        self.lidar["prop"] = sup(c.prop_lidar_loss_mult * c.carving_mult / max(n_lidar, 1))
+        self.lidar["decoder"] = c.appearance_dim > 0 and c.lidar_decoder and target_intensity is not None
+        if self.lidar["decoder"]:
+            A = c.appearance_dim
+            f32 = dict(device=dev, dtype=torch.float32)
+            self.lidar.update(target_intensity=target_intensity, sensor_idx=sensor_idx, x=torch.empty(n_lidar, self.C + A, **f32),
+                              y=torch.empty(n_lidar, 2, **f32), g_y=torch.empty(n_lidar, 2, **f32),
+                              g_x=torch.empty(n_lidar, self.C + A, **f32), inv_ret=torch.ones(1, **f32))
+            self.g_features_extra = torch.zeros(B, self.C, **f32)  # rows outside the lidar segment stay zero
+            dec = self.model.lidar_decoder
+            ws, bs = dec.weights()
+            self.lidar["mlp"] = ops._mlp_struct(ws, bs)
+            self.lidar["mlp_grads"] = ops._mlp_grads_struct([w.grad for w in ws], [b.grad for b in bs])
 
     def _timed(self, name: str, launch):
         """Run `launch()` (one library call on the current stream); with self.timers set, bracket it with
@@ -331,10 +372,32 @@ class FusedTrainStep:
         check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n,
                                                                  p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
+        lid = self.lidar
+        if lid is not None and lid["decoder"]:
+            # per-ray lidar decoder on [rendered features | appearance] of the lidar rows, its losses and its backward; the
+            # gradient on the rendered features re-enters nr_render_train as grad_features_extra
+            emb = self.model.appearance_embedding.weight
+            E, r0, nl_ = self.model._num_embeds_per_sensor, lid["row0"], lid["n"]
+            assert times is not None, "the appearance embedding needs the rays' times"
+            check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
+                                       p(self.features), p(self.depth), st), "composite_fwd")
+            check(lib.nr_appearance_concat_fwd(p(self.features), self.C, p(emb), emb.shape[1], p(times), p(lid["sensor_idx"]),
+                                               c.duration, E, r0, nl_, p(lid["x"]), st), "appearance_fwd")
+            check(lib.nr_mlp_fwd(byref(lid["mlp"]), p(lid["x"]), nl_, p(lid["y"]), st), "lidar_decoder_fwd")
+            torch.div(1.0, lid["did_return"][r0:r0 + nl_].sum().clamp(min=1).float(), out=lid["inv_ret"][0])
+            check(lib.nr_lidar_head_loss(p(lid["y"]), p(lid["target_intensity"][r0:]), p(lid["did_return"][r0:]), nl_,
+                                         p(lid["inv_ret"]), c.intensity_mult, c.ray_drop_loss_mult, p(lid["g_y"]), p(self.loss), st),
+                  "lidar_head_loss")
+            check(lib.nr_mlp_bwd(byref(lid["mlp"]), p(lid["x"]), p(lid["g_y"]), nl_, p(lid["g_x"]), byref(lid["mlp_grads"]), st),
+                  "lidar_decoder_bwd")
+            check(lib.nr_appearance_concat_bwd(p(lid["g_x"]), self.C, emb.shape[1], p(times), p(lid["sensor_idx"]), c.duration, E,
+                                               r0, nl_, p(self.g_features_extra), p(emb.grad), emb.shape[0], st), "appearance_bwd")
         check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
                                   p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
                                   p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
-                                  p(self.g_feature), p(self.loss), st), "render_train")
+                                  p(self.g_feature), p(self.loss),
+                                  p(self.g_features_extra) if (lid is not None and lid["decoder"]) else None,
+                                  byref(lid["main"]) if lid is not None else None, st), "render_train")
         # ---- backward.  The field's MFMA backward needs 1 wave/SIMD worth of registers and ~127 KB of LDS per
         #      workgroup, so LDS-heavy kernels sharing the CUs with it (and it with them) crawl: forking all three
         #      chains (main grid scatter + Adam / proposal round 1 / proposal round 0) right after the render launch
@@ -364,7 +427,8 @@ class FusedTrainStep:
             check(lib.nr_interlevel_loss_to_density(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]),
                                                     p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
                                                     losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
-                                                    p(self.loss), sp_), "interlevel_loss")
+                                                    p(self.loss), byref(self.lidar["prop"]) if self.lidar is not None else None,
+                                                    sp_), "interlevel_loss")
             check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                           p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 

@@ -53,6 +53,9 @@ class HotPathConfig:
     intensity_mult: float = 0.1
     ray_drop_loss_mult: float = 0.01
     non_return_lidar_distance: float = 150.0
+    carving_mult: float = 0.01  # LossSettings.carving_mult, neuradar.py:92
+    carving_epsilon: float = 0.1  # :94
+    prop_lidar_loss_mult: float = 0.1  # :96
     non_return_loss_mult: float = 0.1
     quantile_threshold: float = 0.95
 

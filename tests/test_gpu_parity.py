@@ -671,7 +671,7 @@ def test_fused_render_matches_separate_kernels(S, C):
 
     a, b = outs(), outs()
     _lib.check(lib.nr_render_train(p(alpha), p(feature), p(eu), p(sp), p(tf), p(td), B, S, C, *mults, p(a["w"]), p(a["acc"]),
-                                   p(a["f"]), p(a["d"]), p(a["ga"]), p(a["gf"]), p(a["loss"]), st()), "render_train")
+                                   p(a["f"]), p(a["d"]), p(a["ga"]), p(a["gf"]), p(a["loss"]), None, None, st()), "render_train")
     g_f, g_d, g_w = torch.empty(B, C, **f32), torch.empty(B, **f32), torch.empty(B, S, **f32)
     _lib.check(lib.nr_composite_fwd(p(alpha), p(feature), p(eu), B, S, C, p(b["w"]), p(b["acc"]), p(b["f"]), p(b["d"]), st()), "fwd")
     _lib.check(lib.nr_supervision_loss(p(b["f"]), C, p(tf), C, p(b["d"]), p(td), B, mults[0], mults[1], p(g_f), p(g_d),
@@ -704,7 +704,7 @@ def test_fused_interlevel_to_density_matches_separate_kernels(Sp):
     _lib.check(lib.nr_interlevel_loss(p(c), S + 1, p(w), S, S - 1, p(cp), p(wp), Sp, B, 0.03, 1.7, p(g_w), p(l1), st()), "il")
     _lib.check(lib.nr_weights_from_density_bwd(p(dens), p(eup), p(g_w), B, Sp, p(g_d1), st()), "wb")
     _lib.check(lib.nr_interlevel_loss_to_density(p(c), S + 1, p(w), S, S - 1, p(cp), p(wp), p(dens), p(eup), Sp, B, 0.03, 1.7,
-                                                 p(g_d2), p(l2), st()), "fused")
+                                                 p(g_d2), p(l2), None, st()), "fused")
     assert_close(cpu(g_d2), cpu(g_d1), rtol=1e-6, atol_scale=1e-7, what="g_density")
     assert_close(cpu(l2.sum()), cpu(l1.sum()), rtol=1e-6, atol_scale=1e-7, what="loss")
 

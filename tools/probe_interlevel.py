@@ -24,7 +24,7 @@ for B in (256, 1024, 4096, 16384):
         lib.nr_weights_from_density_fwd(p(dens), p(eup), B, Sp, p(wp), st())
         gd, loss = torch.empty(B, Sp, **f32), torch.zeros(_lib.NR_LOSS_SLOTS, **f32)
         fn = lambda: lib.nr_interlevel_loss_to_density(p(sp), S + 1, p(wfin), S, S - 1, p(cp), p(wp), p(dens), p(eup), Sp, B, 0.03, 1.0,  # noqa: E731
-                                                       p(gd), p(loss), st())
+                                                       p(gd), p(loss), None, st())
         gw = torch.empty(B, Sp, **f32)
         fn2 = lambda: lib.nr_interlevel_loss(p(sp), S + 1, p(wfin), S, S - 1, p(cp), p(wp), Sp, B, 0.03, 1.0, p(gw), p(loss), st())  # noqa: E731
         fn3 = lambda: lib.nr_weights_from_density_bwd(p(dens), p(eup), p(gw), B, Sp, p(gd), st())  # noqa: E731
