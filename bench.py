@@ -194,6 +194,13 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                    radars=scene.radars if n_scans else None, n_radar_scans=n_scans,
                                    order=("camera", "radar", "lidar") if radar_coherent or mixed is None else ("camera", "lidar", "radar"))
         assert asm.n == n_rays, "workload: ray counts must add up"
+        if n_lidar and os.environ.get("NR_BENCH_LIDAR_SUP", "1") != "0":
+            # the lidar rays of the batch are supervised the reference's way: carving masks on the weights of all three
+            # levels (neuradar.py:529-541,637-650) from the measured ranges / did_return flags the assembler writes
+            is_l = asm.is_lidar[:, 0].to(torch.uint8).contiguous()
+            for k_ in range(2):
+                stepper.set_lidar(is_l, asm.slots[k_]["did_return"], asm.slots[k_]["directions_norm"], asm.offset["lidar"], n_lidar,
+                                  slot=k_)
         n_u = asm.uniform_count()
 
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's

@@ -130,7 +130,7 @@ class FusedTrainStep:
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
 
     def set_lidar(self, is_lidar: Tensor, did_return: Tensor, lidar_range: Tensor, row0: int, n_lidar: int,
-                  target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None) -> None:
+                  target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None, slot: Optional[int] = None) -> None:
         """Describe the lidar rays of the batch (they occupy rows [row0, row0 + n_lidar) of every per-ray array; the layout is
         fixed, the values may be rewritten in place between steps): is_lidar / did_return [B] uint8, lidar_range [B] =
         metadata["directions_norm"].  Adds to the step's loss, for those rays,
@@ -139,11 +139,13 @@ class FusedTrainStep:
             nr_interlevel_loss_to_density;
           * when the model has an appearance embedding and a lidar decoder (config.appearance_dim > 0, config.lidar_decoder):
             decoder([rendered features | appearance(time, sensor_idx)]) -> intensity MSE on returning rays + ray-drop BCE
-            (neuradar.py:432-452,624-636,692-700), with target_intensity [B] and sensor_idx [B] int64."""
+            (neuradar.py:432-452,624-636,692-700), with target_intensity [B] and sensor_idx [B] int64.
+        slot: with pipelined batches (two buffer sets) call once per set; forward_backward(slot=k) uses set k's arrays."""
         from ._lib import NrLidarSup
 
         c, dev, B = self.cfg, self.dev, self.B
         assert is_lidar.dtype == torch.uint8 and did_return.dtype == torch.uint8 and is_lidar.numel() == B
+        prev = self.lidar
         self.lidar = dict(is_lidar=is_lidar, did_return=did_return, range=lidar_range, row0=int(row0), n=int(n_lidar))
 
         def sup(weight):
@@ -166,6 +168,10 @@ class FusedTrainStep:
             ws, bs = dec.weights()
             self.lidar["mlp"] = ops._mlp_struct(ws, bs)
             self.lidar["mlp_grads"] = ops._mlp_grads_struct([w.grad for w in ws], [b.grad for b in bs])
+        if slot is not None:
+            slots = prev if isinstance(prev, list) else [None, None]
+            slots[slot] = self.lidar
+            self.lidar = slots
 
     def _timed(self, name: str, launch):
         """Run `launch()` (one library call on the current stream); with self.timers set, bracket it with
@@ -372,7 +378,7 @@ class FusedTrainStep:
         check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n,
                                                                  p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
-        lid = self.lidar
+        lid = self.lidar[slot] if isinstance(self.lidar, list) else self.lidar
         if lid is not None and lid["decoder"]:
             # per-ray lidar decoder on [rendered features | appearance] of the lidar rows, its losses and its backward; the
             # gradient on the rendered features re-enters nr_render_train as grad_features_extra
@@ -427,7 +433,7 @@ class FusedTrainStep:
             check(lib.nr_interlevel_loss_to_density(p(self.sp[2]), Sm + 1, p(self.w[2]), Sm, Sm - 1, p(self.sp[lvl]),
                                                     p(self.w[lvl]), p(self.dens[lvl]), p(self.eu[lvl]), S, B,
                                                     losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
-                                                    p(self.loss), byref(self.lidar["prop"]) if self.lidar is not None else None,
+                                                    p(self.loss), byref(lid["prop"]) if lid is not None else None,
                                                     sp_), "interlevel_loss")
             check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                           p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
