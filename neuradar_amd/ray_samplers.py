@@ -14,8 +14,12 @@ from .rays import RayBundle, RaySamples
 
 
 def _samples(bundle: RayBundle, spacing: Tensor, euclid: Tensor) -> RaySamples:
+    # cameras/rays.py:336,353: the bundle's metadata "mimics the shape of the rays" -- [B,C] becomes a broadcast [B,S,C]
+    # view (no copy), which is what the reference's caller indexes (models/neuradar.py:978-993)
+    S = euclid.shape[1] - 1
+    meta = {k: v[:, None, :].expand(v.shape[0], S, v.shape[-1]) for k, v in bundle.metadata.items()}
     return RaySamples(bundle.origins, bundle.directions, bundle.pixel_area, spacing, euclid, bundle.nears,
-                      bundle.fars, bundle.times, bundle.metadata, bundle.camera_indices)
+                      bundle.fars, bundle.times, meta, bundle.camera_indices)
 
 
 class PowerSampler(nn.Module):

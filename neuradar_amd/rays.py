@@ -74,7 +74,7 @@ class RaySamples:
     nears: Tensor
     fars: Tensor
     times: Optional[Tensor] = None
-    metadata: Dict[str, Tensor] = field(default_factory=dict)
+    metadata: Dict[str, Tensor] = field(default_factory=dict)  # [B,S,C] broadcast views of the bundle's [B,C] entries
     camera_indices: Optional[Tensor] = None
 
     @property
@@ -120,8 +120,9 @@ class RaySamples:
 
     def drop_last(self) -> "RaySamples":
         """`ray_samples[..., :-1]` (models/neuradar.py:515): discard the last (sky) sample."""
+        meta = {k: v[:, :-1] for k, v in self.metadata.items()}
         return RaySamples(self.origins, self.directions, self.pixel_area, self.spacing[:, :-1], self.euclid[:, :-1],
-                          self.nears, self.fars, self.times, self.metadata, self.camera_indices)
+                          self.nears, self.fars, self.times, meta, self.camera_indices)
 
     def __getitem__(self, idx):
         if idx == (Ellipsis, slice(None, -1, None)):

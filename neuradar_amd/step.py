@@ -127,10 +127,10 @@ class NeuRadarHotPath(nn.Module):
         measured range, non-returns everywhere below non_return_lidar_distance."""
         md = rs.metadata
         mid = (rs.euclid[:, :-1] + rs.euclid[:, 1:])[..., None] * 0.5
-        close_to_hit = (md["directions_norm"][:, None, :] - mid).abs() < carving_epsilon
-        did_return = md["did_return"][:, None, :] if "did_return" in md else torch.ones_like(close_to_hit)
+        close_to_hit = (md["directions_norm"] - mid).abs() < carving_epsilon
+        did_return = md["did_return"] if "did_return" in md else torch.ones_like(close_to_hit)
         in_range = mid < non_return_lidar_distance
-        return md["is_lidar"][:, None, :] & ((did_return & close_to_hit) | ((~did_return) & in_range))
+        return md["is_lidar"] & ((did_return & close_to_hit) | ((~did_return) & in_range))
 
     def _get_appearance_embedding(self, bundle: RayBundle) -> Tensor:
         """neuradar.py:550-568 (temporal appearance)."""
@@ -169,11 +169,11 @@ class NeuRadarHotPath(nn.Module):
         for i, (w, s) in enumerate(zip(prop_w, prop_rs)):
             out[f"prop_depth_{i}"] = render_depth_simple(w, s)
             if lidar:  # :529-531
-                mask = (~s.metadata["is_close_to_lidar"]) & s.metadata["is_lidar"][:, None, :]
+                mask = (~s.metadata["is_close_to_lidar"]) & s.metadata["is_lidar"]
                 out[f"prop_weights_loss_{i}"] = ((w * mask) ** 2).sum()
         if lidar:  # :537-541: weights of lidar samples away from the measured return (carving loss input)
             md = rs.metadata
-            m = ((~md["is_close_to_lidar"][:, :-1]) & md["is_lidar"][:, None, :]).squeeze(-1)
+            m = ((~md["is_close_to_lidar"][:, :-1]) & md["is_lidar"][:, :-1]).squeeze(-1)
             out["non_nearby_weights"] = weights[:, :-1][m]
         # the sky sample is dropped from the lists the regularisers see (:515,534-535)
         out["weights_list"] = prop_w + [weights[:, :-1]]
