@@ -336,18 +336,26 @@ def roofline_probe(model, scene, n_rays):
 
 
 def pmc_traffic(workload, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_hash_kernels_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB ->
-    bytes, FETCH_SIZE as reported -- see the file for the gfx950 caveats).  None when no profile of this
-    workload/kernel is committed: bench.py does not run the profiler itself."""
-    path = os.path.join(ROOT, "profiles", "r01_hash_kernels_pmc.json")
-    if workload != "cam4096_l16f2_w64" or not os.path.exists(path):
-        return None
-    tag = kernel[kernel.index("[") + 1:-1]
-    kind = "bwd" if "bwd" in kernel else "fwd"
-    for name, c in json.load(open(path))["kernels"].items():
-        if kind in name and tag in name:
-            return int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    """HBM-side bytes per launch of the launch site `kernel` from the committed rocprofv3 PMC passes of this workload
+    (profiles/rNN_hash_kernels_pmc*.json, newest round first: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB ->
+    bytes, FETCH_SIZE as reported -- see the file for the gfx950 caveats; summed over the kernels of the site, e.g. merging +
+    bin + apply of one scatter).  None when no profile of this workload/kernel is committed: bench.py does not run the profiler."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hash_kernels_pmc*.json")), reverse=True):
+        doc = json.load(open(path))
+        if doc.get("workload", "cam4096_l16f2_w64") != workload:
+            continue
+        if "launch_sites" in doc:
+            site = doc["launch_sites"].get(kernel)
+            if site and site.get("traffic_bytes"):
+                return int(site["traffic_bytes"])
+            continue
+        tag = kernel[kernel.index("[") + 1:-1]  # round-1 layout: one entry per kernel
+        kind = "bwd" if "bwd" in kernel else "fwd"
+        for name, c in doc["kernels"].items():
+            if kind in name and tag in name:
+                return int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
     return None
 
 

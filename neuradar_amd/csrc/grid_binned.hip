@@ -1,15 +1,26 @@
-// Hash-grid scatter-add for INCOHERENT rows (lidar rays: neighbouring rows share no fine-level cell, so the on-chip
-// dedup of hash_encode_bwd_kernel finds nothing to merge and the launch runs at the memory side's float-atomic rate,
-// one 64-byte request per lane: 20 G requests/s).  Two passes, no atomics on single table entries:
-//   1. bin:   every (row, level, corner) contribution becomes an (entry index, F values) pair, routed by the table slice
-//             ("bucket", 128 KB of table) its entry falls into.  A wave owns 1 024 rows of one level and a private region
-//             of every bucket's queue, so appending needs no global counter: pairs collect in wave-private LDS bins and
-//             leave in runs of >= half a bin with plain stores.
-//   2. apply: one workgroup per (level, bucket) keeps its slice of the gradient table in LDS (128 KB), streams the
-//             bucket's queue and accumulates with LDS float adds, then adds the slice to the table with CONTIGUOUS
-//             atomics (256 B per wave-instruction: the shape the memory side applies at ~1.3 TB/s).
-// Anything that does not fit (a bin or a region overflowing: many rows in one cell) falls back to a direct atomic.
+// Hash-grid scatter-add by TABLE SLICE OWNERSHIP, for levels whose table is hit densely (the NeuRadar proposal grid:
+// 12 M contributions per level onto 1 M entries -- every 64-byte line of the level is touched ~160 times per step, and
+// the merging kernel of grid.hip, which can only fold neighbouring rows, runs at the memory side's float-atomic rate,
+// 20 G requests/s).  Two passes, no atomics on single table entries:
+//   1. bin:   a block takes ROWS rows of one level, one thread per row.  The 8 corners of a row are 4 x-PAIRS
+//             (x, x+1 | y, z): the slice (64 KB of table = the top bits of the entry index) of a pair depends on (y, z)
+//             only, so a pair is ONE record {key, 2 F sums}.  Neighbouring lanes in one cell are summed across the wave
+//             first (VALU segmented scan); the run sums are then MERGED block-wide in an LDS table keyed by the pair and
+//             partitioned by slice: insert-or-add with LDS INTEGER atomics (ds_cmpst_rtn_b32 + ds_add_u64 on 64-bit
+//             fixed-point sums scaled by the block's largest |value|; integer LDS atomics run at several lanes/clk/CU,
+//             ds_add_f32 at 0.33 -- tools/lds_lab.hip).  A partition then leaves as one contiguous run of raw records
+//             (key + integer sums), the "sub-bin" of (level, slice, tile), with the tile's exponent beside it: no global
+//             counter, no global atomic, no conversion.
+//   2. apply: one workgroup per (level, slice) streams the slice's sub-bins and accumulates them in LDS, shifting every
+//             record from its tile's exponent to the level's (36 bits below the level's largest value are kept, 2^12 times
+//             finer than fp32; the sum of the records does not depend on their order).  The slice is then added to the table
+//             with CONTIGUOUS float atomics (other launches add into the same table concurrently; 256 B per
+//             wave-instruction, the shape the memory side takes at ~1.3 TB/s).
+// A record that finds its partition full after four probes, a pair that straddles two slices (negative corner) and
+// non-finite values go to the table directly with float atomics.
 #include <limits.h>
+#include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -17,316 +28,421 @@
 
 namespace {
 
-constexpr int kWaves = 4;           // waves per binning block
-constexpr int kRowsPerWave = 1024;  // rows of one level binned by one wave = one queue region per bucket
-constexpr int kMaxBuckets = 32;
-constexpr int kSliceFloats = 32768;  // 128 KB of gradient table per bucket
+constexpr int kSliceFloats = 16384;  // 128 KB of int64 accumulators per apply block
+constexpr int kMaxSlices = 64;
+constexpr int kFixBits = 44;    // a tile's sums: 44 bits below the tile's largest value (2 048 addends: < 2^55)
+constexpr int kApplyDrop = 8;   // the level's sums: 36 bits below the level's largest (2^14 tiles: < 2^62)
+constexpr int kApplyThreads = 1024;
+constexpr int kNoRecords = INT_MIN;
 
-template <int F> struct BinCfg { static constexpr int CAP = F == 1 ? 64 : 32; };  // entries per wave-private LDS bin
-
-// Orders the wave's LDS traffic for the compiler.  LDS operations of one wave execute in program order, so no wait is
-// needed between a lane's store and another lane's later load; a __builtin_amdgcn_fence here would also drain the
-// wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)) -- after every queue flush: measured 11 k cycles per round.
-__device__ __forceinline__ void wfence() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
+// rows per bin block (one thread each) and slots of the block's LDS merge table.  The table is partitioned by slice
+// (M / slices slots each: 64 at 64 slices, against an expected ROWS * 4 / 64 = M / 128 distinct records per slice when
+// nothing merges), so a partition IS the sub-bin the block leaves for that slice.
+template <int F> struct BinCfg;
+template <> struct BinCfg<1> { static constexpr int ROWS = 512, M = 4096; };
+template <> struct BinCfg<2> { static constexpr int ROWS = 256, M = 2048; };
+template <> struct BinCfg<4> { static constexpr int ROWS = 128, M = 1024; };
+constexpr uint32_t kEmpty = 0xFFFFFFFFu, kReserved = 0xFFFFFFFEu;
 
 struct BinGeom {
-  int rb_log2;   // log2(rows per bucket)
-  int nb;        // buckets per level
-  int cap;       // entries per (bucket, region)
-  int64_t regions;
+  int shift;   // entry index >> shift = slice
+  int ns;      // slices per level
+  int cap;     // records per sub-bin = slots per table partition (power of two)
+  int cap_log2;
+  int64_t nb;  // row tiles
 };
 
 inline bool bin_geom(int F, int log2T, int64_t n, BinGeom* g) {
   if (F != 1 && F != 2 && F != 4) return false;
-  int rows_log2 = 15;  // 32768 floats
-  for (int f = F; f > 1; f >>= 1) --rows_log2;
-  g->rb_log2 = log2T < rows_log2 ? log2T : rows_log2;
-  const int64_t nb = (int64_t)1 << (log2T - g->rb_log2);
-  if (nb > kMaxBuckets) return false;
-  g->nb = (int)nb;
-  const int expect = kRowsPerWave * 8 / g->nb;
-  int cap = (2 * expect + 63) / 64 * 64;
-  if (cap > kRowsPerWave * 8) cap = kRowsPerWave * 8;
-  g->cap = cap;
-  g->regions = nr_cdiv(n, kRowsPerWave);
+  if (log2T > 20) return false;  // (entry index, trailing ones of x) is the 24-bit merge key
+  int entries_log2 = 14;  // kSliceFloats / F entries per slice
+  for (int f = F; f > 1; f >>= 1) --entries_log2;
+  g->shift = log2T < entries_log2 ? log2T : entries_log2;
+  const int64_t ns = (int64_t)1 << (log2T - g->shift);
+  if (ns > kMaxSlices) return false;
+  g->ns = (int)ns;
+  const int rows = F == 1 ? BinCfg<1>::ROWS : F == 2 ? BinCfg<2>::ROWS : BinCfg<4>::ROWS;
+  const int m = F == 1 ? BinCfg<1>::M : F == 2 ? BinCfg<2>::M : BinCfg<4>::M;
+  g->cap = m / g->ns;
+  g->cap_log2 = 0;
+  while ((1 << g->cap_log2) < g->cap) ++g->cap_log2;
+  g->nb = nr_cdiv(n, rows);
   return true;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a workgroup-scope fence for GLOBAL memory
+// (s_waitcnt vmcnt(0)): it would wait for the prefetched loads of the next tile and for the record stores of the last
+// flush on every barrier.  Nothing here communicates through global memory.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// y (|y| < 2^44) -> nearest int64, without the 64-bit conversion sequence of the compiler's float -> long long:
+// the high part rounds to an integer of at most 25 bits, the remainder is exact in fp32
+__device__ __forceinline__ long long fix_i64(float y) {
+  const float hi = rintf(y * 0x1p-20f);
+  const float lo = fmaf(hi, -0x1p20f, y);
+  return ((long long)(int)hi << 20) + (long long)(int)rintf(lo);
+}
+
+// Persistent blocks: a block walks row tiles (ROWS rows) and, per tile, up to kLevelChunk levels; the LDS table is set up
+// once and every flush leaves the slots it read empty again.  Two barriers per (tile, level): A -- the wave maxima are
+// visible and the previous flush is complete; B -- all inserts are done.  Everything a tile needs from memory (position,
+// std, the gradients of all its levels) is requested one tile ahead.
+constexpr int kLevelChunk = 8;
+
 template <int F>
-__global__ void __launch_bounds__(kWaves * 64)
-bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int log2T,
-           const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int nb, int rb_log2,
-           int cap, int64_t regions, uint32_t* __restrict__ qidx, float* __restrict__ qval, uint32_t* __restrict__ qcnt) {
-  constexpr int CAP = BinCfg<F>::CAP, LINE = 32;  // a flush moves exactly LINE entries: one aligned 128-B line of indices
-  __shared__ uint32_t s_idx[kWaves][kMaxBuckets][CAP];
-  __shared__ float s_val[kWaves][kMaxBuckets][CAP * F];
-  __shared__ uint32_t s_cnt[kWaves][kMaxBuckets];
-  __shared__ uint32_t s_off[kWaves][kMaxBuckets];
-  const int level = blockIdx.y, lane = nr_lane(), wave = threadIdx.x >> 6;
-  const int64_t region = (int64_t)blockIdx.x * kWaves + wave;
-  if (region >= regions) return;
-  uint32_t (*bidx)[CAP] = s_idx[wave];
-  float (*bval)[CAP * F] = s_val[wave];
-  uint32_t* cnt = s_cnt[wave];
-  uint32_t* off = s_off[wave];
-  if (lane < kMaxBuckets) { cnt[lane] = 0u; off[lane] = 0u; }
-  wfence();
-  const float scale = scalings[level];
-  const uint32_t mask = (1u << log2T) - 1u, lmask = (1u << rb_log2) - 1u;
-  float* tbase = gtable + (((int64_t)level << log2T) * F);
-  const float* gl = gout + (int64_t)level * sl;
-  auto qbase = [&](int b) { return (((int64_t)level * nb + b) * regions + region) * cap; };
+__global__ void __launch_bounds__(BinCfg<F>::ROWS)
+bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
+           int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int ns,
+           int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, unsigned long long* __restrict__ rsum,
+           uint32_t* __restrict__ cntg, int* __restrict__ tile_exp) {
+  constexpr int ROWS = BinCfg<F>::ROWS, M = BinCfg<F>::M, WAVES = ROWS / NR_WAVE;
+  // keys [M] | 64-bit sums [M][2][F].  Exactly half a CU's LDS at F = 1 (two blocks per CU), so the WAVES floats of the
+  // block maximum live in the sums of the table's last slots, which are taken out of service (kReserved never matches)
+  __shared__ __attribute__((aligned(16))) uint32_t lds[M + M * 4 * F];
+  uint32_t* keys = lds;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + M);
+  constexpr int kScratchSlots = (WAVES * 4 + 16 * F - 1) / (16 * F);
+  float* wmax = reinterpret_cast<float*>(acc + (size_t)(M - kScratchSlots) * 2 * F);
+  const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the flush's sub-bin addresses stay in SGPRs)
+  const int cap = 1 << cap_log2;
+  const uint32_t mask = (1u << log2T) - 1u, pmask = (uint32_t)cap - 1u;
+  for (int i = tid; i < M; i += ROWS) keys[i] = i < M - kScratchSlots ? kEmpty : kReserved;
+  for (int i = tid; i < M * 2 * F; i += ROWS) acc[i] = 0ull;
+  __syncthreads();
 
-  // moves the first `take` (<= 64) entries of bin b to the wave's region of bucket b; the rest slides to the front
-  auto flush_bin = [&](int b, uint32_t take) {
-    const uint32_t have = cnt[b] < (uint32_t)CAP ? cnt[b] : (uint32_t)CAP;  // the same address in every lane: broadcast
-    const uint32_t o = off[b];
-    const int64_t dst = qbase(b) + o;
-    uint32_t li = 0u, li2 = 0u;
-    float v[F], v2[F];
-    const bool mine = (uint32_t)lane < take, rest = take + lane < have;
-    if (mine) {
-      li = bidx[b][lane];
+  const int nl = L - level0 < kLevelChunk ? L - level0 : kLevelChunk;
+  int64_t tile = blockIdx.x;
+  if (tile >= nb) return;
+  float px[3] = {0.0f, 0.0f, 0.0f}, pstd = 0.0f, pg[kLevelChunk][F];
+  auto fetch = [&](int64_t t) {
+    const int64_t row = t * ROWS + tid;
+    const bool in = row < n;
+    if (in) {
 #pragma unroll
-      for (int f = 0; f < F; ++f) v[f] = bval[b][lane * F + f];
+      for (int a = 0; a < 3; ++a) px[a] = x[row * 3 + a];
+      if (std != nullptr) pstd = std[row];
     }
-    if (rest) {
-      li2 = bidx[b][take + lane];
 #pragma unroll
-      for (int f = 0; f < F; ++f) v2[f] = bval[b][(take + lane) * F + f];
-    }
-    wfence();
-    if (mine) {
-      if (o + lane < (uint32_t)cap) {
-        qidx[dst + lane] = li;
+    for (int l = 0; l < kLevelChunk; ++l)
 #pragma unroll
-        for (int f = 0; f < F; ++f) qval[(dst + lane) * F + f] = v[f];
-      } else {  // this wave's region of the bucket is full: straight to the table
-#pragma unroll
-        for (int f = 0; f < F; ++f) unsafeAtomicAdd(tbase + ((((int64_t)b << rb_log2) + li) * F + f), v[f]);
-      }
-    }
-    if (rest) {
-      bidx[b][lane] = li2;
-#pragma unroll
-      for (int f = 0; f < F; ++f) bval[b][lane * F + f] = v2[f];
-    }
-    if (lane == 0) {
-      off[b] = o + take < (uint32_t)cap ? o + take : (uint32_t)cap;
-      cnt[b] = have - take;
-    }
-    wfence();
+      for (int f = 0; f < F; ++f) pg[l][f] = in && l < nl ? gout[(int64_t)(level0 + l) * sl + row * sn + f] : 0.0f;
   };
-  auto flush_lines = [&]() {  // until no bin holds a full line (a bin can hold two)
-    while (true) {
-      const uint32_t c = lane < nb ? cnt[lane] : 0u;
-      unsigned long long full = __ballot(c >= (uint32_t)LINE);
-      if (!full) break;
-      while (full) {
-        const int b2 = __builtin_ctzll(full);
-        full &= full - 1ull;
-        flush_bin(b2, LINE);
-      }
-    }
-  };
-
-  const int64_t r0 = region * kRowsPerWave;
-  float nx[3] = {0.0f, 0.0f, 0.0f}, nstd = 0.0f, ng[F];
-#pragma unroll
-  for (int f = 0; f < F; ++f) ng[f] = 0.0f;
-  auto fetch = [&](int64_t row) {  // the NEXT round's inputs are requested before this round is processed
-    if (row < n) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) nx[a] = x[row * 3 + a];
-      if (std != nullptr) nstd = std[row];
-#pragma unroll
-      for (int f = 0; f < F; ++f) ng[f] = gl[row * sn + f];
-    }
-  };
-  fetch(r0 + lane);
+  fetch(tile);
 #pragma unroll 1
-  for (int it = 0; it < kRowsPerWave / 64; ++it) {
-    const int64_t row = r0 + it * 64 + lane;
-    if (r0 + it * 64 >= n) break;  // wave-uniform
-    const bool valid = row < n;
-    float cx[3] = {nx[0], nx[1], nx[2]}, cstd = nstd, cg[F];
+  for (; tile < nb; tile += gridDim.x) {
+    float cx[3], cstd, cg[kLevelChunk][F];
 #pragma unroll
-    for (int f = 0; f < F; ++f) cg[f] = ng[f];
-    if (it + 1 < kRowsPerWave / 64) fetch(row + 64);
-    int lo[3] = {INT_MIN + lane, 0, 0};  // invalid lanes: a cell of their own
-    float v[8][F];
+    for (int a = 0; a < 3; ++a) cx[a] = px[a];
+    cstd = pstd;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner)
+    for (int l = 0; l < kLevelChunk; ++l)
 #pragma unroll
-      for (int f = 0; f < F; ++f) v[corner][f] = 0.0f;
-    if (valid) {
-      float cw[3], g[F];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float p = cx[a] * scale;
-        const float fl = floorf(p);
-        lo[a] = (int)fl;
-        cw[a] = p - fl;
-      }
-      float r = 1.0f;
-      if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * cstd, 1.0f);
-#pragma unroll
-      for (int f = 0; f < F; ++f) g[f] = cg[f] * r;
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner) {
-        const bool hx = corner & 1, hy = corner & 2, hz = corner & 4;
-        const float w = (hx ? cw[0] : 1.0f - cw[0]) * (hy ? cw[1] : 1.0f - cw[1]) * (hz ? cw[2] : 1.0f - cw[2]);
-#pragma unroll
-        for (int f = 0; f < F; ++f) v[corner][f] = g[f] * w;
-      }
-    }
-    // runs of consecutive lanes in one cell (neighbouring samples of a ray at the coarse levels) are summed on the
-    // wave: segmented inclusive scan on DPP moves, the run's last lane carries the sum (as hash_encode_bwd_kernel)
-    const bool head = lane == 0 || !(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[0]) == lo[0] &&
-                                     nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]) == lo[1] &&
-                                     nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[2]) == lo[2]);
-    // ballot, not a DPP move: the compiler may re-evaluate a cheap DPP inside the divergent loops below, where a
-    // disabled source lane makes it return its `old` operand (seen: lanes in the middle of a run appended as tails)
-    const unsigned long long heads = __ballot(head);
-    const bool tail = lane == NR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull) != 0ull;
-    int flag = head ? 1 : 0;
-    auto scan_step = [&](auto ctrl, auto rowmask) {
-      constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-      const float take = flag ? 0.0f : 1.0f;
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-#pragma unroll
-        for (int f = 0; f < F; ++f) v[corner][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, v[corner][f]), take, v[corner][f]);
-      flag |= nr_dpp_i<C, R>(0, flag);
-    };
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
-    // all eight corners of a run tail are appended in one round: eight LDS counter bumps in flight, one fence
-    uint32_t hs[8];
-    unsigned pend = 0u;
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-      hs[corner] = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
-      bool nz = false;
-#pragma unroll
-      for (int f = 0; f < F; ++f) nz = nz || v[corner][f] != 0.0f;
-      if (nz && tail && valid) pend |= 1u << corner;
-    }
+      for (int f = 0; f < F; ++f) cg[l][f] = pg[l][f];
+    if (tile + gridDim.x < nb) fetch(tile + gridDim.x);
 #pragma unroll 1
-    while (__any(pend != 0u)) {
-      uint32_t pos[8];
+    for (int li = 0; li < nl; ++li) {
+      const int level = level0 + li;
+      float g[F], mag = 0.0f;
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-        pos[corner] = (pend >> corner) & 1u ? atomicAdd(&cnt[hs[corner] >> rb_log2], 1u) : 0xFFFFFFFFu;  // LDS, wave-private
+      for (int f = 0; f < F; ++f) {
+        g[f] = cg[0][f];
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-        if (pos[corner] < (uint32_t)CAP) {  // a full bin is retried after the flush
-          const int b = (int)(hs[corner] >> rb_log2);
-          bidx[b][pos[corner]] = hs[corner] & lmask;
+        for (int l = 1; l < kLevelChunk; ++l) g[f] = li == l ? cg[l][f] : g[f];  // (li is uniform: a select, no indexing)
+        mag += fabsf(g[f]);
+      }
+      const float scale = scalings[level];
+      float* base = gtable + (((int64_t)level << log2T) * F);
+      // ---- 1. the row's four x-pairs, in registers
+      uint32_t ia[4], tz = 0;
+      float va[4][F], vb[4][F], mq[4];
+      float vmax = 0.0f;
+      int lo[3] = {INT_MIN + lane, INT_MIN + lane, INT_MIN + lane};  // rows without a gradient: a cell of their own
 #pragma unroll
-          for (int f = 0; f < F; ++f) bval[b][pos[corner] * F + f] = v[corner][f];
-          pend &= ~(1u << corner);
+      for (int q = 0; q < 4; ++q) {
+        ia[q] = 0;
+#pragma unroll
+        for (int f = 0; f < F; ++f) va[q][f] = vb[q][f] = 0.0f;
+      }
+      if (mag != 0.0f) {  // zero gradients (masked samples, rows past n) are skipped, like in the merging kernel
+        float cw[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float p = cx[a] * scale;
+          const float fl = floorf(p);
+          lo[a] = (int)fl;
+          cw[a] = p - fl;
         }
-      wfence();
-      flush_lines();
+        float r = 1.0f;
+        if (std != nullptr) r = 1.0f / fmaxf(scale * 2.0f * cstd, 1.0f);
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] *= r;
+        tz = (uint32_t)__builtin_ctz(~(uint32_t)lo[0] | 0x80000000u);  // trailing ones of x: (x + 1) ^ x = 2^(tz + 1) - 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool hy = q & 1, hz = q & 2;
+          const uint32_t h = ((uint32_t)(lo[1] + (hy ? 1 : 0)) * 2654435761u) ^ ((uint32_t)(lo[2] + (hz ? 1 : 0)) * 805459861u);
+          ia[q] = ((uint32_t)lo[0] ^ h) & mask;
+          // the weights in the merging kernel's order: wx * wy * wz, then g * w
+          const float wa = (1.0f - cw[0]) * (hy ? cw[1] : 1.0f - cw[1]) * (hz ? cw[2] : 1.0f - cw[2]);
+          const float wb = cw[0] * (hy ? cw[1] : 1.0f - cw[1]) * (hz ? cw[2] : 1.0f - cw[2]);
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            va[q][f] = g[f] * wa;
+            vb[q][f] = g[f] * wb;
+          }
+        }
+      }
+      // ---- 1b. neighbouring lanes in one cell (camera pixels at a coarse level, samples of one ray in one cell) are
+      // summed across the wave first, VALU only (the segmented scan of grid.hip): the last lane of a run carries the
+      // run's sum to the table, so the LDS atomics see one lane per cell and no two lanes of a wave on one address
+      const bool head = lane == 0 || !(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[0]) == lo[0] &&
+                                       nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]) == lo[1] &&
+                                       nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[2]) == lo[2]);
+      const unsigned long long heads = __ballot(head);
+      if (heads != ~0ull) {  // (uniform) some run is longer than one lane
+        int flag = head ? 1 : 0;
+        auto scan_step = [&](auto ctrl, auto rowmask) {
+          constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
+          const float take = flag ? 0.0f : 1.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              va[q][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, va[q][f]), take, va[q][f]);
+              vb[q][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, vb[q][f]), take, vb[q][f]);
+            }
+          flag |= nr_dpp_i<C, R>(0, flag);
+        };
+        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
+        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+      }
+      const bool tail = lane == NR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float m = 0.0f;
+        bool finite = true;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          finite = finite && fabsf(va[q][f]) <= 3.0e38f && fabsf(vb[q][f]) <= 3.0e38f;  // (false for NaN)
+          m = fmaxf(m, fmaxf(fabsf(va[q][f]), fabsf(vb[q][f])));
+        }
+        mq[q] = !tail ? 0.0f : finite ? m : -1.0f;  // 0: nothing to add; -1: goes to the table directly
+        if (tail && finite) vmax = fmaxf(vmax, m);
+      }
+      // ---- 2. block maximum -> the tile's fixed-point scale on this level
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, NR_WAVE));
+      if (lane == 0) wmax[wave] = vmax;
+      lds_barrier();  // A
+      float bmax = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) bmax = fmaxf(bmax, wmax[w]);
+      // bmax < 2^e (exponent field of the float; denormal maxima count as 2^-126); sums in units of 2^(e - 44)
+      int e = (int)((__float_as_uint(bmax) >> 23) & 0xFFu) - 126;
+      e = e < kFixBits - 126 ? kFixBits - 126 : e;  // (the scale stays a normal float)
+      const float fix = __uint_as_float((uint32_t)(kFixBits - e + 127) << 23);
+      // ---- 3. merge: insert-or-add into the slice's partition of the table (LDS integer atomics)
+      const uint32_t pair = tz < 14u ? (2u << tz) - 1u : 0u;  // ia ^ ib
+      const uint32_t key_hi = tz << 20;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (mq[q] == 0.0f) continue;
+        const uint32_t ib = (ia[q] ^ pair) & mask;
+        int slot = -1;
+        if (mq[q] > 0.0f && pair != 0u && (ia[q] >> shift) == (ib >> shift)) {
+          const uint32_t key = ia[q] | key_hi, part = (ia[q] >> shift) << cap_log2;
+          uint32_t s0 = ia[q] & pmask;
+#pragma unroll 1
+          for (int probe = 0; probe < 4 && slot < 0; ++probe) {
+            const uint32_t old = atomicCAS(&keys[part + s0], kEmpty, key);  // ds_cmpst_rtn_b32
+            if (old == kEmpty || old == key) slot = (int)(part + s0);
+            s0 = (s0 + 1u) & pmask;
+          }
+        }
+        if (slot >= 0) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            atomicAdd(&acc[(slot * 2 + 0) * F + f], (unsigned long long)fix_i64(va[q][f] * fix));  // ds_add_u64
+            atomicAdd(&acc[(slot * 2 + 1) * F + f], (unsigned long long)fix_i64(vb[q][f] * fix));
+          }
+        } else {
+          // partition full, pair across two slices (negative corner) or non-finite values: straight to the table
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+            if (va[q][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)ia[q] * F + f, va[q][f]);
+          const uint32_t ib2 = (ia[q] ^ ((2u << tz) - 1u)) & mask;  // tz <= 31: 2u << 31 wraps to 0, all ones
+#pragma unroll
+          for (int f = 0; f < F; ++f)
+            if (vb[q][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)ib2 * F + f, vb[q][f]);
+        }
+      }
+      lds_barrier();  // B
+      // ---- 4. every partition leaves as one contiguous run of raw records, its sub-bin, and is empty again afterwards
+      const int64_t tl = (int64_t)level * nb + tile;
+      const int64_t sub_stride = nb << cap_log2;
+      int64_t sub = ((int64_t)level * ns + wave) * sub_stride + (tile << cap_log2);
+      for (int s = wave; s < ns; s += WAVES, sub += WAVES * sub_stride) {
+        uint32_t* dk = rkey + sub;                      // (scalar bases, 32-bit lane offsets)
+        unsigned long long* ds = rsum + sub * (2 * F);
+        uint32_t count = 0;
+        for (int c0 = 0; c0 < cap; c0 += NR_WAVE) {
+          const int sl_ = (s << cap_log2) + c0 + lane;
+          const uint32_t key = c0 + lane < cap ? keys[sl_] : kEmpty;
+          const bool occ = key < kReserved;
+          const unsigned long long bal = __ballot(occ);
+          if (bal == 0ull) continue;
+          if (occ) {
+            const uint32_t at = count + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            dk[at] = key;
+#pragma unroll
+            for (int k = 0; k < 2 * F; ++k) {
+              ds[at * (2 * F) + k] = acc[sl_ * 2 * F + k];
+              acc[sl_ * 2 * F + k] = 0ull;
+            }
+            keys[sl_] = kEmpty;
+          }
+          count += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) cntg[tl * ns + s] = count;
+      }
+      if (tid == 0) tile_exp[tl] = bmax > 0.0f ? e : kNoRecords;
     }
   }
-  {  // what is left: partial lines
-    const uint32_t c = lane < nb ? cnt[lane] : 0u;
-    unsigned long long some = __ballot(c > 0u);
-    while (some) {
-      const int b2 = __builtin_ctzll(some);
-      some &= some - 1ull;
-      const uint32_t have = cnt[b2] < (uint32_t)CAP ? cnt[b2] : (uint32_t)CAP;
-      flush_bin(b2, have);
-    }
-  }
-  if (lane < nb) qcnt[((int64_t)level * nb + lane) * regions + region] = off[lane];
 }
 
 template <int F>
-__global__ void __launch_bounds__(1024)
-apply_kernel(const uint32_t* __restrict__ qidx, const float* __restrict__ qval, const uint32_t* __restrict__ qcnt,
-             int64_t regions, int cap, int nb, int rb_log2, int log2T, float* __restrict__ gtable) {
-  __shared__ float slice[kSliceFloats];
-  const int level = blockIdx.y, b = blockIdx.x, lane = nr_lane(), wave = threadIdx.x >> 6;
-  const int count = (1 << rb_log2) * F;
-  for (int i = threadIdx.x; i < count; i += blockDim.x) slice[i] = 0.0f;
+__global__ void __launch_bounds__(kApplyThreads)
+apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __restrict__ rsum, const uint32_t* __restrict__ cntg,
+             const int* __restrict__ tile_exp, int64_t nb, int ns, int shift, int cap_log2, int log2T, float* __restrict__ gtable) {
+  __shared__ unsigned long long acc[kSliceFloats];
+  __shared__ uint32_t cnts[kApplyThreads];  // count | right shift << 16
+  __shared__ int red[kApplyThreads / NR_WAVE];
+  const int tid = threadIdx.x, slice = blockIdx.x, level = blockIdx.y;
+  const int slice_floats = (1 << shift) * F;
+  for (int i = tid; i < slice_floats; i += kApplyThreads) acc[i] = 0ull;
+  // the level's exponent: the largest of its tiles'
+  int e_l = kNoRecords;
+  for (int64_t b = tid; b < nb; b += kApplyThreads) e_l = max(e_l, tile_exp[(int64_t)level * nb + b]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) e_l = max(e_l, __shfl_xor(e_l, o, NR_WAVE));
+  if ((tid & (NR_WAVE - 1)) == 0) red[tid >> 6] = e_l;
   __syncthreads();
-  const int64_t q0 = ((int64_t)level * nb + b) * regions;
-  // A lane takes 4 CONSECUTIVE entries (16-byte loads): rows of one cell sit next to each other in the queue, and
-  // neighbouring lanes adding to one LDS address serialise inside the instruction; the lane sums equal neighbours itself.
-  const int waves = blockDim.x >> 6;
-  constexpr int kInFlight = 2;  // regions per wave whose loads are issued before the first LDS add
-  for (int64_t reg0 = wave; reg0 < regions; reg0 += (int64_t)waves * kInFlight) {
-    uint32_t have[kInFlight];
+  e_l = kNoRecords;
+  for (int w = 0; w < kApplyThreads / NR_WAVE; ++w) e_l = max(e_l, red[w]);
+  if (e_l == kNoRecords) return;  // nothing was binned on this level
+  const uint32_t mask = (1u << log2T) - 1u, in_mask = (1u << shift) - 1u;
+  const int64_t sub0 = (((int64_t)level * ns + slice) * nb) << cap_log2;
+  constexpr int kBatch = 4;
+  for (int64_t b0 = 0; b0 < nb; b0 += kApplyThreads) {
+    __syncthreads();
+    {
+      uint32_t c = 0;
+      if (b0 + tid < nb) {
+        const int e_b = tile_exp[(int64_t)level * nb + b0 + tid];
+        if (e_b != kNoRecords) {
+          c = cntg[((int64_t)level * nb + b0 + tid) * ns + slice];
+          int sh = e_l - e_b + kApplyDrop;
+          sh = sh > 63 ? 63 : sh;
+          c |= (uint32_t)sh << 16;
+        }
+      }
+      cnts[tid] = c;
+    }
+    __syncthreads();
+    const int64_t blocks_here = nb - b0 < kApplyThreads ? nb - b0 : kApplyThreads;
+    const int64_t slots = blocks_here << cap_log2;
+    // kBatch records per thread are requested before the first is accumulated
+    for (int64_t i0 = tid; i0 < slots; i0 += (int64_t)kBatch * kApplyThreads) {
+      uint32_t key[kBatch], sh[kBatch];
+      unsigned long long q[kBatch][2 * F];
+      bool ok[kBatch];
 #pragma unroll
-    for (int r = 0; r < kInFlight; ++r) have[r] = reg0 + r * waves < regions ? qcnt[q0 + reg0 + r * waves] : 0u;
-    uint32_t most = 0u;
+      for (int k = 0; k < kBatch; ++k) {
+        const int64_t i = i0 + (int64_t)k * kApplyThreads;
+        ok[k] = false;
+        sh[k] = 0;
+        key[k] = 0;
+        if (i < slots) {
+          const uint32_t c = cnts[i >> cap_log2];
+          ok[k] = ((uint32_t)i & ((1u << cap_log2) - 1u)) < (c & 0xFFFFu);
+          sh[k] = c >> 16;
+        }
+        if (ok[k]) {
+          const int64_t at = sub0 + (b0 << cap_log2) + i;
+          key[k] = rkey[at];
 #pragma unroll
-    for (int r = 0; r < kInFlight; ++r) most = have[r] > most ? have[r] : most;
-    for (uint32_t i0 = 0; i0 < most; i0 += 256) {
-      uint4 li[kInFlight];
-      float v[kInFlight][4][F];
-#pragma unroll
-      for (int r = 0; r < kInFlight; ++r) {
-        const int64_t base = (q0 + reg0 + r * waves) * cap;  // cap is a multiple of 64 entries: 16-byte aligned
-        const uint32_t i = i0 + lane * 4;
-        li[r] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int f = 0; f < F; ++f) v[r][e][f] = 0.0f;
-        if (i < have[r]) {  // entries past `have` inside the 4-group are stale memory: masked below
-          li[r] = *reinterpret_cast<const uint4*>(qidx + base + i);
-          const float4* pv = reinterpret_cast<const float4*>(qval + (base + i) * F);
-#pragma unroll
-          for (int q = 0; q < F; ++q) {
-            const float4 t4 = pv[q];
-            const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[r][(q * 4 + j) / F][(q * 4 + j) % F] = tt[j];
-          }
+          for (int j = 0; j < 2 * F; ++j) q[k][j] = rsum[at * (2 * F) + j];
         }
       }
 #pragma unroll
-      for (int r = 0; r < kInFlight; ++r) {
-        const uint32_t i = i0 + lane * 4;
-        const uint32_t idx4[4] = {li[r].x, li[r].y, li[r].z, li[r].w};
-        float acc[F];
+      for (int k = 0; k < kBatch; ++k) {
+        if (!ok[k]) continue;
+        const uint32_t a = key[k] & mask, t = key[k] >> 20;
+        const uint32_t b = (a ^ ((2u << t) - 1u)) & mask;
+        const uint32_t ea = (a & in_mask) * F, eb = (b & in_mask) * F;
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = i + e < have[r];
-#pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] += ok ? v[r][e][f] : 0.0f;
-          const bool last = e == 3 || !(i + e + 1 < have[r]) || idx4[e + 1 < 4 ? e + 1 : 3] != idx4[e];
-          if (ok && last) {
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-              if (acc[f] != 0.0f) atomicAdd(&slice[idx4[e] * F + f], acc[f]);  // ds_add_f32
-              acc[f] = 0.0f;
-            }
-          }
+        for (int f = 0; f < F; ++f) {
+          const long long qa = (long long)q[k][f] >> sh[k], qb = (long long)q[k][F + f] >> sh[k];
+          if (qa != 0) atomicAdd(&acc[ea + f], (unsigned long long)qa);  // ds_add_u64
+          if (qb != 0) atomicAdd(&acc[eb + f], (unsigned long long)qb);
         }
       }
     }
   }
   __syncthreads();
-  float* out = gtable + ((((int64_t)level << log2T) + ((int64_t)b << rb_log2)) * F);
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    const float v = slice[i];
-    if (v != 0.0f) unsafeAtomicAdd(out + i, v);  // other launches add into the same table concurrently
+  const float unfix = ldexpf(1.0f, e_l - kFixBits + kApplyDrop);
+  float* out = gtable + ((((int64_t)level << log2T) + ((int64_t)slice << shift)) * F);
+  for (int i = tid; i < slice_floats; i += kApplyThreads) {
+    const long long a = (long long)acc[i];
+    if (a != 0) unsafeAtomicAdd(out + i, (float)a * unfix);  // other launches add into the same table concurrently
   }
+}
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+inline int nr_num_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int v = 0;
+    cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+  }
+  return cus[dev];
+}
+
+struct Workspace {
+  uint32_t* cntg;
+  int* tile_exp;
+  uint32_t* rkey;
+  unsigned long long* rsum;
+  int64_t bytes;
+};
+
+inline Workspace carve(void* workspace, int L, int F, const BinGeom& g) {
+  Workspace w;
+  char* p = static_cast<char*>(workspace);
+  const int64_t slots = (int64_t)L * g.ns * g.nb * g.cap;
+  w.cntg = reinterpret_cast<uint32_t*>(p);
+  p += align_up((int64_t)L * g.nb * g.ns * 4, 256);
+  w.tile_exp = reinterpret_cast<int*>(p);
+  p += align_up((int64_t)L * g.nb * 4, 256);
+  w.rkey = reinterpret_cast<uint32_t*>(p);
+  p += align_up(slots * 4, 256);
+  w.rsum = reinterpret_cast<unsigned long long*>(p);
+  p += align_up(slots * 2 * F * 8, 256);
+  w.bytes = p - static_cast<char*>(workspace);
+  return w;
 }
 
 }  // namespace
@@ -334,8 +450,7 @@ apply_kernel(const uint32_t* __restrict__ qidx, const float* __restrict__ qval, 
 extern "C" int64_t nr_hash_encode_bwd_binned_workspace_bytes(int L, int F, int log2T, int64_t n) {
   BinGeom g;
   if (L < 1 || log2T < 1 || log2T > 30 || n < 0 || !bin_geom(F, log2T, n, &g)) return -1;
-  const int64_t slots = (int64_t)L * g.nb * g.regions;
-  return slots * 4 + slots * g.cap * 4 + slots * g.cap * 4 * F + 256;
+  return carve(nullptr, L, F, g).bytes;
 }
 
 extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
@@ -344,18 +459,17 @@ extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const
   if (n == 0) return 0;
   BinGeom g;
   if (!x || !gout || !scalings || !gtable || !workspace || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
-  if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0) return NR_EINVAL;
-  const int64_t slots = (int64_t)L * g.nb * g.regions;
-  uint32_t* qcnt = static_cast<uint32_t*>(workspace);
-  uint32_t* qidx = qcnt + (slots + 3) / 4 * 4;
-  float* qval = reinterpret_cast<float*>(qidx + slots * g.cap);
-  dim3 grid1((unsigned)nr_cdiv(g.regions, kWaves), (unsigned)L), grid2((unsigned)g.nb, (unsigned)L);
-#define CALL(FF)                                                                                                          \
-  {                                                                                                                        \
-    hipLaunchKernelGGL(bin_kernel<FF>, grid1, dim3(kWaves * 64), 0, nr_s(stream), x, std, scalings, log2T, gout, sn, sl,   \
-                       gtable, n, g.nb, g.rb_log2, g.cap, g.regions, qidx, qval, qcnt);                                       \
-    hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(1024), 0, nr_s(stream), qidx, qval, qcnt, g.regions, g.cap, g.nb,      \
-                       g.rb_log2, log2T, gtable);                                                                          \
+  if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0 || g.nb > INT_MAX) return NR_EINVAL;
+  const Workspace w = carve(workspace, L, F, g);
+  const int64_t persistent = 2 * (int64_t)nr_num_cus();  // two 80-KB tables per CU
+  dim3 grid1((unsigned)(g.nb < persistent ? g.nb : persistent)), grid2((unsigned)g.ns, (unsigned)L);
+#define CALL(FF)                                                                                                           \
+  {                                                                                                                         \
+    for (int l0 = 0; l0 < L; l0 += kLevelChunk)                                                                             \
+      hipLaunchKernelGGL(bin_kernel<FF>, grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, l0, log2T,     \
+                         gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg, w.tile_exp);      \
+    hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, w.rsum, w.cntg, w.tile_exp,   \
+                       g.nb, g.ns, g.shift, g.cap_log2, log2T, gtable);                                                     \
   }
   switch (F) {
     case 1: CALL(1) break;

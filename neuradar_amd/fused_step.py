@@ -115,11 +115,20 @@ class FusedTrainStep:
             for hg in (self.hg_main, self.hg_prop):
                 hg.actor_table_grads()  # raises unless tables and gradients live in their flat buffers
         self._structs()
-        # Incoherent rows (the lidar rays behind the first self.sm rays) go through the two-pass binned scatter where the
-        # table allows it (nr_hash_encode_bwd_binned: the proposal grids; a main grid of <= 32 slices per level): the
-        # merging kernel finds nothing to merge there and runs at the memory side's single-entry atomic rate.
+        # Table scatters go through the two-pass slice-owner kernels where the table allows it (nr_hash_encode_bwd_binned:
+        # the proposal grids; a main grid of <= 2^20 floats per level) when the batch holds incoherent rows (lidar rays
+        # behind the first self.sm rays) -- then for ALL its rows: mixed batch after 1 500 steps 3.73 ms per step, against
+        # 3.81 / 3.95 with the camera / camera + radar rows left to the merging kernel and 4.52 without the binned kernels
+        # (freshly initialised: 3.13 / 3.08 / 3.09 / 3.46).  Camera-only batches stay with the merging kernel, which folds
+        # neighbouring pixels before anything leaves the wave (16 384 rays: 2.62 against 2.73 ms after 1 500 steps).
+        # NR_BINNED=0 / all / lidar and NR_BINNED_FROM=<first binned ray> override (A/B runs).
         self.binned_ws = [None, None, None]
-        self.binned_from = 0 if os.environ.get("NR_BINNED") == "all" else self.sm  # first ray whose rows go through the binned kernels
+        self.binned_from = 0 if self.sm < B else B  # first ray whose rows go through the binned kernels
+        mode = os.environ.get("NR_BINNED", "")
+        if mode in ("all", "lidar"):
+            self.binned_from = 0 if mode == "all" else self.sm
+        if os.environ.get("NR_BINNED_FROM"):
+            self.binned_from = int(os.environ["NR_BINNED_FROM"])
         if os.environ.get("NR_BINNED", "1") != "0" and self.binned_from < B:
             for lvl, S in enumerate(self.S):
                 grid = self.pgrid if lvl < 2 else self.mgrid

@@ -41,12 +41,18 @@ for lvl, grid, tag in ((0, st.pgrid, "prop_s128"), (1, st.pgrid, "prop_s64"), (2
     t_coh = bench.time_kernel(merging(0, n_coh), 10)
     t_lid = bench.time_kernel(merging(n_coh, nl - n_coh), 10)
     t_all = bench.time_kernel(merging(0, nl), 10)
-    need = lib.nr_hash_encode_bwd_binned_workspace_bytes(L, F, T, nl - n_coh)
-    t_bin = float("nan")
+    need = lib.nr_hash_encode_bwd_binned_workspace_bytes(L, F, T, nl)
+    t_bin = t_bin_all = t_bin_coh = float("nan")
     if need > 0:
         ws = torch.empty(need, device=dev, dtype=torch.uint8)
-        t_bin = bench.time_kernel(lambda: lib.nr_hash_encode_bwd_binned(p(x[n_coh:]), p(sd[n_coh:]), p(grid.scalings), L, F, T,
-                                                                        p(g[:, n_coh:, :]), F, nl * F, p(gt), nl - n_coh, p(ws), s()), 10)
+
+        def binned(r0, n):
+            return lambda: lib.nr_hash_encode_bwd_binned(p(x[r0:]), p(sd[r0:]), p(grid.scalings), L, F, T, p(g[:, r0:, :]), F, nl * F,
+                                                         p(gt), n, p(ws), s())
+
+        t_bin = bench.time_kernel(binned(n_coh, nl - n_coh), 10)
+        t_bin_coh = bench.time_kernel(binned(0, n_coh), 10)
+        t_bin_all = bench.time_kernel(binned(0, nl), 10)
     zero = float((g[:, n_coh:, :] == 0).float().mean())
     print(f"{tag}: merging all {t_all * 1e6:7.1f} us = coherent rows {t_coh * 1e6:7.1f} + lidar rows {t_lid * 1e6:7.1f}; "
-          f"binned lidar rows {t_bin * 1e6:7.1f} us; zero gradients among lidar rows {zero:.2f}")
+          f"binned: all {t_bin_all * 1e6:7.1f} = coherent {t_bin_coh * 1e6:7.1f} + lidar {t_bin * 1e6:7.1f} us; zero gradients among lidar rows {zero:.2f}")
