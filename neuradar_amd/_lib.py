@@ -10,7 +10,7 @@ import subprocess
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint32, c_void_p
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libneuradar_hip.so")
+LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.so")  # (NR_LIB_PATH: A/B runs of two builds)
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024

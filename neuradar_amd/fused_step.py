@@ -474,6 +474,8 @@ class FusedTrainStep:
             scatter(lvl, pg, "prop")
 
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
+        # (both proposal chains on one side stream, or on the main stream in front of the main scatter: +6 % / +8 % per
+        # step on the mixed batch -- the three scatters and the main table's Adam do share the chip productively)
         before = {0: (), 1: (0, 1), 2: (1,), 3: (), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
         for i_ in before:
             if side[i_] is not main:

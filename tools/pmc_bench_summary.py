@@ -4,7 +4,8 @@ usage: python tools/pmc_bench_summary.py gpurun_out/pmc_bench_ profiles/r02_hash
 Every dispatch of the step's hash-grid and field kernels is attributed to the launch site bench.py times
 (`hash_encode_bwd[prop_s128]`, ...): the merging scatter and the gathers by their grid size; the two binned-scatter
 kernels (bin_kernel, apply_kernel) inherit the tag of the merging kernel dispatched right before them (the step launches
-merging -> bin -> apply back to back from one host thread; the passes run eagerly, `--no-graph`, so Dispatch_Id is host order)."""
+[merging ->] bin -> apply of the chain whose head (interlevel_loss_kernel<S/64>) was dispatched last before them: the passes
+run eagerly, `--no-graph`, and the host launches a chain's kernels back to back)."""
 import collections
 import csv
 import glob
@@ -61,13 +62,17 @@ unknown = collections.Counter()
 for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     last_bwd = None
+    # the proposal chains: (inter-level loss, prop_density_bwd, scatter) are launched back to back per chain, so a
+    # scatter kernel belongs to the chain of the prop_density_bwd dispatched last before it (larger grid = the 128-sample round)
     for r in rows:
         k, g = short(r["Kernel_Name"]), int(r["Grid_Size"])
+        if k.startswith("interlevel_loss_kernel"):  # head of a proposal chain: <S / 64>
+            last_bwd = "prop_s128" if "kernel<2>" in k else "prop_s64"
+            continue
         if not k.startswith(WANT):
             continue
         if k.startswith("hash_encode_bwd"):
-            t = bwd_tag(k, g, rows_full) or bwd_tag(k, g, rows_coh)
-            last_bwd = t
+            t = bwd_tag(k, g, rows_full) or bwd_tag(k, g, rows_coh) or ("main_s32" if "kernel<4," in k or "kernel<2," in k else last_bwd)
         elif k.startswith(("bin_kernel", "apply_kernel")):
             t = last_bwd
         else:
@@ -94,9 +99,9 @@ for (k, t), c in sorted(res.items(), key=lambda kv: (kv[0][0], str(kv[0][1]))):
 # per launch site of bench.py's roofline: all kernels of one tag and direction
 sites = {}
 for name, e in kernels.items():
-    if " " not in name:
+    k, _, t = name.rpartition(" ")
+    if not re.fullmatch(r"(prop|main)_s\d+", t):
         continue
-    k, t = name.rsplit(" ", 1)
     kind = "fwd" if ("fwd" in k) else "bwd"
     s = sites.setdefault(f"hash_encode_{kind}[{t}]", {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "kernels": []})
     s["FETCH_SIZE"] += e.get("FETCH_SIZE", 0.0)
