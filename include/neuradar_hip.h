@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 10
+#define NR_ABI_VERSION 11
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -70,19 +70,33 @@ int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings,
                        const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                        float* grad_table, int64_t n, int sample_major, nr_stream_t stream);
 
-/* The same scatter-add for INCOHERENT rows (lidar rays: neighbouring rows share no fine-level cell, the on-chip
- * merging of nr_hash_encode_bwd finds nothing and the launch runs at the memory side's rate for single-entry float
- * atomics).  Two passes: contributions are binned by 128-KB table slice into queues in `workspace`, then one workgroup
- * per slice accumulates its queue in LDS and adds the slice to grad_table with contiguous atomics.  Rows are walked as
- * stored; results equal nr_hash_encode_bwd's up to summation order.  Supported when a level's table is at most 32
- * slices (T * F <= 2^20 floats: the NeuRadar proposal grids, the L16/F2/T=2^19 main grid);
- * nr_hash_encode_bwd_binned_workspace_bytes returns -1 otherwise (use nr_hash_encode_bwd).  workspace: that many bytes,
- * 16-byte aligned, caller-owned; no initialisation needed. */
+/* The same scatter-add by TABLE SLICE OWNERSHIP, for tables a step hits densely (the proposal grids) and for incoherent rows
+ * (lidar / radar rays), where the merging of nr_hash_encode_bwd finds little and the launch runs at the memory side's rate for
+ * single-entry float atomics.  Two passes: every block merges the contributions of its rows in an LDS table (64-bit
+ * fixed-point sums, LDS integer atomics) and leaves one run of records per 64-KB table slice in `workspace`; then one
+ * workgroup per slice accumulates its records in LDS and adds the slice to grad_table with contiguous atomics.  Rows are
+ * walked as stored; results equal nr_hash_encode_bwd's up to summation order (sums are kept 36 bits below the level's largest
+ * value: finer than fp32).  Supported when a level's table is at most 64 slices (T * F <= 2^20 floats: the NeuRadar proposal
+ * grids, the L16/F2/T=2^19 main grid); nr_hash_encode_bwd_binned_workspace_bytes returns -1 otherwise (use
+ * nr_hash_encode_bwd).  workspace: that many bytes, 16-byte aligned, caller-owned; no initialisation needed. */
 int64_t nr_hash_encode_bwd_binned_workspace_bytes(int num_levels, int features_per_level, int log2_hashmap_size, int64_t n);
 int nr_hash_encode_bwd_binned(const float* x, const float* std, const float* scalings,
                               int num_levels, int features_per_level, int log2_hashmap_size,
                               const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                               float* grad_table, int64_t n, void* workspace, nr_stream_t stream);
+
+/* The proposal field's backward from d loss / d density to its table in ONE pass (NeuRADProposalField.get_density,
+ * neurad_field.py:208-213, backward of `trunc_exp(features @ w)` + HashEncoding backward): equal to nr_prop_density_bwd
+ * followed by nr_hash_encode_bwd_binned, without the [L, n, F] feature-gradient buffer in between -- every row's
+ * g = g_density * d trunc_exp(feats . w) is recomputed from the forward features where the scatter reads them.
+ * feats: the forward features in the layout of nr_hash_encode_fwd's `out` (strides as there); w [L*F]; g_density [B,S]
+ * ray-major with the row order arguments of nr_prop_density_bwd; grad_table += scatter; g_w [L*F] += sum_rows g * feats.
+ * num_levels <= 8; table limits and workspace as for nr_hash_encode_bwd_binned. */
+int nr_prop_density_scatter_binned(const float* x, const float* std, const float* scalings,
+                                   int num_levels, int features_per_level, int log2_hashmap_size,
+                                   const float* feats, int64_t out_stride_n, int64_t out_stride_l,
+                                   const float* w, const float* g_density, int n_samples, int64_t rows_sample_major,
+                                   float* grad_table, float* g_w, int64_t n, void* workspace, nr_stream_t stream);
 
 /* grad_x [n,3] = d(sum out*grad_out)/dx (overwritten).  Only needed where positions depend on
  * parameters: samples inside dynamic-actor boxes, whose box-frame coordinates follow the learnable

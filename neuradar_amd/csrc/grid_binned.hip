@@ -93,12 +93,24 @@ __device__ __forceinline__ long long fix_i64(float y) {
 // std, the gradients of all its levels) is requested one tile ahead.
 constexpr int kLevelChunk = 8;
 
-template <int F>
+// HEAD: the proposal field's density head is folded in (nr_prop_density_scatter_binned).  `gout` then holds the FORWARD
+// features; the gradient of every level's feature is g * w[k] with g = g_density * d trunc_exp(feats . w), computed here
+// from the tile's own loads exactly as prop_density_bwd_kernel does -- the [L, n, F] gradient buffer is never written or
+// read -- and the head's weight gradient sum_rows g * feats leaves as one partial per block (folded by the apply kernel).
+struct DensityHead {
+  const float* w;          // [L * F]
+  const float* g_density;  // [B, S] ray-major
+  float* partials;         // [blocks, kLevelChunk * F] (workspace)
+  int n_samples;
+  int64_t sm_rays;
+};
+
+template <int F, bool HEAD>
 __global__ void __launch_bounds__(BinCfg<F>::ROWS)
 bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
            int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int ns,
            int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, unsigned long long* __restrict__ rsum,
-           uint32_t* __restrict__ cntg, int* __restrict__ tile_exp) {
+           uint32_t* __restrict__ cntg, int* __restrict__ tile_exp, DensityHead head) {
   constexpr int ROWS = BinCfg<F>::ROWS, M = BinCfg<F>::M, WAVES = ROWS / NR_WAVE;
   // keys [M] | 64-bit sums [M][2][F].  Exactly half a CU's LDS at F = 1 (two blocks per CU), so the WAVES floats of the
   // block maximum live in the sums of the table's last slots, which are taken out of service (kReserved never matches)
@@ -111,14 +123,22 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the flush's sub-bin addresses stay in SGPRs)
   const int cap = 1 << cap_log2;
   const uint32_t mask = (1u << log2T) - 1u, pmask = (uint32_t)cap - 1u;
+  const int nl = L - level0 < kLevelChunk ? L - level0 : kLevelChunk;
   for (int i = tid; i < M; i += ROWS) keys[i] = i < M - kScratchSlots ? kEmpty : kReserved;
   for (int i = tid; i < M * 2 * F; i += ROWS) acc[i] = 0ull;
   __syncthreads();
 
-  const int nl = L - level0 < kLevelChunk ? L - level0 : kLevelChunk;
   int64_t tile = blockIdx.x;
   if (tile >= nb) return;
-  float px[3] = {0.0f, 0.0f, 0.0f}, pstd = 0.0f, pg[kLevelChunk][F];
+  float px[3] = {0.0f, 0.0f, 0.0f}, pstd = 0.0f, pg[kLevelChunk][F], pgd = 0.0f;
+  float wk[kLevelChunk][F], part[kLevelChunk][F];
+#pragma unroll
+  for (int l = 0; l < kLevelChunk; ++l)
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      wk[l][f] = HEAD && l < nl ? head.w[(level0 + l) * F + f] : 0.0f;
+      part[l][f] = 0.0f;
+    }
   auto fetch = [&](int64_t t) {
     const int64_t row = t * ROWS + tid;
     const bool in = row < n;
@@ -127,6 +147,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       for (int a = 0; a < 3; ++a) px[a] = x[row * 3 + a];
       if (std != nullptr) pstd = std[row];
     }
+    if (HEAD) pgd = in ? head.g_density[nr_row_map(row, n, head.n_samples, head.sm_rays).out] : 0.0f;
 #pragma unroll
     for (int l = 0; l < kLevelChunk; ++l)
 #pragma unroll
@@ -143,6 +164,21 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
     for (int l = 0; l < kLevelChunk; ++l)
 #pragma unroll
       for (int f = 0; f < F; ++f) cg[l][f] = pg[l][f];
+    if (HEAD) {  // prop_density_bwd_kernel's arithmetic, in its order
+      float xs = 0.0f;
+#pragma unroll
+      for (int l = 0; l < kLevelChunk; ++l)
+#pragma unroll
+        for (int f = 0; f < F; ++f) xs += cg[l][f] * wk[l][f];
+      const float g = pgd * expf(fminf(fmaxf(xs, -15.0f), 15.0f));  // activations.py:38-41
+#pragma unroll
+      for (int l = 0; l < kLevelChunk; ++l)
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          part[l][f] += g * cg[l][f];
+          cg[l][f] = g * wk[l][f];
+        }
+    }
     if (tile + gridDim.x < nb) fetch(tile + gridDim.x);
 #pragma unroll 1
     for (int li = 0; li < nl; ++li) {
@@ -318,16 +354,39 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       if (tid == 0) tile_exp[tl] = bmax > 0.0f ? e : kNoRecords;
     }
   }
+  if (HEAD) {  // the block's share of the head's weight gradient (the table is idle: its first words carry the wave sums)
+    lds_barrier();
+    float* red = reinterpret_cast<float*>(acc);
+#pragma unroll
+    for (int l = 0; l < kLevelChunk; ++l)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float t = nr_wave_sum(part[l][f]);
+        if (lane == 0) red[wave * (kLevelChunk * F) + l * F + f] = t;
+      }
+    lds_barrier();
+    if (tid < kLevelChunk * F) {
+      float t = 0.0f;
+      for (int w = 0; w < WAVES; ++w) t += red[w * (kLevelChunk * F) + tid];
+      head.partials[(int64_t)blockIdx.x * (kLevelChunk * F) + tid] = t;
+    }
+  }
 }
 
 template <int F>
 __global__ void __launch_bounds__(kApplyThreads)
 apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __restrict__ rsum, const uint32_t* __restrict__ cntg,
-             const int* __restrict__ tile_exp, int64_t nb, int ns, int shift, int cap_log2, int log2T, float* __restrict__ gtable) {
+             const int* __restrict__ tile_exp, int64_t nb, int ns, int shift, int cap_log2, int log2T, float* __restrict__ gtable,
+             const float* __restrict__ head_partials, int head_blocks, int head_dim, float* __restrict__ g_w) {
   __shared__ unsigned long long acc[kSliceFloats];
   __shared__ uint32_t cnts[kApplyThreads];  // count | right shift << 16
   __shared__ int red[kApplyThreads / NR_WAVE];
   const int tid = threadIdx.x, slice = blockIdx.x, level = blockIdx.y;
+  if (head_partials != nullptr && slice == 0 && level == 0 && tid < head_dim) {  // the density head's weight gradient
+    float t = 0.0f;
+    for (int b = 0; b < head_blocks; ++b) t += head_partials[(int64_t)b * (kLevelChunk * F) + tid];
+    unsafeAtomicAdd(g_w + tid, t);
+  }
   const int slice_floats = (1 << shift) * F;
   for (int i = tid; i < slice_floats; i += kApplyThreads) acc[i] = 0ull;
   // the level's exponent: the largest of its tiles'
@@ -426,8 +485,10 @@ struct Workspace {
   int* tile_exp;
   uint32_t* rkey;
   unsigned long long* rsum;
+  float* partials;  // [kMaxBinBlocks][kLevelChunk * F]: the density head's weight-gradient partials
   int64_t bytes;
 };
+constexpr int kMaxBinBlocks = 1024;
 
 inline Workspace carve(void* workspace, int L, int F, const BinGeom& g) {
   Workspace w;
@@ -441,6 +502,8 @@ inline Workspace carve(void* workspace, int L, int F, const BinGeom& g) {
   p += align_up(slots * 4, 256);
   w.rsum = reinterpret_cast<unsigned long long*>(p);
   p += align_up(slots * 2 * F * 8, 256);
+  w.partials = reinterpret_cast<float*>(p);
+  p += align_up((int64_t)kMaxBinBlocks * kLevelChunk * F * 4, 256);
   w.bytes = p - static_cast<char*>(workspace);
   return w;
 }
@@ -453,23 +516,38 @@ extern "C" int64_t nr_hash_encode_bwd_binned_workspace_bytes(int L, int F, int l
   return carve(nullptr, L, F, g).bytes;
 }
 
-extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
-                                         const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace,
-                                         nr_stream_t stream) {
+static int launch_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T, const float* gout,
+                         int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace, nr_stream_t stream,
+                         const DensityHead* head_in, float* g_w) {
   if (n == 0) return 0;
   BinGeom g;
   if (!x || !gout || !scalings || !gtable || !workspace || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0 || g.nb > INT_MAX) return NR_EINVAL;
+  if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
-  const int64_t persistent = 2 * (int64_t)nr_num_cus();  // two 80-KB tables per CU
-  dim3 grid1((unsigned)(g.nb < persistent ? g.nb : persistent)), grid2((unsigned)g.ns, (unsigned)L);
-#define CALL(FF)                                                                                                           \
-  {                                                                                                                         \
-    for (int l0 = 0; l0 < L; l0 += kLevelChunk)                                                                             \
-      hipLaunchKernelGGL(bin_kernel<FF>, grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, l0, log2T,     \
-                         gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg, w.tile_exp);      \
-    hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, w.rsum, w.cntg, w.tile_exp,   \
-                       g.nb, g.ns, g.shift, g.cap_log2, log2T, gtable);                                                     \
+  int64_t persistent = 2 * (int64_t)nr_num_cus();  // two 80-KB tables per CU
+  if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
+  const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
+  dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L);
+  DensityHead head = {nullptr, nullptr, w.partials, 0, 0};
+  if (head_in != nullptr) {
+    head = *head_in;
+    head.partials = w.partials;
+  }
+#define CALL(FF)                                                                                                            \
+  {                                                                                                                          \
+    if (head_in != nullptr)                                                                                                  \
+      hipLaunchKernelGGL((bin_kernel<FF, true>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, 0,      \
+                         log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg, w.tile_exp, \
+                         head);                                                                                              \
+    else                                                                                                                     \
+      for (int l0 = 0; l0 < L; l0 += kLevelChunk)                                                                            \
+        hipLaunchKernelGGL((bin_kernel<FF, false>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, l0,  \
+                           log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg,           \
+                           w.tile_exp, head);                                                                                \
+    hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, w.rsum, w.cntg, w.tile_exp,    \
+                       g.nb, g.ns, g.shift, g.cap_log2, log2T, gtable, head_in != nullptr ? w.partials : nullptr,            \
+                       (int)blocks, L * FF, g_w);                                                                            \
   }
   switch (F) {
     case 1: CALL(1) break;
@@ -480,4 +558,21 @@ extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const
 #undef CALL
   NR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                         const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace,
+                                         nr_stream_t stream) {
+  return launch_binned(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" int nr_prop_density_scatter_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                              const float* feats, int64_t sn, int64_t sl, const float* w, const float* g_density,
+                                              int n_samples, int64_t rows_sample_major, float* gtable, float* g_w, int64_t n,
+                                              void* workspace, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples)))
+    return NR_EINVAL;
+  const DensityHead head = {w, g_density, nullptr, n_samples, rows_sample_major};
+  return launch_binned(x, std, scalings, L, F, log2T, feats, sn, sl, gtable, n, workspace, stream, &head, g_w);
 }

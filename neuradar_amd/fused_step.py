@@ -436,6 +436,11 @@ class FusedTrainStep:
             early = 1 if reducer is not None else 0
         split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
 
+        # proposal levels whose density-head backward rides inside the binned scatter (nr_prop_density_scatter_binned): all
+        # rows binned, no actor rows to patch into the feature gradients -- the [L, n, F] gradient buffer is then never touched
+        head_in_scatter = [self.binned_ws[l_] is not None and self.binned_from == 0 and not self.n_actors and pg.num_levels <= 8
+                           and os.environ.get("NR_FUSE_DENSITY_BWD", "1") != "0" for l_ in (0, 1)]
+
         def chain_head(lvl):
             sp_ = ops._stream()
             S, nl = self.S[lvl], B * self.S[lvl]
@@ -444,8 +449,9 @@ class FusedTrainStep:
                                                     losses.PULSE_WIDTHS[lvl], c.interlevel_loss_mult, p(self.g_dens[lvl]),
                                                     p(self.loss), byref(lid["prop"]) if lid is not None else None,
                                                     sp_), "interlevel_loss")
-            check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
-                                          p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
+            if not head_in_scatter[lvl]:
+                check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
+                                              p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 
         def scatter(lvl, grid, tag):
             """grad_table += scatter of g_feats[lvl] on the current stream: the merging kernel on the coherent rows, the
@@ -458,6 +464,11 @@ class FusedTrainStep:
                 actor_backward(lvl, grid)
 
             def launch():
+                if lvl < 2 and head_in_scatter[lvl]:
+                    return lib.nr_prop_density_scatter_binned(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                              grid.log2_hashmap_size, p(self.feats[lvl]), Fg, nl * Fg, p(w_dec),
+                                                              p(self.g_dens[lvl]), S, self.sm, p(grid.hash_table.grad), p(w_dec.grad),
+                                                              nl, p(self.binned_ws[lvl]), sp_)
                 rc = lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
                                             grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
                                             n_coh, 0, sp_) if n_coh > 0 else 0

@@ -102,3 +102,41 @@ def test_scatters_sum_long_runs_of_one_cell(F, run):
     ops.check(lib.nr_hash_encode_bwd(p(xd), None, p(scd), L, F, log2t, p(gd), L * F, F, p(got_merge), n, 0, st()), "bwd")
     assert_close(got_merge.cpu(), gref, rtol=1e-4, atol_scale=1e-5, what=f"merging kernel, runs of {run}")
     assert_close(got_binned.cpu(), gref, rtol=1e-4, atol_scale=1e-5, what=f"binned kernel, runs of {run}")
+
+
+@pytest.mark.parametrize("sample_major", [0, 1])
+def test_density_head_folded_into_the_binned_scatter(sample_major):
+    """nr_prop_density_scatter_binned == nr_prop_density_bwd followed by nr_hash_encode_bwd_binned (the proposal field's
+    backward, neurad_field.py:208-213): same table gradient (rtol 1e-4 of its scale; the per-row g is computed by the same
+    expressions, the sums differ in order only) and same weight gradient of the density head, with ray-major and
+    sample-major rows; rows with g_density == 0 (masked) contribute nothing."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    torch.manual_seed(5 + sample_major)
+    L, F, log2t, B, S = 6, 1, 20, 1500, 64
+    n = B * S
+    sm = B if sample_major else 0
+    sc = hashgrid.level_scalings(L, 128, 4096).to(DEV)
+    x = torch.rand(n, 3, device=DEV)
+    std = 0.002 * torch.rand(n, device=DEV)
+    feats = 0.3 * torch.randn(L, n, F, device=DEV)
+    w = torch.randn(L * F, device=DEV)
+    g_density = torch.randn(B, S, device=DEV)
+    g_density[::5] = 0.0
+    rows = L << log2t
+    lib, p, st = ops._lib.lib(), ops._p, ops._stream
+    need = lib.nr_hash_encode_bwd_binned_workspace_bytes(L, F, log2t, n)
+    ws = torch.empty(need, device=DEV, dtype=torch.uint8)
+    # two steps
+    g_feats = torch.empty_like(feats)
+    gw_ref, gt_ref = torch.zeros_like(w), torch.zeros(rows, F, device=DEV)
+    ops.check(lib.nr_prop_density_bwd(p(feats), F, n * F, F, p(w), L * F, n, S, sm, None, p(g_density), p(g_feats), p(gw_ref), st()), "dens_bwd")
+    ops.check(lib.nr_hash_encode_bwd_binned(p(x), p(std), p(sc), L, F, log2t, p(g_feats), F, n * F, p(gt_ref), n, p(ws), st()), "binned")
+    # one pass
+    gw, gt = torch.full_like(w, 0.5), torch.zeros(rows, F, device=DEV)
+    ops.check(lib.nr_prop_density_scatter_binned(p(x), p(std), p(sc), L, F, log2t, p(feats), F, n * F, p(w), p(g_density), S, sm,
+                                                 p(gt), p(gw), n, p(ws), st()), "fused")
+    assert_close(gt.cpu(), gt_ref.cpu(), rtol=1e-4, atol_scale=1e-5, what="table gradient")
+    assert torch.equal(gt != 0, gt_ref != 0)
+    assert_close((gw - 0.5).cpu(), gw_ref.cpu(), rtol=1e-4, atol_scale=1e-5, what="head weight gradient (accumulated onto g_w)")
