@@ -98,6 +98,30 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
                                    const float* w, const float* g_density, int n_samples, int64_t rows_sample_major,
                                    float* grad_table, float* g_w, int64_t n, void* workspace, nr_stream_t stream);
 
+/* tiny-cuda-nn-compatible multiresolution hash grid for 3-D and 4-D inputs: what
+ * `tcnn.Encoding(n_input_dims, {"otype": "HashGrid", n_levels, n_features_per_level, log2_hashmap_size, base_resolution,
+ * per_level_scale})` computes with interpolation "Linear" (field_components/encodings.py:361-373,386-401,468-471; the 4-D
+ * actor grid: neurad_encoding.py:112-133,282-293), on tcnn's own parameter layout (levels packed back to back, dense
+ * indexing while resolution^D <= 2^log2_hashmap_size, hashed above, entry = F contiguous values), so that
+ * `tcnn_encoding.params` of a reference checkpoint is usable as it is (as fp32).  x [n,D] in [0,1]; out / grad_out
+ * [n, L*F]; grad_params += (not zeroed).  D in {3,4}, F in {1,2,4,8}, L <= 32.  nr_tcnn_grid_param_count: floats of
+ * `params` (-1: unsupported configuration).  Restated from tiny-cuda-nn's published sources -- the library is not in the
+ * image: see DESIGN.md section 9 for what pins it. */
+int64_t nr_tcnn_grid_param_count(int n_dims, int num_levels, int features_per_level, int log2_hashmap_size,
+                                 int base_resolution, float per_level_scale);
+/* The level geometry the kernels use, into HOST arrays: scales[L] (x * scale + 0.5 = grid position), resolutions[L],
+ * offsets[L+1] (entries; level l owns [offsets[l], offsets[l+1])).  scale_l = exp2f(l * log2f(per_level_scale)) * base - 1 is
+ * evaluated in float32 on the host; exp2f implementations differ by a few ulp, so a table trained elsewhere sees its
+ * positions shifted by up to ~1e-6 of a cell per unit of resolution. */
+int nr_tcnn_grid_geometry(int n_dims, int num_levels, int log2_hashmap_size, int base_resolution, float per_level_scale,
+                          float* scales, uint32_t* resolutions, uint32_t* offsets);
+int nr_tcnn_grid_fwd(const float* x, const float* params, int n_dims, int num_levels, int features_per_level,
+                     int log2_hashmap_size, int base_resolution, float per_level_scale, float* out, int64_t n,
+                     nr_stream_t stream);
+int nr_tcnn_grid_bwd(const float* x, int n_dims, int num_levels, int features_per_level, int log2_hashmap_size,
+                     int base_resolution, float per_level_scale, const float* grad_out, float* grad_params, int64_t n,
+                     nr_stream_t stream);
+
 /* grad_x [n,3] = d(sum out*grad_out)/dx (overwritten).  Only needed where positions depend on
  * parameters: samples inside dynamic-actor boxes, whose box-frame coordinates follow the learnable
  * trajectories (require_actor_grad, field_components/neurad_encoding.py:83,176). */

@@ -52,6 +52,10 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
+    "nr_tcnn_grid_param_count": [I, I, I, I, I, F],
+    "nr_tcnn_grid_geometry": [I, I, I, I, F, P, P, P],
+    "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],
+    "nr_tcnn_grid_bwd": [P, I, I, I, I, I, F, P, P, L, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
     "nr_actor_candidates": [P, P, P, L, I, P, P, P, P, P, P, I, I, P, P, P],
     "nr_actor_w2b_fwd": [P, L, I, I, P, P, P, P, P, P, P, P],
@@ -104,7 +108,8 @@ PROTOTYPES = {
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
-             "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64}
+             "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
+             "nr_tcnn_grid_param_count": c_int64}
 
 _lib = None
 

@@ -58,6 +58,8 @@ class FusedTrainStep:
         self.S = (*c.num_proposal_samples, c.num_nerf_samples)
         f32 = dict(device=dev, dtype=torch.float32)
         self.prop = model.proposal_fields[-1]  # both rounds use proposal_fields[1] (neuradar.py:302 quirk)
+        if model.field.hashgrid.config.layout != "torch" or self.prop.hashgrid.config.layout != "torch":
+            raise NotImplementedError("the fused step runs on the torch table layout; tcnn-layout tables (tcnn_compat) use the modular path")
         self.pgrid, self.mgrid = self.prop.hashgrid.static_grid, model.field.hashgrid.static_grid
         self.nears = torch.zeros(B, **f32)
         self.fars = torch.empty(B, **f32)

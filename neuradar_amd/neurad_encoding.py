@@ -45,6 +45,11 @@ class NeuRADHashEncodingConfig:  # neurad_encoding.py:71-84
     actor: ActorSettings = field(default_factory=ActorSettings)
     disable_actors: bool = False
     require_actor_grad: bool = True
+    layout: str = "torch"
+    """"torch": the reference's torch tables ([L*T, F], all levels hashed; one 3-D grid per actor) -- the layout of the hot
+    path.  "tcnn": tiny-cuda-nn's function and parameter layout (tcnn_compat.TcnnHashEncoding), with the single 4-D
+    xyz + actor-id grid when actor.use_4d_hashgrid -- for evaluating / fine-tuning tables trained through the reference's
+    tcnn path (SURVEY 8f-4); modular path only, trajectories are not optimised through it."""
 
     def setup(self, **kwargs) -> "NeuRADHashEncoding":
         return NeuRADHashEncoding(self, **kwargs)
@@ -60,6 +65,11 @@ class NeuRADHashEncoding(nn.Module):
         n_actors = 0 if dynamic_actors is None or config.disable_actors else getattr(dynamic_actors, "n_actors", 0)
         self.n_actors = n_actors
         self.static_scale = float(static_scale)
+        if config.layout == "tcnn":
+            self._build_tcnn_grids(n_actors)
+            return
+        if config.layout != "torch":
+            raise ValueError(f"unknown table layout {config.layout!r}")
         self.static_grid = HashEncoding(
             implementation=implementation, features_per_level=config.static.hashgrid_dim,
             num_levels=config.static.num_levels, min_res=config.static.base_res, max_res=config.static.max_res,
@@ -72,6 +82,71 @@ class NeuRADHashEncoding(nn.Module):
                          log2_hashmap_size=config.actor.log2_hashmap_size) for _ in range(n_actors)])
         self.scene_repr_dim = self.static_grid.get_out_dim()
 
+    # ------------------------------------------------------------------------------------------ tcnn layout (f-4)
+    def _build_tcnn_grids(self, n_actors: int) -> None:
+        """neurad_encoding.py:104-133 with implementation="tcnn": static 3-D grid; ONE 4-D (xyz, actor id / n_actors) grid for
+        all actors when actor.use_4d_hashgrid (:112-116), else one 3-D grid per actor."""
+        from .tcnn_compat import TcnnHashEncoding
+
+        c = self.config
+        self.static_grid = TcnnHashEncoding(features_per_level=c.static.hashgrid_dim, num_levels=c.static.num_levels,
+                                            min_res=c.static.base_res, max_res=c.static.max_res,
+                                            log2_hashmap_size=c.static.log2_hashmap_size)
+        self.actor_4d = bool(c.actor.use_4d_hashgrid)
+        n_grids, dims = ((1, 4) if self.actor_4d else (n_actors, 3)) if n_actors > 0 else (0, 3)
+        self.actor_grids = nn.ModuleList([
+            TcnnHashEncoding(features_per_level=c.actor.hashgrid_dim, num_levels=c.actor.num_levels, min_res=c.actor.base_res,
+                             max_res=c.actor.max_res, log2_hashmap_size=c.actor.log2_hashmap_size, n_input_dims=dims)
+            for _ in range(n_grids)])
+        self.scene_repr_dim = self.static_grid.get_out_dim()
+
+    @staticmethod
+    def _rescale(feats: Tensor, std: Tensor, grid) -> Tensor:
+        """_rescale_grid_features (neurad_encoding.py:309-316): per level 1 / max(1, 2 * scaling_l * std)."""
+        n, L = feats.shape[0], grid.num_levels
+        w = 1.0 / torch.clamp(2.0 * grid.scalings[None, :] * std[:, None], min=1.0)
+        return (feats.view(n, L, -1) * w[:, :, None]).view(n, -1)
+
+    def _encode_samples_tcnn(self, rs, level_major: bool, want_dirs: bool, flip: Optional[Tensor]):
+        """encode_samples for layout="tcnn": the same chain (:152-189) composed from the tcnn-layout grid op and torch
+        elementwise ops; rows are ray-major (row b*S+s)."""
+        g = self.static_grid
+        B, S = rs.shape
+        n, L, F_ = B * S, g.num_levels, g.features_per_level
+        x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, self.static_scale,
+                                            sample_major_rows=False)
+        feats = self._rescale(g(x01), std01, g)
+        dirs = None
+        if self.n_actors > 0:
+            geom = self.actor_geometry(rs, flip)
+            dev = feats.device
+            slot = torch.empty(n, device=dev, dtype=torch.int32)
+            x01a, std01a = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
+            dirs = torch.empty(n, 3, device=dev) if want_dirs else None
+            lib, p = ops._lib.lib(), ops._p
+            K = self.MAX_CANDIDATES
+            ops.check(lib.nr_actor_assign(p(rs.origins.contiguous()), p(rs.directions.contiguous()), p(rs.pixel_area.reshape(-1).contiguous()),
+                                          p(rs.euclid.contiguous()), B, S, 0, p(geom["cand"]), K, p(geom["w2b"].detach()), p(geom["centres"]),
+                                          p(geom["bounds"]), self.config.actor.actor_scale, p(geom["flip"]), p(slot), p(x01a), p(std01a),
+                                          p(dirs), ops._stream()), "nr_actor_assign")
+            inside = slot >= 0
+            ray = torch.arange(n, device=dev) // S
+            actor = geom["cand"][ray, slot.clamp(min=0).long()].long()  # actor id of the box the sample sits in
+            ag = self.actor_grids[0]
+            if self.actor_4d:  # _get_actor_features_fast (:282-293): 4th coordinate = actor index / n_actors
+                pos4 = torch.cat([x01a, (actor.float() / self.n_actors)[:, None]], dim=-1)
+                fa = self._rescale(ag(pos4), std01a, ag)
+            else:  # _get_actor_features_slow (:295-307)
+                fa = torch.zeros(n, ag.get_out_dim(), device=dev)
+                for a, grid in enumerate(self.actor_grids):
+                    fa = torch.where((inside & (actor == a))[:, None], self._rescale(grid(x01a), std01a, grid), fa)
+            if fa.shape[1] != feats.shape[1]:
+                raise ValueError("actor and static grids must have the same output width (neurad_encoding.py:186)")
+            feats = torch.where(inside[:, None], fa, feats)
+        if level_major:
+            return feats.view(n, L, F_).permute(1, 0, 2).contiguous(), (F_, n * F_), dirs, False
+        return feats, (g.get_out_dim(), F_), dirs, False
+
     def get_out_dim(self) -> int:
         return self.scene_repr_dim
 
@@ -80,7 +155,7 @@ class NeuRADHashEncoding(nn.Module):
         gradients) into their shared buffers right away, so that optimizers built afterwards see the final storage."""
         out = super()._apply(fn, *args, **kwargs)
         self._actor_flat = None
-        if self.n_actors > 0:
+        if self.n_actors > 0 and self.config.layout == "torch":
             self._actor_tables()
         return out
 
@@ -96,6 +171,8 @@ class NeuRADHashEncoding(nn.Module):
         = get_fast_isotropic_gaussian(1) (cameras/rays.py:109-124) -> static_contraction
         (neurad_encoding.py:169) -> static_grid -> _rescale_grid_features (:277-280,309-316) -> actor
         features written over the static ones (:175-187)."""
+        if self.config.layout == "tcnn":
+            return self._encode_samples_tcnn(ray_samples, level_major, directions, flip)
         g = self.static_grid
         B, S = ray_samples.shape
         rows_sm = bool(rows_sample_major)
