@@ -132,6 +132,8 @@ class NeuRADHashEncoding(nn.Module):
             inside = slot >= 0
             ray = torch.arange(n, device=dev) // S
             actor = geom["cand"][ray, slot.clamp(min=0).long()].long()  # actor id of the box the sample sits in
+            if getattr(self.actors, "actor_to_id", None) is not None:  # (:183: hash-grid id of the actor)
+                actor = self.actors.actor_to_id.to(dev)[actor].long()
             ag = self.actor_grids[0]
             if self.actor_4d:  # _get_actor_features_fast (:282-293): 4th coordinate = actor index / n_actors
                 pos4 = torch.cat([x01a, (actor.float() / self.n_actors)[:, None]], dim=-1)
@@ -140,8 +142,7 @@ class NeuRADHashEncoding(nn.Module):
                 fa = torch.zeros(n, ag.get_out_dim(), device=dev)
                 for a, grid in enumerate(self.actor_grids):
                     fa = torch.where((inside & (actor == a))[:, None], self._rescale(grid(x01a), std01a, grid), fa)
-            if fa.shape[1] != feats.shape[1]:
-                raise ValueError("actor and static grids must have the same output width (neurad_encoding.py:186)")
+            fa = torch.nn.functional.pad(fa, (0, feats.shape[1] - fa.shape[1]))  # zero-padded to scene_repr_dim (:186)
             feats = torch.where(inside[:, None], fa, feats)
         if level_major:
             return feats.view(n, L, F_).permute(1, 0, 2).contiguous(), (F_, n * F_), dirs, False

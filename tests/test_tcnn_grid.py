@@ -137,7 +137,7 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
     g = load_golden("actors")
     actors = DynamicActors.from_state(g["actor_positions"], g["actor_rotations_6d"], g["actor_timestamps"], g["actor_present"],
                                       g["actor_sizes"])
-    st_, ac_ = (StaticSettings(hashgrid_dim=4, num_levels=4, base_res=16, max_res=256, log2_hashmap_size=12),
+    st_, ac_ = (StaticSettings(hashgrid_dim=4, num_levels=8, base_res=16, max_res=2048, log2_hashmap_size=12),
                 ActorSettings(hashgrid_dim=4, num_levels=4, base_res=8, max_res=64, log2_hashmap_size=10, use_4d_hashgrid=True, flip_prob=0.0))
     cfg = NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=st_, actor=ac_, layout="tcnn"))
     torch.manual_seed(3)
@@ -147,11 +147,11 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
     # (i) a tcnn-style state dict
     n_s, n_a = hg.static_grid.tcnn_encoding.params.numel(), hg.actor_grids[0].tcnn_encoding.params.numel()
     sd = {"hashgrid.static_grid.tcnn_encoding.params": torch.randn(n_s), "hashgrid.actor_grids.0.tcnn_encoding.params": torch.randn(n_a),
-          "mlp_geo.tcnn_encoding.params": 0.1 * torch.randn(32 * 16 + 48 * 32), "sdf_to_density.beta": torch.tensor([17.0])}
+          "mlp_geo.tcnn_encoding.params": 0.1 * torch.randn(32 * 32 + 48 * 32), "sdf_to_density.beta": torch.tensor([17.0])}
     used = load_tcnn_state_dict(field, sd)
     assert sorted(used) == sorted(sd), (used, list(sd))
     assert float(field.sdf_to_density.beta) == 17.0 and float(field.mlp_geo.layers[0].bias.abs().max()) == 0.0
-    assert torch.equal(field.mlp_geo.layers[1].weight.cpu(), sd["mlp_geo.tcnn_encoding.params"][32 * 16:].view(48, 32)[:33])
+    assert torch.equal(field.mlp_geo.layers[1].weight.cpu(), sd["mlp_geo.tcnn_encoding.params"][32 * 32:].view(48, 32)[:33])
     # (ii) rays towards the actors
     gen = torch.Generator().manual_seed(11)
     B, S = 64, 48
@@ -171,8 +171,8 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
         outs = field(rs)
         assert outs[FieldHeadNames.FEATURE].shape == (B, S, 32) and bool(torch.isfinite(outs[FieldHeadNames.ALPHA]).all())
     feats, strides, _, rows_sm = hg.encode_samples(rs, level_major=False)
-    assert not rows_sm and feats.shape == (B * S, 16)
-    go = torch.randn(B * S, 16, generator=gen)
+    assert not rows_sm and feats.shape == (B * S, 32)
+    go = torch.randn(B * S, 32, generator=gen)
     (feats * dv(go)).sum().backward()
     # the same by hand from oracle pieces
     x01, std01 = ops.contract_gaussians(rs.origins, rs.directions, rs.pixel_area, rs.euclid, 100.0, sample_major_rows=False)
@@ -188,6 +188,7 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
     inside = (slot >= 0).cpu()
     assert 0.02 < float(inside.float().mean()) < 0.9, "the test rays must cross actor boxes"
     actor = geom["cand"][torch.arange(n, device=DEV) // S, slot.clamp(min=0).long()].long().cpu()
+    assert not hasattr(actors, "actor_to_id") or actors.actor_to_id is None or torch.equal(actors.actor_to_id.cpu(), torch.arange(actors.n_actors))
     g3 = tg.geometry(3, st_.num_levels, 4, st_.log2_hashmap_size, st_.base_res, float(hg.static_grid.growth_factor))
     g4 = tg.geometry(4, ac_.num_levels, 4, ac_.log2_hashmap_size, ac_.base_res, float(hg.actor_grids[0].growth_factor))
     ps = sd["hashgrid.static_grid.tcnn_encoding.params"].clone().requires_grad_(True)
@@ -200,7 +201,7 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
     fs = rescale(tg.encode(x01.cpu(), ps, g3), std01.cpu(), hg.static_grid.scalings.cpu())
     pos4 = torch.cat([x01a.cpu(), (actor.float() / actors.n_actors)[:, None]], dim=-1)
     fa = rescale(tg.encode(torch.where(inside[:, None], pos4, torch.zeros_like(pos4)), pa, g4), std01a.cpu(), hg.actor_grids[0].scalings.cpu())
-    want = torch.where(inside[:, None], fa, fs)
+    want = torch.where(inside[:, None], torch.nn.functional.pad(fa, (0, 16)), fs)  # 4 actor levels of 8: zero-padded (:186)
     torch.testing.assert_close(feats.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-5)
     (want * go).sum().backward()
     for got, ref, what in ((hg.static_grid.tcnn_encoding.params.grad, ps.grad, "static"), (hg.actor_grids[0].tcnn_encoding.params.grad, pa.grad, "4-D actor")):
