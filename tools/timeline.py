@@ -9,6 +9,8 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(anonymous namespace\)::|at::native::|void ", "", r["Kernel_Name"])[:60]  # noqa: E731
 gsz = lambda r: int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)  # noqa: E731
 props = [i for i, r in enumerate(rows) if "prop_field_fwd" in r["Kernel_Name"]]
+if not props:  # level-major proposal forward (mixed batches): the F = 1 gather launch opens the step
+    props = [i for i, r in enumerate(rows) if "hash_encode_fwd_kernel<1>" in r["Kernel_Name"]]
 idx = [i for i in props if gsz(rows[i]) == max(gsz(rows[j]) for j in props)]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
