@@ -88,14 +88,18 @@ inline int check_field(const nr_field_t* f, int* hid) {
   return 0;
 }
 
-inline unsigned field_bwd_blocks(int64_t n) {
+// Blocks of the backward launches = gradient slabs in the workspace.  One block per CU (one wave per SIMD) for the fp32
+// kernels, whose dW accumulators leave room for no second wave; the 16-bit kernels at width 32 fit two waves per SIMD
+// (<= 256 registers), so they get two blocks per CU.
+constexpr int kMaxBwdBlocks = 512;
+inline unsigned field_bwd_blocks(int64_t n, const nr_field_t* field, int hid) {
   const int64_t tiles = nr_cdiv(n, 32);
-  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 256 ? nr_cdiv(tiles, 4) : 256);
+  int cap = field->dtype != NR_DTYPE_F32 && hid == 32 ? kMaxBwdBlocks : 256;
   if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
     const int v = atoi(e);
-    if (v > 0 && v <= 256 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+    if (v > 0 && v <= kMaxBwdBlocks) cap = v;
   }
-  return blocks;
+  return (unsigned)(nr_cdiv(tiles, 4) < cap ? nr_cdiv(tiles, 4) : cap);
 }
 
 // reduced-precision variants (mlp_lp.hip), dispatched from the entry points in mlp.hip on nr_field_t.dtype

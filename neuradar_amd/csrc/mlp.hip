@@ -605,7 +605,7 @@ extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t
     for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
     for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
   }
-  const unsigned blocks = field_bwd_blocks(n);
+  const unsigned blocks = field_bwd_blocks(n, field, hid);
   float* slab = workspace + ws_floats(n);  // [blocks][G_TOTAL] after the d_e / d_sdf tiles
   if (field->dtype != NR_DTYPE_F32) {  // bf16 / fp16 operands (mlp_lp.hip); same workspace / slab layout, same reduce
     const int rc = field_bwd_lp(field, hid, feats, sn, sl, F, dirs, S, rows_sample_major, n, g_feature, g_alpha, g_sdf, g_feats,
@@ -654,7 +654,7 @@ extern "C" int nr_field_grad_reduce(const nr_field_t* field, const float* worksp
   if (check_field(field, &hid) != 0 || !workspace || !grads || n < 0) return NR_EINVAL;
   for (int l = 0; l < 2; ++l) if (!grads->geo.weight[l] || !grads->geo.bias[l]) return NR_EINVAL;
   for (int l = 0; l < 3; ++l) if (!grads->feat.weight[l] || !grads->feat.bias[l]) return NR_EINVAL;
-  const unsigned blocks = field_bwd_blocks(n);
+  const unsigned blocks = field_bwd_blocks(n, field, hid);
   const float* slab = workspace + ws_floats(n);
   if (hid == 32)
     hipLaunchKernelGGL((field_grad_reduce_kernel<32, 32>), dim3((unsigned)nr_cdiv(FieldImage<32, 32>::G_TOTAL, 64)), dim3(1024), 0,
@@ -670,7 +670,7 @@ extern "C" int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_
   int hid = 0;
   if (check_field(field, &hid) != 0 || n < 0) return -1;
   const int64_t g_total = hid == 32 ? FieldImage<32, 32>::G_TOTAL : FieldImage<32, 64>::G_TOTAL;
-  return ws_floats(n) + 256 * g_total;  // d_e / d_sdf tiles + one gradient slab per block (<= 256 blocks)
+  return ws_floats(n) + kMaxBwdBlocks * g_total;  // d_e / d_sdf tiles + one gradient slab per block
 }
 
 extern "C" int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n) {

@@ -264,11 +264,24 @@ field_fwd_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn,
   const float beta = fabsf(fld.beta[0]) + kBetaMin;
   const int64_t tiles = nr_cdiv_dev(n, 32);
   const FeatOff<FW> foff{sl, F};
+  // the next tile's features are requested before the current tile's chain of five layers starts: the chain is one
+  // dependent sequence per wave, a tile's 16 loads would otherwise be exposed latency in front of it
+  f32x16 xn[1];
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t s0 = t0 * 32 + i;
+    load_rows<32>(xn, feats + (t0 < tiles && s0 < n ? s0 * sn : 0), t0 < tiles && s0 < n, h, foff);
+  }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
     f32x16 x0[1], h1[HT], e[1], f1[HT], f2[HT], o[1];
-    load_rows<32>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
+    x0[0] = xn[0];
+    {
+      const int64_t tn = tile + (int64_t)gridDim.x * 4, sn_ = tn * 32 + i;
+      const bool vn = tn < tiles && sn_ < n;
+      load_rows<32>(xn, feats + (vn ? sn_ * sn : 0), vn, h, foff);
+    }
     PTile xp[1] = {to_ptile<T>(x0[0])};
     dense_lp<T, 2, HT>(xp, h1, lds + I::oG1f, fb + I::bG1, lane, h);
     PTile h1p[HT];
@@ -303,7 +316,7 @@ field_fwd_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn,
 
 // ---- backward, feature half: recompute the forward, backward through mlp_feature and the sigmoid ---------------------
 template <typename T, int HID, int FW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HID == 32 ? 2 : 1)))
 field_bwd_feat_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, int64_t sl, int F,
                          const float* __restrict__ dirs, int S, int rows_sm, int64_t n, const float* __restrict__ g_feature,
                          const float* __restrict__ g_alpha, const float* __restrict__ g_sdf, float* __restrict__ ws,
@@ -338,6 +351,11 @@ field_bwd_feat_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_
   bF3[0] = 0.0f;
   const int64_t tiles = nr_cdiv_dev(n, 32);
   const FeatOff<FW> foff{sl, F};
+  f32x16 xn[1];  // the next tile's features, requested one tile ahead (see field_fwd_lp_kernel)
+  {
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + wave, s0 = t0 * 32 + i;
+    load_rows<32>(xn, feats + (t0 < tiles && s0 < n ? s0 * sn : 0), t0 < tiles && s0 < n, h, foff);
+  }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
@@ -346,7 +364,12 @@ field_bwd_feat_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_
     float sdf;
     {  // forward again
       f32x16 x0[1], h1[HT], e[1], f1[HT], f2[HT];
-      load_rows<32>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
+      x0[0] = xn[0];
+      {
+        const int64_t tn = tile + (int64_t)gridDim.x * 4, sn_ = tn * 32 + i;
+        const bool vn = tn < tiles && sn_ < n;
+        load_rows<32>(xn, feats + (vn ? sn_ * sn : 0), vn, h, foff);
+      }
       PTile xp[1] = {to_ptile<T>(x0[0])};
       dense_lp<T, 2, HT>(xp, h1, lds + I::oG1f, fb + I::bG1, lane, h);
       PTile h1p[HT];
@@ -451,20 +474,32 @@ field_bwd_geo_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t
   bG2[0] = 0.0f;
   const int64_t tiles = nr_cdiv_dev(n, 32);
   const FeatOff<FW> foff{sl, F};
+  f32x16 xn[1], wn;  // the next tile's features and its d_e / d_sdf rows from the feature half, one tile ahead
+  float wn_sdf = 0.0f;
+  auto request = [&](int64_t t) {
+    const int64_t s_ = t * 32 + i;
+    const bool v = t < tiles && s_ < n;
+    load_rows<32>(xn, feats + (v ? s_ * sn : 0), v, h, foff);
+    const float* wt = ws + (t < tiles ? t : 0) * kWsTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wn[r] = wt[r * 64 + lane];
+    wn_sdf = wt[16 * 64 + lane];
+  };
+  request((int64_t)blockIdx.x * 4 + wave);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
     f32x16 x0[1], h1[HT], d_e, d_h1[HT], d_x0[1];
-    load_rows<32>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
+    x0[0] = xn[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d_e[r] = wn[r] * gs;
+    const float d_sdf = wn_sdf;
+    request(tile + (int64_t)gridDim.x * 4);
     PTile xp[1] = {to_ptile<T>(x0[0])};
     dense_lp<T, 2, HT>(xp, h1, lds, fb + I::bG1, lane, h);
     PTile h1p[HT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) { relu_tile(h1[t]); h1p[t] = to_ptile<T>(h1[t]); }
-    const float* wt = ws + tile * kWsTile;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d_e[r] = wt[r * 64 + lane] * gs;
-    const float d_sdf = wt[16 * 64 + lane];
     if (h == 0) bSdf += d_sdf;
     PTile d_ep[1] = {to_ptile<T>(d_e)};
     dense_dw_lp<T, HT, 1>(d_ep, h1p, aG2, bG2, scr, lane);   // mlp_geo.layers[1] rows 1..C

@@ -32,7 +32,17 @@ def _run(tmp, tag, world, extra):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), WORKER, "--out", out, *extra]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        # two processes sharing one device through gloo's host path: seen once in ~20 runs of the suite to stall in the
+        # rendezvous of a freshly started pair (the same command by itself takes 8 s); one more attempt on a new port
+        import warnings
+
+        warnings.warn(f"{tag}: the {world}-process run did not finish within 240 s; retrying once")
+        if world > 1:
+            cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, f"{tag}: rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
     return [torch.load(f"{out}.rank{k}", weights_only=False) for k in range(world)]
 
