@@ -382,7 +382,7 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
   __shared__ uint32_t cnts[kApplyThreads];  // count | right shift << 16
   __shared__ int red[kApplyThreads / NR_WAVE];
   const int tid = threadIdx.x, slice = blockIdx.x, level = blockIdx.y;
-  if (head_partials != nullptr && slice == 0 && level == 0 && tid < head_dim) {  // the density head's weight gradient
+  if (head_partials != nullptr && slice == 0 && level == 0 && blockIdx.z == 0 && tid < head_dim) {  // the density head's weight gradient
     float t = 0.0f;
     for (int b = 0; b < head_blocks; ++b) t += head_partials[(int64_t)b * (kLevelChunk * F) + tid];
     unsafeAtomicAdd(g_w + tid, t);
@@ -401,12 +401,20 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
   if (e_l == kNoRecords) return;  // nothing was binned on this level
   const uint32_t mask = (1u << log2T) - 1u, in_mask = (1u << shift) - 1u;
   const int64_t sub0 = (((int64_t)level * ns + slice) * nb) << cap_log2;
-  constexpr int kBatch = 4;
-  for (int64_t b0 = 0; b0 < nb; b0 += kApplyThreads) {
+  // Sub-bins are mostly far from full (a third at the finest level, a few records at the coarse ones), so a wave takes
+  // EIGHT sub-bins per pass, eight lanes each, kBatch records per lane requested before the first is accumulated; walking
+  // every slot of every sub-bin with one lane per slot made this kernel as long as the bin kernel.  blockIdx.z halves the
+  // tile range (768 blocks at one per CU = three even rounds instead of one and a half).
+  constexpr int kBatch = 4, kWaves = kApplyThreads / NR_WAVE;
+  const int lane = tid & (NR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sub = lane >> 3, l8 = lane & 7;
+  const int64_t half = (nb + gridDim.z - 1) / gridDim.z, t_begin = (int64_t)blockIdx.z * half;
+  const int64_t t_end = t_begin + half < nb ? t_begin + half : nb;
+  for (int64_t b0 = t_begin; b0 < t_end; b0 += kApplyThreads) {
     __syncthreads();
     {
       uint32_t c = 0;
-      if (b0 + tid < nb) {
+      if (b0 + tid < t_end) {
         const int e_b = tile_exp[(int64_t)level * nb + b0 + tid];
         if (e_b != kNoRecords) {
           c = cntg[((int64_t)level * nb + b0 + tid) * ns + slice];
@@ -418,42 +426,40 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
       cnts[tid] = c;
     }
     __syncthreads();
-    const int64_t blocks_here = nb - b0 < kApplyThreads ? nb - b0 : kApplyThreads;
-    const int64_t slots = blocks_here << cap_log2;
-    // kBatch records per thread are requested before the first is accumulated
-    for (int64_t i0 = tid; i0 < slots; i0 += (int64_t)kBatch * kApplyThreads) {
-      uint32_t key[kBatch], sh[kBatch];
-      unsigned long long q[kBatch][2 * F];
-      bool ok[kBatch];
+    const int tiles_here = (int)(t_end - b0 < kApplyThreads ? t_end - b0 : kApplyThreads);
+    for (int tg = wave * 8; tg < tiles_here; tg += kWaves * 8) {
+      const int t = tg + sub;
+      const uint32_t c = t < tiles_here ? cnts[t] : 0u;
+      const uint32_t cnt = c & 0xFFFFu;
+      const int sh = (int)(c >> 16);
+      const int64_t at0 = sub0 + ((b0 + t) << cap_log2);
+      for (uint32_t r0 = 0; __any(r0 < cnt); r0 += kBatch * 8) {
+        uint32_t key[kBatch];
+        unsigned long long q[kBatch][2 * F];
+        bool ok[kBatch];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        const int64_t i = i0 + (int64_t)k * kApplyThreads;
-        ok[k] = false;
-        sh[k] = 0;
-        key[k] = 0;
-        if (i < slots) {
-          const uint32_t c = cnts[i >> cap_log2];
-          ok[k] = ((uint32_t)i & ((1u << cap_log2) - 1u)) < (c & 0xFFFFu);
-          sh[k] = c >> 16;
+        for (int k = 0; k < kBatch; ++k) {
+          const uint32_t r = r0 + k * 8 + l8;
+          ok[k] = r < cnt;
+          key[k] = 0;
+          if (ok[k]) {
+            key[k] = rkey[at0 + r];
+#pragma unroll
+            for (int j = 0; j < 2 * F; ++j) q[k][j] = rsum[(at0 + r) * (2 * F) + j];
+          }
         }
-        if (ok[k]) {
-          const int64_t at = sub0 + (b0 << cap_log2) + i;
-          key[k] = rkey[at];
 #pragma unroll
-          for (int j = 0; j < 2 * F; ++j) q[k][j] = rsum[at * (2 * F) + j];
-        }
-      }
+        for (int k = 0; k < kBatch; ++k) {
+          if (!ok[k]) continue;
+          const uint32_t a = key[k] & mask, tz = key[k] >> 20;
+          const uint32_t b = (a ^ ((2u << tz) - 1u)) & mask;
+          const uint32_t ea = (a & in_mask) * F, eb = (b & in_mask) * F;
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) {
-        if (!ok[k]) continue;
-        const uint32_t a = key[k] & mask, t = key[k] >> 20;
-        const uint32_t b = (a ^ ((2u << t) - 1u)) & mask;
-        const uint32_t ea = (a & in_mask) * F, eb = (b & in_mask) * F;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const long long qa = (long long)q[k][f] >> sh[k], qb = (long long)q[k][F + f] >> sh[k];
-          if (qa != 0) atomicAdd(&acc[ea + f], (unsigned long long)qa);  // ds_add_u64
-          if (qb != 0) atomicAdd(&acc[eb + f], (unsigned long long)qb);
+          for (int f = 0; f < F; ++f) {
+            const long long qa = (long long)q[k][f] >> sh, qb = (long long)q[k][F + f] >> sh;
+            if (qa != 0) atomicAdd(&acc[ea + f], (unsigned long long)qa);  // ds_add_u64
+            if (qb != 0) atomicAdd(&acc[eb + f], (unsigned long long)qb);
+          }
         }
       }
     }
@@ -528,7 +534,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   int64_t persistent = 2 * (int64_t)nr_num_cus();  // two 80-KB tables per CU
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
-  dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L);
+  dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L, g.nb >= 64 ? 2u : 1u);
   DensityHead head = {nullptr, nullptr, w.partials, 0, 0};
   if (head_in != nullptr) {
     head = *head_in;
