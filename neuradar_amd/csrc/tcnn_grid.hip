@@ -84,12 +84,14 @@ tcnn_grid_kernel(const float* __restrict__ x, const float* __restrict__ params, 
     cell[d] = (uint32_t)(int)fl;
     w[d] = pos - fl;
   }
-  float acc[F], go[F];
+  float acc[F], go[F], gmag = 0.0f;
 #pragma unroll
   for (int f = 0; f < F; ++f) {
     acc[f] = 0.0f;
     go[f] = BWD ? grad_out[i * (int64_t)(L * F) + level * F + f] : 0.0f;
+    gmag += fabsf(go[f]);
   }
+  if (BWD && gmag == 0.0f) return;  // masked rows: no gradient, whatever their position holds
 #pragma unroll
   for (int corner = 0; corner < (1 << D); ++corner) {
     float weight = 1.0f;

@@ -130,6 +130,10 @@ class NeuRADHashEncoding(nn.Module):
                                           p(geom["bounds"]), self.config.actor.actor_scale, p(geom["flip"]), p(slot), p(x01a), p(std01a),
                                           p(dirs), ops._stream()), "nr_actor_assign")
             inside = slot >= 0
+            # rows outside every box keep whatever the buffers held: give them a harmless position (their features are
+            # masked out below, their gradient is exactly zero)
+            x01a = torch.where(inside[:, None], x01a, torch.zeros_like(x01a))
+            std01a = torch.where(inside, std01a, torch.ones_like(std01a))
             ray = torch.arange(n, device=dev) // S
             actor = geom["cand"][ray, slot.clamp(min=0).long()].long()  # actor id of the box the sample sits in
             if getattr(self.actors, "actor_to_id", None) is not None:  # (:183: hash-grid id of the actor)
