@@ -15,7 +15,7 @@ for w in cam4096_neuradar cam16384_neuradar mixed16384_neuradar_actors; do
 done
 python bench.py --mlp-dtype float32 --secondary '' --no-cpu-baseline > $O/bench_mixed_fp32.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -o out --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o out --output-format csv -- python3 $R/bench.py --no-cpu-baseline --secondary '' > $O/bench_default_under_rocprof.log 2>&1
 cd $R
 python tools/timeline.py $O/stats/out_kernel_trace.csv > $O/step_timeline.txt 2>&1
 python tools/kernel_avgs.py $O/stats/out_kernel_trace.csv > $O/kernel_avgs_by_grid.txt 2>&1
