@@ -140,3 +140,28 @@ def test_density_head_folded_into_the_binned_scatter(sample_major):
     assert_close(gt.cpu(), gt_ref.cpu(), rtol=1e-4, atol_scale=1e-5, what="table gradient")
     assert torch.equal(gt != 0, gt_ref != 0)
     assert_close((gw - 0.5).cpu(), gw_ref.cpu(), rtol=1e-4, atol_scale=1e-5, what="head weight gradient (accumulated onto g_w)")
+
+
+def test_binned_entry_points_reject_bad_arguments_and_accept_empty_input():
+    """n = 0 is a no-op (0); NULL pointers, a misaligned workspace, more than 8 levels for the folded density head and a
+    row order that does not fit n are NR_EINVAL, like every other entry of the ABI."""
+    from neuradar_amd import ops
+
+    lib, p, st = ops._lib.lib(), ops._p, ops._stream
+    L, F, log2t, n, S = 6, 1, 12, 640, 64
+    x, sd, sc = torch.rand(n, 3, device=DEV), torch.rand(n, device=DEV), torch.arange(1, L + 1, device=DEV).float() * 16
+    feats, w, gd = torch.randn(L, n, F, device=DEV), torch.randn(L * F, device=DEV), torch.randn(n // S, S, device=DEV)
+    gt, gw = torch.zeros(L << log2t, F, device=DEV), torch.zeros(L * F, device=DEV)
+    ws = torch.empty(lib.nr_hash_encode_bwd_binned_workspace_bytes(L, F, log2t, n) + 16, device=DEV, dtype=torch.uint8)
+    args = lambda n_=n, ws_=ws, L_=L, sm=0: (p(x), p(sd), p(sc), L_, F, log2t, p(feats), F, n * F, p(w), p(gd), S, sm, p(gt), p(gw), n_, p(ws_), st())  # noqa: E731
+    assert lib.nr_prop_density_scatter_binned(*args(n_=0)) == 0 and float(gt.abs().sum()) == 0.0
+    assert lib.nr_prop_density_scatter_binned(*args()) == 0 and float(gt.abs().sum()) > 0.0
+    assert lib.nr_prop_density_scatter_binned(*args(ws_=ws[4:])) != 0          # workspace not 16-byte aligned
+    assert lib.nr_prop_density_scatter_binned(*args(sm=n // S + 1)) != 0      # more sample-major rays than rays
+    assert lib.nr_prop_density_scatter_binned(p(x), p(sd), p(sc), L, F, log2t, p(feats), F, n * F, None, p(gd), S, 0, p(gt), p(gw), n, p(ws), st()) != 0
+    assert lib.nr_hash_encode_bwd_binned(p(x), p(sd), p(sc), L, F, log2t, None, F, n * F, p(gt), n, p(ws), st()) != 0
+    assert lib.nr_hash_encode_bwd_binned_workspace_bytes(9, F, log2t, n) > 0   # the plain scatter takes any number of levels ...
+    sc9, f9 = torch.arange(1, 10, device=DEV).float() * 16, torch.randn(9, n, F, device=DEV)
+    ws9 = torch.empty(lib.nr_hash_encode_bwd_binned_workspace_bytes(9, F, log2t, n), device=DEV, dtype=torch.uint8)
+    assert lib.nr_prop_density_scatter_binned(p(x), p(sd), p(sc9), 9, F, log2t, p(f9), F, n * F, p(torch.randn(9, device=DEV)), p(gd), S, 0,
+                                              p(torch.zeros(9 << log2t, F, device=DEV)), p(torch.zeros(9, device=DEV)), n, p(ws9), st()) != 0  # ... the folded head at most 8
