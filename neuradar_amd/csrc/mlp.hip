@@ -83,12 +83,22 @@ field_fwd_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn, in
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   const float beta = fabsf(fld.beta[0]) + kBetaMin;
   const int64_t tiles = nr_cdiv_dev(n, 32);
+  // the next tile's features are requested before the current tile's chain of layers starts (one dependent chain per wave)
+  auto foff = [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); };
+  f32x16 xn[I::IT];
+  auto request = [&](int64_t t) {
+    const int64_t s_ = t * 32 + i;
+    const bool v = t < tiles && s_ < n;
+    load_rows<IN>(xn, feats + (v ? s_ * sn : 0), v, h, foff);
+  };
+  request((int64_t)blockIdx.x * 4 + wave);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
     f32x16 x0[I::IT], h1[I::HT], e[1], cat[2], f1[I::HT], f2[I::HT], o[1];
-    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h,
-                  [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); });
+#pragma unroll
+    for (int t = 0; t < I::IT; ++t) x0[t] = xn[t];
+    request(tile + (int64_t)gridDim.x * 4);
     dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
     dense_fwd<HID, kC, false>(h1, e, lw + I::oG2, i, h);
     const float sdf = sdf_row<HID>(h1, lw + I::oSdf, h);
@@ -269,17 +279,30 @@ field_bwd_geo_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn
   zero_tiles(aG2[0]); zero_tiles(aSdf);
   bG2[0] = 0.0f;
   const int64_t tiles = nr_cdiv_dev(n, 32);
+  // the next tile's features and its d_e / d_sdf rows from the feature half are requested one tile ahead
+  auto foff = [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); };
+  f32x16 xn[I::IT], wn;
+  float wn_sdf = 0.0f;
+  auto request = [&](int64_t t) {
+    const int64_t s_ = t * 32 + i;
+    const bool v = t < tiles && s_ < n;
+    load_rows<IN>(xn, feats + (v ? s_ * sn : 0), v, h, foff);
+    const float* wt = ws + (t < tiles ? t : 0) * kWsTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wn[r] = wt[r * 64 + lane];
+    wn_sdf = wt[16 * 64 + lane];
+  };
+  request((int64_t)blockIdx.x * 4 + wave);
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
     const int64_t smp = tile * 32 + i;
     const bool valid = smp < n;
     f32x16 x0[I::IT], h1[I::HT], d_e[1], d_h1[I::HT], d_x0[I::IT];
-    auto foff = [&](int k) { const int Fq = FW > 0 ? FW : F; return (int64_t)(k / Fq) * sl + (k % Fq); };
-    load_rows<IN>(x0, feats + (valid ? smp * sn : 0), valid, h, foff);
-    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
-    const float* wt = ws + tile * kWsTile;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d_e[0][r] = wt[r * 64 + lane];
-    const float d_sdf = wt[16 * 64 + lane];
+    for (int t = 0; t < I::IT; ++t) x0[t] = xn[t];
+    d_e[0] = wn;
+    const float d_sdf = wn_sdf;
+    request(tile + (int64_t)gridDim.x * 4);
+    dense_fwd<IN, HID, true>(x0, h1, lw + I::oG1, i, h);
     if (h == 0) bSdf += d_sdf;
     // mlp_geo.layers[1]: rows 1..C -> e (MFMA), row 0 -> sdf (per-lane partial products, reduced at the end)
     dense_bwd_dw_reg<HID, kC>(d_e, h1, aG2, bG2, scr, i, h);
