@@ -101,9 +101,9 @@ __device__ __forceinline__ unsigned long long pack_cell(const int* lo) {
 
 __device__ __forceinline__ void wave_fence() {
   // LDS operations of one wave execute in order; this only pins the compiler's ordering
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 template <int F, int CAP>

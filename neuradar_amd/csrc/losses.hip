@@ -132,9 +132,9 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   // The edges go through LDS for the search: lanes leave the loop at different times, and a shuffle
   // cannot read a lane that has already dropped out of the loop.
   if (lane < E) q[lane] = ci;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   int other = 0;
   if (lane < K) {
     int lo = 0, hi = E;
@@ -151,9 +151,9 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     knot[1 + rank] = mine;
     val[1 + rank] = jump;  // temporarily: slope jump at this knot
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   // sorted order: lane j holds knot j (j < K)
   const float xj = lane < K ? knot[1 + lane] : 0.0f;
   const float sj = lane < K ? val[1 + lane] : 0.0f;
@@ -191,9 +191,9 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     knot[0] = 0.0f; val[0] = 0.0f; cdf[0] = 0.0f;
     knot[K + 1] = 1.0f; val[K + 1] = 0.0f; cdf[K + 1] = 1.0f;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   // ---- query the piecewise-quadratic cdf at the proposal edges (:638-651) ----
   const int NK = K + 2;
 #pragma unroll
@@ -213,9 +213,9 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
     t = fminf(fmaxf(t, 0.0f), 1.0f);
     q[j] = f0 + (x - x0) * (v0 + v1 * t + v0 * (1.0f - t)) * 0.5f;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   // ---- loss and its gradient w.r.t. the proposal weights (:700-704) ----
   const float k = mult / (float)n_rays;
   float l = 0.0f, lc = 0.0f;
@@ -248,17 +248,17 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   if (carve) l += lidar.weight * nr_wave_sum(lc);
   if (lane == 0) unsafeAtomicAdd(loss_slot(loss), l);
   if constexpr (ITEMS > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();  // every lane has read its q[j], q[j+1]
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 #pragma unroll
     for (int t = 0; t < kPerLane; ++t) {
       const int j = lane + t * NR_WAVE;
       if (j < Sp) q[j] = gj[t];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     nr_weights_bwd_ray<ITEMS>(dens_p, delta_p, [&](int s) { return q[s]; }, Sp, g_density_p + ray * Sp);
   }
 }

@@ -135,9 +135,9 @@ __device__ __forceinline__ void dense_bwd_dx(const f32x16 (&dz)[(M + 31) / 32], 
 
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS operations of one wave execute in order; this only pins the compiler's ordering.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 __device__ __forceinline__ void stage_tile(float* scr, const f32x16& t, int i, int h) {

@@ -142,9 +142,9 @@ __device__ __forceinline__ void pdf_resample_ray(const float (&win)[ITEMS], cons
   for (int j = lane; j <= S; j += NR_WAVE) bins[j] = spacing_in_ray[j];
   // the wave's own LDS writes are read back by other lanes of the same wave: LDS ops of one
   // wave execute in order, the fence only stops the compiler from moving them
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
   const int num_bins = S_out + 1;
   const float s_near = nr_power_fn(near * scaling, lam), s_far = nr_power_fn(far * scaling, lam);
@@ -181,17 +181,17 @@ __device__ __forceinline__ void pdf_resample_ray(const float (&win)[ITEMS], cons
     }
   }
   if (keep_edges) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();  // every lane is done searching the old bins
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 #pragma unroll
     for (int t = 0; t < kOutPerLane; ++t) {
       const int j = lane + t * NR_WAVE;
       if (j < num_bins) bins[j] = eu_new[t];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   }
 }
 
