@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 11
+#define NR_ABI_VERSION 12
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -69,6 +69,13 @@ int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings,
                        int num_levels, int features_per_level, int log2_hashmap_size,
                        const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                        float* grad_table, int64_t n, int sample_major, nr_stream_t stream);
+/* The same with the size of a wave's private merge table chosen by the caller: wave_cells = 0 (the default of the feature
+ * width), 128 or 256 cells.  Only F = 4 has two configurations; 256 (512 samples per wave) is for batches that contain
+ * incoherent rows (lidar / radar rays): fewer atomics per sample, more of the chip left to the kernels running beside it. */
+int nr_hash_encode_bwd_tuned(const float* x, const float* std, const float* scalings,
+                             int num_levels, int features_per_level, int log2_hashmap_size,
+                             const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
+                             float* grad_table, int64_t n, int sample_major, int wave_cells, nr_stream_t stream);
 
 /* The same scatter-add by TABLE SLICE OWNERSHIP, for tables a step hits densely (the proposal grids) and for incoherent rows
  * (lidar / radar rays), where the merging of nr_hash_encode_bwd finds little and the launch runs at the memory side's rate for

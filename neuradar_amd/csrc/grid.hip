@@ -90,7 +90,13 @@ template <int F> struct BwdCfg;
 template <int C, int P, int WV> struct BwdCfgT { static constexpr int CHUNK = C, CAP = P, W = WV; };
 template <> struct BwdCfg<1> : BwdCfgT<NR_BWD_F1> {};
 template <> struct BwdCfg<2> : BwdCfgT<NR_BWD_F2> {};
-template <> struct BwdCfg<4> { static constexpr int CHUNK = 256, CAP = 128, W = 2; };
+#ifndef NR_BWD_F4
+#define NR_BWD_F4 256, 128, 2
+#endif
+#ifndef NR_BWD_F4_WIDE
+#define NR_BWD_F4_WIDE 512, 256, 1
+#endif
+template <> struct BwdCfg<4> : BwdCfgT<NR_BWD_F4> {};
 template <> struct BwdCfg<8> { static constexpr int CHUNK = 256, CAP = 64, W = 2; };
 constexpr unsigned long long kEmptyKey = ~0ull;
 
@@ -443,29 +449,45 @@ extern "C" int nr_prop_field_fwd(const float* x, const float* std, const float* 
   return 0;
 }
 
-extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
-                                  const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
-                                  int sample_major, nr_stream_t stream) {
+// wave_cells: cells of a wave's private table; 0 = the default of the feature width.  F = 4 knows a second, wide
+// configuration (512 samples per wave, 256 cells, one wave per block) for batches with incoherent rows: it issues fewer
+// atomics per sample and leaves more of the chip to the kernels that run beside it (mixed batch: step -3 % fresh, -6 %
+// after 1 500 steps; camera-only 16 384 rays +3 %, which is why it is the caller's choice).
+extern "C" int nr_hash_encode_bwd_tuned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                        const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
+                                        int sample_major, int wave_cells, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
-#define CALL(FF)                                                                                                  \
+  if (wave_cells != 0 && wave_cells != 128 && wave_cells != 256) return NR_EINVAL;
+#define LAUNCH(FF, CHUNK, CAP, W)                                                                                  \
   {                                                                                                               \
-    using C = BwdCfg<FF>;                                                                                         \
-    dim3 grid((unsigned)nr_cdiv(n, (int64_t)C::W * C::CHUNK), (unsigned)L), block(C::W * 64);                      \
-    hipLaunchKernelGGL((hash_encode_bwd_kernel<FF, C::CHUNK, C::CAP, C::W>), grid, block, 0, nr_s(stream), x, std, \
-                       scalings, log2T, gout, sn, sl, gtable, n, sample_major);                                   \
+    dim3 grid((unsigned)nr_cdiv(n, (int64_t)(W) * (CHUNK)), (unsigned)L), block((W) * 64);                         \
+    hipLaunchKernelGGL((hash_encode_bwd_kernel<FF, CHUNK, CAP, W>), grid, block, 0, nr_s(stream), x, std, scalings, \
+                       log2T, gout, sn, sl, gtable, n, sample_major);                                             \
   }
+#define LAUNCH_X(...) LAUNCH(__VA_ARGS__)
+#define CALL(FF) LAUNCH(FF, BwdCfg<FF>::CHUNK, BwdCfg<FF>::CAP, BwdCfg<FF>::W)
   switch (F) {
     case 1: CALL(1) break;
     case 2: CALL(2) break;
-    case 4: CALL(4) break;
+    case 4:
+      if (wave_cells == 256) LAUNCH_X(4, NR_BWD_F4_WIDE) else CALL(4)
+      break;
     case 8: CALL(8) break;
     default: return NR_EINVAL;
   }
 #undef CALL
+#undef LAUNCH_X
+#undef LAUNCH
   NR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                  const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
+                                  int sample_major, nr_stream_t stream) {
+  return nr_hash_encode_bwd_tuned(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, sample_major, 0, stream);
 }
 
 extern "C" int nr_hash_encode_bwd_input(const float* x, const float* std, const float* table, const float* scalings, int L,

@@ -475,9 +475,12 @@ class FusedTrainStep:
                                                               grid.log2_hashmap_size, p(self.feats[lvl]), Fg, nl * Fg, p(w_dec),
                                                               p(self.g_dens[lvl]), S, self.sm, p(grid.hash_table.grad), p(w_dec.grad),
                                                               nl, p(self.binned_ws[lvl]), sp_)
-                rc = lib.nr_hash_encode_bwd(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
-                                            grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
-                                            n_coh, 0, sp_) if n_coh > 0 else 0
+                # batches with incoherent rows: the wide per-wave table of the F = 4 merging kernel (fewer atomics per sample,
+                # more of the chip left to the two binned scatters and Adam beside it: step -3 % fresh, -6 % after 1 500 steps)
+                cells = 256 if self.sm < B and os.environ.get("NR_WIDE_MERGE", "1") != "0" else 0
+                rc = lib.nr_hash_encode_bwd_tuned(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                  grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
+                                                  n_coh, 0, cells, sp_) if n_coh > 0 else 0
                 if rc == 0 and n_coh < nl:
                     rc = lib.nr_hash_encode_bwd_binned(p(self.x01[lvl][n_coh:]), p(self.std[lvl][n_coh:]), p(grid.scalings),
                                                        grid.num_levels, Fg, grid.log2_hashmap_size,

@@ -165,3 +165,28 @@ def test_binned_entry_points_reject_bad_arguments_and_accept_empty_input():
     ws9 = torch.empty(lib.nr_hash_encode_bwd_binned_workspace_bytes(9, F, log2t, n), device=DEV, dtype=torch.uint8)
     assert lib.nr_prop_density_scatter_binned(p(x), p(sd), p(sc9), 9, F, log2t, p(f9), F, n * F, p(torch.randn(9, device=DEV)), p(gd), S, 0,
                                               p(torch.zeros(9 << log2t, F, device=DEV)), p(torch.zeros(9, device=DEV)), n, p(ws9), st()) != 0  # ... the folded head at most 8
+
+
+@pytest.mark.parametrize("rows", ["incoherent", "runs"])
+def test_wide_merging_configuration_equals_the_default(rows):
+    """nr_hash_encode_bwd_tuned(wave_cells=256) -- the F = 4 configuration the fused step uses for batches with lidar / radar
+    rays -- sums the same gradient as the default configuration (rtol 1e-4 of its scale) and writes the same rows, on
+    incoherent rows and on runs of rows in one cell, at the NeuRadar main grid's size; other widths ignore the argument."""
+    from neuradar_amd import ops
+    from oracle import hashgrid
+
+    torch.manual_seed(4)
+    L, F, log2t, n = 8, 4, 22, 4661 * 32 + 7
+    sc = hashgrid.level_scalings(L, 32, 8192).to(DEV)
+    x = torch.rand(n, 3, device=DEV)
+    if rows == "runs":
+        x = (torch.rand(n // 24 + 1, 3, device=DEV).repeat_interleave(24, dim=0)[:n] + 2e-5 * torch.rand(n, 3, device=DEV)).clamp(0, 1)
+    std = 0.002 * torch.rand(n, device=DEV)
+    gout = torch.randn(n, L * F, device=DEV)
+    lib, p, st = ops._lib.lib(), ops._p, ops._stream
+    want, got = torch.zeros(L << log2t, F, device=DEV), torch.zeros(L << log2t, F, device=DEV)
+    ops.check(lib.nr_hash_encode_bwd(p(x), p(std), p(sc), L, F, log2t, p(gout), L * F, F, p(want), n, 0, st()), "default")
+    ops.check(lib.nr_hash_encode_bwd_tuned(p(x), p(std), p(sc), L, F, log2t, p(gout), L * F, F, p(got), n, 0, 256, st()), "wide")
+    assert_close(got.cpu(), want.cpu(), rtol=1e-4, atol_scale=1e-5, what=f"wide merge tables, {rows}")
+    assert torch.equal(got != 0, want != 0)
+    assert lib.nr_hash_encode_bwd_tuned(p(x), p(std), p(sc), L, F, log2t, p(gout), L * F, F, p(got), n, 0, 192, st()) != 0  # unknown size
