@@ -39,7 +39,11 @@ constexpr int kNoRecords = INT_MIN;
 // (M / slices slots each: 64 at 64 slices, against an expected ROWS * 4 / 64 = M / 128 distinct records per slice when
 // nothing merges), so a partition IS the sub-bin the block leaves for that slice.
 template <int F> struct BinCfg;
-template <> struct BinCfg<1> { static constexpr int ROWS = 512, M = 4096; };
+#ifndef NR_BIN_F1
+#define NR_BIN_F1 512, 4096
+#endif
+template <int R, int MM> struct BinCfgT { static constexpr int ROWS = R, M = MM; };
+template <> struct BinCfg<1> : BinCfgT<NR_BIN_F1> {};
 template <> struct BinCfg<2> { static constexpr int ROWS = 256, M = 2048; };
 template <> struct BinCfg<4> { static constexpr int ROWS = 128, M = 1024; };
 constexpr uint32_t kEmpty = 0xFFFFFFFFu, kReserved = 0xFFFFFFFEu;
@@ -531,7 +535,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0 || g.nb > INT_MAX) return NR_EINVAL;
   if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
-  int64_t persistent = 2 * (int64_t)nr_num_cus();  // two 80-KB tables per CU
+  int64_t persistent = (BinCfg<1>::M > 4096 && F == 1 ? 1 : BinCfg<1>::M < 4096 && F == 1 ? 4 : 2) * (int64_t)nr_num_cus();  // tables per CU that fit its LDS
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
   dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L, g.nb >= 64 ? 2u : 1u);
