@@ -326,7 +326,9 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int64_t want = nr_cdiv(n / 4 + 1, 256);
-  const unsigned blocks = (unsigned)(want < 4096 ? want : 4096);
+  int64_t cap = 4096;
+  if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
                      wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad);
   NR_LAUNCH_CHECK();
