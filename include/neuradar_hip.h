@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 12
+#define NR_ABI_VERSION 13
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -104,6 +104,20 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
                                    const float* feats, int64_t out_stride_n, int64_t out_stride_l,
                                    const float* w, const float* g_density, int n_samples, int64_t rows_sample_major,
                                    float* grad_table, float* g_w, int64_t n, void* workspace, nr_stream_t stream);
+
+/* Single-head self-attention of the radar decoder's transformer encoder layer (detr/models/transformer.py:
+ * 176-189 via nn.MultiheadAttention(d_model, 1), models/neuradar.py:250,463-491): out = dropout(softmax(q k^T / sqrt(d))) v
+ * per scan, fp32.  q, k, v, out, grad_* [n_scans, n, d] (d in {32, 48, 64}); lse [n_scans, n] (the forward's log-sum-exp, kept
+ * for the backward).  Dropout on the probabilities: dropout_p in [0, 1), the keep decisions are a hash of (seed, scan, query,
+ * key) -- the same in the forward and the backward -- or, when keep_mask [n_scans, n, n] (0 / 1) is not NULL, taken from it.
+ * The backward ACCUMULATES into grad_q / grad_k / grad_v (+=; the caller zeroes them).  workspace:
+ * nr_attention_workspace_floats(n_scans, n, d) floats, the same buffer for the forward and its backward is fine. */
+int64_t nr_attention_workspace_floats(int64_t n_scans, int64_t n, int d);
+int nr_attention_fwd(const float* q, const float* k, const float* v, int64_t n_scans, int64_t n, int d, float dropout_p,
+                     uint32_t seed, const float* keep_mask, float* out, float* lse, float* workspace, nr_stream_t stream);
+int nr_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* grad_out,
+                     int64_t n_scans, int64_t n, int d, float dropout_p, uint32_t seed, const float* keep_mask,
+                     float* grad_q, float* grad_k, float* grad_v, float* workspace, nr_stream_t stream);
 
 /* tiny-cuda-nn-compatible multiresolution hash grid for 3-D and 4-D inputs: what
  * `tcnn.Encoding(n_input_dims, {"otype": "HashGrid", n_levels, n_features_per_level, log2_hashmap_size, base_resolution,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 12
+NR_ABI_VERSION = 13
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -53,6 +53,9 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
+    "nr_attention_workspace_floats": [L, L, I],
+    "nr_attention_fwd": [P, P, P, L, L, I, F, c_uint32, P, P, P, P, P],
+    "nr_attention_bwd": [P, P, P, P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P],
     "nr_tcnn_grid_param_count": [I, I, I, I, I, F],
     "nr_tcnn_grid_geometry": [I, I, I, I, F, P, P, P],
     "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],
@@ -110,7 +113,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
-             "nr_tcnn_grid_param_count": c_int64}
+             "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64}
 
 _lib = None
 

@@ -42,8 +42,9 @@ def sine_position_embedding(xyz: Tensor, num_channels: int, temperature: float =
 
 
 class _EncoderLayer(nn.Module):
-    def __init__(self, d_model: int, dim_feedforward: int, dropout: float) -> None:
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "torch") -> None:
         super().__init__()
+        self.attention = attention  # "torch": F.scaled_dot_product_attention; "hip": nr_attention_fwd/bwd
         self.self_attn = nn.MultiheadAttention(d_model, 1, dropout=dropout)  # parameter container (names, init)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
@@ -59,7 +60,14 @@ class _EncoderLayer(nn.Module):
         qk = x2 + pos
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         q, k, v = F.linear(qk, w[:C], b[:C]), F.linear(qk, w[C:2 * C], b[C:2 * C]), F.linear(x2, w[2 * C:], b[2 * C:])
-        att = F.scaled_dot_product_attention(q, k, v, dropout_p=self.p_drop if self.training else 0.0)
+        p_att = self.p_drop if self.training else 0.0
+        if self.attention == "hip":
+            # nr_attention_fwd/bwd: exact fp32, the hash of (seed, query, key) decides the drops (a new seed per call, derived
+            # on the host from torch's seed -- no device read).  3x slower than torch's fused kernel at one radar scan.
+            self._calls = getattr(self, "_calls", 0) + 1
+            att = ops.attention(q, k, v, p_att, seed=torch.initial_seed() + 7919 * self._calls)
+        else:
+            att = F.scaled_dot_product_attention(q, k, v, dropout_p=p_att)
         x = x + F.dropout(self.self_attn.out_proj(att), self.p_drop, self.training)
         x2 = self.norm2(x)
         if self.training and self.p_drop > 0:  # dropout sits between the two linears: plain torch ops
@@ -70,9 +78,9 @@ class _EncoderLayer(nn.Module):
 
 
 class _Encoder(nn.Module):
-    def __init__(self, d_model: int, dim_feedforward: int, dropout: float) -> None:
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "torch") -> None:
         super().__init__()
-        self.layers = nn.ModuleList([_EncoderLayer(d_model, dim_feedforward, dropout)])
+        self.layers = nn.ModuleList([_EncoderLayer(d_model, dim_feedforward, dropout, attention)])
         self.norm = nn.LayerNorm(d_model)
 
 
@@ -80,9 +88,9 @@ class Transformer(nn.Module):
     """detr.models.transformer.Transformer(d_model, nhead=1, num_encoder_layers=1, dim_feedforward=64, dropout=0.1,
     normalize_before=True): same parameter names (`encoder.layers.0.self_attn.in_proj_weight`, ..., `encoder.norm.*`)."""
 
-    def __init__(self, d_model: int = 48, dim_feedforward: int = 64, dropout: float = 0.1) -> None:
+    def __init__(self, d_model: int = 48, dim_feedforward: int = 64, dropout: float = 0.1, attention: str = "torch") -> None:
         super().__init__()
-        self.encoder = _Encoder(d_model, dim_feedforward, dropout)
+        self.encoder = _Encoder(d_model, dim_feedforward, dropout, attention)
         for p in self.parameters():  # transformer.py:52-55
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)

@@ -159,6 +159,39 @@ def mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> Tenso
     return _Mlp.apply(x, len(weights), *weights, *biases)
 
 
+class _Attention(torch.autograd.Function):
+    """nr_attention_fwd / nr_attention_bwd: single-head softmax attention per scan, q / k / v [N, n, D]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, seed, keep_mask):
+        q, k, v = _f32(q, "q"), _f32(k, "k"), _f32(v, "v")
+        N, n, D = q.shape
+        out, lse = torch.empty_like(q), torch.empty((N, n), device=q.device, dtype=torch.float32)
+        ws = torch.empty(max(int(_lib.lib().nr_attention_workspace_floats(N, n, D)), 1), device=q.device, dtype=torch.float32)
+        check(_lib.lib().nr_attention_fwd(_p(q), _p(k), _p(v), N, n, D, float(dropout_p), int(seed) & 0xFFFFFFFF, _p(keep_mask), _p(out),
+                                          _p(lse), _p(ws), _stream()), "nr_attention_fwd")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg, ctx.mask, ctx.ws = (float(dropout_p), int(seed) & 0xFFFFFFFF), keep_mask, ws
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse = ctx.saved_tensors
+        N, n, D = q.shape
+        gq, gk, gv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        check(_lib.lib().nr_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(g.contiguous().float()), N, n, D, ctx.cfg[0], ctx.cfg[1],
+                                          _p(ctx.mask), _p(gq), _p(gk), _p(gv), _p(ctx.ws), _stream()), "nr_attention_bwd")
+        return gq, gk, gv, None, None, None
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, dropout_p: float = 0.0, seed: int = 0, keep_mask: Optional[Tensor] = None) -> Tensor:
+    """softmax(q k^T / sqrt(D)) (with dropout on the probabilities) v, one head, per scan: q, k, v [N, n, D], D in {32, 48, 64}
+    (what nn.MultiheadAttention(d_model, nhead=1) computes between its projections).  keep_mask [N, n, n] of 0 / 1 replaces
+    the kernel's own dropout decisions (tests)."""
+    return _Attention.apply(q.contiguous(), k.contiguous(), v.contiguous(), dropout_p, seed,
+                            None if keep_mask is None else keep_mask.contiguous().float())
+
+
 class _Field(torch.autograd.Function):
     """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
 

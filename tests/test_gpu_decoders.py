@@ -101,3 +101,94 @@ def test_field_density_branch_vs_reference_golden():
     w, _ = render_weight_from_alpha(alpha[..., 0])
     want, _, _ = orender.render_weight_from_density(g["edges"][:, :-1], g["edges"][:, 1:], g["density"][..., 0])
     assert_close(w.cpu(), want, rtol=1e-4, atol_scale=1e-5, what="weights from density")
+
+
+def _attention_reference(q, k, v, keep, p):
+    """torch fp64: softmax(q k^T / sqrt(D)), dropout with the given keep mask, times v."""
+    s = (q.double() @ k.double().transpose(1, 2)) / (q.shape[-1] ** 0.5)
+    pr = torch.softmax(s, dim=-1)
+    if keep is not None:
+        pr = pr * keep.double() / (1.0 - p)
+    return pr @ v.double()
+
+
+@pytest.mark.parametrize("shape", [(1, 3531, 48), (2, 257, 48), (1, 64, 32), (3, 65, 64), (1, 1, 48)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_kernels_match_torch(shape, p):
+    """nr_attention_fwd / nr_attention_bwd against softmax attention in float64 (rtol 1e-4 of each tensor's scale), with an
+    explicit keep mask for p > 0: the radar scan's size (107 x 33 tokens, d_model 48), several scans, token counts around
+    the 64-row tiles, a single token."""
+    from neuradar_amd import ops
+
+    N, n, D = shape
+    gen = torch.Generator().manual_seed(N * 1000 + n)
+    q, k, v = (torch.randn(N, n, D, generator=gen) for _ in range(3))
+    go = torch.randn(N, n, D, generator=gen)
+    keep = (torch.rand(N, n, n, generator=gen) >= p).float() if p > 0 else None
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attention_reference(qr, kr, vr, keep, p)
+    ref.backward(go.double())
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention(qd, kd, vd, p, seed=5, keep_mask=None if keep is None else keep.to(DEV))
+    out.backward(go.to(DEV))
+    assert_close(out.detach().cpu(), ref.detach().float(), rtol=1e-4, atol_scale=1e-5, what="attention output")
+    for got, want, what in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+        if n == 1 and what != "dv":  # one token: the softmax is the constant 1, dq = dk = 0 up to rounding
+            assert float(got.abs().max()) < 1e-6, what
+            continue
+        assert_close(got.cpu(), want.float(), rtol=1e-4, atol_scale=2e-5, what=what)
+
+
+def test_attention_dropout_by_hash_is_consistent_between_forward_and_backward():
+    """Without an explicit mask the keep decisions come from the hash of (seed, scan, query, key).  (i) about 1 - p of the
+    probabilities survive: with v = 1 the output is sum_j P_ij keep_ij / (1 - p), mean 1; (ii) the backward uses the SAME
+    decisions: the gradient of sum(out * go) with respect to v equals finite differences of the forward at that seed;
+    (iii) another seed gives another mask."""
+    from neuradar_amd import ops
+
+    torch.manual_seed(2)
+    N, n, D, p = 1, 512, 48, 0.25
+    q, k = torch.randn(N, n, D, device=DEV), torch.randn(N, n, D, device=DEV)
+    ones = torch.ones(N, n, D, device=DEV)
+    o = ops.attention(q, k, ones, p, seed=11)
+    assert abs(float(o.mean()) - 1.0) < 0.02 and float(o.std()) > 1e-3
+    assert not torch.equal(o, ops.attention(q, k, ones, p, seed=12))
+    assert torch.equal(o, ops.attention(q, k, ones, p, seed=11))
+    v = torch.randn(N, n, D, device=DEV, requires_grad=True)
+    go = torch.randn(N, n, D, device=DEV)
+    (ops.attention(q, k, v, p, seed=11) * go).sum().backward()
+    d = torch.zeros_like(v)
+    d[0, 37, 5] = 1.0
+    fd = ((ops.attention(q, k, v.detach() + 0.5 * d, p, seed=11) - ops.attention(q, k, v.detach() - 0.5 * d, p, seed=11)) * go).sum()
+    assert abs(float(fd) - float(v.grad[0, 37, 5])) <= 1e-3 * max(1.0, abs(float(fd)))  # (linear in v: the difference is exact up to rounding)
+
+
+def test_transformer_layer_with_hip_attention(monkeypatch):
+    """decoders.Transformer(attention="hip") in eval mode at the radar scan's size against the same layer with its attention
+    evaluated in float64 (same parameters): output rtol 1e-4, gradient of the input rtol 1e-3 of its scale; the default
+    (torch's fused attention) is checked against the same reference at the looser 2e-2 its reduced internal precision
+    allows."""
+    from neuradar_amd import ops
+    from neuradar_amd.decoders import Transformer
+
+    torch.manual_seed(0)
+    hip = Transformer(d_model=48, attention="hip").to(DEV).eval()
+    tor = Transformer(d_model=48, attention="torch").to(DEV).eval()
+    tor.load_state_dict(hip.state_dict())
+    src, pos = torch.randn(1, 3531, 48, device=DEV), torch.randn(1, 3531, 48, device=DEV)
+    wgt = torch.randn(1, 3531, 48, device=DEV)  # (sum(y^2) is constant behind the final LayerNorm: its gradient is pure rounding)
+
+    def run(m):
+        x = src.clone().requires_grad_(True)
+        y = m(x, pos)
+        (y * wgt).sum().backward()
+        return y.detach().cpu(), x.grad.cpu()
+
+    y_hip, g_hip = run(hip)
+    y_tor, g_tor = run(tor)
+    monkeypatch.setattr(ops, "attention", lambda q, k, v, p, seed=0: _attention_reference(q, k, v, None, 0.0).float())
+    y_ref, g_ref = run(hip)
+    assert_close(y_hip, y_ref, rtol=1e-4, atol_scale=1e-5, what="encoder output, hip attention")
+    assert_close(g_hip, g_ref, rtol=1e-3, atol_scale=1e-4, what="input gradient, hip attention")
+    assert_close(y_tor, y_ref, rtol=2e-2, atol_scale=2e-3, what="encoder output, torch attention")
+    assert_close(g_tor, g_ref, rtol=2e-2, atol_scale=2e-2, what="input gradient, torch attention")
