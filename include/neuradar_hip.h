@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 13
+#define NR_ABI_VERSION 14
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -150,6 +150,11 @@ int nr_hash_encode_bwd_input(const float* x, const float* std, const float* tabl
                              int num_levels, int features_per_level, int log2_hashmap_size,
                              const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                              float* grad_x, int64_t n, nr_stream_t stream);
+
+/* Keyframe interval of each ray's time (utils/poses.py:108-121): right = searchsorted(timestamps, t), left = max(right-1, 0),
+ * right clamped to the last stamp, frac = clamp((t - ts[left]) / (ts[right] - ts[left] + 1e-6), 0, 1).  left / right int64 [n]. */
+int nr_actor_keyframes(const float* times, int64_t n_rays, const float* timestamps, int n_timestamps, int64_t* left,
+                       int64_t* right, float* frac, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dynamic actors without host synchronisation (reference: two `nonzero`s and a Python loop over

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 13
+NR_ABI_VERSION = 14
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],
     "nr_tcnn_grid_bwd": [P, I, I, I, I, I, F, P, P, L, P],
     "nr_hash_encode_bwd_input": [P, P, P, P, I, I, I, P, L, L, P, L, P],
+    "nr_actor_keyframes": [P, L, P, I, P, P, P, P],
     "nr_actor_candidates": [P, P, P, L, I, P, P, P, P, P, P, I, I, P, P, P],
     "nr_actor_w2b_fwd": [P, L, I, I, P, P, P, P, P, P, P, P],
     "nr_actor_w2b_bwd": [P, L, I, I, P, P, P, P, P, P, P, P, P],

@@ -19,6 +19,27 @@ namespace {
 
 constexpr float kEps = 1.0e-7f;  // neurad_encoding.py:33
 
+// Keyframe interval of every ray's time: right = searchsorted(timestamps, t) (first stamp >= t), left = max(right - 1, 0),
+// right clamped to the last stamp, frac = clamp((t - ts[left]) / (ts[right] - ts[left] + 1e-6), 0, 1) -- the arithmetic of
+// utils/poses.py:108-121 -- in one launch (the same in torch ops is a dozen tiny launches at the top of every step).
+__global__ void __launch_bounds__(256)
+actor_keyframes_kernel(const float* __restrict__ times, int64_t n, const float* __restrict__ stamps, int n_stamps,
+                       int64_t* __restrict__ left, int64_t* __restrict__ right, float* __restrict__ frac) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const float t = times[b];
+  int lo = 0, hi = n_stamps;
+  while (lo < hi) {  // first index with stamps[i] >= t
+    const int m = (lo + hi) >> 1;
+    if (stamps[m] < t) lo = m + 1; else hi = m;
+  }
+  const int l = lo - 1 < 0 ? 0 : lo - 1, r = lo > n_stamps - 1 ? n_stamps - 1 : lo;
+  const float f = (t - stamps[l]) / (stamps[r] - stamps[l] + 1.0e-6f);
+  left[b] = l;
+  right[b] = r;
+  frac[b] = fminf(fmaxf(f, 0.0f), 1.0f);
+}
+
 __global__ void __launch_bounds__(256)
 actor_candidates_kernel(const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ euclid,
                         int S, const int64_t* __restrict__ left, const int64_t* __restrict__ right, const float* __restrict__ frac,
@@ -454,6 +475,16 @@ extern "C" int nr_actor_candidates(const float* origins, const float* directions
     return NR_EINVAL;
   hipLaunchKernelGGL(actor_candidates_kernel, dim3((unsigned)nr_cdiv(n_rays, 256)), dim3(256), 0, nr_s(stream), origins, directions,
                      euclid, S, left, right, frac, positions, present, bounds, n_actors, n_rays, K, cand, overflow);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_actor_keyframes(const float* times, int64_t n_rays, const float* timestamps, int n_timestamps, int64_t* left,
+                                  int64_t* right, float* frac, nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!times || !timestamps || !left || !right || !frac || n_timestamps < 1 || n_rays < 0) return NR_EINVAL;
+  hipLaunchKernelGGL(actor_keyframes_kernel, dim3((unsigned)nr_cdiv(n_rays, 256)), dim3(256), 0, nr_s(stream), times, n_rays,
+                     timestamps, n_timestamps, left, right, frac);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -241,22 +241,22 @@ class NeuRADHashEncoding(nn.Module):
         dev = rs.origins.device
         times = rs.times[:, 0].contiguous()
         ts = act.unique_timestamps
-        right = torch.searchsorted(ts, times)
-        left = (right - 1).clamp(min=0)
-        right = right.clamp(max=len(ts) - 1)
-        frac = ((times - ts[left]) / (ts[right] - ts[left] + 1e-6)).clamp(0.0, 1.0)
+        lib, p = ops._lib.lib(), ops._p
+        left, right = torch.empty(B, device=dev, dtype=torch.int64), torch.empty(B, device=dev, dtype=torch.int64)
+        frac = torch.empty(B, device=dev, dtype=torch.float32)
+        ops.check(lib.nr_actor_keyframes(p(times), B, p(ts.contiguous()), ts.numel(), p(left), p(right), p(frac), ops._stream()),
+                  "nr_actor_keyframes")
         bounds = act.actor_bounds().contiguous()
         cand = torch.empty((B, K), device=dev, dtype=torch.int32)
         if not hasattr(self, "actor_overflow") or self.actor_overflow.device != dev:
             self.actor_overflow = torch.zeros(1, device=dev, dtype=torch.int32)
-        lib, p = ops._lib.lib(), ops._p
         euclid = rs.euclid.contiguous()
         ops.check(lib.nr_actor_candidates(p(rs.origins.contiguous()), p(rs.directions.contiguous()), p(euclid), B, euclid.shape[1] - 1,
-                                          p(left), p(right), p(frac.contiguous()), p(act.actor_positions.detach().contiguous()),
+                                          p(left), p(right), p(frac), p(act.actor_positions.detach().contiguous()),
                                           p(act.actor_present_at_time.to(torch.uint8).contiguous()), p(bounds), act.n_actors, K,
                                           p(cand), p(self.actor_overflow), ops._stream()), "nr_actor_candidates")
         with torch.enable_grad() if self.config.require_actor_grad else torch.no_grad():
-            w2b, centres = _ActorPoses.apply(act.actor_rotations_6d, act.actor_positions, cand, left, right, frac.contiguous())
+            w2b, centres = _ActorPoses.apply(act.actor_rotations_6d, act.actor_positions, cand, left, right, frac)
         if flip is None and draw_flip and self.training and self.config.actor.flip_prob > EPS:  # per-ray random x-flip (:218-225)
             flip = torch.bernoulli(torch.full((B,), self.config.actor.flip_prob, device=dev)) * -2 + 1
         if not self.training:
