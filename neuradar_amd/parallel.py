@@ -124,8 +124,7 @@ class GradAllReducer:
         val = send[1 + cap:]
         count.zero_()
         compact(grad, row_width, idx, val, count)
-        counts = [st["counts"][r:r + 1] for r in range(self.world)]
-        dist.all_gather(counts, count, group=self.sparse_group)
+        self._all_gather(st["counts"], count)
         n_rows = st["counts"].cpu()  # the step's one host read: sizes the list exchange (all ranks read the same numbers)
         max_rows = int(n_rows.max())
         if max_rows == 0:  # nobody touched the table: nothing to exchange, nothing to apply
@@ -141,12 +140,21 @@ class GradAllReducer:
         piece = 1 + m + m * row_width
         out = torch.empty(self.world * piece, device=grad.device, dtype=torch.float32)
         mine = torch.cat([send[:1 + m], val[:m * row_width]])
-        dist.all_gather([out[r * piece:(r + 1) * piece] for r in range(self.world)], mine, group=self.sparse_group)
+        self._all_gather(out, mine)
         for r in range(self.world):
             seg = out[r * piece:(r + 1) * piece]
             apply(seg[1:1 + m].view(torch.int32), seg[1 + m:], seg[:1].view(torch.int32), row_width, grad)
         self.last_sparse = {"mode": "sparse", "rows": n_rows.tolist(), "bytes": self.world * piece * 4}
         return self.last_sparse
+
+    def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        """out [world * len(mine)] <- every rank's `mine`, in rank order.  RCCL gathers straight into the flat buffer; gloo
+        (CPU tests) only knows the list form."""
+        if dist.get_backend(self.sparse_group) == "nccl":
+            dist.all_gather_into_tensor(out, mine, group=self.sparse_group)
+        else:
+            n = mine.numel()
+            dist.all_gather([out[r * n:(r + 1) * n] for r in range(self.world)], mine, group=self.sparse_group)
 
     def bytes_per_step(self) -> int:
         esz = 4 if self.table_dtype is None else torch.empty((), dtype=self.table_dtype).element_size()
