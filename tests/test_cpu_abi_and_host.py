@@ -120,3 +120,35 @@ def test_flat_adam_schedule_matches_reference_formula():
     for step in (0, 1, 250, 499, 500, 501, 10000, 20000, 30000):
         got = float(opt._schedule(torch.tensor(float(step))))
         assert abs(got - ref(step)) <= 1e-6 * ref(step) + 1e-12, (step, got, ref(step))
+
+
+def test_flat_adam_steps_back_to_back_tables_as_one_buffer():
+    """FlatAdam._coalesce: parameters that are consecutive views of ONE storage, with gradients that are consecutive views
+    of another (the per-actor hash tables of a field), become one (param, grad) buffer = one Adam launch; a parameter with
+    storage of its own, a gap, or gradients that are not back to back break the run.  The merged buffers alias the
+    parameters' memory."""
+    import torch
+    from torch import nn
+
+    from neuradar_amd.step import FlatAdam
+
+    n = 70_000
+    flat_p, flat_g = torch.arange(3 * n, dtype=torch.float32), torch.zeros(3 * n)
+    views = []
+    for a in range(3):
+        p = nn.Parameter(flat_p[a * n:(a + 1) * n].view(n // 2, 2))
+        p.grad = flat_g[a * n:(a + 1) * n].view(n // 2, 2)
+        views.append(p)
+    lone = nn.Parameter(torch.ones(n))
+    lone.grad = torch.zeros(n)
+    gap = nn.Parameter(torch.ones(2 * n)[n:])  # same storage as nothing else
+    gap.grad = torch.zeros(n)
+    bufs = FlatAdam._coalesce([views[0], views[1], lone, views[2], gap])
+    assert [b.numel() for b, _ in bufs] == [2 * n, n, n, n]
+    assert bufs[0][0].data_ptr() == views[0].data_ptr() and bufs[0][1].data_ptr() == views[0].grad.data_ptr()
+    bufs[0][0][n] = -5.0  # first element of the second table, through the merged buffer
+    assert float(views[1].reshape(-1)[0]) == -5.0
+    # gradients not back to back: no merge
+    views[1].grad = torch.zeros(n // 2, 2)
+    assert [b.numel() for b, _ in FlatAdam._coalesce([views[0], views[1]])] == [n, n]
+    assert [b.numel() for b, _ in FlatAdam._coalesce(views[:1])] == [n]
