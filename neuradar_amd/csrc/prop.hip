@@ -113,21 +113,30 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
     p = p - step_size * (mm / denom);
     if (zero_grad) g = 0.0f;
   };
+#ifndef NR_ADAM_TEMPORAL  // the 4.3-GB stream of the NeuRadar table bypasses L2 retention: what the scatters and the
+  //                         sampling rounds beside / after it keep there survives (step -1.5 % fresh, -3 % after 1 500 steps)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto ld = [](const float4* q) { f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(q)); return make_float4(t.x, t.y, t.z, t.w); };
+  auto stv = [](float4* q, float4 x) { f4 t = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4*>(q)); };
+#else
+  auto ld = [](const float4* q) { return *q; };
+  auto stv = [](float4* q, float4 x) { *q = x; };
+#endif
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 g = g4[i];
+    float4 g = ld(g4 + i);
     const bool had_grad = g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f;
     const uint8_t seen = seen_grad != nullptr ? seen_grad[i] : (uint8_t)1;
     if (can_skip && !had_grad && seen == 0) continue;  // never had a gradient: m = v = 0 without reading them (4 B/param)
-    float4 mm = m4[i];
-    float4 vv = v4[i];
+    float4 mm = ld(m4 + i);
+    float4 vv = ld(v4 + i);
     if (can_skip && !had_grad && mm.x == 0.0f && mm.y == 0.0f && mm.z == 0.0f && mm.w == 0.0f && vv.x == 0.0f && vv.y == 0.0f &&
         vv.z == 0.0f && vv.w == 0.0f)
       continue;  // fixed point: no parameter read, no stores (12 B/param)
     if (seen_grad != nullptr && seen == 0) seen_grad[i] = 1;
-    float4 p = p4[i];
+    float4 p = ld(p4 + i);
     upd(p.x, g.x, mm.x, vv.x); upd(p.y, g.y, mm.y, vv.y); upd(p.z, g.z, mm.z, vv.z); upd(p.w, g.w, mm.w, vv.w);
-    p4[i] = p; m4[i] = mm; v4[i] = vv;
-    if (zero_grad && had_grad) g4[i] = g;  // a gradient that is already zero is not zeroed again (28 B/param)
+    stv(p4 + i, p); stv(m4 + i, mm); stv(v4 + i, vv);
+    if (zero_grad && had_grad) stv(g4 + i, g);  // a gradient that is already zero is not zeroed again (28 B/param)
   }
   if (blockIdx.x == 0)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) upd(param[i], grad[i], m[i], v[i]);
