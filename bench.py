@@ -598,6 +598,16 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                 "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
                                       "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows],
                 "field_mlp_us": {k: round(v * 1e6, 2) for k, v in mlp_times.items()}}
+        bwd = [r for r in rows if "bwd" in r["kernel"]]
+        if stepper is not None and len(bwd) == 3:
+            # the three scatters start within ~80 us of each other and share the chip (and HBM) until the longest ends:
+            # one launch site's GB/s above is a share of that, the phase's aggregate is what the chip delivers meanwhile
+            span = max(r["seconds"] for r in bwd)
+            total = sum(r["bytes"] for r in bwd)
+            roof["scatter_phase"] = {"sites": [r["kernel"] for r in bwd], "span_us": round(span * 1e6, 2), "bytes": total,
+                                     "achieved": round(total / span / 1e9, 1), "frac": round(total / span / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "algorithmic bytes of the three concurrent scatters / the longest one's duration; "
+                                             "the main table's Adam (up to 32 B per parameter) streams beside them and is not counted"}
     if rank == 0 and world == 1 and want_cpu:
         cpu = cpu_baseline(model, stepper, fwd_bwd, targets, args.cpu_sample_rays, args.cpu_threads)
     result = {"workload": workload, "wl": wl, "value": value, "ms_per_step": ms_per_step, "n_rays": n_rays, "use_graph": bool(use_graph),
