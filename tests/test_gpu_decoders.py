@@ -133,8 +133,9 @@ def test_attention_kernels_match_torch(shape, p):
     out.backward(go.to(DEV))
     assert_close(out.detach().cpu(), ref.detach().float(), rtol=1e-4, atol_scale=1e-5, what="attention output")
     for got, want, what in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
-        if n == 1 and what != "dv":  # one token: the softmax is the constant 1, dq = dk = 0 up to rounding
-            assert float(got.abs().max()) < 1e-6, what
+        if n == 1 and what != "dv":  # one token: the softmax is the constant 1, dq = dk = 0 up to rounding (dP and delta are
+            # the same dot product of ~7-sized terms summed in two orders: a few 1e-7, times k or q)
+            assert float(got.abs().max()) < 2e-5, what
             continue
         assert_close(got.cpu(), want.float(), rtol=1e-4, atol_scale=2e-5, what=what)
 
