@@ -1,24 +1,21 @@
 // Single-head self-attention of the radar decoder's transformer encoder layer (detr/models/transformer.py:
 // 176-189 through nn.MultiheadAttention(d_model, nhead = 1), models/neuradar.py:250,463-491): out = dropout(softmax(Q K^T /
-// sqrt(D))) V over the n tokens of one scan (107 x 33 = 3 531 rays), D = d_model = 48, forward and backward in fp32.
-// The score matrix (12.5 M entries per scan) never exists: one lane owns one query (forward, dQ) or one key (dK, dV) row in
-// registers and walks the rows of the other side, which every lane of the wave reads at the same address (scalar loads);
-// softmax is the online form, the backward recomputes the probabilities from the forward's log-sum-exp.  The work is 100
-// multiply-adds per (query, key) pair on the vector ALUs, exact fp32 with a dropout mask that the backward can reproduce.
-// Measured at the radar scan's size: forward 238 us, forward + backward 1.25 ms, against 140 us / 0.39 ms of torch's
-// fused attention (a matrix-core flash kernel) -- this is the dependency-free, bit-reproducible implementation of the op, not
-// the fast one: `decoders.Transformer(attention="hip")` selects it, the default stays torch's.  An MFMA version (32 x 32 x 2
-// fp32 tiles for Q K^T and P V) is what would close the gap; the decoder is outside the path the metric times.
+// sqrt(D))) V over the n tokens of one scan (107 x 33 = 3 531 rays), D = d_model = 48, forward and backward in fp32 on the
+// matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands, the products are exact fp32 -- this op needs no reduced precision).
+// The score matrix (12.5 M entries per scan) never exists: flash-style tiles with the online softmax in the forward, the
+// probabilities recomputed from the forward's log-sum-exp in the backward.  Measured at the radar scan's size (kernels):
+// forward 41 us + 4 us merge, backward 79 (query side) + 112 us (key side) with QW = 2; QW = 1 (more, lighter waves): forward
+// + backward 204 us against 424 us of torch's attention (hipBLASLt GEMMs + softmax kernels on this build) and 1 250 us of
+// this file's first version (one lane per query on the vector ALUs).  PMC (tools/pmc_attention.sh): the matrix cores are busy
+// 37 % of the forward's cycles; the rest is waits on LDS / the staged loads with ~2 waves per SIMD.
 // Dropout on the probabilities (training, p = 0.1 in the reference) is a counter-based hash of (seed, scan, query, key),
 // identical in the forward and both backward passes; a caller may pass the keep mask explicitly instead (tests).
 #include <math.h>
-#include <stdlib.h>
 
 #include "nr_common.h"
 
 namespace {
 
-constexpr int kTile = 64;  // rows of the other side per LDS tile
 
 __device__ __forceinline__ uint32_t att_hash(uint32_t v) {
   uint32_t s = v * 747796405u + 2891336453u;
@@ -45,76 +42,6 @@ __device__ __forceinline__ float drop_factor(const Drop& d, int64_t scan, int64_
   return keep / (1.0f - d.p);
 }
 
-// The rows of the other side are read straight from global memory at WAVE-UNIFORM addresses: the compiler turns them
-// into scalar loads (s_load_dwordx8/16 through the scalar cache) and the multiply-adds take them as SGPR operands.  The first
-// version staged 64-row tiles in LDS and read them back as broadcasts: 24 ds_read_b128 per (query, key) pair kept the LDS
-// pipe busier than the 96 multiply-adds kept the vector ALUs (forward 227 us, 2.1 ms with the backward).
-template <int D>
-__device__ __forceinline__ float dot_row(const float (&a)[D], const float* __restrict__ b) {
-  float s = 0.0f;
-#pragma unroll
-  for (int c = 0; c < D; ++c) s += a[c] * b[c];
-  return s;
-}
-
-template <int D>
-__device__ __forceinline__ void axpy_row(float (&acc)[D], float a, const float* __restrict__ b) {
-#pragma unroll
-  for (int c = 0; c < D; ++c) acc[c] += a * b[c];
-}
-
-// forward: lane = query, blockIdx.z = part of the key range (a scan has 56 waves' worth of queries: the key range is
-// split so that the launch fills the chip).  Every part leaves (acc, m, l) of its keys; attention_merge_kernel combines them.
-template <int D>
-__global__ void __launch_bounds__(64)
-attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t n, float scale,
-                     Drop drop, int64_t keys_per_part, float* __restrict__ part) {
-  const int64_t scan = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;
-  const float* qs = q + scan * n * D;
-  const float* ks = k + scan * n * D;
-  const float* vs = v + scan * n * D;
-  float qi[D], acc[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    qi[c] = valid ? qs[(int64_t)i * D + c] * scale : 0.0f;
-    acc[c] = 0.0f;
-  }
-  float m = -INFINITY, l = 0.0f;
-  const int64_t j_begin = (int64_t)blockIdx.z * keys_per_part, j_end = j_begin + keys_per_part < n ? j_begin + keys_per_part : n;
-  for (int64_t j0 = j_begin; j0 < j_end; j0 += kTile) {
-    const int tj = (int)(j_end - j0 < kTile ? j_end - j0 : kTile);
-    // the tile's scores first, then ONE rescale of the accumulator per tile
-    float s[kTile], tmax = m;
-#pragma unroll
-    for (int j = 0; j < kTile; ++j) {
-      s[j] = j < tj ? dot_row<D>(qi, ks + (j0 + j) * D) : -INFINITY;
-      tmax = fmaxf(tmax, s[j]);
-    }
-    const float corr = m == -INFINITY ? 0.0f : expf(m - tmax);
-    l *= corr;
-#pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] *= corr;
-    m = tmax;
-#pragma unroll
-    for (int j = 0; j < kTile; ++j) {
-      if (j >= tj) continue;
-      const float p = expf(s[j] - m);
-      l += p;
-      const float pd = drop.p > 0.0f && valid ? p * drop_factor(drop, scan, n, i, (int)(j0 + j)) : p;
-      axpy_row<D>(acc, pd, vs + (j0 + j) * D);
-    }
-  }
-  if (valid) {
-    float* o = part + (((int64_t)blockIdx.z * gridDim.y + scan) * n + i) * (D + 2);
-#pragma unroll
-    for (int c = 0; c < D; ++c) o[c] = acc[c];
-    o[D] = m;
-    o[D + 1] = l;
-  }
-}
-
 // ---- matrix-core version.  v_mfma_f32_16x16x4_f32 tiles (fp32 operands: the op stays exact fp32), one wave = QW groups of
 // 16 queries, the block's waves share 64-key tiles of K and V in LDS.  Everything is kept TRANSPOSED so that no value ever
 // changes lanes between the two products:
@@ -127,10 +54,10 @@ attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, c
 // hold one query) per 64 keys; the row sums stay per lane until the end.
 typedef float att_f4 __attribute__((ext_vector_type(4)));
 #ifndef NR_ATT_QW
-#define NR_ATT_QW 2
+#define NR_ATT_QW 1
 #endif
 #ifndef NR_ATT_WAVES
-#define NR_ATT_WAVES 1024
+#define NR_ATT_WAVES 2048
 #endif
 
 template <int D>
@@ -142,6 +69,7 @@ struct AttMfma {
   static constexpr int DS = D / 4;    // contraction steps of S (per slot: D/4 consecutive d)
   static constexpr int DT = D / 16;   // 16-row tiles of O^T
   static constexpr int ROWS = 16 * QW * W;  // queries per block
+  static constexpr int PS = D + 4;    // floats per row of a part's partial result: acc [D] | m | l | pad (16-byte rows)
 };
 
 __device__ __forceinline__ float att_xor_max(float x) {
@@ -293,7 +221,7 @@ attention_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__
     const int i = q0 + 16 * g + lq;
     const float lt = att_xor_sum(l[g]);
     if (i >= n) continue;
-    float* op = part + (((int64_t)blockIdx.z * gridDim.y + scan) * n + i) * (D + 2);
+    float* op = part + (((int64_t)blockIdx.z * gridDim.y + scan) * n + i) * C::PS;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -544,118 +472,42 @@ attention_bwd_kv_mfma_kernel(const float* __restrict__ q, const float* __restric
   }
 }
 
+// combines the parts' (acc, m, l): one thread per (row, four output columns)
 template <int D>
 __global__ void __launch_bounds__(256)
 attention_merge_kernel(const float* __restrict__ part, int parts, int64_t rows, float* __restrict__ out, float* __restrict__ lse) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+  constexpr int C4 = D / 4, PS = AttMfma<D>::PS;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const int64_t r = idx / C4;
+  const int c = (int)(idx - r * C4);
   float m = -INFINITY;
-  for (int p = 0; p < parts; ++p) m = fmaxf(m, part[((int64_t)p * rows + r) * (D + 2) + D]);
-  float l = 0.0f, acc[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) acc[c] = 0.0f;
+  for (int p = 0; p < parts; ++p) m = fmaxf(m, part[((int64_t)p * rows + r) * PS + D]);
+  float l = 0.0f;
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int p = 0; p < parts; ++p) {
-    const float* o = part + ((int64_t)p * rows + r) * (D + 2);
+    const float* o = part + ((int64_t)p * rows + r) * PS;
     const float w = o[D] == -INFINITY ? 0.0f : expf(o[D] - m);
     l += w * o[D + 1];
-#pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] += w * o[c];
+    const float4 t = *reinterpret_cast<const float4*>(o + 4 * c);
+    acc.x += w * t.x; acc.y += w * t.y; acc.z += w * t.z; acc.w += w * t.w;
   }
   const float inv = 1.0f / l;
-#pragma unroll
-  for (int c = 0; c < D; ++c) out[r * D + c] = acc[c] * inv;
-  lse[r] = m + logf(l);
-}
-
-// backward, query side: lane = query.  delta_i = dO_i . out_i;  dS_ij = P_ij (dP_ij - delta_i);  dQ_i = scale sum_j dS_ij K_j
-template <int D>
-__global__ void __launch_bounds__(64)
-attention_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                       const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ g_out, int64_t n,
-                       float scale, Drop drop, int64_t keys_per_part, float* __restrict__ g_q, float* __restrict__ delta) {
-  const int64_t scan = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < n;
-  const int64_t row = scan * n + i;
-  float qi[D], go[D], acc[D], dl = 0.0f;
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    qi[c] = valid ? q[row * D + c] * scale : 0.0f;
-    go[c] = valid ? g_out[row * D + c] : 0.0f;
-    dl += valid ? go[c] * out[row * D + c] : 0.0f;
-    acc[c] = 0.0f;
-  }
-  const float li = valid ? lse[row] : 0.0f;
-  if (valid && blockIdx.z == 0) delta[row] = dl;
-  const int64_t j_begin = (int64_t)blockIdx.z * keys_per_part, j_end = j_begin + keys_per_part < n ? j_begin + keys_per_part : n;
-  const float* ks = k + scan * n * D;
-  const float* vs = v + scan * n * D;
-#pragma unroll 2
-  for (int64_t j = j_begin; j < j_end; ++j) {
-    const float p = expf(dot_row<D>(qi, ks + j * D) - li);
-    float dp = dot_row<D>(go, vs + j * D);
-    if (drop.p > 0.0f && valid) dp *= drop_factor(drop, scan, n, i, (int)j);
-    axpy_row<D>(acc, p * (dp - dl), ks + j * D);
-  }
-  if (valid) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) unsafeAtomicAdd(g_q + row * D + c, acc[c] * scale);  // (one addend per key part)
-  }
-}
-
-// backward, key side: lane = key.  dV_j = sum_i Pd_ij dO_i;  dK_j = scale sum_i dS_ij Q_i
-template <int D>
-__global__ void __launch_bounds__(64)
-attention_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                        const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ g_out, int64_t n,
-                        float scale, Drop drop, int64_t rows_per_part, float* __restrict__ g_k, float* __restrict__ g_v) {
-  const int64_t scan = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = j < n;
-  const int64_t row = scan * n + j;
-  float kj[D], vj[D], gk[D], gv[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    kj[c] = valid ? k[row * D + c] * scale : 0.0f;
-    vj[c] = valid ? v[row * D + c] : 0.0f;
-    gk[c] = gv[c] = 0.0f;
-  }
-  const int64_t i_begin = (int64_t)blockIdx.z * rows_per_part, i_end = i_begin + rows_per_part < n ? i_begin + rows_per_part : n;
-  const float* qs = q + scan * n * D;
-  const float* gs = g_out + scan * n * D;
-#pragma unroll 2
-  for (int64_t i = i_begin; i < i_end; ++i) {
-    const float p = expf(dot_row<D>(kj, qs + i * D) - lse[scan * n + i]);
-    const float f = drop.p > 0.0f && valid ? drop_factor(drop, scan, n, (int)i, j) : 1.0f;
-    axpy_row<D>(gv, p * f, gs + i * D);
-    const float dp = dot_row<D>(vj, gs + i * D) * f;
-    axpy_row<D>(gk, p * (dp - delta[scan * n + i]), qs + i * D);
-  }
-  if (valid) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      unsafeAtomicAdd(g_k + row * D + c, gk[c] * scale);  // (one addend per query part)
-      unsafeAtomicAdd(g_v + row * D + c, gv[c]);
-    }
-  }
+  *reinterpret_cast<float4*>(out + r * D + 4 * c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  if (c == 0) lse[r] = m + logf(l);
 }
 
 inline bool bad(const void* a, const void* b, const void* c) { return !a || !b || !c; }
 
-inline int att_parts(int64_t n_scans, int64_t n) {  // parts of the other side's range: ~1 024 waves in the launch
-  const int64_t waves = nr_cdiv(n, 64) * n_scans;  // (4 096 waves: forward 238 -> 262 us, backward twice as long: one atomic
-  int64_t parts = nr_cdiv(1024, waves);             //  addend per part and gradient element)
-  const int64_t max_parts = nr_cdiv(n, kTile);
-  parts = parts < 1 ? 1 : parts > 32 ? 32 : parts;
-  return (int)(parts > max_parts ? max_parts : parts);
-}
+constexpr int kMaxParts = 32;
 
+// parts of the other side's range: a scan is n / 16 / QW waves' worth of rows, the launch wants ~2 per SIMD
 template <int D>
 inline int att_parts_mfma(int64_t n_scans, int64_t n) {
   const int64_t waves = nr_cdiv(n, AttMfma<D>::ROWS) * AttMfma<D>::W * n_scans;
   int64_t parts = nr_cdiv(NR_ATT_WAVES, waves);
   const int64_t max_parts = nr_cdiv(n, AttMfma<D>::KT);
-  parts = parts < 1 ? 1 : parts > 32 ? 32 : parts;
+  parts = parts < 1 ? 1 : parts > kMaxParts ? kMaxParts : parts;
   return (int)(parts > max_parts ? max_parts : parts);
 }
 
@@ -664,7 +516,7 @@ inline int att_parts_mfma(int64_t n_scans, int64_t n) {
 extern "C" int64_t nr_attention_workspace_floats(int64_t n_scans, int64_t n, int d) {
   if (n_scans < 0 || n < 0 || (d != 32 && d != 48 && d != 64)) return -1;
   if (n_scans == 0 || n == 0) return 0;
-  return (int64_t)32 * n_scans * n * (d + 2) + n_scans * n;  // forward partials (at most 32 parts) | backward delta
+  return (int64_t)kMaxParts * n_scans * n * (d + 4) + n_scans * n;  // forward partials (at most kMaxParts parts) | backward delta
 }
 
 extern "C" int nr_attention_fwd(const float* q, const float* k, const float* v, int64_t n_scans, int64_t n, int d, float dropout_p,
@@ -675,23 +527,16 @@ extern "C" int nr_attention_fwd(const float* q, const float* k, const float* v, 
     return NR_EINVAL;
   const Drop drop = {keep_mask, seed, dropout_p};
   const float scale = 1.0f / sqrtf((float)d);
-  const int parts = att_parts(n_scans, n);
-  const int64_t per = nr_cdiv(nr_cdiv(n, parts), kTile) * kTile;
-  dim3 grid((unsigned)nr_cdiv(n, 64), (unsigned)n_scans, (unsigned)nr_cdiv(n, per)), block(64);
   const int64_t rows = n_scans * n;
-  static const bool valu = getenv("NR_ATT_VALU") != nullptr;  // A/B knob: the vector-ALU kernels
 #define CALL(DD)                                                                                                              \
   {                                                                                                                            \
-    if (valu)                                                                                                                  \
-      hipLaunchKernelGGL(attention_fwd_kernel<DD>, grid, block, 0, nr_s(stream), q, k, v, n, scale, drop, per, workspace);      \
-    else {                                                                                                                     \
-      const int64_t per_m = nr_cdiv(nr_cdiv(n, att_parts_mfma<DD>(n_scans, n)), kTile) * kTile;                                \
-      grid.z = (unsigned)nr_cdiv(n, per_m);                                                                                    \
-      hipLaunchKernelGGL(attention_fwd_mfma_kernel<DD>, dim3((unsigned)nr_cdiv(n, AttMfma<DD>::ROWS), grid.y, grid.z),          \
-                         dim3(AttMfma<DD>::W * 64), 0, nr_s(stream), q, k, v, n, scale, drop, per_m, workspace);               \
-    }                                                                                                                          \
-    hipLaunchKernelGGL(attention_merge_kernel<DD>, dim3((unsigned)nr_cdiv(rows, 256)), dim3(256), 0, nr_s(stream), workspace, \
-                       (int)grid.z, rows, out, lse);                                                                           \
+    using A = AttMfma<DD>;                                                                                                     \
+    const int64_t per = nr_cdiv(nr_cdiv(n, att_parts_mfma<DD>(n_scans, n)), A::KT) * A::KT;                                    \
+    const dim3 grid((unsigned)nr_cdiv(n, A::ROWS), (unsigned)n_scans, (unsigned)nr_cdiv(n, per));                              \
+    hipLaunchKernelGGL(attention_fwd_mfma_kernel<DD>, grid, dim3(A::W * 64), 0, nr_s(stream), q, k, v, n, scale, drop, per,    \
+                       workspace);                                                                                             \
+    hipLaunchKernelGGL(attention_merge_kernel<DD>, dim3((unsigned)nr_cdiv(rows * (DD / 4), 256)), dim3(256), 0, nr_s(stream), \
+                       workspace, (int)grid.z, rows, out, lse);                                                                \
   }
   switch (d) {
     case 32: CALL(32) break;
@@ -713,24 +558,16 @@ extern "C" int nr_attention_bwd(const float* q, const float* k, const float* v, 
     return NR_EINVAL;
   const Drop drop = {keep_mask, seed, dropout_p};
   const float scale = 1.0f / sqrtf((float)d);
-  const int parts = att_parts(n_scans, n);
-  const int64_t per = nr_cdiv(nr_cdiv(n, parts), kTile) * kTile;
-  dim3 grid((unsigned)nr_cdiv(n, 64), (unsigned)n_scans, (unsigned)nr_cdiv(n, per)), block(64);
-  float* delta = workspace + (int64_t)32 * n_scans * n * (d + 2);
-  static const bool valu = getenv("NR_ATT_VALU") != nullptr;
-#define CALL(DD)                                                                                                             \
-  if (valu) {                                                                                                                 \
-    hipLaunchKernelGGL(attention_bwd_q_kernel<DD>, grid, block, 0, nr_s(stream), q, k, v, out, lse, g_out, n, scale, drop, per, \
-                       g_q, delta);                                                                                           \
-    hipLaunchKernelGGL(attention_bwd_kv_kernel<DD>, grid, block, 0, nr_s(stream), q, k, v, lse, delta, g_out, n, scale, drop,  \
-                       per, g_k, g_v);                                                                                        \
-  } else {                                                                                                                    \
-    const int64_t per_m = nr_cdiv(nr_cdiv(n, att_parts_mfma<DD>(n_scans, n)), kTile) * kTile;                                 \
-    const dim3 gm((unsigned)nr_cdiv(n, AttMfma<DD>::ROWS), (unsigned)n_scans, (unsigned)nr_cdiv(n, per_m));                    \
-    hipLaunchKernelGGL(attention_bwd_q_mfma_kernel<DD>, gm, dim3(AttMfma<DD>::W * 64), 0, nr_s(stream), q, k, v, out, lse,     \
-                       g_out, n, scale, drop, per_m, g_q, delta);                                                             \
-    hipLaunchKernelGGL(attention_bwd_kv_mfma_kernel<DD>, gm, dim3(AttMfma<DD>::W * 64), 0, nr_s(stream), q, k, v, lse, delta,  \
-                       g_out, n, scale, drop, per_m, g_k, g_v);                                                               \
+  float* delta = workspace + (int64_t)kMaxParts * n_scans * n * (d + 4);
+#define CALL(DD)                                                                                                              \
+  {                                                                                                                            \
+    using A = AttMfma<DD>;                                                                                                     \
+    const int64_t per = nr_cdiv(nr_cdiv(n, att_parts_mfma<DD>(n_scans, n)), A::KT) * A::KT;                                    \
+    const dim3 grid((unsigned)nr_cdiv(n, A::ROWS), (unsigned)n_scans, (unsigned)nr_cdiv(n, per));                              \
+    hipLaunchKernelGGL(attention_bwd_q_mfma_kernel<DD>, grid, dim3(A::W * 64), 0, nr_s(stream), q, k, v, out, lse, g_out, n,   \
+                       scale, drop, per, g_q, delta);                                                                          \
+    hipLaunchKernelGGL(attention_bwd_kv_mfma_kernel<DD>, grid, dim3(A::W * 64), 0, nr_s(stream), q, k, v, lse, delta, g_out,   \
+                       n, scale, drop, per, g_k, g_v);                                                                         \
   }
   switch (d) {
     case 32: CALL(32) break;

@@ -5,9 +5,10 @@
   * radar decoder   DETR-style encoder, one pre-norm layer, ONE head of width d_model = 48, feed-forward 64
                     (detr/models/transformer.py:32-70,143-205), sine position embedding of the rendered 3-D points
                     (detr/models/position_encoding_3d.py:56-103), then three width-16 heads (:251-278,463-491).
-                    Feed-forward block and heads run on the MFMA MLP kernels (nr_mlp_fwd/bwd); layer norms, the q/k/v and
-                    output projections and the n x n attention of one scan (n = 3 531 ZOD / 4 545 VoD rays) are torch-ROCm
-                    ops -- per RAY, once per step, 0.1 % of the step's FLOPs (SURVEY section 2 lists them as standard ops).
+                    Feed-forward block and heads run on the MFMA MLP kernels (nr_mlp_fwd/bwd), the n x n attention of one
+                    scan (n = 3 531 ZOD / 4 545 VoD rays) on nr_attention_fwd/bwd (fp32 MFMA flash tiles: forward +
+                    backward 204 us against 424 us of torch's attention); layer norms and the q/k/v and output projections
+                    are torch-ROCm ops -- per RAY, once per step, 0.1 % of the step's FLOPs.
   * RGB decoder     the 7x7 residual CNN on 32x32 feature patches (:225-240,455-461; model_components/cnns.py:21-47):
                     torch-ROCm convolutions (MIOpen), same module tree as the reference's nn.Sequential.
 """
@@ -42,9 +43,12 @@ def sine_position_embedding(xyz: Tensor, num_channels: int, temperature: float =
 
 
 class _EncoderLayer(nn.Module):
-    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "torch") -> None:
+    HIP_WIDTHS = (32, 48, 64)  # head widths nr_attention_fwd/bwd are built for
+
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "hip") -> None:
         super().__init__()
-        self.attention = attention  # "torch": F.scaled_dot_product_attention; "hip": nr_attention_fwd/bwd
+        # "hip": nr_attention_fwd/bwd (other widths than HIP_WIDTHS take torch's kernel); "torch": F.scaled_dot_product_attention
+        self.attention = attention
         self.self_attn = nn.MultiheadAttention(d_model, 1, dropout=dropout)  # parameter container (names, init)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
@@ -61,9 +65,9 @@ class _EncoderLayer(nn.Module):
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         q, k, v = F.linear(qk, w[:C], b[:C]), F.linear(qk, w[C:2 * C], b[C:2 * C]), F.linear(x2, w[2 * C:], b[2 * C:])
         p_att = self.p_drop if self.training else 0.0
-        if self.attention == "hip":
-            # nr_attention_fwd/bwd: exact fp32, the hash of (seed, query, key) decides the drops (a new seed per call, derived
-            # on the host from torch's seed -- no device read).  3x slower than torch's fused kernel at one radar scan.
+        if self.attention == "hip" and C in self.HIP_WIDTHS:
+            # nr_attention_fwd/bwd: exact fp32 on the matrix cores, the hash of (seed, query, key) decides the drops (a new seed
+            # per call, derived on the host from torch's seed -- no device read)
             self._calls = getattr(self, "_calls", 0) + 1
             att = ops.attention(q, k, v, p_att, seed=torch.initial_seed() + 7919 * self._calls)
         else:
@@ -78,7 +82,7 @@ class _EncoderLayer(nn.Module):
 
 
 class _Encoder(nn.Module):
-    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "torch") -> None:
+    def __init__(self, d_model: int, dim_feedforward: int, dropout: float, attention: str = "hip") -> None:
         super().__init__()
         self.layers = nn.ModuleList([_EncoderLayer(d_model, dim_feedforward, dropout, attention)])
         self.norm = nn.LayerNorm(d_model)
@@ -88,7 +92,7 @@ class Transformer(nn.Module):
     """detr.models.transformer.Transformer(d_model, nhead=1, num_encoder_layers=1, dim_feedforward=64, dropout=0.1,
     normalize_before=True): same parameter names (`encoder.layers.0.self_attn.in_proj_weight`, ..., `encoder.norm.*`)."""
 
-    def __init__(self, d_model: int = 48, dim_feedforward: int = 64, dropout: float = 0.1, attention: str = "torch") -> None:
+    def __init__(self, d_model: int = 48, dim_feedforward: int = 64, dropout: float = 0.1, attention: str = "hip") -> None:
         super().__init__()
         self.encoder = _Encoder(d_model, dim_feedforward, dropout, attention)
         for p in self.parameters():  # transformer.py:52-55

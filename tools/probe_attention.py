@@ -23,7 +23,10 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
-for n, D in ((3531, 48), (4545, 48), (3531, 64), (3531, 32)):
+SHAPES = ((3531, 48), (4545, 48), (3531, 64), (3531, 32))
+if len(sys.argv) == 3:
+    SHAPES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for n, D in SHAPES:
     torch.manual_seed(0)
     q, k, v = (torch.randn(1, n, D, device=dev, requires_grad=True) for _ in range(3))
     go = torch.randn(1, n, D, device=dev)
