@@ -107,7 +107,8 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
 
 /* Single-head self-attention of the radar decoder's transformer encoder layer (detr/models/transformer.py:
  * 176-189 via nn.MultiheadAttention(d_model, 1), models/neuradar.py:250,463-491): out = dropout(softmax(q k^T / sqrt(d))) v
- * per scan, fp32.  q, k, v, out, grad_* [n_scans, n, d] (d in {32, 48, 64}); lse [n_scans, n] (the forward's log-sum-exp, kept
+ * per scan, fp32 on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products).  q, k, v, out, grad_* [n_scans, n, d]
+ * (d in {32, 48, 64}, rows 16-byte aligned); lse [n_scans, n] (the forward's log-sum-exp, kept
  * for the backward).  Dropout on the probabilities: dropout_p in [0, 1), the keep decisions are a hash of (seed, scan, query,
  * key) -- the same in the forward and the backward -- or, when keep_mask [n_scans, n, n] (0 / 1) is not NULL, taken from it.
  * The backward ACCUMULATES into grad_q / grad_k / grad_v (+=; the caller zeroes them).  workspace:
