@@ -41,7 +41,7 @@ WORKLOADS = {
     "cam16384_l16f2_w64": dict(rays=16384, grid=dict(hashgrid_dim=2, num_levels=16, base_res=16, max_res=1024,
                                                      log2_hashmap_size=19), hidden=64),
     # BASELINE.json configs[2] shape: 8 192 camera rays (8 patches) + 4 661 lidar points + 1 ZOD radar scan
-    # (107 x 33 = 3 531 rays) = 16 384 rays, NeuRadar's own field; fp32 (the bf16 MLP of configs[2] is not built)
+    # (107 x 33 = 3 531 rays) = 16 384 rays, NeuRadar's own field (bf16 MFMA operands by default, --mlp-dtype)
     "mixed16384_neuradar": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1,
                                 grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
     # the same batch in a scene with 12 dynamic actors (vehicles on the road ahead of the ego car, learnable trajectories,
