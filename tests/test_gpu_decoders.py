@@ -140,6 +140,25 @@ def test_attention_kernels_match_torch(shape, p):
         assert_close(got.cpu(), want.float(), rtol=1e-4, atol_scale=2e-5, what=what)
 
 
+def test_attention_with_peaked_softmax():
+    """Logits of several hundred (q, k eight times the unit scale: every query attends to one or two keys, all other
+    probabilities underflow): the online softmax and the recomputation from the log-sum-exp stay finite and match float64."""
+    from neuradar_amd import ops
+
+    gen = torch.Generator().manual_seed(31)
+    q, k, v, go = (torch.randn(2, 333, 48, generator=gen) * s for s in (8.0, 8.0, 1.0, 1.0))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _attention_reference(qr, kr, vr, None, 0.0)
+    ref.backward(go.double())
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention(qd, kd, vd)
+    out.backward(go.to(DEV))
+    assert torch.isfinite(out).all() and all(torch.isfinite(t.grad).all() for t in (qd, kd, vd))
+    assert_close(out.detach().cpu(), ref.detach().float(), rtol=1e-4, atol_scale=1e-4, what="attention output")
+    for got, want, what in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+        assert_close(got.cpu(), want.float(), rtol=1e-3, atol_scale=1e-3, what=what)
+
+
 def test_attention_dropout_by_hash_is_consistent_between_forward_and_backward():
     """Without an explicit mask the keep decisions come from the hash of (seed, scan, query, key).  (i) about 1 - p of the
     probabilities survive: with v = 1 the output is sum_j P_ij keep_ij / (1 - p), mean 1; (ii) the backward uses the SAME
