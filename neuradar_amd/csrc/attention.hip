@@ -56,6 +56,12 @@ typedef float att_f4 __attribute__((ext_vector_type(4)));
 #ifndef NR_ATT_QW
 #define NR_ATT_QW 1
 #endif
+#ifndef NR_ATT_W
+#define NR_ATT_W 4
+#endif
+#ifndef NR_ATT_KT
+#define NR_ATT_KT 64
+#endif
 #ifndef NR_ATT_WAVES
 #define NR_ATT_WAVES 2048
 #endif
@@ -63,8 +69,8 @@ typedef float att_f4 __attribute__((ext_vector_type(4)));
 template <int D>
 struct AttMfma {
   static constexpr int QW = NR_ATT_QW;  // groups of 16 queries per wave
-  static constexpr int W = 4;         // waves per block
-  static constexpr int KT = 64;       // keys per LDS tile
+  static constexpr int W = NR_ATT_W;  // waves per block
+  static constexpr int KT = NR_ATT_KT;  // keys per LDS tile
   static constexpr int STR = D + 4;   // LDS row stride in floats (16-byte aligned rows, rows 4 apart on different banks)
   static constexpr int DS = D / 4;    // contraction steps of S (per slot: D/4 consecutive d)
   static constexpr int DT = D / 16;   // 16-row tiles of O^T
