@@ -10,7 +10,7 @@ from neuradar_amd import _lib, ops  # noqa: E402
 
 dev = torch.device("cuda")
 lib, p, st = _lib.lib(), ops._p, ops._stream
-B, S, C = 4096, 32, 32
+B, S, C = int(os.environ.get("PROBE_B", "4096")), 32, 32
 f32 = dict(device=dev, dtype=torch.float32)
 torch.manual_seed(0)
 alpha = torch.rand(B, S, **f32) * 0.3
@@ -33,7 +33,7 @@ for Sp in (64, 128):
     gd = torch.empty(B, Sp, **f32)
     wfin = torch.softmax(torch.randn(B, S, **f32), dim=1) * 0.9
     fn = lambda: lib.nr_interlevel_loss_to_density(p(sp), S + 1, p(wfin), S, S - 1, p(cp), p(wp), p(dens), p(eup), Sp, B, 0.03, 1.0,  # noqa: E731
-                                                   p(gd), p(loss), st())
+                                                   p(gd), p(loss), None, st())
     print(f"interlevel_loss_to_density Sp={Sp}: {bench.time_kernel(fn, 50) * 1e6:7.1f} us")
     n, L = B * Sp, 6
     feats = torch.randn(L, n, 1, **f32)
