@@ -3,11 +3,14 @@
 // sqrt(D))) V over the n tokens of one scan (107 x 33 = 3 531 rays), D = d_model = 48, forward and backward in fp32 on the
 // matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands, the products are exact fp32 -- this op needs no reduced precision).
 // The score matrix (12.5 M entries per scan) never exists: flash-style tiles with the online softmax in the forward, the
-// probabilities recomputed from the forward's log-sum-exp in the backward.  Measured at the radar scan's size (kernels):
-// forward 41 us + 4 us merge, backward 79 (query side) + 112 us (key side) with QW = 2; QW = 1 (more, lighter waves): forward
-// + backward 204 us against 424 us of torch's attention (hipBLASLt GEMMs + softmax kernels on this build) and 1 250 us of
-// this file's first version (one lane per query on the vector ALUs).  PMC (tools/pmc_attention.sh): the matrix cores are busy
-// 37 % of the forward's cycles; the rest is waits on LDS / the staged loads with ~2 waves per SIMD.
+// probabilities recomputed from the forward's log-sum-exp in the backward.  Measured at the radar scan's size (kernel
+// trace): forward 36 us + 8 us merge of the key parts, backward 63 us (query side) + 93 us (key side): forward + backward
+// 200 us against 373-424 us of torch's attention (hipBLASLt GEMMs + softmax kernels on this build) and 1 250 us of this
+// file's first version (one lane per query on the vector ALUs).  PMC (tools/pmc_attention.sh): the matrix cores are busy
+// 39 / 34 / 32 % of the three kernels' cycles (12.5 M scores x 24 / 36 / 48 MFMA steps = 16 / 24 / 31 us at the 155 TF/s
+// fp32 matrix peak); the rest is waits on LDS and on the staged loads at ~2 light waves per SIMD.  Tile size, waves per
+// block, query groups per wave and the part count are build-time knobs (NR_ATT_*): 64 keys x 4 waves x 1 group measured
+// fastest at this size (128-key tiles: +12 %; two groups per wave: +20 %).
 // Dropout on the probabilities (training, p = 0.1 in the reference) is a counter-based hash of (seed, scan, query, key),
 // identical in the forward and both backward passes; a caller may pass the keep mask explicitly instead (tests).
 #include <math.h>
