@@ -8,14 +8,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from neuradar_amd import ops  # noqa: E402
-from oracle import hashgrid  # noqa: E402
+from neuradar_amd.encodings import HashEncoding  # noqa: E402
 
 dev = torch.device("cuda")
 lib, p, st = ops._lib.lib(), ops._p, ops._stream
 for tag, L, F, log2t, rmin, rmax, rays, S in (("prop_s128", 6, 1, 20, 128, 4096, 4661, 128), ("prop_s64", 6, 1, 20, 128, 4096, 4661, 64),
                                               ("l16f2_s32", 16, 2, 19, 16, 1024, 4661, 32), ("prop_s128_16k", 6, 1, 20, 128, 4096, 16384, 128)):
     n = rays * S
-    sc = hashgrid.level_scalings(L, rmin, rmax).to(dev)
+    sc = HashEncoding(num_levels=L, min_res=rmin, max_res=rmax, log2_hashmap_size=12, features_per_level=F).scalings.to(dev)
     torch.manual_seed(0)
     # lidar-like: rays from one origin in random directions, power-spaced samples, ray-major rows
     o = torch.tensor([0.5, 0.5, 0.5], device=dev)
