@@ -536,6 +536,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
   int64_t persistent = (BinCfg<1>::M > 4096 && F == 1 ? 1 : BinCfg<1>::M < 4096 && F == 1 ? 4 : 2) * (int64_t)nr_num_cus();  // tables per CU that fit its LDS
+  if (const char* e = getenv("NR_BIN_BLOCKS_PER_CU")) persistent = (int64_t)atoi(e) * nr_num_cus() / 2 > 0 ? (int64_t)atoi(e) * nr_num_cus() / 2 : persistent;  // (halves of a CU: tuning knob)
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
   dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L, g.nb >= 64 ? 2u : 1u);
