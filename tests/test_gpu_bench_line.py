@@ -1,0 +1,34 @@
+"""bench.py's contract with the driver: ONE JSON line with the agreed keys, the roofline and cpu_baseline objects, exactly the
+requested number of timed steps (a short run of the default workload, as a child process like the driver starts it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05",
+                          "--cpu-sample-rays", "64", "--secondary", ""], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert base["metric"].startswith(r["metric"]) and r["unit"] == "rays/s"  # (BASELINE's metric string goes on with PSNR / GPU counts)
+    assert r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["data"] == "synthetic" and r["dtype"] in ("bf16", "f16", "f32")
+    assert r["config"]["workload"] == "mixed16384_neuradar" and "model" not in r["config"]
+    assert r["value"] > 0 and abs(r["value"] - 16384 / (r["ms_per_step"] * 1e-3)) < 0.01 * r["value"]
+    roof = r["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert abs(roof["achieved"] - roof["bytes_per_launch"] / (roof["avg_us"] * 1e-6) / 1e9) < 0.01 * roof["achieved"]
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "rays/s" and cpu["sample"]
