@@ -331,6 +331,46 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       const int64_t tl = (int64_t)level * nb + tile;
       const int64_t sub_stride = nb << cap_log2;
       int64_t sub = ((int64_t)level * ns + wave) * sub_stride + (tile << cap_log2);
+      constexpr int NP = M / (NR_WAVE * WAVES);  // partitions per wave when a partition is one wave-width of slots
+      if (cap_log2 == 6) {
+        // (the usual geometry: ns = M / 64.)  The wave's partitions are read NB at a time -- keys first, then the sums of
+        // the occupied slots, then the stores: two LDS round trips per BATCH instead of per partition (the flush was 44 %
+        // of the kernel's wave-cycles with one partition in flight)
+        constexpr int NB = F == 1 ? 4 : 2;  // (registers: NB * 2F 64-bit sums; the kernel must stay at 128 VGPRs for two blocks per CU)
+        static_assert(NP % NB == 0, "partitions per wave");
+#pragma unroll 1
+        for (int j0 = 0; j0 < NP; j0 += NB) {
+          uint32_t kk[NB];
+          unsigned long long bal[NB], av[NB][2 * F];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) kk[j] = keys[((wave + (j0 + j) * WAVES) << 6) + lane];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const bool occ = kk[j] < kReserved;
+            bal[j] = __ballot(occ);
+            const int sl_ = ((wave + (j0 + j) * WAVES) << 6) + lane;
+#pragma unroll
+            for (int k = 0; k < 2 * F; ++k) av[j][k] = occ ? acc[sl_ * 2 * F + k] : 0ull;
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int sp_ = wave + (j0 + j) * WAVES;
+            const int sl_ = (sp_ << 6) + lane;
+            const int64_t subj = sub + (int64_t)(j0 + j) * WAVES * sub_stride;
+            if (kk[j] < kReserved) {
+              const uint32_t at = (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull));
+              rkey[subj + at] = kk[j];
+#pragma unroll
+              for (int k = 0; k < 2 * F; ++k) {
+                rsum[(subj + at) * (2 * F) + k] = av[j][k];
+                acc[sl_ * 2 * F + k] = 0ull;
+              }
+              keys[sl_] = kEmpty;
+            }
+            if (lane == 0) cntg[tl * ns + sp_] = (uint32_t)__popcll(bal[j]);
+          }
+        }
+      } else {
       for (int s = wave; s < ns; s += WAVES, sub += WAVES * sub_stride) {
         uint32_t* dk = rkey + sub;                      // (scalar bases, 32-bit lane offsets)
         unsigned long long* ds = rsum + sub * (2 * F);
@@ -354,6 +394,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
           count += (uint32_t)__popcll(bal);
         }
         if (lane == 0) cntg[tl * ns + s] = count;
+      }
       }
       if (tid == 0) tile_exp[tl] = bmax > 0.0f ? e : kNoRecords;
     }
