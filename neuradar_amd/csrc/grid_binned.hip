@@ -109,6 +109,15 @@ struct DensityHead {
   int64_t sm_rays;
 };
 
+// -DNR_BIN_CLOCKS: wave-cycles per phase of the bin pass, summed over all waves (tools/probe_bin_phases.py reads them
+// through nr_debug_bin_clocks, which only this build exports)
+#ifdef NR_BIN_CLOCKS
+__device__ unsigned long long g_bin_clocks[8];
+#define NR_CLK(i) { const long long t_ = clock64(); clk[i] += t_ - tlast; tlast = t_; }
+#else
+#define NR_CLK(i)
+#endif
+
 template <int F, bool HEAD>
 __global__ void __launch_bounds__(BinCfg<F>::ROWS)
 bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
@@ -158,6 +167,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       for (int f = 0; f < F; ++f) pg[l][f] = in && l < nl ? gout[(int64_t)(level0 + l) * sl + row * sn + f] : 0.0f;
   };
   fetch(tile);
+#ifdef NR_BIN_CLOCKS
+  long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
 #pragma unroll 1
   for (; tile < nb; tile += gridDim.x) {
     float cx[3], cstd, cg[kLevelChunk][F];
@@ -184,6 +196,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
         }
     }
     if (tile + gridDim.x < nb) fetch(tile + gridDim.x);
+    NR_CLK(0)
 #pragma unroll 1
     for (int li = 0; li < nl; ++li) {
       const int level = level0 + li;
@@ -283,7 +296,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, NR_WAVE));
       if (lane == 0) wmax[wave] = vmax;
+      NR_CLK(1)
       lds_barrier();  // A
+      NR_CLK(2)
       float bmax = 0.0f;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) bmax = fmaxf(bmax, wmax[w]);
@@ -326,7 +341,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
             if (vb[q][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)ib2 * F + f, vb[q][f]);
         }
       }
+      NR_CLK(3)
       lds_barrier();  // B
+      NR_CLK(4)
       // ---- 4. every partition leaves as one contiguous run of raw records, its sub-bin, and is empty again afterwards
       const int64_t tl = (int64_t)level * nb + tile;
       const int64_t sub_stride = nb << cap_log2;
@@ -397,8 +414,13 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       }
       }
       if (tid == 0) tile_exp[tl] = bmax > 0.0f ? e : kNoRecords;
+      NR_CLK(5)
     }
   }
+#ifdef NR_BIN_CLOCKS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_bin_clocks[i], (unsigned long long)clk[i]);
+#endif
   if (HEAD) {  // the block's share of the head's weight gradient (the table is idle: its first words carry the wave sums)
     lds_barrier();
     float* red = reinterpret_cast<float*>(acc);
@@ -628,3 +650,15 @@ extern "C" int nr_prop_density_scatter_binned(const float* x, const float* std, 
   const DensityHead head = {w, g_density, nullptr, n_samples, rows_sample_major};
   return launch_binned(x, std, scalings, L, F, log2T, feats, sn, sl, gtable, n, workspace, stream, &head, g_w);
 }
+
+#ifdef NR_BIN_CLOCKS
+extern "C" int nr_debug_bin_clocks(unsigned long long* out8, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bin_clocks), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bin_clocks), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
