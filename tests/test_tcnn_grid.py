@@ -200,7 +200,9 @@ def test_tcnn_layout_field_with_4d_actor_grid_and_checkpoint_loading():
 
     fs = rescale(tg.encode(x01.cpu(), ps, g3), std01.cpu(), hg.static_grid.scalings.cpu())
     pos4 = torch.cat([x01a.cpu(), (actor.float() / actors.n_actors)[:, None]], dim=-1)
-    fa = rescale(tg.encode(torch.where(inside[:, None], pos4, torch.zeros_like(pos4)), pa, g4), std01a.cpu(), hg.actor_grids[0].scalings.cpu())
+    # (rows outside every box carry whatever the buffers held: NaN there would reach pa.grad as 0 * NaN through `where`)
+    std_a = torch.where(inside, std01a.cpu(), torch.ones_like(std01a.cpu()))
+    fa = rescale(tg.encode(torch.where(inside[:, None], pos4, torch.zeros_like(pos4)), pa, g4), std_a, hg.actor_grids[0].scalings.cpu())
     want = torch.where(inside[:, None], torch.nn.functional.pad(fa, (0, 16)), fs)  # 4 actor levels of 8: zero-padded (:186)
     torch.testing.assert_close(feats.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-5)
     (want * go).sum().backward()
