@@ -19,7 +19,6 @@
 
 namespace {
 
-
 __device__ __forceinline__ uint32_t att_hash(uint32_t v) {
   uint32_t s = v * 747796405u + 2891336453u;
   uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
@@ -45,7 +44,7 @@ __device__ __forceinline__ float drop_factor(const Drop& d, int64_t scan, int64_
   return keep / (1.0f - d.p);
 }
 
-// ---- matrix-core version.  v_mfma_f32_16x16x4_f32 tiles (fp32 operands: the op stays exact fp32), one wave = QW groups of
+// ---- tiling.  v_mfma_f32_16x16x4_f32 tiles (fp32 operands: the op stays exact fp32), one wave = QW groups of
 // 16 queries, the block's waves share 64-key tiles of K and V in LDS.  Everything is kept TRANSPOSED so that no value ever
 // changes lanes between the two products:
 //   S^T [16 keys x 16 queries]  = K_tile (A operand: lane = key l%16, contraction slot l/16 = a quarter of the d range,
