@@ -274,13 +274,25 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
         for (int f = 0; f < F; ++f) v[corner][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, v[corner][f]), take, v[corner][f]);
       flag |= nr_dpp_i<C, R>(0, flag);
     };
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
-    scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+    // a step changes nothing once every lane's partial sum has reached its run's head (flag = 1 everywhere: take = 0), so
+    // the scan stops there -- no step at all where every lane is a cell of its own (the fine levels), all seven only where
+    // a run crosses a 16-lane row.  Same sums bit for bit; 2 x 8 x F vector instructions per skipped step.
+    do {
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
+      if (__ballot(flag == 0) == 0ull) break;
+      scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+    } while (false);
     const int next_head = nr_dpp_i<NR_DPP_WAVE_SHL1, 0xF>(1, head ? 1 : 0);
     float mag = 0.0f;
 #pragma unroll

@@ -271,13 +271,22 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
             }
           flag |= nr_dpp_i<C, R>(0, flag);
         };
-        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
-        scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+        // (the scan stops once every lane has reached its run's head: the remaining steps would add nothing)
+        do {
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+        } while (false);
       }
       const bool tail = lane == NR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull);
 #pragma unroll
