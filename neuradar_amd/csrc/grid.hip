@@ -253,13 +253,15 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     auto same_cell = [&](int lx, int ly, int lz) { return lx == lo[0] && ly == lo[1] && lz == lo[2]; };
     {
       const bool same = same_cell(nr_xor32_i(lo[0]), nr_xor32_i(lo[1]), nr_xor32_i(lo[2]));
+      if (__ballot(same) != 0ull) {  // (uniform: no exchange where no lane shares its cell with lane ^ 32)
 #pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
+        for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const float o = nr_xor32_f(v[corner][f]);
-          if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
-        }
+          for (int f = 0; f < F; ++f) {
+            const float o = nr_xor32_f(v[corner][f]);
+            if (same) v[corner][f] = lane < 32 ? v[corner][f] + o : 0.0f;
+          }
+      }
     }
     const bool head = lane == 0 || !same_cell(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[0]),
                                               nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]),
