@@ -296,12 +296,12 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
       scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
     } while (false);
     const int next_head = nr_dpp_i<NR_DPP_WAVE_SHL1, 0xF>(1, head ? 1 : 0);
-    float mag = 0.0f;
+    uint32_t any_bits = 0u;  // "some |v| is not zero" from the values' bits: one three-input OR per two values instead of an add each
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-      for (int f = 0; f < F; ++f) mag += fabsf(v[corner][f]);
-    const bool nz = mag != 0.0f;
+      for (int f = 0; f < F; ++f) any_bits |= __float_as_uint(v[corner][f]);
+    const bool nz = (any_bits & 0x7FFFFFFFu) != 0u;
     const bool want = (lane == NR_WAVE - 1 || next_head) && nz;
     {  // make room BEFORE inserting: with <= 3/4 load the probes (almost) always succeed
       const int need = __popcll(__ballot(want));
