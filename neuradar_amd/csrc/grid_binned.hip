@@ -302,9 +302,8 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
         if (tail && finite) vmax = fmaxf(vmax, m);
       }
       // ---- 2. block maximum -> the tile's fixed-point scale on this level
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, NR_WAVE));
-      if (lane == 0) wmax[wave] = vmax;
+      vmax = nr_wave_max_to_lane63(vmax);
+      if (lane == NR_WAVE - 1) wmax[wave] = vmax;
       NR_CLK(1)
       lds_barrier();  // A
       NR_CLK(2)

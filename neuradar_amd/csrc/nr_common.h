@@ -141,12 +141,25 @@ constexpr int NR_DPP_ROW_SHR = 0x110;   // + n: lane i <- lane i-n inside its ro
 constexpr int NR_DPP_WAVE_SHL1 = 0x130; // lane i <- lane i+1 (whole wave)
 constexpr int NR_DPP_WAVE_SHR1 = 0x138; // lane i <- lane i-1 (whole wave)
 constexpr int NR_DPP_ROW_BCAST15 = 0x142;  // lane 15 of row r -> every lane of row r+1
+constexpr int NR_DPP_ROW_BCAST31 = 0x143;  // lane 31 -> every lane of rows 2 and 3
 // value of lane (l ^ 32): v_permlane32_swap exchanges the upper half of one register with the lower half of another
 __device__ __forceinline__ int nr_xor32_i(int x) {
   auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
   return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
 }
 __device__ __forceinline__ float nr_xor32_f(float x) { return __int_as_float(nr_xor32_i(__float_as_int(x))); }
+
+// maximum over the wave, valid in LANE 63 only: six v_max_f32 with DPP operands (prefix maxima inside the rows of 16, then
+// the two row broadcasts) instead of six ds_bpermute round trips
+__device__ __forceinline__ float nr_wave_max_to_lane63(float v) {
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_SHR + 1, 0xF>(v, v));
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_SHR + 2, 0xF>(v, v));
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_SHR + 4, 0xF>(v, v));
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_SHR + 8, 0xF>(v, v));
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_BCAST15, 0xA>(v, v));
+  v = fmaxf(v, nr_dpp_f<NR_DPP_ROW_BCAST31, 0xC>(v, v));
+  return v;
+}
 
 // ---- wave64 scans / reductions ----------------------------------------------------------------
 __device__ __forceinline__ int nr_lane() { return threadIdx.x & (NR_WAVE - 1); }
