@@ -164,10 +164,17 @@ __device__ __forceinline__ float nr_wave_max_to_lane63(float v) {
 // ---- wave64 scans / reductions ----------------------------------------------------------------
 __device__ __forceinline__ int nr_lane() { return threadIdx.x & (NR_WAVE - 1); }
 
+// sum over the wave, in every lane: prefix sums inside the rows of 16 and the two row broadcasts on DPP operands (lane 63
+// ends up with the total), then one readlane -- seven vector instructions instead of six ds_bpermute round trips through
+// the LDS crossbar.  (The order of the additions is fixed: rows left to right, then rows 0+1, 2+3, then the halves.)
 __device__ __forceinline__ float nr_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, NR_WAVE);
-  return v;
+  v += nr_dpp_f<NR_DPP_ROW_SHR + 1, 0xF>(0.0f, v);
+  v += nr_dpp_f<NR_DPP_ROW_SHR + 2, 0xF>(0.0f, v);
+  v += nr_dpp_f<NR_DPP_ROW_SHR + 4, 0xF>(0.0f, v);
+  v += nr_dpp_f<NR_DPP_ROW_SHR + 8, 0xF>(0.0f, v);
+  v += nr_dpp_f<NR_DPP_ROW_BCAST15, 0xA>(0.0f, v);
+  v += nr_dpp_f<NR_DPP_ROW_BCAST31, 0xC>(0.0f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), NR_WAVE - 1));
 }
 
 // inclusive prefix sum across the wave
