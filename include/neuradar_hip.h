@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 14
+#define NR_ABI_VERSION 15
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -172,8 +172,9 @@ int nr_actor_keyframes(const float* times, int64_t n_rays, const float* timestam
  *                        x *= flip[ray] (+-1 or NULL, :218-225), ScaledSceneContraction(actor_scale) -> x01a [n,3], std01a [n];
  *                        dirs_sample [n_rays*S,3] (ray-major, nullable) <- the view direction of every sample: rotated into the
  *                        box, normalised and flipped for actor samples (:210-215), the ray's direction otherwise.
- *   nr_actor_encode_fwd  feats rows of actor samples <- the actor's grid (tables [A][L*T,F], shared scalings [L]) with the
- *                        per-level rescale, levels L..static_levels-1 zeroed (:186-187); F must equal the static grid's F.
+ *   nr_actor_encode_fwd  feats rows of actor samples <- the actor's grid (tables [A][L*T,F], shared scalings [L]; the grid of
+ *                        actor a is tables[table_of_actor[a]] -- DynamicActors.actor_to_id, neurad_encoding.py:183, which the
+ *                        closed-loop server rewrites -- or tables[a] when table_of_actor is NULL) with the per-level rescale, levels L..static_levels-1 zeroed (:186-187); F must equal the static grid's F.
  *   nr_actor_encode_bwd  g_tables += scatter of those rows of g_feats, which are then ZEROED (the static grid was overwritten
  *                        there); with g_w2b [n_rays,K,3,4] (caller-zeroed, nullable) += d loss / d w2b through the grid's input
  *                        gradient, the contraction and the flip (require_actor_grad, :83,176).
@@ -197,13 +198,13 @@ int nr_actor_assign(const float* origins, const float* directions, const float* 
                     const float* centres, const float* bounds, float actor_scale, const float* flip, int* slot_of_row,
                     float* x01a, float* std01a, float* dirs_sample, nr_stream_t stream);
 int nr_actor_encode_fwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
-                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const float* scalings,
-                        int num_levels, int features_per_level, int log2_hashmap_size, float* feats, int64_t feat_stride_n,
-                        int64_t feat_stride_l, int static_levels, nr_stream_t stream);
+                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const int* table_of_actor,
+                        const float* scalings, int num_levels, int features_per_level, int log2_hashmap_size, float* feats,
+                        int64_t feat_stride_n, int64_t feat_stride_l, int static_levels, nr_stream_t stream);
 int nr_actor_encode_bwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
-                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const float* scalings,
-                        int num_levels, int features_per_level, int log2_hashmap_size, float* grad_feats, int64_t feat_stride_n,
-                        int64_t feat_stride_l, int static_levels, float* grad_tables, const float* origins,
+                        int64_t n_rays, int n_samples, int sample_major_rows, const float* tables, const int* table_of_actor,
+                        const float* scalings, int num_levels, int features_per_level, int log2_hashmap_size, float* grad_feats,
+                        int64_t feat_stride_n, int64_t feat_stride_l, int static_levels, float* grad_tables, const float* origins,
                         const float* directions, const float* pixel_area, const float* euclid, const float* w2b,
                         float actor_scale, const float* flip, float* grad_w2b, nr_stream_t stream);
 
@@ -400,6 +401,25 @@ int nr_composite_bwd(const float* alpha, const float* feature, const float* eucl
 /* render_depth_simple alone (proposal depths, neuradar.py:527-528). */
 int nr_depth_from_weights(const float* weights, const float* euclid, int64_t n_rays, int n_samples,
                           float* depth, nr_stream_t stream);
+
+/* nerfacc's batched helpers by themselves (nerfacc==0.5.2, packed_info=None / ray_indices=None branches), for callers that
+ * use them one by one: models/neuradar.py:1016 `render_weight_from_alpha(alphas) -> (weights, transmittance)`,
+ * :1018-1022 `render_weight_from_density(t_starts, t_ends, sigmas) -> (weights, transmittance, alphas)`,
+ * models/neurad.py:727-728 / model_components/renderers.py:88,345 `accumulate_along_rays(weights, values)`.
+ *   T_i = prod_{j<i}(1 - alpha_j) (also where alpha_i = 0), w_i = alpha_i T_i; no sky fix-up; any n_samples.
+ * Density mode (t_starts, t_ends non-null): the input is sigma, alpha = 1 - exp(-sigma (t_end - t_start)), `alphas` receives it.
+ * Backward: grad_weights / grad_transmittance / grad_alphas are each nullable; grad_in is d/d(alpha) or d/d(sigma). */
+int nr_render_weights_fwd(const float* alphas_or_sigmas, const float* t_starts, const float* t_ends, int64_t n_rays,
+                          int n_samples, float* weights, float* transmittance, float* alphas, nr_stream_t stream);
+int nr_render_weights_bwd(const float* alphas_or_sigmas, const float* t_starts, const float* t_ends,
+                          const float* transmittance, const float* grad_weights, const float* grad_transmittance,
+                          const float* grad_alphas, int64_t n_rays, int n_samples, float* grad_in, nr_stream_t stream);
+/* out[b][c] = sum_s weights[b][s] * values[b][s][c]; values == NULL: out[b] = sum_s weights[b][s] (n_channels ignored).
+ * Backward: grad_weights [n_rays,S] and grad_values [n_rays,S,C] are each nullable. */
+int nr_accumulate_fwd(const float* weights, const float* values, int64_t n_rays, int n_samples, int n_channels,
+                      float* out, nr_stream_t stream);
+int nr_accumulate_bwd(const float* weights, const float* values, const float* grad_out, int64_t n_rays, int n_samples,
+                      int n_channels, float* grad_weights, float* grad_values, nr_stream_t stream);
 
 /* Lidar supervision of the weights (the "carving" terms of models/neuradar.py:529-531,537-541,637-638,650 with
  * _compute_is_close_to_lidar :971-994): for a lidar ray, a sample is "close" when |range - t_mid| < carving_epsilon (the ray

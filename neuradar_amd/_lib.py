@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 14
+NR_ABI_VERSION = 15
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -66,8 +66,8 @@ PROTOTYPES = {
     "nr_actor_w2b_fwd": [P, L, I, I, P, P, P, P, P, P, P, P],
     "nr_actor_w2b_bwd": [P, L, I, I, P, P, P, P, P, P, P, P, P],
     "nr_actor_assign": [P, P, P, P, L, I, I, P, I, P, P, P, F, P, P, P, P, P, P],
-    "nr_actor_encode_fwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P],
-    "nr_actor_encode_bwd": [P, P, P, P, I, L, I, I, P, P, I, I, I, P, L, L, I, P, P, P, P, P, P, F, P, P, P],
+    "nr_actor_encode_fwd": [P, P, P, P, I, L, I, I, P, P, P, I, I, I, P, L, L, I, P],
+    "nr_actor_encode_bwd": [P, P, P, P, I, L, I, I, P, P, P, I, I, I, P, L, L, I, P, P, P, P, P, P, F, P, P, P],
     "nr_contract_gaussians": [P, P, P, P, L, I, F, I, P, P, P],
     "nr_mlp_fwd": [POINTER(NrMlp), P, L, P, P],
     "nr_mlp_bwd": [POINTER(NrMlp), P, P, L, P, POINTER(NrMlpGrads), P],
@@ -90,6 +90,10 @@ PROTOTYPES = {
     "nr_pdf_resample": [P, P, P, P, P, L, I, I, F, F, F, P, P, P],
     "nr_composite_fwd": [P, P, P, L, I, I, P, P, P, P, P],
     "nr_composite_bwd": [P, P, P, P, P, P, P, P, L, I, I, P, P, P],
+    "nr_render_weights_fwd": [P, P, P, L, I, P, P, P, P],
+    "nr_render_weights_bwd": [P, P, P, P, P, P, P, L, I, P, P],
+    "nr_accumulate_fwd": [P, P, L, I, I, P, P],
+    "nr_accumulate_bwd": [P, P, P, L, I, I, P, P, P],
     "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P, POINTER(NrLidarSup), P],
     "nr_appearance_concat_fwd": [P, I, P, I, P, P, F, I, L, L, P, P],
     "nr_appearance_concat_bwd": [P, I, I, P, P, F, I, L, L, P, P, L, P],

@@ -191,15 +191,16 @@ template <int F>
 __global__ void __launch_bounds__(256)
 actor_encode_fwd_kernel(const float* __restrict__ x01a, const float* __restrict__ std01a, const int* __restrict__ slot_of_row,
                         const int* __restrict__ cand, int K, int S, int sm, int64_t n, const float* __restrict__ tables,
-                        const float* __restrict__ scalings, int L, int log2T, float* __restrict__ feats, int64_t sn, int64_t sl,
-                        int static_levels) {
+                        const int* __restrict__ table_of_actor, const float* __restrict__ scalings, int L, int log2T,
+                        float* __restrict__ feats, int64_t sn, int64_t sl, int static_levels) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   const int slot = slot_of_row[row];
   if (slot < 0) return;
   const NrRowMap rm = nr_row_map(row, n, S, sm);
   const int a = cand[rm.ray * K + slot];
-  const float* table = tables + (((int64_t)a * L) << log2T) * F;
+  const int tid = table_of_actor ? table_of_actor[a] : a;  // actor_to_id: the actor's hash grid (neurad_encoding.py:183)
+  const float* table = tables + (((int64_t)tid * L) << log2T) * F;
   for (int level = 0; level < static_levels; ++level) {
     float feat[F];
     if (level < L) {
@@ -246,7 +247,8 @@ template <int F>
 __global__ void __launch_bounds__(256)
 actor_encode_bwd_kernel(const float* __restrict__ x01a, const float* __restrict__ std01a, const int* __restrict__ slot_of_row,
                         const int* __restrict__ cand, int K, int S, int sm, int64_t n, const float* __restrict__ tables,
-                        const float* __restrict__ scalings, int L, int log2T, float* __restrict__ g_feats, int64_t sn, int64_t sl,
+                        const int* __restrict__ table_of_actor, const float* __restrict__ scalings, int L, int log2T,
+                        float* __restrict__ g_feats, int64_t sn, int64_t sl,
                         int static_levels, float* __restrict__ g_tables, const float* __restrict__ origins,
                         const float* __restrict__ directions, const float* __restrict__ pixel_area, const float* __restrict__ euclid,
                         const float* __restrict__ w2b, float actor_scale, const float* __restrict__ flip, float* __restrict__ g_w2b) {
@@ -256,12 +258,13 @@ actor_encode_bwd_kernel(const float* __restrict__ x01a, const float* __restrict_
   if (slot < 0) return;
   const NrRowMap rm = nr_row_map(row, n, S, sm);
   const int a = cand[rm.ray * K + slot];
+  const int tid = table_of_actor ? table_of_actor[a] : a;  // actor_to_id (neurad_encoding.py:183)
   const uint32_t mask = (1u << log2T) - 1u;
   float acc[3] = {0.0f, 0.0f, 0.0f};
   for (int level = 0; level < L; ++level) {
     const float scale = scalings[level];
     const Corner c = make_corner(x01a, row, scale);
-    const int64_t base = ((((int64_t)a * L + level) << log2T)) * F;
+    const int64_t base = ((((int64_t)tid * L + level) << log2T)) * F;
     float r = 1.0f / fmaxf(scale * 2.0f * std01a[row], 1.0f);
     float g[F];
     float* gi = g_feats + row * sn + (int64_t)level * sl;
@@ -505,8 +508,9 @@ extern "C" int nr_actor_assign(const float* origins, const float* directions, co
 }
 
 extern "C" int nr_actor_encode_fwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
-                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const float* scalings, int L,
-                                   int F, int log2T, float* feats, int64_t sn, int64_t sl, int static_levels, nr_stream_t stream) {
+                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const int* table_of_actor,
+                                   const float* scalings, int L, int F, int log2T, float* feats, int64_t sn, int64_t sl,
+                                   int static_levels, nr_stream_t stream) {
   if (n_rays == 0) return 0;
   if (!x01a || !std01a || !slot_of_row || !cand || !tables || !scalings || !feats || L < 1 || static_levels < L || log2T < 1 ||
       log2T > 30 || S < 1 || K < 1 || n_rays < 0)
@@ -514,7 +518,7 @@ extern "C" int nr_actor_encode_fwd(const float* x01a, const float* std01a, const
   const int64_t n = n_rays * S;
   dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
 #define CALL(FF) hipLaunchKernelGGL(actor_encode_fwd_kernel<FF>, grid, block, 0, nr_s(stream), x01a, std01a, slot_of_row, cand, K, S, \
-                                    sample_major_rows, n, tables, scalings, L, log2T, feats, sn, sl, static_levels)
+                                    sample_major_rows, n, tables, table_of_actor, scalings, L, log2T, feats, sn, sl, static_levels)
   switch (F) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;
@@ -527,8 +531,9 @@ extern "C" int nr_actor_encode_fwd(const float* x01a, const float* std01a, const
 }
 
 extern "C" int nr_actor_encode_bwd(const float* x01a, const float* std01a, const int* slot_of_row, const int* cand, int K,
-                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const float* scalings, int L,
-                                   int F, int log2T, float* g_feats, int64_t sn, int64_t sl, int static_levels, float* g_tables,
+                                   int64_t n_rays, int S, int sample_major_rows, const float* tables, const int* table_of_actor,
+                                   const float* scalings, int L, int F, int log2T, float* g_feats, int64_t sn, int64_t sl,
+                                   int static_levels, float* g_tables,
                                    const float* origins, const float* directions, const float* pixel_area, const float* euclid,
                                    const float* w2b, float actor_scale, const float* flip, float* g_w2b, nr_stream_t stream) {
   if (n_rays == 0) return 0;
@@ -539,7 +544,7 @@ extern "C" int nr_actor_encode_bwd(const float* x01a, const float* std01a, const
   const int64_t n = n_rays * S;
   dim3 grid((unsigned)nr_cdiv(n, 256)), block(256);
 #define CALL(FF) hipLaunchKernelGGL(actor_encode_bwd_kernel<FF>, grid, block, 0, nr_s(stream), x01a, std01a, slot_of_row, cand, K, S, \
-                                    sample_major_rows, n, tables, scalings, L, log2T, g_feats, sn, sl, static_levels, g_tables,         \
+                                    sample_major_rows, n, tables, table_of_actor, scalings, L, log2T, g_feats, sn, sl, static_levels, g_tables, \
                                     origins, directions, pixel_area, euclid, w2b, actor_scale, flip, g_w2b)
   switch (F) {
     case 1: CALL(1); break;

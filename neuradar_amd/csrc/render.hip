@@ -239,7 +239,194 @@ depth_kernel(const float* __restrict__ weights, const float* __restrict__ euclid
   if (lane == 0) depth[ray] = d;
 }
 
+// ---- nerfacc's batched helpers by themselves (models/neuradar.py:1016-1022, models/neurad.py:727-728) ----
+// One wavefront per ray, any S: chunks of 64 samples with the running transmittance carried from chunk to chunk.
+// density mode (t_starts != nullptr): in = sigma, alpha = 1 - exp(-sigma * (t_end - t_start)).
+__global__ void __launch_bounds__(256)
+weights_from_alpha_fwd_kernel(const float* __restrict__ in, const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+                              int64_t n_rays, int S, float* __restrict__ weights, float* __restrict__ trans,
+                              float* __restrict__ alphas) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  float carry = 1.0f;
+  for (int s0 = 0; s0 < S; s0 += NR_WAVE) {
+    const int s = s0 + lane;
+    const int64_t o = ray * S + s;
+    float a = 0.0f;
+    if (s < S) a = t_starts ? 1.0f - expf(-in[o] * (t_ends[o] - t_starts[o])) : in[o];
+    const float incl = nr_wave_incl_prod(1.0f - a);
+    const float up = __shfl_up(incl, 1, NR_WAVE);
+    const float T = carry * (lane == 0 ? 1.0f : up);
+    if (s < S) {
+      weights[o] = a * T;
+      trans[o] = T;
+      if (alphas) alphas[o] = a;
+    }
+    carry *= __shfl(incl, NR_WAVE - 1, NR_WAVE);
+  }
+}
+
+// w_i = a_i T_i, T_i = prod_{j<i}(1 - a_j).  With H_s = g_w_s a_s + g_T_s (everything that reaches T_s):
+//   d a_j = g_w_j T_j - T_j R_j,   R_j = sum_{s>j} H_s prod_{j<i<s}(1 - a_i) = H_{j+1} + (1 - a_{j+1}) R_{j+1}
+// (division-free: safe for alpha -> 1).  Chunks are walked from the far end with R carried across them.
+__global__ void __launch_bounds__(256)
+weights_from_alpha_bwd_kernel(const float* __restrict__ in, const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+                              const float* __restrict__ trans, const float* __restrict__ g_w, const float* __restrict__ g_T,
+                              const float* __restrict__ g_a, int64_t n_rays, int S, float* __restrict__ g_in) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  float R_next = 0.0f, A_next = 0.0f, H_next = 0.0f;  // R, (1 - a), H of the first sample of the chunk behind this one
+  for (int s0 = (S - 1) / NR_WAVE * NR_WAVE; s0 >= 0; s0 -= NR_WAVE) {
+    const int s = s0 + lane;
+    const int64_t o = ray * S + s;
+    const bool on = s < S;
+    float a = 0.0f, delta = 0.0f;
+    if (on) {
+      if (t_starts) {
+        delta = t_ends[o] - t_starts[o];
+        a = 1.0f - expf(-in[o] * delta);
+      } else {
+        a = in[o];
+      }
+    }
+    const float gw = (on && g_w) ? g_w[o] : 0.0f;
+    const float H = gw * a + ((on && g_T) ? g_T[o] : 0.0f);
+    // affine map of lane j: R_j = B_j + A_j R_{j+1}, with (A_j, B_j) = (1 - a_{j+1}, H_{j+1}); the last lane's successor is
+    // the first sample of the chunk behind
+    float A = __shfl_down(1.0f - a, 1, NR_WAVE), Bv = __shfl_down(H, 1, NR_WAVE);
+    if (lane == NR_WAVE - 1) { A = A_next; Bv = H_next; }
+    if (s + 1 >= S) { A = 0.0f; Bv = 0.0f; }
+#pragma unroll
+    for (int k = 1; k < NR_WAVE; k <<= 1) {
+      const float A2 = __shfl_down(A, k, NR_WAVE), B2 = __shfl_down(Bv, k, NR_WAVE);
+      if (lane + k < NR_WAVE) {
+        Bv = Bv + A * B2;
+        A = A * A2;
+      }
+    }
+    // lane j now maps R_{s0+64} (= R of the next chunk's first sample) to R_j
+    const float R = Bv + A * R_next;
+    if (on) {
+      const float T = trans[o];
+      float ga = T * (gw - R) + (g_a ? g_a[o] : 0.0f);
+      g_in[o] = t_starts ? ga * delta * (1.0f - a) : ga;
+    }
+    R_next = __shfl(R, 0, NR_WAVE);
+    A_next = __shfl(1.0f - a, 0, NR_WAVE);
+    H_next = __shfl(H, 0, NR_WAVE);
+  }
+}
+
+// accumulate_along_rays, batched branch: out[b][c] = sum_s w[b][s] * values[b][s][c] (values == nullptr: C = 1, sum_s w).
+__global__ void __launch_bounds__(256)
+accumulate_fwd_kernel(const float* __restrict__ w, const float* __restrict__ values, int64_t n_rays, int S, int C,
+                      float* __restrict__ out) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  if (values == nullptr) {
+    float sum = 0.0f;
+    for (int s = lane; s < S; s += NR_WAVE) sum += w[ray * S + s];
+    sum = nr_wave_sum(sum);
+    if (lane == 0) out[ray] = sum;
+    return;
+  }
+  for (int c0 = 0; c0 < C; c0 += NR_WAVE) {
+    const int c = c0 + lane;
+    float sum = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += NR_WAVE) {
+      const float wl = s0 + lane < S ? w[ray * S + s0 + lane] : 0.0f;
+      const int ns = min(NR_WAVE, S - s0);
+      for (int k = 0; k < ns; ++k) {
+        const float ws = __shfl(wl, k, NR_WAVE);
+        if (c < C) sum += values[(ray * S + s0 + k) * C + c] * ws;
+      }
+    }
+    if (c < C) out[ray * C + c] = sum;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+accumulate_bwd_kernel(const float* __restrict__ w, const float* __restrict__ values, const float* __restrict__ g_out,
+                      int64_t n_rays, int S, int C, float* __restrict__ g_w, float* __restrict__ g_values) {
+  const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  const int lane = nr_lane();
+  if (values == nullptr) {
+    const float g = g_out[ray];
+    for (int s = lane; s < S; s += NR_WAVE) g_w[ray * S + s] = g;
+    return;
+  }
+  for (int s0 = 0; s0 < S; s0 += NR_WAVE) {
+    const float wl = s0 + lane < S ? w[ray * S + s0 + lane] : 0.0f;
+    const int ns = min(NR_WAVE, S - s0);
+    float gws = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += NR_WAVE) {
+      const int c = c0 + lane;
+      const float g = c < C ? g_out[ray * C + c] : 0.0f;
+      for (int k = 0; k < ns; ++k) {
+        const float ws = __shfl(wl, k, NR_WAVE);
+        float part = 0.0f;
+        if (c < C) {
+          const int64_t o = (ray * S + s0 + k) * C + c;
+          part = g * values[o];
+          if (g_values) g_values[o] = g * ws;
+        }
+        part = nr_wave_sum(part);
+        if (lane == k) gws += part;
+      }
+    }
+    if (g_w && s0 + lane < S) g_w[ray * S + s0 + lane] = gws;
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_render_weights_fwd(const float* alphas_or_sigmas, const float* t_starts, const float* t_ends, int64_t n_rays,
+                                     int S, float* weights, float* transmittance, float* alphas, nr_stream_t stream) {
+  if (n_rays == 0 || S == 0) return 0;
+  if (!alphas_or_sigmas || !weights || !transmittance || (t_starts == nullptr) != (t_ends == nullptr) || S < 0 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(weights_from_alpha_fwd_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
+                     alphas_or_sigmas, t_starts, t_ends, n_rays, S, weights, transmittance, alphas);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_render_weights_bwd(const float* alphas_or_sigmas, const float* t_starts, const float* t_ends,
+                                     const float* transmittance, const float* grad_weights, const float* grad_transmittance,
+                                     const float* grad_alphas, int64_t n_rays, int S, float* grad_in, nr_stream_t stream) {
+  if (n_rays == 0 || S == 0) return 0;
+  if (!alphas_or_sigmas || !transmittance || !grad_in || (t_starts == nullptr) != (t_ends == nullptr) || S < 0 || n_rays < 0)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(weights_from_alpha_bwd_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream),
+                     alphas_or_sigmas, t_starts, t_ends, transmittance, grad_weights, grad_transmittance, grad_alphas, n_rays, S,
+                     grad_in);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_accumulate_fwd(const float* weights, const float* values, int64_t n_rays, int S, int C, float* out,
+                                 nr_stream_t stream) {
+  if (n_rays == 0) return 0;
+  if (!weights || !out || S < 0 || n_rays < 0 || (values && C < 1)) return NR_EINVAL;
+  hipLaunchKernelGGL(accumulate_fwd_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream), weights,
+                     values, n_rays, S, C, out);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_accumulate_bwd(const float* weights, const float* values, const float* grad_out, int64_t n_rays, int S, int C,
+                                 float* grad_weights, float* grad_values, nr_stream_t stream) {
+  if (n_rays == 0 || S == 0) return 0;
+  if (!weights || !grad_out || S < 0 || n_rays < 0 || (values && C < 1) || (!values && !grad_weights)) return NR_EINVAL;
+  hipLaunchKernelGGL(accumulate_bwd_kernel, dim3((unsigned)nr_cdiv(n_rays, kWavesPerBlock)), dim3(256), 0, nr_s(stream), weights,
+                     values, grad_out, n_rays, S, C, grad_weights, grad_values);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_composite_fwd(const float* alpha, const float* feature, const float* euclid, int64_t n_rays, int S,
                                 int C, float* weights, float* accumulation, float* features, float* depth,

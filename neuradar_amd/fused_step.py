@@ -47,6 +47,9 @@ class FusedTrainStep:
         self._streams = None
         self.timers = None  # dict name -> [(start, end) events]: set by a caller that wants in-step kernel times (eager only)
         assert len(c.num_proposal_samples) == 2
+        if not c.field.use_sdf:
+            raise NotImplementedError("FusedTrainStep composites sigmoid-SDF alphas (use_sdf=True, the reference's default); "
+                                      "the density branch (neuradar.py:1018-1022) runs on the modular path")
         self.model, self.cfg, self.B = model, c, n_rays
         self.sm = n_rays if coherent_rays is None else int(coherent_rays)
         self.early_fork = os.environ.get("NR_EARLY_FORK")  # schedule override for A/B runs, see forward_backward
@@ -304,6 +307,7 @@ class FusedTrainStep:
             geom = self.hg_main.actor_geometry(SimpleNamespace(origins=origins, directions=directions, times=times.reshape(B, 1),
                                                                euclid=self.eu[0]), flip=None, draw_flip=False)
             geom["w2b_d"] = geom["w2b"].detach()
+            geom["table_ids"] = self.hg_main.actor_table_ids()  # actor -> hash grid (actors.actor_to_id, neurad_encoding.py:183)
             flips = flips if flips is not None else (None, None, None)
             self.field_struct.sample_dirs = self.a_dirs.data_ptr()
 
@@ -318,8 +322,8 @@ class FusedTrainStep:
                                       p(self.a_dirs) if lvl == 2 else None, st_), "actor_assign")
             Fg = grid.features_per_level
             check(lib.nr_actor_encode_fwd(p(self.a_x01[lvl]), p(self.a_std[lvl]), p(self.a_slot[lvl]), p(geom["cand"]), K_, B, S_,
-                                          self.sm, p(hg._actor_tables()), p(ag.scalings), ag.num_levels, ag.features_per_level,
-                                          ag.log2_hashmap_size, p(self.feats[lvl]), Fg, B * S_ * Fg, grid.num_levels, st_),
+                                          self.sm, p(hg._actor_tables()), p(geom["table_ids"]), p(ag.scalings), ag.num_levels,
+                                          ag.features_per_level, ag.log2_hashmap_size, p(self.feats[lvl]), Fg, B * S_ * Fg, grid.num_levels, st_),
                   "actor_encode_fwd")
 
         def actor_backward(lvl, grid):
@@ -329,8 +333,8 @@ class FusedTrainStep:
             Fg = grid.features_per_level
             want_pose = lvl == 2 and hg.config.require_actor_grad and geom["w2b"].requires_grad
             check(lib.nr_actor_encode_bwd(p(self.a_x01[lvl]), p(self.a_std[lvl]), p(self.a_slot[lvl]), p(geom["cand"]), K_, B, S_,
-                                          self.sm, p(hg._actor_tables()), p(ag.scalings), ag.num_levels, ag.features_per_level,
-                                          ag.log2_hashmap_size, p(self.g_feats[lvl]), Fg, B * S_ * Fg, grid.num_levels,
+                                          self.sm, p(hg._actor_tables()), p(geom["table_ids"]), p(ag.scalings), ag.num_levels,
+                                          ag.features_per_level, ag.log2_hashmap_size, p(self.g_feats[lvl]), Fg, B * S_ * Fg, grid.num_levels,
                                           p(hg.actor_table_grads()), o, d, area, p(self.eu[lvl]), p(geom["w2b_d"]),
                                           hg.config.actor.actor_scale, p(flips[lvl]), p(self.g_w2b) if want_pose else None,
                                           ops._stream()), "actor_encode_bwd")
@@ -574,7 +578,11 @@ class FusedTrainStep:
             for i in range(len(field_opt.buffers)):
                 field_opt.step_buffer(i, scale)
             # whatever else the table optimizer holds (per-actor grids) and the trajectory optimizer
-            others = [(table_opt, i) for i in range(len(table_opt.buffers)) if i not in (i_prop, i_main)]
+            # ... except the tables of proposal_fields[:-1]: never evaluated (the reference's late-binding lambda,
+            # neuradar.py:302), so their gradient is identically zero -- neither all-reduced nor walked by Adam
+            dead = {p_.data_ptr() for f_ in self.model.proposal_fields[:-1] for p_ in f_.parameters()}
+            others = [(table_opt, i) for i in range(len(table_opt.buffers))
+                      if i not in (i_prop, i_main) and table_opt.buffers[i][0].data_ptr() not in dead]
             others += [(o_, i) for o_ in optimizers[2:] for i in range(len(o_.buffers))]
             if reducer is not None:
                 for o_, i in others:

@@ -263,6 +263,13 @@ class NeuRADHashEncoding(nn.Module):
             flip = None
         return dict(cand=cand, w2b=w2b, centres=centres, bounds=bounds, flip=flip)
 
+    def actor_table_ids(self) -> Optional[Tensor]:
+        """actors.actor_to_id as int32 [A] (neurad_encoding.py:183: `actor_hashgrid_idx = self.actors.actor_to_id[actor_idx]`;
+        the closed-loop server rewrites the buffer, so it is re-read on every call) -- the table_of_actor argument of
+        nr_actor_encode_fwd/bwd; None when the actors module carries no such buffer (identity)."""
+        ids = getattr(self.actors, "actor_to_id", None)
+        return None if ids is None else ids.to(device=self._actor_tables().device, dtype=torch.int32).contiguous()
+
     def _overwrite_actor_features(self, buf: Tensor, level_major: bool, rs, want_dirs: bool, flip: Optional[Tensor],
                                   sample_major_rows: int = 0):
         """neurad_encoding.py:175-229,295-307 on the device: nr_actor_assign + nr_actor_encode_fwd (backward:
@@ -287,7 +294,7 @@ class NeuRADHashEncoding(nn.Module):
         strides = (F_, n * F_) if level_major else (g.get_out_dim(), F_)
         meta = dict(slot=slot, x01a=x01a, std01a=std01a, cand=geom["cand"], K=K, B=B, S=S, sm=sample_major_rows, strides=strides,
                     static_levels=L_s, L=ag.num_levels, F=ag.features_per_level, log2t=ag.log2_hashmap_size, scalings=ag.scalings,
-                    o=o, d=d, area=area, euclid=euclid, flip=geom["flip"], actor_scale=self.config.actor.actor_scale)
+                    table_ids=self.actor_table_ids(), o=o, d=d, area=area, euclid=euclid, flip=geom["flip"], actor_scale=self.config.actor.actor_scale)
         assert ag.features_per_level == F_, "actor grids must have the static grid's features per level"
         _ActorEncode.apply(buf, geom["w2b"], self._actor_tables(), meta, *[gr.hash_table for gr in self.actor_grids])
         return dirs
@@ -330,7 +337,8 @@ class _ActorEncode(torch.autograd.Function):
         m = meta
         lib, p = ops._lib.lib(), ops._p
         ops.check(lib.nr_actor_encode_fwd(p(m["x01a"]), p(m["std01a"]), p(m["slot"]), p(m["cand"]), m["K"], m["B"], m["S"], m["sm"],
-                                          p(flat), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(buf), m["strides"][0], m["strides"][1],
+                                          p(flat), p(m["table_ids"]), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(buf), m["strides"][0],
+                                          m["strides"][1],
                                           m["static_levels"], ops._stream()), "nr_actor_encode_fwd")
         ctx.mark_dirty(buf)
         ctx.meta, ctx.flat, ctx.w2b = m, flat, w2b.detach()
@@ -345,7 +353,7 @@ class _ActorEncode(torch.autograd.Function):
         g_flat = torch.zeros_like(flat)
         g_w2b = torch.zeros_like(ctx.w2b) if ctx.want_pose else None
         ops.check(lib.nr_actor_encode_bwd(p(m["x01a"]), p(m["std01a"]), p(m["slot"]), p(m["cand"]), m["K"], m["B"], m["S"], m["sm"],
-                                          p(flat), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(g_buf), m["strides"][0],
+                                          p(flat), p(m["table_ids"]), p(m["scalings"]), m["L"], m["F"], m["log2t"], p(g_buf), m["strides"][0],
                                           m["strides"][1], m["static_levels"], p(g_flat), p(m["o"]), p(m["d"]), p(m["area"]),
                                           p(m["euclid"]), p(ctx.w2b), m["actor_scale"], p(m["flip"]), p(g_w2b), ops._stream()),
                   "nr_actor_encode_bwd")

@@ -409,6 +409,81 @@ def composite(alpha: Tensor, feature: Tensor, euclid: Tensor):
     return _Composite.apply(alpha, feature, euclid)
 
 
+class _RenderWeights(torch.autograd.Function):
+    """nr_render_weights_fwd/bwd: nerfacc's batched render_weight_from_alpha / render_weight_from_density."""
+
+    @staticmethod
+    def forward(ctx, x, t_starts, t_ends):
+        x = _f32(x, "alphas / sigmas")
+        shape = x.shape
+        S = shape[-1] if x.dim() else 1
+        x2 = x.reshape(-1, S)
+        density = t_starts is not None
+        ts = _f32(t_starts, "t_starts").reshape(-1, S) if density else None
+        te = _f32(t_ends, "t_ends").reshape(-1, S) if density else None
+        w, T = torch.empty_like(x2), torch.empty_like(x2)
+        a = torch.empty_like(x2) if density else None
+        check(_lib.lib().nr_render_weights_fwd(_p(x2), _p(ts), _p(te), x2.shape[0], S, _p(w), _p(T), _p(a), _stream()),
+              "nr_render_weights_fwd")
+        ctx.save_for_backward(x2, ts, te, T)
+        ctx.shape = shape
+        if density:
+            return w.view(shape), T.view(shape), a.view(shape)
+        return w.view(shape), T.view(shape)
+
+    @staticmethod
+    def backward(ctx, g_w, g_T, g_a=None):
+        x2, ts, te, T = ctx.saved_tensors
+        S = x2.shape[1]
+        c = lambda t: None if t is None else t.contiguous().view(-1, S)  # noqa: E731
+        g_in = torch.empty_like(x2)
+        check(_lib.lib().nr_render_weights_bwd(_p(x2), _p(ts), _p(te), _p(T), _p(c(g_w)), _p(c(g_T)), _p(c(g_a)), x2.shape[0], S,
+                                               _p(g_in), _stream()), "nr_render_weights_bwd")
+        return g_in.view(ctx.shape), None, None
+
+
+def render_weights(alphas: Tensor) -> Tuple[Tensor, Tensor]:
+    """alphas [..., S] -> (weights, transmittance), T_i = prod_{j<i}(1 - alpha_j) (models/neuradar.py:1016)."""
+    return _RenderWeights.apply(alphas, None, None)
+
+
+def render_weights_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(weights, transmittance, alphas) with alpha = 1 - exp(-sigma (t_end - t_start)) (models/neuradar.py:1018-1022)."""
+    return _RenderWeights.apply(sigmas, t_starts, t_ends)
+
+
+class _Accumulate(torch.autograd.Function):
+    """nr_accumulate_fwd/bwd: nerfacc's batched accumulate_along_rays."""
+
+    @staticmethod
+    def forward(ctx, weights, values):
+        w = _f32(weights, "weights")
+        B, S = w.shape
+        v = _f32(values, "values") if values is not None else None
+        C = v.shape[-1] if v is not None else 1
+        out = torch.empty((B, C), device=w.device, dtype=torch.float32)
+        check(_lib.lib().nr_accumulate_fwd(_p(w), _p(v), B, S, C, _p(out), _stream()), "nr_accumulate_fwd")
+        ctx.save_for_backward(w, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, v = ctx.saved_tensors
+        B, S = w.shape
+        C = v.shape[-1] if v is not None else 1
+        g_w = torch.zeros_like(w) if ctx.needs_input_grad[0] else None
+        g_v = torch.zeros_like(v) if (v is not None and ctx.needs_input_grad[1]) else None
+        if g_w is not None or g_v is not None:
+            check(_lib.lib().nr_accumulate_bwd(_p(w), _p(v), _p(g.contiguous()), B, S, C, _p(g_w), _p(g_v), _stream()),
+                  "nr_accumulate_bwd")
+        return g_w, g_v
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None) -> Tensor:
+    """weights [B,S], values [B,S,C] or None -> [B,C] ([B,1])."""
+    return _Accumulate.apply(weights, values)
+
+
 def depth_from_weights(weights: Tensor, euclid: Tensor) -> Tensor:
     weights = _f32(weights.detach(), "weights")
     B, S = weights.shape

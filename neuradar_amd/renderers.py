@@ -6,7 +6,6 @@ the reference-named pieces below are thin views over it for callers that use the
 """
 from typing import Optional, Tuple
 
-import torch
 from torch import Tensor, nn
 
 from . import ops
@@ -20,26 +19,42 @@ def composite(alpha: Tensor, feature: Tensor, ray_samples: RaySamples):
     return w[..., None], acc[:, None], feats, depth[:, None]
 
 
-def render_weight_from_alpha(alphas: Tensor) -> Tuple[Tensor, Tensor]:
-    """nerfacc batched branch: alphas [B,S] -> (weights, transmittance).  Implemented with the fused
-    kernel on a dummy feature; the sky fix-up of the last sample is undone."""
-    B, S = alphas.shape
-    dummy = torch.zeros((B, S, 1), device=alphas.device)
-    edges = torch.zeros((B, S + 1), device=alphas.device)
-    w, acc, _, _ = ops.composite(alphas, dummy, edges)
-    w = torch.cat([w[:, :-1], w[:, -1:] - (1 - acc[:, None])], dim=-1)
-    trans = torch.where(alphas > 0, w / alphas.clamp_min(1e-30), torch.ones_like(w))
-    return w, trans
+def render_weight_from_alpha(alphas: Tensor, packed_info=None, ray_indices=None, n_rays=None, prefix_trans=None
+                             ) -> Tuple[Tensor, Tensor]:
+    """nerfacc.render_weight_from_alpha, batched branch (call site models/neuradar.py:1016): alphas [B,S] ->
+    (weights, transmittance) with T_i = prod_{j<i}(1 - alpha_j) -- also where alpha_i = 0 -- and w_i = alpha_i T_i."""
+    if packed_info is not None or ray_indices is not None or prefix_trans is not None:
+        raise NotImplementedError("only nerfacc's batched branch (no packed_info / ray_indices) is on NeuRadar's path")
+    return ops.render_weights(alphas)
+
+
+def render_weight_from_density(t_starts: Tensor, t_ends: Tensor, sigmas: Tensor, packed_info=None, ray_indices=None,
+                               n_rays=None, prefix_trans=None) -> Tuple[Tensor, Tensor, Tensor]:
+    """nerfacc.render_weight_from_density, batched branch (models/neuradar.py:1018-1022, use_sdf=False):
+    (weights, transmittance, alphas), alpha = 1 - exp(-sigma (t_end - t_start))."""
+    if packed_info is not None or ray_indices is not None or prefix_trans is not None:
+        raise NotImplementedError("only nerfacc's batched branch (no packed_info / ray_indices) is on NeuRadar's path")
+    return ops.render_weights_from_density(t_starts, t_ends, sigmas)
+
+
+def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None, ray_indices=None, n_rays=None) -> Tensor:
+    """nerfacc.accumulate_along_rays, batched branch (models/neurad.py:727-728, renderers.py:88,345): weights [B,S],
+    values [B,S,C] -> [B,C]; values None -> [B,1]."""
+    if ray_indices is not None:
+        raise NotImplementedError("only nerfacc's batched branch (ray_indices=None) is on NeuRadar's path")
+    return ops.accumulate_along_rays(weights, values)
 
 
 class FeatureRenderer(nn.Module):
     def forward(self, features: Tensor, weights: Tensor, ray_indices=None, num_rays=None) -> Tensor:
-        return torch.sum(features * weights, dim=-2)  # renderers.py:85 (unpacked branch)
+        """renderers.py:59-90: features [B,S,C], weights [B,S,1] -> [B,C]."""
+        return accumulate_along_rays(weights[..., 0], features, ray_indices, num_rays)
 
 
 class AccumulationRenderer(nn.Module):
     def forward(self, weights: Tensor, ray_indices=None, num_rays=None) -> Tensor:
-        return torch.sum(weights, dim=-2)  # renderers.py:349
+        """renderers.py:322-350: weights [B,S,1] -> [B,1]."""
+        return accumulate_along_rays(weights[..., 0], None, ray_indices, num_rays)
 
 
 def render_depth_simple(weights: Tensor, ray_samples: RaySamples, ray_indices=None, num_rays: Optional[int] = None

@@ -30,7 +30,7 @@ def test_build_and_every_declared_symbol_is_exported():
     assert len(fns) >= 23
     for name in fns:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert lib.nr_abi_version() == 14
+    assert lib.nr_abi_version() == _lib.NR_ABI_VERSION
 
 
 def test_ctypes_prototypes_match_header_arity():

@@ -32,13 +32,16 @@ def _model_with_actors(g):
     return model, actors
 
 
-@pytest.mark.parametrize("coherent", [None, 0.5])
-def test_fused_step_with_two_actors_matches_autograd_path(coherent):
+@pytest.mark.parametrize("coherent,permuted", [(None, False), (0.5, False), (0.5, True)])
+def test_fused_step_with_two_actors_matches_autograd_path(coherent, permuted):
     from neuradar_amd.fused_step import FusedTrainStep
     from neuradar_amd.rays import RayBundle
 
     g = load_golden("actors")
     model, actors = _model_with_actors(g)
+    if permuted:  # actor a's hash grid is actor_grids[actor_to_id[a]] (neurad_encoding.py:183) in the fused launches too; the
+        with torch.no_grad():  # modular path with a permuted map is pinned to the reference golden in test_gpu_parity.py
+            actors.actor_to_id.copy_(torch.tensor([1, 0]))
     gen = torch.Generator().manual_seed(11)
     B = 96
     # rays from around the origin towards the actors' trajectories, times inside the trajectories' span

@@ -1276,6 +1276,52 @@ def test_dynamic_actors_vs_reference_golden():
         assert_close(cpu(gr), g["grad_" + k], rtol=1e-3, atol_scale=1e-4, what="grad " + k)
 
 
+def test_dynamic_actors_honour_actor_to_id():
+    """neurad_encoding.py:183: the hash grid of actor a is actor_grids[actor_to_id[a]].  With the two actors' tables
+    swapped AND actor_to_id = [1, 0] the reference golden must come out unchanged -- modular path (values, table
+    gradients land in the swapped grids) and the fused step's launches (same kernels, same table_of_actor array)."""
+    from neuradar_amd.dynamic_actors import DynamicActors
+    from neuradar_amd.field_heads import FieldHeadNames
+    from neuradar_amd.neurad_encoding import ActorSettings, NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.rays import RaySamples
+
+    g = load_golden("actors")
+    actors = DynamicActors.from_state(g["actor_positions"], g["actor_rotations_6d"], g["actor_timestamps"],
+                                      g["actor_present"], g["actor_sizes"]).to(DEV)
+    assert actors.n_actors == 2
+    grid_cfg = NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=int(g["log2t"])),
+                                        actor=ActorSettings(flip_prob=0.25, log2_hashmap_size=int(g["actor_log2t"])))
+    fld = NeuRADFieldConfig(grid=grid_cfg).setup(actors=actors, static_scale=100.0).to(DEV)
+    with torch.no_grad():
+        fld.hashgrid.static_grid.hash_table.copy_(g["table"])
+        for i, gr in enumerate(fld.hashgrid.actor_grids):
+            gr.hash_table.copy_(g[f"actor{1 - i}_table"])  # swapped
+        for i, l in enumerate(fld.mlp_geo.layers):
+            l.weight.copy_(g[f"geo_w{i}"]); l.bias.copy_(g[f"geo_b{i}"])
+        for i, l in enumerate(fld.mlp_feature.layers):
+            l.weight.copy_(g[f"feat_w{i}"]); l.bias.copy_(g[f"feat_b{i}"])
+        fld.sdf_to_density.beta.copy_(g["beta"])
+        actors.actor_to_id.copy_(torch.tensor([1, 0]))
+    e = g["edges"]
+    B = e.shape[0]
+    rs = RaySamples(dev(g["origins"]), dev(g["directions"]), dev(g["pixel_area"]), dev(torch.zeros_like(e)), dev(e),
+                    dev(torch.zeros(B, 1)), dev(torch.full((B, 1), 1e6)), times=dev(g["times"]))
+    fld.train()
+    out = fld(rs, flip=dev(g["flip"]))
+    assert_close(cpu(out[FieldHeadNames.FEATURE]), g["train_feature"], rtol=1e-4, atol_scale=1e-5, what="train feature")
+    assert_close(cpu(out[FieldHeadNames.ALPHA]), g["train_alpha"], rtol=1e-4, atol_scale=1e-5, what="train alpha")
+    loss = (out[FieldHeadNames.FEATURE] * dev(g["g_feature"])).sum() + (out[FieldHeadNames.ALPHA] * dev(g["g_alpha"])).sum()
+    g0, g1 = torch.autograd.grad(loss, [fld.hashgrid.actor_grids[0].hash_table, fld.hashgrid.actor_grids[1].hash_table])
+    assert_close(cpu(g0), g["grad_hashgrid_actor_grids_1_hash_table"], rtol=1e-3, atol_scale=1e-4, what="grad of grid 0 = actor 1's")
+    assert_close(cpu(g1), g["grad_hashgrid_actor_grids_0_hash_table"], rtol=1e-3, atol_scale=1e-4, what="grad of grid 1 = actor 0's")
+    # without the indirection (identity map on swapped tables) the features differ: the check above is not vacuous
+    with torch.no_grad():
+        actors.actor_to_id.copy_(torch.tensor([0, 1]))
+        wrong = fld(rs, flip=dev(g["flip"]))[FieldHeadNames.FEATURE]
+    assert float((cpu(wrong) - g["train_feature"]).abs().max()) > 1e-3 * float(g["train_feature"].abs().max())
+
+
 # ------------------------------------------------------------------------------------------------ mixed sensors, a19, a20
 def test_mixed_sensor_batch_with_appearance_and_lidar_masks_vs_oracle():
     """configs[2]-style batch: camera patch + lidar points + one ZOD radar scan generated on the device,
