@@ -10,7 +10,9 @@ Restates
   * model_components/radar_utils.py:35-51       MultiBernoulli
   * model_components/radar_utils.py:54-93,95-118,156-168   calculate_radar_loss / get_cost_matrix / get_radar_loss,
                                                 "euclidean" (deterministic head) branch, scipy's Hungarian matching
-  * model_components/radar_utils.py:170-229     sample_radar_points, "euclidean" branch
+  * model_components/radar_utils.py:105-118,130-154  the "nll" (probabilistic head, the reference's default neuradar.py:114) cost
+                                                matrix and loss: Laplace log-likelihoods of the detections
+  * model_components/radar_utils.py:170-229     sample_radar_points, "euclidean" and "nll" branches
   * model_components/radar_utils.py:380-420     chamfer_distance (bidirectional mean nearest-neighbour distance; the
                                                 reference asks sklearn's exact kd-tree, here brute force: same value)
 Parameters are passed as a dict with the reference's state_dict names (prefix removed).
@@ -87,7 +89,8 @@ def decode_radar(features: torch.Tensor, depth: torch.Tensor, directions_spher: 
     sph = directions_spher.view(num_scans, -1, 2)
     theta, phi = sph[..., 1:2], sph[..., 0:1]  # _get_cartesian_coords(depth, theta = elevation, phi = azimuth), :1025-1029
     xyz = torch.cat((depth * torch.cos(phi) * torch.cos(theta), depth * torch.sin(phi) * torch.cos(theta), depth * torch.sin(theta)), dim=2)
-    pos = sine_position_embedding(xyz, C)
+    with torch.no_grad():  # PositionEmbeddingCoordsSine.forward (position_encoding_3d.py:133-135): no gradient to the points
+        pos = sine_position_embedding(xyz, C)
     out = encoder(features.view(num_scans, -1, C).permute(0, 2, 1), pos, p)
     offset = 1.5 * torch.tanh(head(out, p, "offset_head"))
     ep = torch.sigmoid(head(out, p, "existence_probability_head"))
@@ -95,18 +98,25 @@ def decode_radar(features: torch.Tensor, depth: torch.Tensor, directions_spher: 
     return torch.cat((ep, xyz + offset, unc), dim=-1)
 
 
-def rgb_decode(cam_features: torch.Tensor, patch_size: Tuple[int, int], p: Dict[str, torch.Tensor], upsample: int = 3) -> torch.Tensor:
-    """neuradar.py:225-240,455-461 in eval mode.  cam_features [n_patches * h * w, C] -> rgb [n_patches, h*up, w*up, 3]."""
+def rgb_decode(cam_features: torch.Tensor, patch_size: Tuple[int, int], p: Dict[str, torch.Tensor], upsample: int = 3,
+               training: bool = False) -> torch.Tensor:
+    """neuradar.py:225-240,455-461.  cam_features [n_patches * h * w, C] -> rgb [n_patches, h*up, w*up, 3].  training=True:
+    batch norm normalises with the batch's own (biased) statistics, as nn.BatchNorm2d does in train mode."""
     x = cam_features.view(-1, *patch_size, cam_features.shape[-1]).permute(0, 3, 1, 2)
     pre = "rgb_decoder."
     x = torch.relu(F.conv2d(x, p[pre + "0.weight"], p[pre + "0.bias"]))
 
+    def bn(y, k):
+        if training:
+            return F.batch_norm(y, None, None, p[k + "weight"], p[k + "bias"], True)
+        return F.batch_norm(y, p[k + "running_mean"], p[k + "running_var"], p[k + "weight"], p[k + "bias"], False)
+
     def block(x, i):  # BasicBlock(kernel 7, padding 3, batch norm), cnns.py:21-47
         b = f"{pre}{i}.main_branch."
         y = F.conv2d(x, p[b + "0.weight"], p[b + "0.bias"], padding=3)
-        y = F.batch_norm(y, p[b + "1.running_mean"], p[b + "1.running_var"], p[b + "1.weight"], p[b + "1.bias"], False)
+        y = bn(y, b + "1.")
         y = F.conv2d(torch.relu(y), p[b + "3.weight"], p[b + "3.bias"], padding=3)
-        y = F.batch_norm(y, p[b + "4.running_mean"], p[b + "4.running_var"], p[b + "4.weight"], p[b + "4.bias"], False)
+        y = bn(y, b + "4.")
         return torch.relu(x + y)
 
     x = block(block(x, 2), 3)
@@ -121,33 +131,91 @@ def multi_bernoulli(pred: torch.Tensor) -> Dict[str, torch.Tensor]:
     return {"ep": pred[..., 0].clamp(min=EPS, max=1 - EPS), "xyz": pred[..., 1:4], "scale": pred[..., 4:7].clamp(min=MIN_VAR)}
 
 
-def radar_loss_euclidean(radar_batch: torch.Tensor, prediction: torch.Tensor, indices: torch.Tensor):
-    """calculate_radar_loss(loss_type="euclidean") (radar_utils.py:54-93,95-103,156-168): per scan, detections are matched
-    to predictions by the Hungarian algorithm on cost = distance - log(existence probability); matched predictions pay
-    -log r + distance, unmatched ones -log(1 - r); mean over predictions, then over scans.  Returns (loss, the last
-    scan's association [n, 2])."""
+def laplace_log_prob(x: torch.Tensor, loc: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """torch.distributions.Laplace.log_prob: -log(2 b) - |x - mu| / b."""
+    return -torch.log(2 * scale) - torch.abs(x - loc) / scale
+
+
+def cost_matrix(gt: torch.Tensor, mb: Dict[str, torch.Tensor], method: str) -> torch.Tensor:
+    """get_cost_matrix (radar_utils.py:95-127): [n predictions, m detections].  "euclidean": distance - log r;
+    "nll": log(1 - r) - log r - sum of the three Laplace log-likelihoods.  Infinite entries -> MAX_COST = 1e9."""
+    if method == "euclidean":
+        cost = torch.cdist(mb["xyz"], gt[:, :3]) - mb["ep"].log()[:, None]
+    else:
+        ll = sum(laplace_log_prob(gt[None, :, a], mb["xyz"][:, None, a], mb["scale"][:, None, a]) for a in range(3))
+        cost = ((1 - mb["ep"]).log() - mb["ep"].log())[:, None] - ll
+    return torch.where(cost.isinf(), torch.full_like(cost, 1e9), cost)
+
+
+def hungarian(cost: torch.Tensor) -> torch.Tensor:
+    """scipy.optimize.linear_sum_assignment on the [n, m] cost -> association [n]: detection index or -1."""
     from scipy.optimize import linear_sum_assignment
 
+    row, col = linear_sum_assignment(cost.detach().numpy())
+    assoc = -torch.ones(cost.shape[0], dtype=torch.long)
+    assoc[torch.as_tensor(row, dtype=torch.long)] = torch.as_tensor(col, dtype=torch.long)
+    return assoc
+
+
+def scan_loss(gt: torch.Tensor, mb: Dict[str, torch.Tensor], assoc: torch.Tensor, loss_type: str) -> torch.Tensor:
+    """get_radar_loss (radar_utils.py:130-168) of one scan: unmatched predictions pay -log(1 - r); a matched one pays
+    -log r + |xyz - detection| ("euclidean") or -log r - Laplace log-likelihood of its detection ("nll"); sum / n."""
+    matched = assoc > -1
+    per = -(1 - mb["ep"]).log()
+    if bool(matched.any()):
+        tgt = gt[assoc[matched], :3]
+        if loss_type == "euclidean":
+            pay = torch.norm(mb["xyz"][matched] - tgt, dim=-1)
+        else:
+            pay = -sum(laplace_log_prob(tgt[:, a], mb["xyz"][matched, a], mb["scale"][matched, a]) for a in range(3))
+        per = per.clone()
+        per[matched] = pay - mb["ep"].log()[matched]
+    return per.sum() / mb["ep"].shape[-1]
+
+
+def radar_loss(radar_batch: torch.Tensor, prediction: torch.Tensor, indices: torch.Tensor, loss_type: str = "nll",
+               training: bool = True):
+    """calculate_radar_loss (radar_utils.py:54-93): scans are the runs of `indices` starting where indices[:, 1] == 0; per
+    scan the Hungarian matching on the EUCLIDEAN cost while training (:77-78; the loss type's own cost otherwise), then
+    scan_loss; mean over scans.  Returns (loss, [association [n] per scan])."""
     seg = (indices[:, 1] == 0).nonzero(as_tuple=True)[0]
     seg = torch.cat((seg, torch.tensor([indices.shape[0]])))
-    losses, association = [], None
+    losses, assocs = [], []
     for i in range(seg.numel() - 1):
         gt = radar_batch[seg[i]:seg[i + 1], :3]
         mb = multi_bernoulli(prediction[i])
-        n = mb["ep"].shape[-1]
-        cost = torch.cdist(mb["xyz"], gt) - mb["ep"].log()[:, None]
-        row, col = linear_sum_assignment(cost.detach().numpy())
-        association = -torch.ones((n, 2))
-        association[:, 0] = torch.arange(n)
-        association[torch.as_tensor(row, dtype=torch.long), 1] = torch.as_tensor(col).float()
-        matched = association[:, 1] > -1
-        per = -(1 - mb["ep"]).log()
-        per = torch.where(matched, -mb["ep"].log(), per)
-        d = torch.norm(mb["xyz"][matched] - gt[association[matched, 1].long()], dim=-1)
-        per = per.clone()
-        per[matched] = per[matched] + d
-        losses.append(per.sum() / n)
-    return torch.stack(losses).mean(), association
+        assoc = hungarian(cost_matrix(gt, mb, "euclidean" if training else loss_type))
+        losses.append(scan_loss(gt, mb, assoc, loss_type))
+        assocs.append(assoc)
+    return torch.stack(losses).mean(), assocs
+
+
+def radar_loss_euclidean(radar_batch: torch.Tensor, prediction: torch.Tensor, indices: torch.Tensor):
+    """The deterministic head of BASELINE configs[2]: (loss, the last scan's association [n, 2] as the reference returns it)."""
+    loss, assocs = radar_loss(radar_batch, prediction, indices, "euclidean", True)
+    n = assocs[-1].numel()
+    return loss, torch.stack([torch.arange(n).float(), assocs[-1].float()], dim=1)
+
+
+def sample_radar_points_nll(radar_output: torch.Tensor, max_detections: int = 1000):
+    """radar_utils.py:181-213, "nll": walk the LAST scan's predictions in index order; each draws u ~ U(0,1) (torch.rand) and
+    is kept when u < r and it is among the max_detections most probable; a kept one draws x, y, z from its Laplace
+    distributions (rsample) right away -- the global torch generator is consumed in exactly that order.
+    Returns (points [m,3], indices [m])."""
+    from torch.distributions.laplace import Laplace
+
+    mb = multi_bernoulli(radar_output[-1])
+    ep = mb["ep"].flatten()
+    top = set(torch.argsort(ep, descending=True)[:max_detections].tolist())
+    pts, idx = [], []
+    for i in range(ep.numel()):
+        u = torch.rand(1)
+        if bool(u < ep[i]) and i in top:
+            idx.append(i)
+            pts.append(torch.stack([Laplace(mb["xyz"][i, a], mb["scale"][i, a]).rsample(torch.Size([1])).view(()) for a in range(3)]))
+    if not pts:
+        return torch.empty(0, 3), torch.empty(0, dtype=torch.long)
+    return torch.stack(pts), torch.tensor(idx, dtype=torch.long)
 
 
 def sample_radar_points(radar_output: torch.Tensor, threshold: float = 0.5, max_detections: int = 1000):

@@ -745,7 +745,108 @@ def golden_model():
     save("model", **out)
 
 
+def golden_model_train():
+    """The TRAINING branch behind the rendered features, from the reference NeuRadarModel's own methods (dropout set to 0
+    on the instance -- the masks are torch-RNG draws -- batch norm in training mode): decode_features (neuradar.py:
+    410-493) on a mixed batch (2 camera patches 8x8, 60 lidar rays, 2 radar scans of 90 rays) -> get_metrics_dict /
+    get_loss_dict (:588-704) with radar_loss_type "nll" (the reference's default, :114) and "euclidean": every loss term,
+    the Hungarian associations, d(total loss)/d(features, depth) and parameter gradients; the evaluation-side "nll" cost
+    matrix (radar_utils.py:105-118) and the nll branch of sample_radar_points (:181-213) under a fixed torch seed.
+    Parameters are those of model.npz (same construction seed); only the inputs and results are stored here."""
+    from nerfstudio.model_components import radar_utils as ru
+
+    nm, model = _build_reference_model()
+    g = torch.Generator().manual_seed(17)
+    model.train()
+    for m in model.radar_decoder.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    n_patch, ps, n_lid, n_scan, nr = 2, 8, 60, 2, 90
+    n_cam = n_patch * ps * ps
+    n = n_cam + n_lid + n_scan * nr
+    feats = (torch.randn(n, 48, generator=g) * 0.5).requires_grad_(True)
+    is_l = torch.zeros(n, 1, dtype=torch.bool)
+    is_l[n_cam:n_cam + n_lid] = True
+    is_r = torch.zeros(n, 1, dtype=torch.bool)
+    is_r[n_cam + n_lid:] = True
+    depth = (torch.rand(n, 1, generator=g) * 80.0 + 1.0).requires_grad_(True)
+    spher = torch.stack([torch.rand(n, generator=g) * 1.6 - 0.8, torch.rand(n, generator=g) * 0.48 - 0.08], dim=-1)
+    prop_depth = [(torch.rand(n, 1, generator=g) * 90.0).requires_grad_(True) for _ in range(2)]
+    image = torch.rand(n_patch, ps * 3, ps * 3, 3, generator=g)
+    did = torch.rand(n, 1, generator=g) < 0.85
+    lidar_pts = torch.cat([torch.randn(n_lid, 3, generator=g), torch.rand(n_lid, 1, generator=g), torch.rand(n_lid, 1, generator=g) * 0.1], dim=1)
+    dist_l = torch.rand(n_lid, 1, generator=g) * 100.0 + 2.0
+    dets = [27, 1]  # detections per scan (one scan with a single detection: the squeeze(0) quirk of radar_utils.py:142-144)
+    radar_batch = torch.cat([torch.cat([torch.randn(m, 3, generator=g) * 15.0 + torch.tensor([30.0, 0.0, 0.0]), torch.rand(m, 6, generator=g)], 1)
+                             for m in dets])
+    indices = torch.cat([torch.stack([torch.full((m,), float(i)), torch.arange(m).float()], 1) for i, m in enumerate(dets)]).long()
+    out = dict(features=feats, depth=depth, spher=spher, is_lidar=is_l, is_radar=is_r, prop_depth_0=prop_depth[0],
+               prop_depth_1=prop_depth[1], image=image, did_return=did, lidar=lidar_pts, distance=dist_l, radar=radar_batch,
+               radar_indices=indices, n_patch=n_patch, patch=ps, n_scan=n_scan)
+    named = dict(model.named_parameters())
+    dec = [k for k in named if k.split(".")[0] in ("rgb_decoder", "lidar_decoder", "radar_decoder", "offset_head",
+                                                    "radar_uncertainty_head", "existence_probability_head")]
+    for k in dec:  # fingerprint: the parameters are model.npz's
+        out["param_sum." + k] = named[k].double().sum()
+    for loss_type in ("nll", "euclidean"):
+        model.config.loss.radar_loss_type = loss_type
+        rgb, intensity, drop, radar_output = model.decode_features(feats, (ps, ps), depth, spher, is_lidar=is_l, is_radar=is_r,
+                                                                   num_radar_scans=n_scan)
+        outputs = {"rgb": rgb, "intensity": intensity.float(), "ray_drop_logits": drop.float(), "radar_output": radar_output,
+                   "depth": depth, "prop_depth_0": prop_depth[0], "prop_depth_1": prop_depth[1],
+                   "non_nearby_weights": torch.zeros(1), "prop_weights_loss_0": torch.tensor(0.0), "prop_weights_loss_1": torch.tensor(0.0)}
+        batch = {"image": image, "lidar": lidar_pts, "is_lidar": is_l, "did_return": did, "distance": dist_l,
+                 "radar": radar_batch.clone(), "radar_indices": indices}
+        metrics, _ = model.get_metrics_dict(dict(outputs), dict(batch))
+        losses = model.get_loss_dict(dict(outputs), dict(batch), metrics)
+        conf = model.config.loss
+        # the proposal-level lidar depth terms enter get_loss_dict only next to "weights_list" (:679-688): added here with the
+        # same multipliers so that their gradient is part of the vector
+        for i in range(2):
+            losses[f"depth_loss_{i}"] = conf.prop_lidar_loss_mult * conf.depth_mult * metrics[f"depth_loss_{i}"]
+        keep = ["rgb_loss", "depth_loss", "intensity_loss", "ray_drop_loss", "radar_loss", "depth_loss_0", "depth_loss_1"]
+        total = sum(losses[k] for k in keep)
+        wrt = [feats, depth, prop_depth[0], prop_depth[1]] + [named[k] for k in dec]
+        grads = torch.autograd.grad(total, wrt, allow_unused=True)
+        t = loss_type + "."
+        out.update({t + "rgb": rgb, t + "intensity": intensity, t + "ray_drop_logits": drop, t + "radar_output": radar_output,
+                    t + "total": total, t + "g_features": grads[0], t + "g_depth": grads[1], t + "g_prop_depth_0": grads[2],
+                    t + "g_prop_depth_1": grads[3]})
+        for k in keep:
+            out[t + "loss." + k] = losses[k]
+        for k, gr in zip(dec, grads[4:]):
+            if gr is None:
+                continue
+            out[t + "gsum." + k] = gr.double().sum()
+            out[t + "gabs." + k] = gr.double().abs().sum()
+            if gr.numel() <= 4096:
+                out[t + "grad." + k] = gr
+        # per-scan associations (calculate_radar_loss returns the last one only): the same calls, scan by scan
+        seg = [0, dets[0], dets[0] + dets[1]]
+        for i in range(n_scan):
+            gt = radar_batch[seg[i]:seg[i + 1], :3]
+            mb = ru.MultiBernoulli(prediction=radar_output[i].detach())
+            c = ru.get_cost_matrix(gt, mb, "euclidean")  # training: always the euclidean cost (radar_utils.py:77-78)
+            row, col = ru.linear_sum_assignment(c.numpy())
+            assoc = -torch.ones(mb.n_mb, dtype=torch.long)
+            assoc[torch.as_tensor(row)] = torch.as_tensor(col)
+            out[t + f"cost_{i}"] = c
+            out[t + f"assoc_{i}"] = assoc
+            out[t + f"scan_loss_{i}"] = ru.get_radar_loss(gt, mb, torch.stack([torch.arange(mb.n_mb).float(), assoc.float()], 1), loss_type)
+            if loss_type == "nll" and gt.shape[0] > 1:  # (a single detection breaks the reference's own broadcast at :118)
+                out[f"nll.evalcost_{i}"] = ru.get_cost_matrix(gt, mb, "nll")
+    # ---- sample_radar_points, "nll" branch: Bernoulli draw per prediction, Laplace rsample per kept coordinate
+    ro = radar_output.detach().clone()
+    ro[..., 0] = torch.rand(ro.shape[:-1], generator=g)
+    torch.manual_seed(2024)
+    pts, ber = ru.sample_radar_points(ro, loss_type="nll", max_detections=50)
+    out.update(sample_radar_output=ro, sample_seed=2024, sample_max_detections=50, sample_points=pts, sample_ber=ber)
+    save("model_train", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "field_density", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors", "model"]
+    which = sys.argv[1:] or ["hash", "gaussian_contraction", "field", "field_autocast", "field_density", "sh_mlp", "sampler", "pipeline", "losses", "raygen", "actors", "model", "model_train"]
     for w in which:
         globals()["golden_" + w]()
