@@ -46,6 +46,19 @@ WORKLOADS = {
                                 grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
     # the same batch in a scene with 12 dynamic actors (vehicles on the road ahead of the ego car, learnable trajectories,
     # one 3-D hash grid per actor and field: neurad_encoding.py:112-133, dynamic_actors.py:98-147)
+    # BASELINE configs[2] as the reference trains it ("neuradar full ... deterministic head"): the same batch supervised THROUGH
+    # the modality decoders -- RGB CNN on the camera patches, lidar MLP with the quantile-masked lidar losses, radar transformer
+    # + heads with the Hungarian-matched euclidean radar loss (neuradar.py:410-493,588-704) -- all inside the step
+    "mixed16384_neuradar_full": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1, decoders=True, radar_loss="euclidean",
+                                     grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
+    # configs[4] per-GPU shape: 16 384 rays, the DETR radar encoder in the step, fp16 MFMA operands, the default (nll) radar loss
+    "mixed16384_neuradar_full_fp16": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1, decoders=True, radar_loss="nll",
+                                          mlp_dtype="float16",
+                                          grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
+    # configs[3] per-GPU shape: 8 192 rays with one VoD radar scan (101 x 45 = 4 545 rays, vod_dataparser.py:46-48), the
+    # probabilistic (nll) radar head: 2 camera patches + 1 599 lidar points + the scan
+    "mixed8192_vod_nll": dict(rays=8192, cam_rays=2048, lidar_rays=1599, radar_scans=1, decoders=True, radar_loss="nll", radar="vod",
+                              grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
     "mixed16384_neuradar_actors": dict(rays=16384, cam_rays=8192, lidar_rays=4661, radar_scans=1, actors=12,
                                        grid=dict(hashgrid_dim=4, num_levels=8, base_res=32, max_res=8192, log2_hashmap_size=22), hidden=32),
 }
@@ -80,6 +93,8 @@ def build_model(wl, device, mlp_dtype="float32", grad_scale=1.0):
     cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(**wl["grid"])),
                                                 geo_hidden_dim=wl["hidden"], nff_hidden_dim=wl["hidden"],
                                                 mlp_dtype=mlp_dtype, mlp_grad_scale=grad_scale))
+    if wl.get("decoders"):  # appearance embedding (16) + the modality decoders, sensors: camera, lidar, radar
+        cfg.appearance_dim, cfg.num_sensors, cfg.decoders, cfg.radar_loss_type = 16, 3, True, wl.get("radar_loss", "nll")
     torch.manual_seed(0)  # identical replicas on every rank
     actors = synthetic_actors(wl["actors"]) if wl.get("actors") else None
     return NeuRadarHotPath(cfg, actors=actors).to(device).train()
@@ -91,7 +106,7 @@ class SyntheticScene:
 
     H, W, PATCH, STRIDE = 1080, 1920, 32, 3
 
-    def __init__(self, device, seed):
+    def __init__(self, device, seed, radar="zod"):
         from neuradar_amd.sensors import Cameras
 
         g = torch.Generator().manual_seed(seed)
@@ -139,9 +154,23 @@ class SyntheticScene:
         self.points_per_lidar = torch.bincount(owner, minlength=n)
         r2w = l2w.clone()
         r2w[:, 2, 3] = 0.5
-        self.radars = Radars(r2w.to(device), t.to(device), radar_azimuth_ray_divergence=0.015,  # zod_dataparser.py:138-140
-                             radar_elevation_ray_divergence=0.015, min_azimuth=-0.80, max_azimuth=0.80,
-                             min_elevation=-0.08, max_elevation=0.4)
+        if radar == "vod":  # vod_dataparser.py:46-48: 101 x 45 rays
+            self.radars = Radars(r2w.to(device), t.to(device), radar_azimuth_ray_divergence=0.02, radar_elevation_ray_divergence=0.02,
+                                 min_azimuth=-1.0, max_azimuth=1.0, min_elevation=-0.39, max_elevation=0.49)
+        else:
+            self.radars = Radars(r2w.to(device), t.to(device), radar_azimuth_ray_divergence=0.015,  # zod_dataparser.py:138-140
+                                 radar_elevation_ray_divergence=0.015, min_azimuth=-0.80, max_azimuth=0.80,
+                                 min_elevation=-0.08, max_elevation=0.4)
+        # supervision data of the decoders (data layer, synthetic): detections of every radar scan in the sensor frame (a fixed
+        # number per scan: x forward 5..100 m inside the FOV), padded columns like the reference's [x, y, z, ...] rows
+        self.radar_detections_per_scan = 200
+        rr = 5.0 + 95.0 * torch.rand(n, self.radar_detections_per_scan, generator=g)
+        ra = -0.75 + 1.5 * torch.rand(n, self.radar_detections_per_scan, generator=g)
+        re = -0.05 + 0.3 * torch.rand(n, self.radar_detections_per_scan, generator=g)
+        self.radar_points = torch.stack([rr * torch.cos(re) * torch.cos(ra), rr * torch.cos(re) * torch.sin(ra), rr * torch.sin(re),
+                                         torch.rand(n, self.radar_detections_per_scan, generator=g),
+                                         torch.rand(n, self.radar_detections_per_scan, generator=g)], dim=-1).to(device)
+        self.image_seed = seed
         ar = torch.arange(self.PATCH, device=device) * self.STRIDE
         self.dy, self.dx = torch.meshgrid(ar, ar, indexing="ij")
 
@@ -177,6 +206,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             if os.environ.get("NR_LIDAR_COHERENT", "0") == "1":  # measured slower (3.49 vs 3.15 ms): lidar rows stay ray-major
                 n_coh = n_rays
         stepper = FusedTrainStep(model, n_rays, coherent_rays=n_coh)
+        decoders = bool(model.config.decoders)
         S0 = model.config.num_proposal_samples[0]
         dev = tgt_f.device
 
@@ -200,8 +230,31 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             is_l = asm.is_lidar[:, 0].to(torch.uint8).contiguous()
             for k_ in range(2):
                 stepper.set_lidar(is_l, asm.slots[k_]["did_return"], asm.slots[k_]["directions_norm"], asm.offset["lidar"], n_lidar,
-                                  slot=k_)
+                                  slot=k_, prop_depth_loss=decoders)
         n_u = asm.uniform_count()
+        dec_batches = None
+        if decoders:
+            # the decoders' supervision (neuradar.py:588-704): the patches' colours, the sampled lidar points' intensities, the
+            # detections of the drawn radar scan -- gathered on the device next to the batch assembly (data layer: synthetic)
+            from neuradar_amd.decoder_losses import DecoderLossHead, DecoderLossSettings
+
+            gi = torch.Generator(device=dev).manual_seed(scene.image_seed)
+            up = scene.PATCH * 3
+            sizes = {"camera": n_cam, "lidar": n_lidar, "radar": n_rays - n_cam - n_lidar}
+            layout = {k_: (asm.offset[k_], sizes[k_]) for k_ in sizes}
+            m_det = scene.radar_detections_per_scan
+            head = DecoderLossHead(model, layout, scene.PATCH, n_scans, m_det,
+                                   DecoderLossSettings(radar_loss_type=model.config.radar_loss_type),
+                                   cnn_autocast={"float32": None, "bfloat16": torch.bfloat16, "float16": torch.float16}[
+                                       model.field.config.mlp_dtype if os.environ.get("NR_CNN_AUTOCAST", "1") != "0" else "float32"])
+            sensor = torch.zeros(n_rays, dtype=torch.int64, device=dev)
+            sensor[asm.seg("lidar")], sensor[asm.seg("radar")] = 1, 2
+            dec_batches = [dict(image=torch.rand(n_p, up, up, 3, device=dev, generator=gi), did_return=asm.slots[k_]["did_return"],
+                                range=asm.slots[k_]["directions_norm"], target_intensity=torch.zeros(n_rays, device=dev),
+                                directions_spher=asm.slots[k_]["directions_spher"],
+                                radar=torch.zeros(max(n_scans, 1) * m_det, scene.radar_points.shape[-1], device=dev),
+                                radar_seg=(torch.arange(n_scans + 1, device=dev, dtype=torch.int32) * m_det)) for k_ in range(2)]
+            stepper.set_decoders(head, dec_batches, sensor)
 
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
         # per-ray jitter for the two rounds (:326) and the random numbers of the batch assembly.
@@ -228,8 +281,16 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
         def assemble(slot):
             """This step's rays into buffer set `slot` (on the current stream); returns (origins, directions, area, fars)."""
             s_ = asm.assemble(r[n_t + 2 * n_rays:n_t + 2 * n_rays + n_u], slot)
-            if has_actors:
+            if has_actors or decoders:
                 times_of[slot] = s_["times"]
+            if decoders:
+                b_ = dec_batches[slot]
+                if n_lidar:  # intensity (column 3) of the sampled points: rows cum_points[lidar] + point of nr_gen_rays_lidar_sampled
+                    li = s_["lidar_indices"]
+                    torch.index_select(scene.lidar_points[:, 3], 0, asm.cum_points[li[:, 0]] + li[:, 1],
+                                       out=b_["target_intensity"][asm.offset["lidar"]:asm.offset["lidar"] + n_lidar])
+                if n_scans:
+                    torch.index_select(scene.radar_points, 0, s_["scan_indices"][:n_scans], out=b_["radar"].view(n_scans, -1, b_["radar"].shape[-1]))
                 u3 = r[n_t + 2 * n_rays + n_u:].view(3, n_rays)
                 for i_ in range(3):
                     torch.sub(1.0, torch.lt(u3[i_], flip_p[i_]).float(), alpha=2.0, out=flip_buf[slot][i_])  # -1 with probability p
@@ -258,12 +319,12 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             else:
                 tail = lambda: hip_ops.uniform_fill(r, seed, epoch)  # noqa: E731
             o_, d_, a_, f_ = rays[k]
-            return stepper.forward_backward(o_, d_, a_, f_, tgt_f, tgt_d[:, 0],
+            return stepper.forward_backward(o_, d_, a_, f_, None if decoders else tgt_f, None if decoders else tgt_d[:, 0],
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
                                             after_sampling=tail, slot=k, prepared=True,
-                                            times=times_of[k] if has_actors else None,
+                                            times=times_of[k] if (has_actors or decoders) else None,
                                             flips=list(flip_buf[k]) if has_actors else None)
 
         fwd_bwd.state = state if pipelined else None
@@ -408,6 +469,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
 
     wl = WORKLOADS[workload]
     n_rays = wl["rays"]
+    mlp_dtype = wl.get("mlp_dtype", mlp_dtype)
 
     grad_scale = args.mlp_grad_scale if args.mlp_grad_scale is not None else (8192.0 if mlp_dtype == "float16" else 1.0)
     model = build_model(wl, device, mlp_dtype, grad_scale)
@@ -423,10 +485,16 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     if "trajectory_opt" in groups:  # Adam lr 1e-3 -> 1e-4, 2 500 warm-up steps (method_configs.py:401-405)
         opts.append(FlatAdam(groups["trajectory_opt"], lr=1e-3 * lr_scale, eps=1e-15, lr_final=1e-4 * lr_scale, max_steps=20001,
                              warmup_steps=2500))
+    if "cnn" in groups:  # method_configs.py:384-409: cnn AdamW 1e-3 -> 1e-4 (wd 1e-6, 2 500 warm-up), transformer AdamW 1e-3 -> 1e-7
+        # (wd 1e-7, 10 001 steps, 5 000 warm-up); radar_angle_head is built but never evaluated (grad None: skipped like torch.optim)
+        opts.append(FlatAdam(groups["cnn"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-6, adamw=True, lr_final=1e-4 * lr_scale,
+                             max_steps=20001, warmup_steps=2500))
+        opts.append(FlatAdam(groups["transformer"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-7 * lr_scale,
+                             max_steps=10001, warmup_steps=5000, skip=list(model.radar_angle_head.parameters())))
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None,
                              sparse_tables=not args.dense_allreduce and not args.autograd)
-    scene = SyntheticScene(device, seed=1000 + rank)  # seed + rank, like scripts/train.py:104
+    scene = SyntheticScene(device, seed=1000 + rank, radar=wl.get("radar", "zod"))  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
     # fused step: optimizer (and for world > 1 the overlapped gradient all-reduce) inside forward_backward
@@ -563,6 +631,17 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
 
     roof, cpu = None, None
     mlp_times = {}
+    decoders_us = None
+    if not want_roofline and stepper is not None and stepper.dec is not None:
+        # what the decoder segment costs inside the running step: HIP events around it (composite -> CNN / lidar MLP / radar
+        # transformer + heads, their losses incl. the linear sum assignment, and the segment's backward), eager steps
+        stepper.timers = {}
+        for _ in range(10):
+            fwd_bwd()
+            optim()
+        barrier()
+        decoders_us = stepper.kernel_times().get("decoders", 0.0) * 1e6
+        stepper.timers = None
     if want_roofline and stepper is not None:
         # the hash-grid (and field) launches timed LIVE inside the step: HIP events on the stream each launch
         # runs on, the same eager step as above (graph replays cannot carry per-kernel events), 20 steps
@@ -618,7 +697,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
               "blocks": n_blocks, "ms_min": per_block[0] / args.steps * 1e3, "ms_max": per_block[-1] / args.steps * 1e3,
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                              if reducer.last_sparse.get("mode") == "sparse" else 0)) if world > 1 else 0,
-              "exchange": (reducer.last_sparse or "dense") if world > 1 else None}
+              "exchange": (reducer.last_sparse or "dense") if world > 1 else None, "decoders_us": decoders_us, "mlp_dtype": mlp_dtype}
     del graphs, stepper, fwd_bwd, optim, model, opts, reducer, scene
     torch.cuda.empty_cache()
     return result
@@ -634,6 +713,8 @@ def main():
                     "largest single-GPU configuration")
     ap.add_argument("--secondary", default="cam4096_l16f2_w64", help="second workload reported in the same line ('' = none); "
                     "default: BASELINE.json configs[1]")
+    ap.add_argument("--full-model", default="mixed16384_neuradar_full,mixed8192_vod_nll,mixed16384_neuradar_full_fp16",
+                    help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step block until this much has been timed")
     ap.add_argument("--mlp-dtype", default="bfloat16", choices=["float32", "bfloat16", "float16"],
                     help="MFMA operand type of the field MLP stack (fp32 accumulation in every case)")
@@ -676,6 +757,22 @@ def main():
         secondary = {"workload": sec["workload"], "value": round(sec["value"], 1), "unit": "rays/s", "ms_per_step": round(sec["ms_per_step"], 4),
                      "ms_per_step_min": round(sec["ms_min"], 4), "ms_per_step_max": round(sec["ms_max"], 4), "timed_blocks": sec["blocks"],
                      "rays_per_gpu_per_step": sec["n_rays"], "main_grid": sec["wl"]["grid"], "mlp_width": sec["wl"]["hidden"]}
+    full_model = []
+    if args.full_model and not args.autograd:
+        # BASELINE configs[2] "full" / configs[3] / configs[4] per-GPU shapes: the step supervised through the modality decoders
+        # (RGB CNN, lidar MLP, radar transformer + heads, Hungarian-matched radar loss), same timing rules, reported beside the headline
+        for w_ in args.full_model.split(","):
+            fr = measure(args, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
+            full_model.append({"workload": w_, "value": round(fr["value"], 1), "unit": "rays/s", "ms_per_step": round(fr["ms_per_step"], 4),
+                               "ms_per_step_min": round(fr["ms_min"], 4), "ms_per_step_max": round(fr["ms_max"], 4),
+                               "timed_blocks": fr["blocks"], "rays_per_gpu_per_step": fr["n_rays"], "graph": fr["use_graph"],
+                               "rays": {"camera": fr["wl"]["cam_rays"], "lidar": fr["wl"]["lidar_rays"],
+                                        "radar": fr["n_rays"] - fr["wl"]["cam_rays"] - fr["wl"]["lidar_rays"]},
+                               "radar_loss": fr["wl"].get("radar_loss"), "radar_grid": fr["wl"].get("radar", "zod"),
+                               "mlp_operands": fr["mlp_dtype"],
+                               "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
+                               "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
+                                           "the linear sum assignment on the device"})
     if rank == 0:
         r, wl = main_res, main_res["wl"]
         line = {
@@ -693,7 +790,7 @@ def main():
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"]},
-            "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary,
+            "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "full_model": full_model,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -111,14 +111,39 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
  * (d in {32, 48, 64}, rows 16-byte aligned); lse [n_scans, n] (the forward's log-sum-exp, kept
  * for the backward).  Dropout on the probabilities: dropout_p in [0, 1), the keep decisions are a hash of (seed, scan, query,
  * key) -- the same in the forward and the backward -- or, when keep_mask [n_scans, n, n] (0 / 1) is not NULL, taken from it.
+ * seed_epoch (device float, nullable): a step counter the kernels fold into the seed, so that a captured graph draws new masks
+ * on every replay (as nr_uniform_fill's epoch).
  * The backward ACCUMULATES into grad_q / grad_k / grad_v (+=; the caller zeroes them).  workspace:
  * nr_attention_workspace_floats(n_scans, n, d) floats, the same buffer for the forward and its backward is fine. */
 int64_t nr_attention_workspace_floats(int64_t n_scans, int64_t n, int d);
 int nr_attention_fwd(const float* q, const float* k, const float* v, int64_t n_scans, int64_t n, int d, float dropout_p,
-                     uint32_t seed, const float* keep_mask, float* out, float* lse, float* workspace, nr_stream_t stream);
+                     uint32_t seed, const float* seed_epoch, const float* keep_mask, float* out, float* lse, float* workspace,
+                     nr_stream_t stream);
 int nr_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* grad_out,
-                     int64_t n_scans, int64_t n, int d, float dropout_p, uint32_t seed, const float* keep_mask,
-                     float* grad_q, float* grad_k, float* grad_v, float* workspace, nr_stream_t stream);
+                     int64_t n_scans, int64_t n, int d, float dropout_p, uint32_t seed, const float* seed_epoch,
+                     const float* keep_mask, float* grad_q, float* grad_k, float* grad_v, float* workspace, nr_stream_t stream);
+
+/* Radar point-set loss on the device (model_components/radar_utils.py:54-168, called from
+ * models/neuradar.py:652-662): the reference copies a cost matrix to the host and runs scipy's linear_sum_assignment per scan
+ * in the middle of every training step.
+ *   pred        [n_scans, n_pred, 7] = (existence probability, x, y, z, three Laplace scales) -- decode_features' radar_output
+ *   detections  rows of det_stride >= 3 floats (x, y, z first), scan after scan; seg [n_scans + 1] (device, int32) = first row of
+ *               every scan (the reference derives it from radar_indices[:, 1] == 0 with a host sync, :59-61)
+ *   max_detections  upper bound of a scan's detection count: sizes the launch and the workspace, the counts themselves are
+ *               read on the device.  Limits: min(detections, n_pred) <= 1024, max(...) <= 8192 per scan.
+ * nr_radar_assign: cost matrix (cost_type 0 = "euclidean": distance - log r, the one training always uses, :77-78; 1 = "nll",
+ * :105-118; MultiBernoulli's clamps :38-45 applied; inf -> 1e9) + rectangular linear sum assignment (shortest augmenting
+ * paths, float64 duals -- the algorithm behind scipy.optimize.linear_sum_assignment) -> assoc [n_scans, n_pred] int32:
+ * index of the matched detection inside its scan, or -1.  Where the optimum is not unique (exactly equal sums) the choice
+ * among the optima may differ from scipy's.
+ * nr_radar_loss: loss (NR_LOSS_SLOTS partial sums) += mult * mean_scans( sum_k l_k / n_pred ) with l_k = -log(1 - r_k) for an
+ * unmatched prediction and -log r_k + |xyz_k - det| (loss_type 0, :156-164) or -log r_k - Laplace log-likelihood of det
+ * (loss_type 1, :132-154) for a matched one; grad_pred [n_scans, n_pred, 7] = its gradient (overwritten). */
+int64_t nr_radar_assign_workspace_bytes(int n_scans, int64_t n_pred, int max_detections);
+int nr_radar_assign(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
+                    int max_detections, int cost_type, int* assoc, void* workspace, nr_stream_t stream);
+int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
+                  const int* assoc, int loss_type, float mult, float* grad_pred, float* loss, nr_stream_t stream);
 
 /* tiny-cuda-nn-compatible multiresolution hash grid for 3-D and 4-D inputs: what
  * `tcnn.Encoding(n_input_dims, {"otype": "HashGrid", n_levels, n_features_per_level, log2_hashmap_size, base_resolution,
@@ -433,7 +458,40 @@ typedef struct nr_lidar_sup {
   float carving_epsilon;       /* 0.1   (LossSettings.carving_epsilon, neuradar.py:94) */
   float non_return_distance;   /* 150 m (non_return_lidar_distance, :102) */
   float weight;
+  /* lidar depth loss on the level's own rendered depth (the proposal levels' depth_loss_i, neuradar.py:641-648,679-688; no
+   * quantile mask there): depth_weight * |target - depth| per lidar ray, target = range (returned) or max(depth, 150 m)
+   * (not returned, loss x non_return_loss_mult).  depth_weight already holds prop_lidar_loss_mult * depth_mult / n_lidar;
+   * 0 = off.  Read by nr_interlevel_loss_to_density only (the main level's depth loss needs the batch quantile:
+   * nr_lidar_depth_quantile / nr_lidar_losses below). */
+  float depth_weight;
+  float non_return_loss_mult;  /* 0.1 (:104) */
 } nr_lidar_sup_t;
+
+/* Lidar losses of the training step on the lidar rays' rendered depth and decoder outputs (models/neuradar.py:612-636 with the
+ * multipliers of :690-700), without the reference's boolean-mask indexing and torch.quantile host paths:
+ *   unreduced_i = |target_i - depth_i|, target = range (returned ray) or max(depth_i, non_return_distance) (not returned: the
+ *   loss x non_return_loss_mult); q = torch.quantile(unreduced, quantile) (linear interpolation between the two order statistics
+ *   around quantile * (n - 1)); mask = unreduced < q
+ *   depth_loss = depth_mult * mean(unreduced[mask]);  intensity_loss = intensity_mult * mean((sigmoid(y0) - target_intensity)^2
+ *   over mask & returned);  ray_drop_loss = ray_drop_mult * BCEWithLogits(y1, !returned) over all lidar rays.
+ * The lidar rays are rows [row0, row0 + n) of the per-ray arrays (depth, did_return, range, target_intensity: [n_rays]); y
+ * [n, 2] are the lidar decoder's outputs (intensity logit, ray-drop logit).
+ * nr_lidar_depth_quantile: unreduced [n] and stats [8] = (x_lo, x_hi, q, 1 / count(mask), 1 / count(mask & returned), ...)
+ * (an empty mask -- the reference's mean of an empty tensor is nan -- contributes 0 here).
+ * nr_lidar_losses: loss +=; grad_depth [n_rays]: rows of the lidar segment are written; grad_y [n, 2] overwritten. */
+typedef struct nr_lidar_losses {
+  const uint8_t* did_return;
+  const float* range;
+  const float* target_intensity;
+  int64_t row0, n;
+  float non_return_distance;   /* 150 m */
+  float non_return_loss_mult;  /* 0.1 */
+  float quantile;              /* 0.95 (quantile_threshold, :96) */
+  float depth_mult, intensity_mult, ray_drop_mult;
+} nr_lidar_losses_t;
+int nr_lidar_depth_quantile(const float* depth, const nr_lidar_losses_t* cfg, float* unreduced, float* stats, nr_stream_t stream);
+int nr_lidar_losses(const float* depth, const float* y, const nr_lidar_losses_t* cfg, const float* unreduced, const float* stats,
+                    float* grad_depth, float* grad_y, float* loss, nr_stream_t stream);
 
 /* One-launch training tail of a ray batch: nr_composite_fwd, then the bench loss
  *   rgb_mult * mean((features - target_features)^2) + depth_mult * mean(|depth - target_depth|)
@@ -442,12 +500,16 @@ typedef struct nr_lidar_sup {
  * points above compute the same values; this one saves four launches and their round trips).
  * alpha [n_rays,S], feature [n_rays*S,C], euclid/spacing [n_rays,S+1], targets [n_rays,C]/[n_rays];
  * S <= 64, C <= 32.  Outputs: weights [n_rays,S], accumulation, depth [n_rays], features [n_rays,C],
- * grad_alpha [n_rays,S], grad_feature [n_rays*S,C]; loss (NR_LOSS_SLOTS partial sums) +=. */
+ * grad_alpha [n_rays,S], grad_feature [n_rays*S,C]; loss (NR_LOSS_SLOTS partial sums) +=.
+ * grad_features_extra [n_rays,C] / grad_depth_extra [n_rays] (nullable): gradients arriving from the decoders behind the
+ * rendered features / depth, added to the supervision's own; target_features / target_depth may be NULL when rgb_mult /
+ * depth_mult is 0 (the decoders' losses supervise instead). */
 int nr_render_train(const float* alpha, const float* feature, const float* euclid, const float* spacing,
                     const float* target_features, const float* target_depth, int64_t n_rays, int n_samples,
                     int n_channels, float rgb_mult, float depth_mult, float distortion_mult,
                     float* weights, float* accumulation, float* features, float* depth,
                     float* grad_alpha, float* grad_feature, float* loss, const float* grad_features_extra,
+                    const float* grad_depth_extra,
                     const nr_lidar_sup_t* lidar, nr_stream_t stream);
 /* grad_features_extra [n_rays,C] (nullable): an upstream gradient on the rendered features from a consumer the launch does
  * not contain (per-ray decoders), added to the supervision term's.  lidar (nullable): carving term on the first S-1

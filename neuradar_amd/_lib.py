@@ -34,7 +34,13 @@ class NrField(Structure):
 
 class NrLidarSup(Structure):
     _fields_ = [("is_lidar", c_void_p), ("did_return", c_void_p), ("range", c_void_p), ("carving_epsilon", c_float),
-                ("non_return_distance", c_float), ("weight", c_float)]
+                ("non_return_distance", c_float), ("weight", c_float), ("depth_weight", c_float), ("non_return_loss_mult", c_float)]
+
+
+class NrLidarLosses(Structure):
+    _fields_ = [("did_return", c_void_p), ("range", c_void_p), ("target_intensity", c_void_p), ("row0", c_int64), ("n", c_int64),
+                ("non_return_distance", c_float), ("non_return_loss_mult", c_float), ("quantile", c_float), ("depth_mult", c_float),
+                ("intensity_mult", c_float), ("ray_drop_mult", c_float)]
 
 
 class NrFieldGrads(Structure):
@@ -54,8 +60,11 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
     "nr_attention_workspace_floats": [L, L, I],
-    "nr_attention_fwd": [P, P, P, L, L, I, F, c_uint32, P, P, P, P, P],
-    "nr_attention_bwd": [P, P, P, P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P],
+    "nr_attention_fwd": [P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P],
+    "nr_attention_bwd": [P, P, P, P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P, P],
+    "nr_radar_assign_workspace_bytes": [I, L, I],
+    "nr_radar_assign": [P, I, L, P, I, P, I, I, P, P, P],
+    "nr_radar_loss": [P, I, L, P, I, P, P, I, F, P, P, P],
     "nr_tcnn_grid_param_count": [I, I, I, I, I, F],
     "nr_tcnn_grid_geometry": [I, I, I, I, F, P, P, P],
     "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],
@@ -94,7 +103,9 @@ PROTOTYPES = {
     "nr_render_weights_bwd": [P, P, P, P, P, P, P, L, I, P, P],
     "nr_accumulate_fwd": [P, P, L, I, I, P, P],
     "nr_accumulate_bwd": [P, P, P, L, I, I, P, P, P],
-    "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P, POINTER(NrLidarSup), P],
+    "nr_render_train": [P, P, P, P, P, P, L, I, I, F, F, F, P, P, P, P, P, P, P, P, P, POINTER(NrLidarSup), P],
+    "nr_lidar_depth_quantile": [P, POINTER(NrLidarLosses), P, P, P],
+    "nr_lidar_losses": [P, P, POINTER(NrLidarLosses), P, P, P, P, P, P],
     "nr_appearance_concat_fwd": [P, I, P, I, P, P, F, I, L, L, P, P],
     "nr_appearance_concat_bwd": [P, I, I, P, P, F, I, L, L, P, P, L, P],
     "nr_lidar_head_loss": [P, P, P, L, P, F, F, P, P, P],
@@ -118,7 +129,8 @@ PROTOTYPES = {
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
-             "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64}
+             "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
+             "nr_radar_assign_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -29,7 +29,13 @@ struct Drop {
   const float* mask;  // [N, n, n] keep values (0 / 1) or NULL
   uint32_t seed;
   float p;            // drop probability
+  const float* epoch; // device-resident step counter (nullable): folded into the seed by the kernel, so that replays of a captured
+                      // graph draw a new mask every step (the host-side seed is baked into the graph)
 };
+__device__ __forceinline__ Drop drop_of_step(Drop d) {
+  if (d.epoch != nullptr) d.seed += (uint32_t)d.epoch[0] * 0x85EBCA6Bu;
+  return d;
+}
 
 // keep(i, j) / (1 - p): the factor torch's dropout applies to a probability
 __device__ __forceinline__ float drop_factor(const Drop& d, int64_t scan, int64_t n, int i, int j) {
@@ -116,7 +122,8 @@ struct AttStage {
 template <int D>
 __global__ void __launch_bounds__(AttMfma<D>::W * 64)
 attention_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t n, float scale,
-                          Drop drop, int64_t keys_per_part, float* __restrict__ part) {
+                          Drop drop_in, int64_t keys_per_part, float* __restrict__ part) {
+  const Drop drop = drop_of_step(drop_in);
   using C = AttMfma<D>;
   constexpr int QW = C::QW, KT = C::KT, STR = C::STR, DS = C::DS, DT = C::DT, NKT = KT / 16;
   __shared__ __attribute__((aligned(16))) float ks[KT * STR];
@@ -271,7 +278,8 @@ template <int D>
 __global__ void __launch_bounds__(AttMfma<D>::W * 64)
 attention_bwd_q_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                             const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ g_out, int64_t n,
-                            float scale, Drop drop, int64_t keys_per_part, float* __restrict__ g_q, float* __restrict__ delta) {
+                            float scale, Drop drop_in, int64_t keys_per_part, float* __restrict__ g_q, float* __restrict__ delta) {
+  const Drop drop = drop_of_step(drop_in);
   using C = AttMfma<D>;
   constexpr int QW = C::QW, KT = C::KT, STR = C::STR, DS = C::DS, DT = C::DT, NKT = KT / 16;
   __shared__ __attribute__((aligned(16))) float ks[KT * STR];
@@ -373,7 +381,8 @@ template <int D>
 __global__ void __launch_bounds__(AttMfma<D>::W * 64)
 attention_bwd_kv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                              const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ g_out, int64_t n,
-                             float scale, Drop drop, int64_t rows_per_part, float* __restrict__ g_k, float* __restrict__ g_v) {
+                             float scale, Drop drop_in, int64_t rows_per_part, float* __restrict__ g_k, float* __restrict__ g_v) {
+  const Drop drop = drop_of_step(drop_in);
   using C = AttMfma<D>;
   constexpr int QW = C::QW, KT = C::KT, STR = C::STR, DS = C::DS, DT = C::DT, NKT = KT / 16;
   __shared__ __attribute__((aligned(16))) float qt_[KT * STR];
@@ -528,12 +537,12 @@ extern "C" int64_t nr_attention_workspace_floats(int64_t n_scans, int64_t n, int
 }
 
 extern "C" int nr_attention_fwd(const float* q, const float* k, const float* v, int64_t n_scans, int64_t n, int d, float dropout_p,
-                                uint32_t seed, const float* keep_mask, float* out, float* lse, float* workspace,
-                                nr_stream_t stream) {
+                                uint32_t seed, const float* seed_epoch, const float* keep_mask, float* out, float* lse,
+                                float* workspace, nr_stream_t stream) {
   if (n_scans == 0 || n == 0) return 0;
   if (bad(q, k, v) || !out || !lse || !workspace || n_scans < 0 || n < 0 || n > INT_MAX / 2 || !(dropout_p >= 0.0f) || dropout_p >= 1.0f)
     return NR_EINVAL;
-  const Drop drop = {keep_mask, seed, dropout_p};
+  const Drop drop = {keep_mask, seed, dropout_p, seed_epoch};
   const float scale = 1.0f / sqrtf((float)d);
   const int64_t rows = n_scans * n;
 #define CALL(DD)                                                                                                              \
@@ -559,12 +568,13 @@ extern "C" int nr_attention_fwd(const float* q, const float* k, const float* v, 
 
 extern "C" int nr_attention_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse,
                                 const float* g_out, int64_t n_scans, int64_t n, int d, float dropout_p, uint32_t seed,
-                                const float* keep_mask, float* g_q, float* g_k, float* g_v, float* workspace, nr_stream_t stream) {
+                                const float* seed_epoch, const float* keep_mask, float* g_q, float* g_k, float* g_v, float* workspace,
+                                nr_stream_t stream) {
   if (n_scans == 0 || n == 0) return 0;
   if (bad(q, k, v) || bad(out, lse, g_out) || bad(g_q, g_k, g_v) || !workspace || n_scans < 0 || n < 0 || n > INT_MAX / 2 ||
       !(dropout_p >= 0.0f) || dropout_p >= 1.0f)
     return NR_EINVAL;
-  const Drop drop = {keep_mask, seed, dropout_p};
+  const Drop drop = {keep_mask, seed, dropout_p, seed_epoch};
   const float scale = 1.0f / sqrtf((float)d);
   float* delta = workspace + (int64_t)kMaxParts * n_scans * n * (d + 4);
 #define CALL(DD)                                                                                                              \

@@ -222,6 +222,21 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
   const bool carve = lidar.is_lidar != nullptr && euclid_p != nullptr && lidar.is_lidar[ray] != 0;
   const bool carve_ret = carve && lidar.did_return[ray] != 0;
   const float carve_range = carve ? lidar.range[ray] : 0.0f;
+  // the level's own lidar depth loss (depth_loss_i, neuradar.py:641-648): depth = sum_j w_j mid_j over ALL its samples
+  float g_pdepth = 0.0f, l_pdepth = 0.0f;
+  if (carve && lidar.depth_weight > 0.0f) {
+    float dsum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kPerLane; ++t) {
+      const int j = lane + t * NR_WAVE;
+      if (j < Sp) dsum += pw[t] * ((euclid_p[ray * (Sp + 1) + j] + euclid_p[ray * (Sp + 1) + j + 1]) / 2.0f);
+    }
+    dsum = nr_wave_sum(dsum);
+    const float scale = carve_ret ? 1.0f : lidar.non_return_loss_mult;
+    const float diff = dsum - (carve_ret ? carve_range : fmaxf(dsum, lidar.non_return_distance));
+    l_pdepth = lidar.depth_weight * scale * fabsf(diff);
+    g_pdepth = lidar.depth_weight * scale * (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+  }
   float gj[kPerLane];
 #pragma unroll
   for (int t = 0; t < kPerLane; ++t) {
@@ -240,12 +255,13 @@ interlevel_loss_kernel(const float* __restrict__ c, int c_stride, const float* _
           lc += p * p;
           gj[t] += 2.0f * lidar.weight * p;
         }
+        gj[t] += g_pdepth * ((euclid_p[ray * (Sp + 1) + j] + euclid_p[ray * (Sp + 1) + j + 1]) / 2.0f);
       }
       if (g_wp != nullptr) g_wp[ray * Sp + j] = gj[t];
     }
   }
   l = k * nr_wave_sum(l);
-  if (carve) l += lidar.weight * nr_wave_sum(lc);
+  if (carve) l += lidar.weight * nr_wave_sum(lc) + l_pdepth;
   if (lane == 0) unsafeAtomicAdd(loss_slot(loss), l);
   if constexpr (ITEMS > 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -363,7 +379,143 @@ lidar_head_loss_kernel(const float* __restrict__ y, const float* __restrict__ ta
   if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss_slot(loss), acc);
 }
 
+// ---- lidar depth / intensity / ray-drop losses with the batch quantile (neuradar.py:612-636) ----
+__device__ __forceinline__ float lidar_unreduced(const float* __restrict__ depth, const nr_lidar_losses_t& c, int64_t i) {
+  const int64_t ray = c.row0 + i;
+  const float d = depth[ray];
+  const bool ret = c.did_return[ray] != 0;
+  const float target = ret ? c.range[ray] : fmaxf(d, c.non_return_distance);
+  return fabsf(target - d) * (ret ? 1.0f : c.non_return_loss_mult);
+}
+
+// Order statistics without a sort: rank_i = #{j : x_j < x_i} + #{j < i : x_j == x_i}; the elements whose ranks are
+// floor / ceil of quantile * (n - 1) are the two values torch.quantile interpolates between.  A block ranks 64 elements,
+// four threads per element each walking a quarter of every LDS tile of the values.
+constexpr int kRankTile = 4096;
+__global__ void __launch_bounds__(256)
+lidar_rank_kernel(const float* __restrict__ depth, nr_lidar_losses_t c, float* __restrict__ unreduced, float* __restrict__ stats) {
+  __shared__ float tile[kRankTile];
+  const int64_t n = c.n;
+  const int part = threadIdx.x >> 6;                                      // 0..3
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);       // my element
+  const float xi = i < n ? lidar_unreduced(depth, c, i) : 0.0f;
+  int rank = 0;
+  for (int64_t t0 = 0; t0 < n; t0 += kRankTile) {
+    const int len = (int)min((int64_t)kRankTile, n - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < len; k += 256) tile[k] = lidar_unreduced(depth, c, t0 + k);
+    __syncthreads();
+    if (i < n) {
+      const int q0 = part * (kRankTile / 4), q1 = min(len, q0 + kRankTile / 4);
+      for (int k = q0; k < q1; ++k) {
+        const float xj = tile[k];
+        rank += (xj < xi || (xj == xi && t0 + k < i)) ? 1 : 0;
+      }
+    }
+  }
+  // sum the four partial ranks of an element
+  __shared__ int parts[4][64];
+  __syncthreads();
+  parts[part][threadIdx.x & 63] = rank;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    rank = parts[0][threadIdx.x] + parts[1][threadIdx.x] + parts[2][threadIdx.x] + parts[3][threadIdx.x];
+    unreduced[i] = xi;
+    const float pos = c.quantile * (float)(n - 1);  // ATen computes the rank in the input's dtype
+    const int lo = (int)floorf(pos), hi = (int)ceilf(pos);
+    if (rank == lo) stats[0] = xi;
+    if (rank == hi) stats[1] = xi;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+lidar_quantile_counts_kernel(const float* __restrict__ unreduced, nr_lidar_losses_t c, float* __restrict__ stats) {
+  const float pos = c.quantile * (float)(c.n - 1);
+  const float w = pos - floorf(pos), a = stats[0], b = stats[1];
+  const float q = w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w);  // at::lerp
+  int cm = 0, cr = 0;
+  for (int64_t i = threadIdx.x; i < c.n; i += blockDim.x) {
+    const bool m = unreduced[i] < q;
+    cm += m ? 1 : 0;
+    cr += (m && c.did_return[c.row0 + i] != 0) ? 1 : 0;
+  }
+  __shared__ int s_m[16], s_r[16];
+  const float fm = nr_wave_sum((float)cm), fr = nr_wave_sum((float)cr);  // (counts < 2^24: exact in float)
+  if (nr_lane() == 0) { s_m[threadIdx.x >> 6] = (int)fm; s_r[threadIdx.x >> 6] = (int)fr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tm = 0, tr = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { tm += s_m[k]; tr += s_r[k]; }
+    stats[2] = q;
+    stats[3] = tm > 0 ? 1.0f / (float)tm : 0.0f;
+    stats[4] = tr > 0 ? 1.0f / (float)tr : 0.0f;
+    stats[5] = (float)tm;
+    stats[6] = (float)tr;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+lidar_losses_kernel(const float* __restrict__ depth, const float* __restrict__ y, nr_lidar_losses_t c,
+                    const float* __restrict__ unreduced, const float* __restrict__ stats, float* __restrict__ g_depth,
+                    float* __restrict__ g_y, float* __restrict__ loss) {
+  const float q = stats[2], inv_m = stats[3], inv_r = stats[4], inv_n = 1.0f / (float)c.n;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = c.row0 + i;
+    const bool ret = c.did_return[ray] != 0;
+    const float un = unreduced[i];
+    const bool in = un < q;
+    const float d = depth[ray];
+    const float diff = d - (ret ? c.range[ray] : fmaxf(d, c.non_return_distance));
+    float gd = 0.0f;
+    if (in) {  // depth_mult * mean(unreduced[mask])
+      acc += c.depth_mult * inv_m * un;
+      gd = c.depth_mult * inv_m * (ret ? 1.0f : c.non_return_loss_mult) * (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+    }
+    g_depth[ray] = gd;
+    const float y0 = y[i * 2], y1 = y[i * 2 + 1];
+    float g0 = 0.0f;
+    if (in && ret) {  // intensity MSE on the returning rays inside the quantile (:627-632)
+      const float s = 1.0f / (1.0f + expf(-y0));
+      const float e = s - c.target_intensity[ray];
+      acc += c.intensity_mult * inv_r * e * e;
+      g0 = 2.0f * c.intensity_mult * inv_r * e * s * (1.0f - s);
+    }
+    const float z = ret ? 0.0f : 1.0f;  // BCE with logits, target = !did_return (:634-636)
+    acc += c.ray_drop_mult * inv_n * (fmaxf(y1, 0.0f) - y1 * z + log1pf(expf(-fabsf(y1))));
+    g_y[i * 2] = g0;
+    g_y[i * 2 + 1] = c.ray_drop_mult * inv_n * (1.0f / (1.0f + expf(-y1)) - z);
+  }
+  acc = nr_wave_sum(acc);
+  if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss_slot(loss), acc);
+}
+
 }  // namespace
+
+static bool lidar_cfg_ok(const nr_lidar_losses_t* c) {
+  return c && c->did_return && c->range && c->target_intensity && c->row0 >= 0 && c->n >= 0 && c->quantile >= 0.0f && c->quantile <= 1.0f;
+}
+
+extern "C" int nr_lidar_depth_quantile(const float* depth, const nr_lidar_losses_t* cfg, float* unreduced, float* stats,
+                                       nr_stream_t stream) {
+  if (!lidar_cfg_ok(cfg) || !depth || !unreduced || !stats) return NR_EINVAL;
+  if (cfg->n == 0) return 0;
+  hipLaunchKernelGGL(lidar_rank_kernel, dim3((unsigned)nr_cdiv(cfg->n, 64)), dim3(256), 0, nr_s(stream), depth, *cfg, unreduced, stats);
+  hipLaunchKernelGGL(lidar_quantile_counts_kernel, dim3(1), dim3(1024), 0, nr_s(stream), unreduced, *cfg, stats);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_lidar_losses(const float* depth, const float* y, const nr_lidar_losses_t* cfg, const float* unreduced,
+                               const float* stats, float* grad_depth, float* grad_y, float* loss, nr_stream_t stream) {
+  if (!lidar_cfg_ok(cfg) || !depth || !y || !unreduced || !stats || !grad_depth || !grad_y || !loss) return NR_EINVAL;
+  if (cfg->n == 0) return 0;
+  const int64_t want = nr_cdiv(cfg->n, 256);
+  hipLaunchKernelGGL(lidar_losses_kernel, dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, nr_s(stream), depth, y, *cfg,
+                     unreduced, stats, grad_depth, grad_y, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_appearance_concat_fwd(const float* features, int C, const float* table, int A, const float* times,
                                         const int64_t* sensor_idx, float duration, int E, int64_t row0, int64_t n_rows, float* out,

@@ -116,7 +116,7 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
                     float dist_mult, float* __restrict__ weights, float* __restrict__ accumulation,
                     float* __restrict__ features, float* __restrict__ depth, float* __restrict__ g_alpha,
                     float* __restrict__ g_feature, float* __restrict__ loss, const float* __restrict__ g_features_extra,
-                    nr_lidar_sup_t lidar) {
+                    const float* __restrict__ g_depth_extra, nr_lidar_sup_t lidar) {
   const int64_t ray = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
   const int lane = nr_lane();
@@ -150,13 +150,14 @@ render_train_kernel(const float* __restrict__ alpha, const float* __restrict__ f
   if (lane < C) features[ray * C + lane] = fsum;
   // ---- supervision: rgb_mult * mean((f - t)^2) + depth_mult * mean(|d - t|) ----
   const float kf = rgb_mult / (float)(n_rays * C), kd = depth_mult / (float)n_rays;
-  const float diff = cvalid ? fsum - target_f[ray * C + c] : 0.0f;
+  const float diff = (cvalid && target_f != nullptr) ? fsum - target_f[ray * C + c] : 0.0f;
   float lossv = sh == 0 ? kf * diff * diff : 0.0f;
   float gF = 2.0f * kf * diff;  // d loss / d features[c], in both halves
   if (g_features_extra != nullptr && cvalid) gF += g_features_extra[ray * C + c];
-  const float dd = d - target_d[ray];
+  const float dd = target_d != nullptr ? d - target_d[ray] : 0.0f;
   if (lane == 0) lossv += kd * fabsf(dd);
-  const float gD = dd > 0.0f ? kd : (dd < 0.0f ? -kd : 0.0f);
+  float gD = dd > 0.0f ? kd : (dd < 0.0f ? -kd : 0.0f);
+  if (g_depth_extra != nullptr) gD += g_depth_extra[ray];
   // ---- distortion loss on the first S-1 samples (losses.py:137-157; sky sample dropped) ----
   const int n_used = S - 1;
   const bool on = lane < n_used;
@@ -467,9 +468,11 @@ extern "C" int nr_render_train(const float* alpha, const float* feature, const f
                                const float* target_features, const float* target_depth, int64_t n_rays, int S, int C,
                                float rgb_mult, float depth_mult, float distortion_mult, float* weights,
                                float* accumulation, float* features, float* depth, float* g_alpha, float* g_feature,
-                               float* loss, const float* g_features_extra, const nr_lidar_sup_t* lidar, nr_stream_t stream) {
+                               float* loss, const float* g_features_extra, const float* g_depth_extra, const nr_lidar_sup_t* lidar,
+                               nr_stream_t stream) {
   if (n_rays == 0) return 0;
-  if (!alpha || !feature || !euclid || !spacing || !target_features || !target_depth || !weights || !accumulation ||
+  if ((!target_features && rgb_mult != 0.0f) || (!target_depth && depth_mult != 0.0f)) return NR_EINVAL;
+  if (!alpha || !feature || !euclid || !spacing || !weights || !accumulation ||
       !features || !depth || !g_alpha || !g_feature || !loss || S < 2 || S > NR_WAVE || C < 1 || C > 32 || n_rays < 0)
     return NR_EINVAL;
   nr_lidar_sup_t lid = {};
@@ -481,11 +484,11 @@ extern "C" int nr_render_train(const float* alpha, const float* feature, const f
   if (S <= 32)
     hipLaunchKernelGGL(render_train_kernel<16>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
                        target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
-                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, lid);
+                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, g_depth_extra, lid);
   else
     hipLaunchKernelGGL(render_train_kernel<32>, grid, dim3(256), 0, nr_s(stream), alpha, feature, euclid, spacing,
                        target_features, target_depth, n_rays, S, C, rgb_mult, depth_mult, distortion_mult, weights,
-                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, lid);
+                       accumulation, features, depth, g_alpha, g_feature, loss, g_features_extra, g_depth_extra, lid);
   NR_LAUNCH_CHECK();
   return 0;
 }

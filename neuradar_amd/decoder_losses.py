@@ -1,0 +1,154 @@
+"""The training branch behind the rendered features of a mixed batch, on the device: `decode_features`
+(models/neuradar.py:410-493) followed by the decoder-dependent terms of `get_metrics_dict` / `get_loss_dict` (:588-704):
+
+  camera rows  -> [patches, C, h, w] -> RGB CNN (training-mode batch norm) -> rgb_mult * MSE(image, rgb)           (:455-461,672-673)
+  lidar rows   -> lidar MLP (MFMA kernels) -> quantile-masked depth L1, intensity MSE, ray-drop BCE               (:432-452,612-636)
+                  [nr_lidar_depth_quantile / nr_lidar_losses: no boolean-mask indexing, no torch.quantile]
+  radar rows   -> sine position embedding of the rendered points, transformer encoder (attention on nr_attention_fwd/bwd),
+                  three heads -> radar_output -> Hungarian-matched "nll" | "euclidean" loss                        (:463-491,652-662)
+                  [nr_radar_assign / nr_radar_loss: cost matrix, linear sum assignment and loss on the device -- the reference
+                   copies the cost matrix to the host and calls scipy every step, radar_utils.py:78]
+
+The segment is a small fixed-shape torch.autograd graph over two leaves (rendered features [B,C], depth [B]) whose heavy
+nodes are HIP launches; it contains no host read, so it is captured into the step's hipGraph with everything else.
+`FusedTrainStep.set_decoders` runs it between the field forward and nr_render_train and feeds d loss / d features and
+d loss / d depth to the render backward (grad_features_extra / grad_depth_extra).
+"""
+from ctypes import byref
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import _lib, ops
+from ._lib import NrLidarLosses, check
+
+
+@dataclass
+class DecoderLossSettings:
+    """LossSettings of models/neuradar.py:80-115 (the decoder-side entries)."""
+
+    rgb_mult: float = 5.0
+    depth_mult: float = 0.01
+    intensity_mult: float = 0.1
+    quantile_threshold: float = 0.95
+    non_return_lidar_distance: float = 150.0
+    non_return_loss_mult: float = 0.1
+    ray_drop_loss_mult: float = 0.01
+    radar_mult: float = 0.02
+    radar_loss_type: str = "nll"  # the reference's default (:114); "euclidean" = the deterministic head
+
+
+class _LidarLosses(torch.autograd.Function):
+    """nr_lidar_depth_quantile + nr_lidar_losses: (depth [B], y [n,2]) -> loss scalar; gradients to both."""
+
+    @staticmethod
+    def forward(ctx, depth, y, cfg: NrLidarLosses, keep):
+        depth, y = ops._f32(depth, "depth"), ops._f32(y, "lidar decoder outputs")
+        n = int(cfg.n)
+        dev = depth.device
+        un = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        stats = torch.zeros(8, device=dev, dtype=torch.float32)
+        slots = torch.zeros(_lib.NR_LOSS_SLOTS, device=dev, dtype=torch.float32)
+        g_depth, g_y = torch.zeros_like(depth), torch.empty_like(y)
+        lib, p = _lib.lib(), ops._p
+        check(lib.nr_lidar_depth_quantile(p(depth), byref(cfg), p(un), p(stats), ops._stream()), "nr_lidar_depth_quantile")
+        check(lib.nr_lidar_losses(p(depth), p(y), byref(cfg), p(un), p(stats), p(g_depth), p(g_y), p(slots), ops._stream()),
+              "nr_lidar_losses")
+        ctx.save_for_backward(g_depth, g_y)
+        ctx.mark_non_differentiable(stats)
+        return slots.sum(), stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        g_depth, g_y = ctx.saved_tensors
+        return g_depth * g, g_y * g, None, None
+
+
+def lidar_losses(depth: Tensor, y: Tensor, did_return: Tensor, lidar_range: Tensor, target_intensity: Tensor, row0: int, n: int,
+                 c: DecoderLossSettings):
+    """depth / did_return (uint8) / lidar_range / target_intensity: per ray [B]; the lidar rays are rows [row0, row0 + n);
+    y [n,2] = lidar decoder outputs.  Returns (depth_mult * depth_loss + intensity_mult * intensity_loss + ray_drop_mult *
+    ray_drop_loss, stats [8]: quantile value at [2], mask count at [5], mask & returned count at [6])."""
+    assert did_return.dtype == torch.uint8 and did_return.is_contiguous() and lidar_range.is_contiguous() and target_intensity.is_contiguous()
+    cfg = NrLidarLosses()
+    cfg.did_return, cfg.range, cfg.target_intensity = did_return.data_ptr(), lidar_range.data_ptr(), target_intensity.data_ptr()
+    cfg.row0, cfg.n = int(row0), int(n)
+    cfg.non_return_distance, cfg.non_return_loss_mult, cfg.quantile = c.non_return_lidar_distance, c.non_return_loss_mult, c.quantile_threshold
+    cfg.depth_mult, cfg.intensity_mult, cfg.ray_drop_mult = c.depth_mult, c.intensity_mult, c.ray_drop_loss_mult
+    return _LidarLosses.apply(depth, y, cfg, (did_return, lidar_range, target_intensity))
+
+
+class DecoderLossHead:
+    """Decoders + their losses for ONE batch layout (segments of camera / lidar / radar rays at fixed offsets).
+
+    model: a NeuRadarHotPath built with `decoders=True` (rgb_decoder, lidar_decoder, radar_decoder, the three heads,
+    appearance_embedding).  layout: {"camera": (row0, n), "lidar": (row0, n), "radar": (row0, n)}; patch = camera patch
+    side in rays; n_scans radar scans of n_radar / n_scans rays each.  max_detections: upper bound of a scan's detections."""
+
+    def __init__(self, model, layout: Dict[str, tuple], patch: int, n_scans: int, max_detections: int,
+                 settings: Optional[DecoderLossSettings] = None, cnn_autocast: Optional[torch.dtype] = None) -> None:
+        self.model, self.layout, self.patch, self.n_scans, self.max_det = model, layout, patch, n_scans, max_detections
+        self.c = settings or DecoderLossSettings()
+        self.cnn_autocast = cnn_autocast
+        dev = next(model.parameters()).device
+        n_rad = layout["radar"][1]
+        self.radar_ws = (torch.empty(_lib.lib().nr_radar_assign_workspace_bytes(n_scans, n_rad // max(n_scans, 1), max_detections),
+                                     device=dev, dtype=torch.uint8) if n_rad else None)
+        self.last: Dict[str, Tensor] = {}
+
+    def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
+               seed_epoch: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """features [B,C] rendered features, depth [B]; times [B], sensor_idx [B] int64 (appearance embedding); batch:
+        image [P,3h,3w,3], did_return [B] uint8, range [B], target_intensity [B], directions_spher [B,2],
+        radar [m,>=3], radar_seg [n_scans+1] int32.  Returns the weighted loss terms (autograd scalars)."""
+        m, c = self.model, self.c
+        B = features.shape[0]
+        if m.config.appearance_dim > 0:  # neuradar.py:518-520: every ray's features are extended by its appearance embedding
+            x = torch.cat([features, m.appearance_of(times, sensor_idx)], dim=-1)
+        else:
+            x = features
+        out: Dict[str, Tensor] = {}
+        r0, n = self.layout["camera"]
+        if n:
+            patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2)
+            if self.cnn_autocast is not None:
+                with torch.autocast("cuda", dtype=self.cnn_autocast):
+                    rgb = m.rgb_decoder(patches)
+                rgb = rgb.float()
+            else:
+                rgb = m.rgb_decoder(patches)
+            rgb = rgb.permute(0, 2, 3, 1)
+            out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
+            self.last["rgb"] = rgb
+        r0, n = self.layout["lidar"]
+        if n:
+            y = m.lidar_decoder(x[r0:r0 + n])
+            out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
+                                                                        batch["target_intensity"], r0, n, c)
+            self.last["lidar_y"] = y
+        r0, n = self.layout["radar"]
+        if n:
+            ro = m.decode_radar(x[r0:r0 + n], depth[r0:r0 + n, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
+                                seed_epoch=seed_epoch)
+            out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, c.radar_loss_type,
+                                                      mult=c.radar_mult, training=True, workspace=self.radar_ws)
+            self.last.update(radar_output=ro, assoc=assoc)
+        return out
+
+    def backward_into(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
+                      loss_slots: Tensor, seed_epoch: Optional[Tensor] = None):
+        """Run the segment on detached leaves of (features, depth), accumulate the parameter gradients into their .grad
+        buffers and the loss value into loss_slots[0]; returns (d loss / d features [B,C], d loss / d depth [B])."""
+        f = features.detach().requires_grad_(True)
+        d = depth.detach().requires_grad_(True)
+        with torch.enable_grad():
+            terms = self.losses(f, d, times, sensor_idx, batch, seed_epoch)
+            total = sum(terms.values())
+        total.backward()
+        loss_slots[0:1].add_(total.detach().reshape(1))
+        self.last["terms"] = {k: v.detach() for k, v in terms.items()}
+        g_d = d.grad if d.grad is not None else torch.zeros_like(depth)
+        return f.grad, g_d

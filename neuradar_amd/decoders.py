@@ -55,8 +55,19 @@ class _EncoderLayer(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.p_drop = dropout
 
-    def forward(self, x: Tensor, pos: Tensor) -> Tensor:
-        """forward_pre (transformer.py:176-189).  x, pos [N, n, C]; attention runs inside a scan (N = scans)."""
+    dropout_step = 0  # calls so far: part of the attention dropout's seed; a trainer that resumes sets it to its step count
+
+    def _dropout_seed(self) -> int:
+        """torch's seed + the call counter + the data-parallel rank: ranks seeded alike still draw different masks, and a
+        resumed run continues the sequence once `dropout_step` is restored (it is host state, like the trainer's step)."""
+        import torch.distributed as dist
+
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return (torch.initial_seed() + 7919 * self.dropout_step + 104729 * rank) & 0xFFFFFFFF
+
+    def forward(self, x: Tensor, pos: Tensor, seed_epoch: Optional[Tensor] = None) -> Tensor:
+        """forward_pre (transformer.py:176-189).  x, pos [N, n, C]; attention runs inside a scan (N = scans).  seed_epoch:
+        device-resident step counter the attention kernels fold into their dropout seed (captured graphs)."""
         from . import ops
 
         C = x.shape[-1]
@@ -67,9 +78,9 @@ class _EncoderLayer(nn.Module):
         p_att = self.p_drop if self.training else 0.0
         if self.attention == "hip" and C in self.HIP_WIDTHS:
             # nr_attention_fwd/bwd: exact fp32 on the matrix cores, the hash of (seed, query, key) decides the drops (a new seed
-            # per call, derived on the host from torch's seed -- no device read)
-            self._calls = getattr(self, "_calls", 0) + 1
-            att = ops.attention(q, k, v, p_att, seed=torch.initial_seed() + 7919 * self._calls)
+            # per call, derived on the host -- no device read; under graph replay the device-side seed_epoch varies it)
+            self.dropout_step += 1
+            att = ops.attention(q, k, v, p_att, seed=self._dropout_seed(), seed_epoch=seed_epoch if p_att > 0 else None)
         else:
             att = F.scaled_dot_product_attention(q, k, v, dropout_p=p_att)
         x = x + F.dropout(self.self_attn.out_proj(att), self.p_drop, self.training)
@@ -100,9 +111,9 @@ class Transformer(nn.Module):
                 nn.init.xavier_uniform_(p)
         self.d_model = d_model
 
-    def forward(self, src: Tensor, pos: Tensor) -> Tensor:
+    def forward(self, src: Tensor, pos: Tensor, seed_epoch: Optional[Tensor] = None) -> Tensor:
         """src, pos [N, n, C] -> [N, n, C]."""
-        return self.encoder.norm(self.encoder.layers[0](src, pos))
+        return self.encoder.norm(self.encoder.layers[0](src, pos, seed_epoch))
 
 
 class BasicBlock(nn.Module):
@@ -141,7 +152,8 @@ class Decoders(nn.Module):
         self.radar_uncertainty_head = mk(3, nn.Softplus())
         self.existence_probability_head = mk(1, nn.Sigmoid())
 
-    def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int) -> Tensor:
+    def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int,
+                     seed_epoch: Optional[Tensor] = None) -> Tensor:
         """neuradar.py:463-491: features / depth / (azimuth, elevation) of the radar rays, scan after scan ->
         radar_output [scans, n, 7] = (existence probability, x, y, z, three Laplace scales)."""
         C = radar_features.shape[-1]
@@ -151,7 +163,7 @@ class Decoders(nn.Module):
         xyz = torch.cat((depth * torch.cos(phi) * torch.cos(theta), depth * torch.sin(phi) * torch.cos(theta), depth * torch.sin(theta)), dim=2)
         with torch.no_grad():
             pos = sine_position_embedding(xyz.detach(), C)
-        out = self.radar_decoder(radar_features.reshape(num_radar_scans, -1, C), pos)
+        out = self.radar_decoder(radar_features.reshape(num_radar_scans, -1, C), pos, seed_epoch)
         offset = 1.5 * self.offset_head(out)
         ep = self.existence_probability_head(out)
         unc = self.radar_uncertainty_head(out)

@@ -106,6 +106,7 @@ class FusedTrainStep:
         # lidar rays of the batch (set_lidar): carving masks on the weights of all three levels; with an appearance embedding
         # and the lidar decoder in the model, the decoder and its two losses run inside the step on the lidar rows
         self.lidar = None
+        self.dec = None  # set_decoders
         self.g_features_extra = None
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
@@ -148,7 +149,8 @@ class FusedTrainStep:
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
 
     def set_lidar(self, is_lidar: Tensor, did_return: Tensor, lidar_range: Tensor, row0: int, n_lidar: int,
-                  target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None, slot: Optional[int] = None) -> None:
+                  target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None, slot: Optional[int] = None,
+                  prop_depth_loss: bool = False) -> None:
         """Describe the lidar rays of the batch (they occupy rows [row0, row0 + n_lidar) of every per-ray array; the layout is
         fixed, the values may be rewritten in place between steps): is_lidar / did_return [B] uint8, lidar_range [B] =
         metadata["directions_norm"].  Adds to the step's loss, for those rays,
@@ -157,7 +159,12 @@ class FusedTrainStep:
             nr_interlevel_loss_to_density;
           * when the model has an appearance embedding and a lidar decoder (config.appearance_dim > 0, config.lidar_decoder):
             decoder([rendered features | appearance(time, sensor_idx)]) -> intensity MSE on returning rays + ray-drop BCE
-            (neuradar.py:432-452,624-636,692-700), with target_intensity [B] and sensor_idx [B] int64.
+            (neuradar.py:432-452,692-700), with target_intensity [B] and sensor_idx [B] int64.  NOTE: this stand-alone lidar
+            segment averages the intensity term over ALL returning rays and has no lidar depth terms; the reference's full
+            lidar loss (95 % quantile mask on the depth L1, intensity on mask & returned, non-return targets, per-proposal
+            depth losses: neuradar.py:612-650) is what `set_decoders` + prop_depth_loss=True compute.
+          * prop_depth_loss=True: depth_loss_i of both proposal levels (neuradar.py:641-648,679-688; prop_lidar_loss_mult *
+            depth_mult * mean over the lidar rays, non-returns pulled beyond 150 m), inside nr_interlevel_loss_to_density.
         slot: with pipelined batches (two buffer sets) call once per set; forward_backward(slot=k) uses set k's arrays."""
         from ._lib import NrLidarSup
 
@@ -170,10 +177,13 @@ class FusedTrainStep:
             s = NrLidarSup()
             s.is_lidar, s.did_return, s.range = is_lidar.data_ptr(), did_return.data_ptr(), lidar_range.data_ptr()
             s.carving_epsilon, s.non_return_distance, s.weight = c.carving_epsilon, c.non_return_lidar_distance, weight
+            s.depth_weight, s.non_return_loss_mult = 0.0, c.non_return_loss_mult
             return s
 
         self.lidar["main"] = sup(c.carving_mult / max(n_lidar, 1))
         self.lidar["prop"] = sup(c.prop_lidar_loss_mult * c.carving_mult / max(n_lidar, 1))
+        if prop_depth_loss:
+            self.lidar["prop"].depth_weight = c.prop_lidar_loss_mult * c.depth_mult / max(n_lidar, 1)
         self.lidar["decoder"] = c.appearance_dim > 0 and c.lidar_decoder and target_intensity is not None
         if self.lidar["decoder"]:
             A = c.appearance_dim
@@ -190,6 +200,17 @@ class FusedTrainStep:
             slots = prev if isinstance(prev, list) else [None, None]
             slots[slot] = self.lidar
             self.lidar = slots
+
+    def set_decoders(self, head, batches, sensor_idx: Tensor) -> None:
+        """Supervise through the modality decoders (decoder_losses.DecoderLossHead: RGB CNN on the camera patches, lidar MLP +
+        the reference's quantile-masked lidar losses, radar transformer + heads + Hungarian-matched radar loss) instead of the
+        bench loss on the rendered features / depth: between nr_field_fwd and nr_render_train the step composites, runs the
+        head's autograd segment (HIP launches + torch glue, no host read) and hands d loss / d features, d loss / d depth to
+        the render backward.  batches[slot]: the dict DecoderLossHead.losses reads (image, did_return, range,
+        target_intensity, directions_spher, radar, radar_seg), one per buffer set; sensor_idx [B] int64.  forward_backward
+        then needs the rays' `times`."""
+        assert self.C == self.cfg.field.nff_out_dim
+        self.dec = dict(head=head, batches=list(batches), sensor_idx=sensor_idx)
 
     def _timed(self, name: str, launch):
         """Run `launch()` (one library call on the current stream); with self.timers set, bracket it with
@@ -288,7 +309,7 @@ class FusedTrainStep:
         RCCL/xGMI beside the main chain, the small-parameter bucket last; Adam applies 1/world (DDP's mean)."""
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
-        assert target_features.shape[1] == self.C and self.C <= 32
+        assert self.C <= 32 and (target_features is None or target_features.shape[1] == self.C)
         main = torch.cuda.current_stream()
         side = self._side_streams() if self.overlap else [main, main]
         lam, scal = c.power_lambda, c.power_scaling
@@ -417,11 +438,23 @@ class FusedTrainStep:
                   "lidar_decoder_bwd")
             check(lib.nr_appearance_concat_bwd(p(lid["g_x"]), self.C, emb.shape[1], p(times), p(lid["sensor_idx"]), c.duration, E,
                                                r0, nl_, p(self.g_features_extra), p(emb.grad), emb.shape[0], st), "appearance_bwd")
+        g_f_extra = self.g_features_extra if (lid is not None and lid["decoder"]) else None
+        g_d_extra, rgb_mult, depth_mult = None, c.rgb_mult, c.depth_mult
+        if self.dec is not None:
+            # the decoders' losses replace the direct supervision: composite -> decoder segment (autograd over HIP launches)
+            # -> gradients on the rendered features / depth, which re-enter the render backward below
+            assert times is not None, "the decoders need the rays' times (appearance embedding)"
+            check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
+                                       p(self.features), p(self.depth), st), "composite_fwd")
+            epoch = optimizers[0].step_t if optimizers is not None else None
+            g_f_extra, g_d_extra = self._timed("decoders", lambda: self.dec["head"].backward_into(
+                self.features, self.depth, times, self.dec["sensor_idx"], self.dec["batches"][slot], self.loss, seed_epoch=epoch))
+            rgb_mult = depth_mult = 0.0
+            target_features = target_depth = None
         check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
-                                  p(target_depth), B, Sm, self.C, c.rgb_mult, c.depth_mult, c.distortion_loss_mult,
+                                  p(target_depth), B, Sm, self.C, rgb_mult, depth_mult, c.distortion_loss_mult,
                                   p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
-                                  p(self.g_feature), p(self.loss),
-                                  p(self.g_features_extra) if (lid is not None and lid["decoder"]) else None,
+                                  p(self.g_feature), p(self.loss), p(g_f_extra), p(g_d_extra),
                                   byref(lid["main"]) if lid is not None else None, st), "render_train")
         # ---- backward.  The field's MFMA backward needs 1 wave/SIMD worth of registers and ~127 KB of LDS per
         #      workgroup, so LDS-heavy kernels sharing the CUs with it (and it with them) crawl: forking all three

@@ -163,15 +163,15 @@ class _Attention(torch.autograd.Function):
     """nr_attention_fwd / nr_attention_bwd: single-head softmax attention per scan, q / k / v [N, n, D]."""
 
     @staticmethod
-    def forward(ctx, q, k, v, dropout_p, seed, keep_mask):
+    def forward(ctx, q, k, v, dropout_p, seed, keep_mask, seed_epoch=None):
         q, k, v = _f32(q, "q"), _f32(k, "k"), _f32(v, "v")
         N, n, D = q.shape
         out, lse = torch.empty_like(q), torch.empty((N, n), device=q.device, dtype=torch.float32)
         ws = torch.empty(max(int(_lib.lib().nr_attention_workspace_floats(N, n, D)), 1), device=q.device, dtype=torch.float32)
-        check(_lib.lib().nr_attention_fwd(_p(q), _p(k), _p(v), N, n, D, float(dropout_p), int(seed) & 0xFFFFFFFF, _p(keep_mask), _p(out),
-                                          _p(lse), _p(ws), _stream()), "nr_attention_fwd")
+        check(_lib.lib().nr_attention_fwd(_p(q), _p(k), _p(v), N, n, D, float(dropout_p), int(seed) & 0xFFFFFFFF, _p(seed_epoch), _p(keep_mask),
+                                          _p(out), _p(lse), _p(ws), _stream()), "nr_attention_fwd")
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.cfg, ctx.mask, ctx.ws = (float(dropout_p), int(seed) & 0xFFFFFFFF), keep_mask, ws
+        ctx.cfg, ctx.mask, ctx.ws, ctx.epoch = (float(dropout_p), int(seed) & 0xFFFFFFFF), keep_mask, ws, seed_epoch
         return out
 
     @staticmethod
@@ -180,16 +180,18 @@ class _Attention(torch.autograd.Function):
         N, n, D = q.shape
         gq, gk, gv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
         check(_lib.lib().nr_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(g.contiguous().float()), N, n, D, ctx.cfg[0], ctx.cfg[1],
-                                          _p(ctx.mask), _p(gq), _p(gk), _p(gv), _p(ctx.ws), _stream()), "nr_attention_bwd")
-        return gq, gk, gv, None, None, None
+                                          _p(ctx.epoch), _p(ctx.mask), _p(gq), _p(gk), _p(gv), _p(ctx.ws), _stream()), "nr_attention_bwd")
+        return gq, gk, gv, None, None, None, None
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, dropout_p: float = 0.0, seed: int = 0, keep_mask: Optional[Tensor] = None) -> Tensor:
+def attention(q: Tensor, k: Tensor, v: Tensor, dropout_p: float = 0.0, seed: int = 0, keep_mask: Optional[Tensor] = None,
+              seed_epoch: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T / sqrt(D)) (with dropout on the probabilities) v, one head, per scan: q, k, v [N, n, D], D in {32, 48, 64}
     (what nn.MultiheadAttention(d_model, nhead=1) computes between its projections).  keep_mask [N, n, n] of 0 / 1 replaces
-    the kernel's own dropout decisions (tests)."""
+    the kernel's own dropout decisions (tests).  seed_epoch: device-resident float step counter folded into the seed by the
+    kernels (a captured graph then draws new masks on every replay)."""
     return _Attention.apply(q.contiguous(), k.contiguous(), v.contiguous(), dropout_p, seed,
-                            None if keep_mask is None else keep_mask.contiguous().float())
+                            None if keep_mask is None else keep_mask.contiguous().float(), seed_epoch)
 
 
 class _Field(torch.autograd.Function):
@@ -491,6 +493,51 @@ def depth_from_weights(weights: Tensor, euclid: Tensor) -> Tensor:
     check(_lib.lib().nr_depth_from_weights(_p(weights), _p(_f32(euclid, "euclid")), B, S, _p(depth), _stream()),
           "nr_depth_from_weights")
     return depth
+
+
+# ------------------------------------------------------------------------------------------------ radar point-set loss
+def radar_assign(pred: Tensor, detections: Tensor, seg: Tensor, max_detections: int, cost_type: str = "euclidean",
+                 workspace: Optional[Tensor] = None) -> Tensor:
+    """nr_radar_assign: pred [scans, n, 7], detections [m_total, >= 3], seg [scans + 1] int32 (device) -> assoc [scans, n] int32
+    (matched detection of every prediction inside its scan, -1 = none): the Hungarian association of
+    radar_utils.py:75-83, no host read."""
+    pred, detections = _f32(pred.detach(), "radar predictions"), _f32(detections, "radar detections")
+    assert pred.dim() == 3 and pred.shape[2] == 7 and seg.dtype == torch.int32 and seg.is_cuda and seg.numel() == pred.shape[0] + 1
+    N, n = pred.shape[:2]
+    need = _lib.lib().nr_radar_assign_workspace_bytes(N, n, max_detections)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=pred.device, dtype=torch.uint8)
+    assoc = torch.empty((N, n), device=pred.device, dtype=torch.int32)
+    check(_lib.lib().nr_radar_assign(_p(pred), N, n, _p(detections), detections.shape[1], _p(seg), max_detections,
+                                     {"euclidean": 0, "nll": 1}[cost_type], _p(assoc), _p(workspace), _stream()), "nr_radar_assign")
+    return assoc
+
+
+class _RadarLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, detections, seg, assoc, loss_type, mult):
+        pred = _f32(pred, "radar predictions")
+        N, n = pred.shape[:2]
+        g_pred = torch.empty_like(pred)
+        slots = torch.zeros(_lib.NR_LOSS_SLOTS, device=pred.device, dtype=torch.float32)
+        check(_lib.lib().nr_radar_loss(_p(pred), N, n, _p(detections), detections.shape[1], _p(seg), _p(assoc),
+                                       {"euclidean": 0, "nll": 1}[loss_type], mult, _p(g_pred), _p(slots), _stream()), "nr_radar_loss")
+        ctx.save_for_backward(g_pred)
+        return slots.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_pred,) = ctx.saved_tensors
+        return g_pred * g, None, None, None, None, None
+
+
+def radar_loss(pred: Tensor, detections: Tensor, seg: Tensor, max_detections: int, loss_type: str = "nll", mult: float = 1.0,
+               training: bool = True, workspace: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """calculate_radar_loss (radar_utils.py:54-93) * mult on the device: association on the euclidean cost while training
+    (:77-78; on the loss type's own cost otherwise), then the matched loss.  Returns (loss scalar, assoc [scans, n])."""
+    detections = _f32(detections, "radar detections")
+    assoc = radar_assign(pred, detections, seg, max_detections, "euclidean" if training else loss_type, workspace)
+    return _RadarLoss.apply(pred, detections, seg, assoc, loss_type, float(mult)), assoc
 
 
 # ------------------------------------------------------------------------------------------------ optimizer

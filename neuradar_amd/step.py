@@ -58,6 +58,11 @@ class HotPathConfig:
     prop_lidar_loss_mult: float = 0.1  # :96
     non_return_loss_mult: float = 0.1
     quantile_threshold: float = 0.95
+    # the modality decoders of neuradar.py:225-278 (RGB CNN, lidar MLP, radar transformer + heads) as attributes of the model,
+    # under the reference's own names; with them the fused step can supervise through the decoders (FusedTrainStep.set_decoders)
+    decoders: bool = False
+    radar_mult: float = 0.02
+    radar_loss_type: str = "nll"  # LossSettings.radar_loss_type (:114); "euclidean" = the deterministic head
 
 
 class NeuRadarHotPath(nn.Module):
@@ -84,7 +89,14 @@ class NeuRadarHotPath(nn.Module):
         if c.appearance_dim > 0:
             self._num_embeds_per_sensor = math.ceil(c.duration * c.temporal_appearance_freq)
             self.appearance_embedding = nn.Embedding(c.num_sensors * self._num_embeds_per_sensor, c.appearance_dim)
-        if c.lidar_decoder:  # neuradar.py:241-248: per-ray MLP on the rendered features (+ appearance embedding)
+        if c.decoders:  # neuradar.py:225-278: registered under the reference's attribute names (state dicts interchange)
+            from .decoders import Decoders
+
+            dec = Decoders(n_features=c.field.nff_out_dim + c.appearance_dim)
+            for name, child in dec.named_children():
+                self.add_module(name, child)
+            object.__setattr__(self, "_decoders", dec)  # the methods (decode_radar, forward) -- not a second registration
+        elif c.lidar_decoder:  # neuradar.py:241-248: per-ray MLP on the rendered features (+ appearance embedding)
             from .mlp import MLP
 
             self.lidar_decoder = MLP(in_dim=c.field.nff_out_dim + c.appearance_dim, layer_width=32, out_dim=2, num_layers=3,
@@ -98,9 +110,29 @@ class NeuRadarHotPath(nn.Module):
             self.dynamic_actors.get_param_groups(groups)  # "trajectory_opt" (dynamic_actors.py:203-205)
         if self.config.appearance_dim > 0:
             groups["fields"] += list(self.appearance_embedding.parameters())
-        if self.config.lidar_decoder:
+        if self.config.lidar_decoder or self.config.decoders:
             groups["fields"] += list(self.lidar_decoder.parameters())  # neuradar.py:343
+        if self.config.decoders:  # neuradar.py:344-353
+            groups["cnn"] = list(self.rgb_decoder.parameters())
+            groups["transformer"] = [p for m in (self.radar_decoder, self.offset_head, self.radar_angle_head,
+                                                 self.radar_uncertainty_head, self.existence_probability_head)
+                                     for p in m.parameters()]
         return groups
+
+    def appearance_of(self, times: Tensor, sensor_idx: Tensor) -> Tensor:
+        """_get_appearance_embedding (neuradar.py:550-568) from per-ray arrays: times [B], sensor_idx [B] int64 -> [B, A]."""
+        from types import SimpleNamespace
+
+        return self._get_appearance_embedding(SimpleNamespace(times=times.reshape(-1, 1), metadata={"sensor_idxs": sensor_idx.reshape(-1, 1)}))
+
+    def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int, seed_epoch=None):
+        """decode_features, radar branch (neuradar.py:463-491) -> radar_output [scans, n, 7]."""
+        return self._decoders.decode_radar(radar_features, depth, directions_spher, num_radar_scans, seed_epoch=seed_epoch)
+
+    def decode_features(self, features: Tensor, patch_size, depth: Tensor, directions_spher: Tensor, is_lidar=None, is_radar=None,
+                        num_radar_scans=None):
+        """neuradar.py:410-493: (rgb, intensity, ray_drop_logit, radar_output)."""
+        return self._decoders(features, patch_size, depth, directions_spher, is_lidar, is_radar, num_radar_scans)
 
     def _get_ray_samples(self, bundle: RayBundle, t_rand=None, jitters=(None, None)):
         """neuradar.py:570-586."""

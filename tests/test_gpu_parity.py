@@ -671,7 +671,7 @@ def test_fused_render_matches_separate_kernels(S, C):
 
     a, b = outs(), outs()
     _lib.check(lib.nr_render_train(p(alpha), p(feature), p(eu), p(sp), p(tf), p(td), B, S, C, *mults, p(a["w"]), p(a["acc"]),
-                                   p(a["f"]), p(a["d"]), p(a["ga"]), p(a["gf"]), p(a["loss"]), None, None, st()), "render_train")
+                                   p(a["f"]), p(a["d"]), p(a["ga"]), p(a["gf"]), p(a["loss"]), None, None, None, st()), "render_train")
     g_f, g_d, g_w = torch.empty(B, C, **f32), torch.empty(B, **f32), torch.empty(B, S, **f32)
     _lib.check(lib.nr_composite_fwd(p(alpha), p(feature), p(eu), B, S, C, p(b["w"]), p(b["acc"]), p(b["f"]), p(b["d"]), st()), "fwd")
     _lib.check(lib.nr_supervision_loss(p(b["f"]), C, p(tf), C, p(b["d"]), p(td), B, mults[0], mults[1], p(g_f), p(g_d),

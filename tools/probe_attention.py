@@ -43,8 +43,8 @@ for n, D in SHAPES:
     o_, lse = torch.empty_like(qd), torch.empty(1, n, device=dev)
     ws = torch.empty(int(lib.nr_attention_workspace_floats(1, n, D)), device=dev)
     gq, gk, gv = (torch.zeros_like(qd) for _ in range(3))
-    fwd = lambda: lib.nr_attention_fwd(p(qd), p(kd), p(vd), 1, n, D, 0.0, 0, None, p(o_), p(lse), p(ws), st())  # noqa: E731
-    bwd = lambda: lib.nr_attention_bwd(p(qd), p(kd), p(vd), p(o_), p(lse), p(go), 1, n, D, 0.0, 0, None, p(gq), p(gk), p(gv),  # noqa: E731
+    fwd = lambda: lib.nr_attention_fwd(p(qd), p(kd), p(vd), 1, n, D, 0.0, 0, None, None, p(o_), p(lse), p(ws), st())  # noqa: E731
+    bwd = lambda: lib.nr_attention_bwd(p(qd), p(kd), p(vd), p(o_), p(lse), p(go), 1, n, D, 0.0, 0, None, None, p(gq), p(gk), p(gv),  # noqa: E731
                                        p(ws), st())
     t_f = timeit(fwd, 50)
     t_fb = t_f + timeit(bwd, 50)

@@ -21,7 +21,7 @@ tf, td = torch.rand(B, C, **f32), torch.rand(B, **f32) * 60
 w, acc, f, d = torch.empty(B, S, **f32), torch.empty(B, **f32), torch.empty(B, C, **f32), torch.empty(B, **f32)
 ga, gf, loss = torch.empty(B, S, **f32), torch.empty(B * S, C, **f32), torch.zeros(_lib.NR_LOSS_SLOTS, **f32)
 fn = lambda: lib.nr_render_train(p(alpha), p(feature), p(eu), p(sp), p(tf), p(td), B, S, C, 1.0, 0.1, 0.002, p(w), p(acc), p(f),  # noqa: E731
-                                 p(d), p(ga), p(gf), p(loss), None, None, st())
+                                 p(d), p(ga), p(gf), p(loss), None, None, None, st())
 print(f"render_train B={B} S={S} C={C}: {bench.time_kernel(fn, 50) * 1e6:7.1f} us")
 # inter-level loss (+ weights backward) of the two proposal levels
 for Sp in (64, 128):
