@@ -291,6 +291,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                        out=b_["target_intensity"][asm.offset["lidar"]:asm.offset["lidar"] + n_lidar])
                 if n_scans:
                     torch.index_select(scene.radar_points, 0, s_["scan_indices"][:n_scans], out=b_["radar"].view(n_scans, -1, b_["radar"].shape[-1]))
+            if has_actors:
                 u3 = r[n_t + 2 * n_rays + n_u:].view(3, n_rays)
                 for i_ in range(3):
                     torch.sub(1.0, torch.lt(u3[i_], flip_p[i_]).float(), alpha=2.0, out=flip_buf[slot][i_])  # -1 with probability p

@@ -93,6 +93,9 @@ class DecoderLossHead:
         self.model, self.layout, self.patch, self.n_scans, self.max_det = model, layout, patch, n_scans, max_detections
         self.c = settings or DecoderLossSettings()
         self.cnn_autocast = cnn_autocast
+        # MIOpen's immediate mode picked its naive (non-tuned) kernels for one 7x7 layer in about every second step of the bench
+        # (17 ms instead of 0.3): let it search once per shape and cache the choice
+        torch.backends.cudnn.benchmark = True
         dev = next(model.parameters()).device
         n_rad = layout["radar"][1]
         self.radar_ws = (torch.empty(_lib.lib().nr_radar_assign_workspace_bytes(n_scans, n_rad // max(n_scans, 1), max_detections),
@@ -113,7 +116,8 @@ class DecoderLossHead:
         out: Dict[str, Tensor] = {}
         r0, n = self.layout["camera"]
         if n:
-            patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2)
+            # [P, h, w, C] -> packed NCHW (MIOpen falls back to naive kernels on the permuted, non-packed view: 28 ms per step)
+            patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2).contiguous()
             if self.cnn_autocast is not None:
                 with torch.autocast("cuda", dtype=self.cnn_autocast):
                     rgb = m.rgb_decoder(patches)

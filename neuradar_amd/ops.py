@@ -486,13 +486,32 @@ def accumulate_along_rays(weights: Tensor, values: Optional[Tensor] = None) -> T
     return _Accumulate.apply(weights, values)
 
 
+class _DepthFromWeights(torch.autograd.Function):
+    """nr_depth_from_weights; backward through nr_accumulate_bwd with values = the samples' midpoints (d depth / d w_s = mid_s:
+    the lidar depth losses on the proposal levels reach the proposal weights this way, neuradar.py:641-648)."""
+
+    @staticmethod
+    def forward(ctx, weights, euclid):
+        weights, euclid = _f32(weights, "weights"), _f32(euclid, "euclid")
+        B, S = weights.shape
+        depth = torch.empty((B,), device=weights.device, dtype=torch.float32)
+        check(_lib.lib().nr_depth_from_weights(_p(weights), _p(euclid), B, S, _p(depth), _stream()), "nr_depth_from_weights")
+        ctx.save_for_backward(weights, euclid)
+        return depth
+
+    @staticmethod
+    def backward(ctx, g):
+        weights, euclid = ctx.saved_tensors
+        B, S = weights.shape
+        mid = ((euclid[:, :-1] + euclid[:, 1:]) / 2.0).contiguous()
+        g_w = torch.empty_like(weights)
+        check(_lib.lib().nr_accumulate_bwd(_p(weights), _p(mid), _p(g.contiguous()), B, S, 1, _p(g_w), None, _stream()), "nr_accumulate_bwd")
+        return g_w, None
+
+
 def depth_from_weights(weights: Tensor, euclid: Tensor) -> Tensor:
-    weights = _f32(weights.detach(), "weights")
-    B, S = weights.shape
-    depth = torch.empty((B,), device=weights.device, dtype=torch.float32)
-    check(_lib.lib().nr_depth_from_weights(_p(weights), _p(_f32(euclid, "euclid")), B, S, _p(depth), _stream()),
-          "nr_depth_from_weights")
-    return depth
+    """render_depth_simple (models/neurad.py:721-728): sum_s w_s (e_s + e_{s+1}) / 2; differentiable in the weights."""
+    return _DepthFromWeights.apply(weights, euclid.detach())
 
 
 # ------------------------------------------------------------------------------------------------ radar point-set loss

@@ -206,7 +206,7 @@ def test_transformer_layer_with_hip_attention(monkeypatch):
 
     y_hip, g_hip = run(hip)
     y_tor, g_tor = run(tor)
-    monkeypatch.setattr(ops, "attention", lambda q, k, v, p, seed=0: _attention_reference(q, k, v, None, 0.0).float())
+    monkeypatch.setattr(ops, "attention", lambda q, k, v, p, seed=0, seed_epoch=None: _attention_reference(q, k, v, None, 0.0).float())
     y_ref, g_ref = run(hip)
     assert_close(y_hip, y_ref, rtol=1e-4, atol_scale=1e-5, what="encoder output, hip attention")
     assert_close(g_hip, g_ref, rtol=1e-3, atol_scale=1e-4, what="input gradient, hip attention")

@@ -31,7 +31,7 @@ def _decoder_model(n_features):
 
 def _load_reference_parameters(dec, names=None):
     g = load_golden("model")
-    sd = {k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}
+    sd = {k[len("param."):]: v for k, v in g.items() if k.startswith("param.") and torch.is_tensor(v)}
     missing = dec.load_state_dict(sd, strict=False)
     assert not [k for k in missing.missing_keys if "num_batches_tracked" not in k], missing
     return sd
@@ -75,14 +75,16 @@ def test_decoder_loss_head_vs_reference_training_branch(loss_type):
     assert_close(grads[0].cpu(), g[t + "g_features"], rtol=1e-3, atol_scale=1e-4, what="d loss / d features")
     assert_close(grads[1].cpu(), g[t + "g_depth"][:, 0], rtol=1e-3, atol_scale=1e-5, what="d loss / d depth")
     checked = 0
+    # (a convolution bias in front of a training-mode batch norm has a mathematically zero gradient: rounding noise ~1e-8 on
+    # both sides, hence the absolute floor)
     for k, gr in zip(names, grads[2:]):
         scale = float(g[t + "gabs." + k])
         if gr is None:
             assert scale == 0.0, k
             continue
-        assert abs(float(gr.double().sum()) - float(g[t + "gsum." + k])) <= 1e-3 * scale + 1e-12, k
-        assert abs(float(gr.double().abs().sum()) - scale) <= 1e-3 * scale + 1e-12, k
-        if (t + "grad." + k) in g:
+        assert abs(float(gr.double().sum()) - float(g[t + "gsum." + k])) <= 1e-3 * scale + 1e-6, k
+        assert abs(float(gr.double().abs().sum()) - scale) <= 1e-3 * scale + 1e-6, k
+        if (t + "grad." + k) in g and scale > 1e-5:
             assert_close(gr.cpu(), g[t + "grad." + k], rtol=2e-3, atol_scale=2e-4, what="grad " + k)
         checked += 1
     assert checked > 40
@@ -241,6 +243,9 @@ def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type):
             continue
         if ref[n_] is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n_
+            continue
+        if float(ref[n_].abs().sum()) < 1e-5 and "main_branch" in n_ and n_.endswith("bias"):
+            assert float(p.grad.abs().sum()) < 1e-5, n_  # convolution bias in front of a training-mode batch norm: zero up to rounding
             continue
         assert_close(p.grad.cpu(), ref[n_].cpu(), rtol=2e-3, atol_scale=2e-4, what="fused grad " + n_)
         checked += 1
