@@ -185,11 +185,15 @@ class SyntheticScene:
         return idx.reshape(-1, 3)
 
 
-def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=False, mixed=None):
+def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=False, mixed=None, scene_targets=False):
     """Returns (fwd_bwd, optim) closures; together they are one training step.
 
     fused=True: the autograd-free FusedTrainStep (the same kernels, chained by hand over preallocated
-    buffers); fused=False: the modular torch.autograd path through the drop-in modules."""
+    buffers); fused=False: the modular torch.autograd path through the drop-in modules.
+
+    scene_targets: supervise with an analytic street canyon (ground plane z = 0, walls at y = +-12 m, nothing beyond 200 m)
+    instead of per-slot random targets: depth and features of every ray are functions of where the ray hits it, lidar ranges
+    likewise, so a model trained for a thousand steps converges to surfaces the way it does on real data (the "trained" block)."""
     from neuradar_amd.sensors import scale_pixel_area
 
     tgt_f, tgt_d = targets
@@ -299,10 +303,28 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             return s_["origins"], s_["directions"], s_["pixel_area"], None
 
         rays = [None, None]
+        if scene_targets:
+            Wf = 0.3 * torch.randn(3, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(77))
+            tgt_slots = [(torch.empty(n_rays, 32, device=dev), torch.empty(n_rays, device=dev)) for _ in range(2)]
+
+            def canyon(slot, o_, d_):
+                big = torch.full_like(d_[:, 0], 200.0)
+                tg = torch.where(d_[:, 2] < -1e-6, -o_[:, 2] / d_[:, 2].clamp(max=-1e-6), big)
+                tw = torch.where(d_[:, 1].abs() > 1e-6, (12.0 * torch.sign(d_[:, 1]) - o_[:, 1]) / torch.where(d_[:, 1].abs() > 1e-6, d_[:, 1], big), big)
+                depth = torch.minimum(torch.minimum(tg, tw), big)
+                tf_, td_ = tgt_slots[slot]
+                td_.copy_(depth)
+                torch.mul(torch.sin((o_ + depth[:, None] * d_) @ Wf), 0.5, out=tf_)
+                if n_lidar:  # the lidar measures the same surfaces (every ray returns inside 200 m)
+                    sl_ = asm.seg("lidar")
+                    asm.slots[slot]["directions_norm"][sl_] = depth[sl_]
+                    asm.slots[slot]["did_return"][sl_] = (depth[sl_] < 150.0).to(torch.uint8)
 
         def head(slot):
             rays[slot] = assemble(slot)
             o_, d_, a_, f_ = rays[slot]
+            if scene_targets:
+                canyon(slot, o_, d_)
             stepper.prepare(slot, o_, d_, a_, f_, r[:n_t].view(n_rays, S0 + 1))
             ready[slot] = True
 
@@ -320,7 +342,8 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             else:
                 tail = lambda: hip_ops.uniform_fill(r, seed, epoch)  # noqa: E731
             o_, d_, a_, f_ = rays[k]
-            return stepper.forward_backward(o_, d_, a_, f_, None if decoders else tgt_f, None if decoders else tgt_d[:, 0],
+            tf_k, td_k = tgt_slots[k] if scene_targets else (tgt_f, tgt_d[:, 0])
+            return stepper.forward_backward(o_, d_, a_, f_, None if decoders else tf_k, None if decoders else td_k,
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
                                             reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
@@ -421,6 +444,23 @@ def pmc_traffic(workload, kernel):
     return None
 
 
+def pmc_mfma_busy(workload):
+    """SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the field MLP kernels from the newest committed PMC passes of this workload
+    (profiles/rNN_hash_kernels_pmc*.json, like pmc_traffic): {kernel: fraction}; None when no profile is committed."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hash_kernels_pmc*.json")), reverse=True):
+        doc = json.load(open(path))
+        if doc.get("workload", "cam4096_l16f2_w64") != workload:
+            continue
+        out = {k.split("<")[0]: round(v["mfma_busy_frac"], 4) for k, v in doc.get("kernels", {}).items()
+               if k.startswith("field_") and "mfma_busy_frac" in v and ("fwd" in k or "bwd" in k)}
+        if out:
+            out["source"] = os.path.basename(path)
+            return out
+    return None
+
+
 def cpu_baseline(model, stepper, fwd_bwd, targets, n_rays_sample, threads):
     """The CPU oracle (port of the reference's torch path) on a bounded sample of the SAME workload (SURVEY 8d /
     BASELINE.md section 2): the model's own parameters, the first `n_rays_sample` rays of the batch the last GPU step
@@ -458,13 +498,16 @@ def cpu_baseline(model, stepper, fwd_bwd, targets, n_rays_sample, threads):
         if it >= 2:
             times.append(time.perf_counter() - t0)
     return {"value": round(B / statistics.median(times), 1), "unit": "rays/s", "cores": threads, "kind": "port",
+            "rays": "camera rays only (the batch's leading patch: no lidar / radar rays, no decoders, no optimizer step)",
             "sample": f"first {B} rays of the step's own batch, the model's own parameters, fwd+bwd of the bench loss (no optimizer "
                       f"step), median of {len(times)} after 2 warm-ups, torch CPU oracle with {threads} threads "
                       f"(host: {logical} logical / {physical} physical cores)"}
 
 
-def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_cpu, min_seconds):
-    """Build `workload`, warm up, time it (see timed_block) and, on request, collect the roofline / CPU-baseline blocks."""
+def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_cpu, min_seconds, trained_steps=0):
+    """Build `workload`, warm up, time it (see timed_block) and, on request, collect the roofline / CPU-baseline blocks.
+    trained_steps > 0: the "trained" regime -- scene-consistent targets (make_step), that many training steps before the timed
+    region instead of --warmup."""
     from neuradar_amd.parallel import GradAllReducer, broadcast_parameters
     from neuradar_amd.step import FlatAdam
 
@@ -501,7 +544,8 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     # fused step: optimizer (and for world > 1 the overlapped gradient all-reduce) inside forward_backward
     fuse_opt = not args.autograd
     fwd_bwd, optim, stepper = make_step(model, scene, opts, reducer, targets, n_rays, fused=not args.autograd,
-                                        fuse_optimizer=fuse_opt, mixed=wl if "cam_rays" in wl else None)
+                                        fuse_optimizer=fuse_opt, mixed=wl if "cam_rays" in wl else None,
+                                        scene_targets=trained_steps > 0)
 
     # world > 1: the RCCL collectives are issued between kernels of the step, so the step is launched
     # eagerly (the fused step is 29 launches: the CPU stays ahead of the GPU)
@@ -523,7 +567,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             # (2: -1.2 %).  NR_GRAPH_UNROLL=1, or --steps / --warmup not multiples of it: one graph per set, in turn
             unroll = int(os.environ.get("NR_GRAPH_UNROLL", "2"))
             pair = slots is not None and fuse_opt and unroll >= 2 and unroll % 2 == 0 and args.steps % unroll == 0 \
-                and args.warmup % unroll == 0
+                and (args.warmup % unroll == 0 or trained_steps > 0)
             if pair:
                 g1 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
@@ -584,7 +628,8 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    n_warm = args.warmup if trained_steps <= 0 else -(-trained_steps // 2) * 2
+    for _ in range(n_warm):
         step()
 
     def timed_block():
@@ -652,6 +697,16 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             optim()
         barrier()
         times = stepper.kernel_times()
+        # ... and SERIALISED: the same eager step with every launch on one stream (no other kernel beside the timed one) -- what
+        # the launch site costs by itself on the step's own rows and gradients
+        stepper.timers = {}
+        overlap_was, stepper.overlap = stepper.overlap, False
+        for _ in range(10):
+            fwd_bwd()
+            optim()
+        barrier()
+        times_serial = stepper.kernel_times()
+        stepper.overlap = overlap_was
         stepper.timers = None
         S0, S1 = model.config.num_proposal_samples
         Sm = model.config.num_nerf_samples
@@ -681,6 +736,12 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                 "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
                                       "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows],
                 "field_mlp_us": {k: round(v * 1e6, 2) for k, v in mlp_times.items()}}
+        if stepper is not None and dom["kernel"] in times_serial:
+            ser = times_serial[dom["kernel"]]
+            roof["serialised_us"] = round(ser * 1e6, 2)
+            roof["frac_serialised"] = round(dom["bytes"] / ser / 1e9 / HBM_PEAK_GBS, 4)
+            roof["all_hash_kernels_serialised_us"] = {k: round(v * 1e6, 2) for k, v in times_serial.items() if k.startswith("hash_encode")}
+        roof["mfma_busy_frac"] = pmc_mfma_busy(workload)
         bwd = [r for r in rows if "bwd" in r["kernel"]]
         if stepper is not None and len(bwd) == 3:
             # the three scatters start within ~80 us of each other and share the chip (and HBM) until the longest ends:
@@ -716,6 +777,8 @@ def main():
                     "default: BASELINE.json configs[1]")
     ap.add_argument("--full-model", default="mixed16384_neuradar_full,mixed8192_vod_nll,mixed16384_neuradar_full_fp16",
                     help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
+    ap.add_argument("--trained-steps", type=int, default=1000, help="report the headline workload again after this many training "
+                    "steps on scene-consistent targets (block `trained`); 0 = skip")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step block until this much has been timed")
     ap.add_argument("--mlp-dtype", default="bfloat16", choices=["float32", "bfloat16", "float16"],
                     help="MFMA operand type of the field MLP stack (fp32 accumulation in every case)")
@@ -774,6 +837,16 @@ def main():
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
                                "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
                                            "the linear sum assignment on the device"})
+    trained = None
+    if args.trained_steps > 0 and not args.autograd:
+        # the headline workload in the TRAINED regime: scene-consistent targets, args.trained_steps training steps, then the same
+        # timing rules (the resampled rounds spread along the rays and every row carries a gradient: DESIGN.md section 5)
+        tr = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, False, min(args.min_seconds, 0.5),
+                     trained_steps=args.trained_steps)
+        trained = {"workload": tr["workload"], "steps_trained": -(-args.trained_steps // 2) * 2, "targets": "analytic street canyon (scene-consistent)",
+                   "value": round(tr["value"], 1), "unit": "rays/s", "ms_per_step": round(tr["ms_per_step"], 4),
+                   "ms_per_step_min": round(tr["ms_min"], 4), "ms_per_step_max": round(tr["ms_max"], 4), "timed_blocks": tr["blocks"],
+                   "roofline": tr["roof"]}
     if rank == 0:
         r, wl = main_res, main_res["wl"]
         line = {
@@ -791,7 +864,7 @@ def main():
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"]},
-            "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "full_model": full_model,
+            "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

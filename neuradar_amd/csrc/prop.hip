@@ -122,21 +122,52 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
   auto ld = [](const float4* q) { return *q; };
   auto stv = [](float4* q, float4 x) { *q = x; };
 #endif
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 g = ld(g4 + i);
-    const bool had_grad = g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f;
-    const uint8_t seen = seen_grad != nullptr ? seen_grad[i] : (uint8_t)1;
-    if (can_skip && !had_grad && seen == 0) continue;  // never had a gradient: m = v = 0 without reading them (4 B/param)
-    float4 mm = ld(m4 + i);
-    float4 vv = ld(v4 + i);
-    if (can_skip && !had_grad && mm.x == 0.0f && mm.y == 0.0f && mm.z == 0.0f && mm.w == 0.0f && vv.x == 0.0f && vv.y == 0.0f &&
-        vv.z == 0.0f && vv.w == 0.0f)
-      continue;  // fixed point: no parameter read, no stores (12 B/param)
-    if (seen_grad != nullptr && seen == 0) seen_grad[i] = 1;
-    float4 p = ld(p4 + i);
-    upd(p.x, g.x, mm.x, vv.x); upd(p.y, g.y, mm.y, vv.y); upd(p.z, g.z, mm.z, vv.z); upd(p.w, g.w, mm.w, vv.w);
-    stv(p4 + i, p); stv(m4 + i, mm); stv(v4 + i, vv);
-    if (zero_grad && had_grad) stv(g4 + i, g);  // a gradient that is already zero is not zeroed again (28 B/param)
+  // Memory-level parallelism: a thread walks kU groups of four parameters per trip.  Their gradients and flags are requested
+  // together, then the moments AND the parameters of the live ones together -- two dependent round trips per kU groups (the
+  // first cut took three per group: g -> (m, v) -> p; PMC: 3.7 TB/s of HBM-side traffic, 60 % of what streams reach).
+#ifndef NR_ADAM_U
+#define NR_ADAM_U 1
+#endif
+  constexpr int kU = NR_ADAM_U;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * kU) {
+    float4 g[kU];
+    uint8_t seen[kU];
+    bool live[kU], had[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const int64_t i = i0 + k * stride;
+      const bool in = i < n4;
+      g[k] = in ? ld(g4 + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      seen[k] = (in && seen_grad != nullptr) ? seen_grad[i] : (uint8_t)1;
+      live[k] = in;
+    }
+    float4 mm[kU], vv[kU], pp[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const int64_t i = i0 + k * stride;
+      had[k] = g[k].x != 0.0f || g[k].y != 0.0f || g[k].z != 0.0f || g[k].w != 0.0f;
+      // never had a gradient: m = v = 0 without reading them, the update is the identity (4 B/param)
+      if (can_skip && !had[k] && seen[k] == 0) live[k] = false;
+      if (live[k]) {
+        mm[k] = ld(m4 + i);
+        vv[k] = ld(v4 + i);
+        pp[k] = ld(p4 + i);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      if (!live[k]) continue;
+      const int64_t i = i0 + k * stride;
+      if (can_skip && !had[k] && mm[k].x == 0.0f && mm[k].y == 0.0f && mm[k].z == 0.0f && mm[k].w == 0.0f && vv[k].x == 0.0f &&
+          vv[k].y == 0.0f && vv[k].z == 0.0f && vv[k].w == 0.0f)
+        continue;  // fixed point (weights restored from a checkpoint without moments): no stores
+      if (seen_grad != nullptr && seen[k] == 0) seen_grad[i] = 1;
+      upd(pp[k].x, g[k].x, mm[k].x, vv[k].x); upd(pp[k].y, g[k].y, mm[k].y, vv[k].y);
+      upd(pp[k].z, g[k].z, mm[k].z, vv[k].z); upd(pp[k].w, g[k].w, mm[k].w, vv[k].w);
+      stv(p4 + i, pp[k]); stv(m4 + i, mm[k]); stv(v4 + i, vv[k]);
+      if (zero_grad && had[k]) stv(g4 + i, g[k]);  // a gradient that is already zero is not zeroed again (28 B/param)
+    }
   }
   if (blockIdx.x == 0)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) upd(param[i], grad[i], m[i], v[i]);

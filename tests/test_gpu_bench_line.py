@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05",
-                          "--cpu-sample-rays", "64", "--secondary", ""], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          "--cpu-sample-rays", "64", "--secondary", "", "--trained-steps", "40", "--full-model", "mixed8192_vod_nll"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -30,5 +30,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 0
     assert abs(roof["achieved"] - roof["bytes_per_launch"] / (roof["avg_us"] * 1e-6) / 1e9) < 0.01 * roof["achieved"]
+    # round 3: the dominant site by itself, the MFMA counter of the field kernels, the trained regime, the decoder workloads
+    assert roof["serialised_us"] > 0 and roof["serialised_us"] <= roof["avg_us"] * 1.25
+    assert abs(roof["frac_serialised"] - roof["bytes_per_launch"] / (roof["serialised_us"] * 1e-6) / 1e9 / roof["peak"]) < 1e-3
+    assert roof["mfma_busy_frac"] is None or all(0 <= v <= 1 for k, v in roof["mfma_busy_frac"].items() if k != "source")
+    tr = r["trained"]
+    assert tr["steps_trained"] == 40 and tr["value"] > 0 and tr["roofline"]["bound"] == "hbm" and tr["roofline"]["serialised_us"] > 0
+    fm = r["full_model"]
+    assert len(fm) == 1 and fm[0]["workload"] == "mixed8192_vod_nll" and fm[0]["value"] > 0 and fm[0]["decoders_us_in_step"] > 0
+    assert fm[0]["rays"] == {"camera": 2048, "lidar": 1599, "radar": 4545} and fm[0]["radar_loss"] == "nll"
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "rays/s" and cpu["sample"]

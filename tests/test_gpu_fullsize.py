@@ -111,3 +111,24 @@ def test_full_size_step_vs_oracle(workload, n_rays):
             diff = (a != 0) != (b != 0)
             resid = float(torch.maximum(a.abs(), b.abs())[diff].max()) if bool(diff.any()) else 0.0
             assert resid <= 1e-6 * float(b.abs().max()), f"grad {k}: rows touched on one side only carry up to {resid:.3e}"
+    if "cam_rays" not in wl:
+        return
+    # ---- the path bench.py TIMES, pinned directly: the fused step with bf16 MFMA operands on the same slice against the
+    #      oracle -- rendered outputs within 5 u of their scale (u = 2^-8, bf16's unit roundoff: the operands of five chained
+    #      layers are rounded, accumulation is fp32), the loss within 1e-3 relative
+    from neuradar_amd.fused_step import FusedTrainStep
+
+    model16 = bench.build_model(wl, torch.device(DEV), "bfloat16").train()
+    model16.load_state_dict(model.state_dict())
+    fused = FusedTrainStep(model16, n_rays, coherent_rays=1024 + 424)  # camera + radar rows sample-major, lidar rows ray-major
+    floss = fused.forward_backward(o.contiguous(), d.contiguous(), area.contiguous(), fars[:, 0].contiguous(), tf.to(DEV), td[:, 0].to(DEV),
+                                   t_rand.to(DEV), j1[:, 0].to(DEV), j2[:, 0].to(DEV))
+    fo = fused.outputs()
+    u = 2.0 ** -8
+    for key, want in (("features", ref["features"]), ("depth", ref["depth"]), ("accumulation", ref["accumulation"]),
+                      ("weights", ref["weights"]), ("prop_weights_0", ref["prop_weights_0"]), ("prop_weights_1", ref["prop_weights_1"])):
+        got, want = cpu(fo[key]).reshape(-1), want.detach().reshape(-1)
+        scale = float(want.abs().max())
+        worst = float((got - want).abs().max())
+        assert worst <= 5 * u * scale, f"fused bf16 {key}: worst |d| = {worst:.3e} at scale {scale:.3e} (> 5u)"
+    assert abs(float(floss.sum()) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(floss.sum()), float(ref_loss))
