@@ -711,7 +711,8 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         S0, S1 = model.config.num_proposal_samples
         Sm = model.config.num_nerf_samples
         pgd, mgd = model.proposal_fields[1].hashgrid.static_grid, model.field.hashgrid.static_grid
-        shapes = {f"prop_s{S0}": (n_rays * S0, pgd), f"prop_s{S1}": (n_rays * S1, pgd), f"main_s{Sm}": (n_rays * Sm, mgd)}
+        shapes = {f"prop_s{S0}": (n_rays * S0, pgd), f"prop_s{S1}": (n_rays * S1, pgd), f"main_s{Sm}": (n_rays * Sm, mgd),
+                  f"prop_s{S0}+s{S1}": (n_rays * (S0 + S1), pgd)}  # (both proposal rounds' scatters as one bin + apply pass)
         rows = []
         for name, sec in times.items():
             if not name.startswith("hash_encode"):
@@ -743,14 +744,14 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             roof["all_hash_kernels_serialised_us"] = {k: round(v * 1e6, 2) for k, v in times_serial.items() if k.startswith("hash_encode")}
         roof["mfma_busy_frac"] = pmc_mfma_busy(workload)
         bwd = [r for r in rows if "bwd" in r["kernel"]]
-        if stepper is not None and len(bwd) == 3:
+        if stepper is not None and len(bwd) in (2, 3):
             # the three scatters start within ~80 us of each other and share the chip (and HBM) until the longest ends:
             # one launch site's GB/s above is a share of that, the phase's aggregate is what the chip delivers meanwhile
             span = max(r["seconds"] for r in bwd)
             total = sum(r["bytes"] for r in bwd)
             roof["scatter_phase"] = {"sites": [r["kernel"] for r in bwd], "span_us": round(span * 1e6, 2), "bytes": total,
                                      "achieved": round(total / span / 1e9, 1), "frac": round(total / span / 1e9 / HBM_PEAK_GBS, 4),
-                                     "note": "algorithmic bytes of the three concurrent scatters / the longest one's duration; "
+                                     "note": "algorithmic bytes of the concurrent scatters / the longest one's duration; "
                                              "the main table's Adam (up to 32 B per parameter) streams beside them and is not counted"}
     if rank == 0 and world == 1 and want_cpu:
         cpu = cpu_baseline(model, stepper, fwd_bwd, targets, args.cpu_sample_rays, args.cpu_threads)

@@ -105,6 +105,19 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
                                    const float* w, const float* g_density, int n_samples, int64_t rows_sample_major,
                                    float* grad_table, float* g_w, int64_t n, void* workspace, nr_stream_t stream);
 
+/* Both proposal rounds in ONE bin pass and ONE apply pass: the rounds evaluate the same field (proposal_fields[1],
+ * models/neuradar.py:302), so their gradients scatter into the same table; round 2's row tiles follow round 1's and the
+ * apply pass walks every table slice once per step instead of once per round.  Arguments as
+ * nr_prop_density_scatter_binned, per round (x, std, feats [L, n, F] level-major with feat_stride_n = sn, g_density [B, S],
+ * n_samples, n = B * S); the workspace holds both rounds: nr_hash_encode_bwd_binned_workspace_bytes(L, F, log2T, n1p + n2p)
+ * with each n rounded up to a multiple of 512. */
+int nr_prop_density_scatter_binned2(const float* x1, const float* std1, const float* feats1, const float* g_density1,
+                                    int n_samples1, int64_t n1, const float* x2, const float* std2, const float* feats2,
+                                    const float* g_density2, int n_samples2, int64_t n2, int64_t rows_sample_major,
+                                    const float* scalings, int num_levels, int features_per_level, int log2_hashmap_size,
+                                    int64_t feat_stride_n, const float* w, float* grad_table, float* g_w, void* workspace,
+                                    nr_stream_t stream);
+
 /* Single-head self-attention of the radar decoder's transformer encoder layer (detr/models/transformer.py:
  * 176-189 via nn.MultiheadAttention(d_model, 1), models/neuradar.py:250,463-491): out = dropout(softmax(q k^T / sqrt(d))) v
  * per scan, fp32 on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products).  q, k, v, out, grad_* [n_scans, n, d]

@@ -118,12 +118,24 @@ __device__ unsigned long long g_bin_clocks[8];
 #define NR_CLK(i)
 #endif
 
+// A second row SEGMENT for the same table (the other proposal round: both rounds scatter into proposal_fields[1]'s table,
+// models/neuradar.py:302): its tiles follow the first segment's in the tile numbering, so ONE bin pass and ONE apply pass
+// serve both -- the apply pass then walks each table slice once per step instead of once per round.
+struct BinSegment {
+  const float* x;
+  const float* std;
+  const float* gout;
+  const float* g_density;
+  int64_t n, sl, sm_rays;
+  int n_samples;
+};
+
 template <int F, bool HEAD>
 __global__ void __launch_bounds__(BinCfg<F>::ROWS)
 bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
            int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int ns,
            int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, unsigned long long* __restrict__ rsum,
-           uint32_t* __restrict__ cntg, int* __restrict__ tile_exp, DensityHead head) {
+           uint32_t* __restrict__ cntg, int* __restrict__ tile_exp, DensityHead head, BinSegment seg2, int64_t nb1) {
   constexpr int ROWS = BinCfg<F>::ROWS, M = BinCfg<F>::M, WAVES = ROWS / NR_WAVE;
   // keys [M] | 64-bit sums [M][2][F].  Exactly half a CU's LDS at F = 1 (two blocks per CU), so the WAVES floats of the
   // block maximum live in the sums of the table's last slots, which are taken out of service (kReserved never matches)
@@ -153,18 +165,26 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       part[l][f] = 0.0f;
     }
   auto fetch = [&](int64_t t) {
-    const int64_t row = t * ROWS + tid;
-    const bool in = row < n;
+    const bool second = t >= nb1;  // (uniform) tiles [nb1, nb) belong to the second segment
+    const float* sx = second ? seg2.x : x;
+    const float* sstd = second ? seg2.std : std;
+    const float* sgout = second ? seg2.gout : gout;
+    const int64_t sn_rows = second ? seg2.n : n, ssl = second ? seg2.sl : sl;
+    const int64_t row = (second ? t - nb1 : t) * ROWS + tid;
+    const bool in = row < sn_rows;
     if (in) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) px[a] = x[row * 3 + a];
-      if (std != nullptr) pstd = std[row];
+      for (int a = 0; a < 3; ++a) px[a] = sx[row * 3 + a];
+      if (std != nullptr) pstd = sstd[row];
     }
-    if (HEAD) pgd = in ? head.g_density[nr_row_map(row, n, head.n_samples, head.sm_rays).out] : 0.0f;
+    if (HEAD)
+      pgd = !in ? 0.0f
+                : second ? seg2.g_density[nr_row_map(row, sn_rows, seg2.n_samples, seg2.sm_rays).out]
+                         : head.g_density[nr_row_map(row, sn_rows, head.n_samples, head.sm_rays).out];
 #pragma unroll
     for (int l = 0; l < kLevelChunk; ++l)
 #pragma unroll
-      for (int f = 0; f < F; ++f) pg[l][f] = in && l < nl ? gout[(int64_t)(level0 + l) * sl + row * sn + f] : 0.0f;
+      for (int f = 0; f < F; ++f) pg[l][f] = in && l < nl ? sgout[(int64_t)(level0 + l) * ssl + row * sn + f] : 0.0f;
   };
   fetch(tile);
 #ifdef NR_BIN_CLOCKS
@@ -597,13 +617,22 @@ extern "C" int64_t nr_hash_encode_bwd_binned_workspace_bytes(int L, int F, int l
   return carve(nullptr, L, F, g).bytes;
 }
 
+// tiles of a launch over two segments: each segment's rows rounded up to whole tiles
+static int64_t tiles_of(int F, int64_t n) {
+  const int rows = F == 1 ? BinCfg<1>::ROWS : F == 2 ? BinCfg<2>::ROWS : BinCfg<4>::ROWS;
+  return nr_cdiv(n, rows);
+}
+
 static int launch_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T, const float* gout,
                          int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace, nr_stream_t stream,
-                         const DensityHead* head_in, float* g_w) {
-  if (n == 0) return 0;
+                         const DensityHead* head_in, float* g_w, const BinSegment* second = nullptr) {
+  if (n == 0 && (second == nullptr || second->n == 0)) return 0;
   BinGeom g;
   if (!x || !gout || !scalings || !gtable || !workspace || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
-  if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0 || g.nb > INT_MAX) return NR_EINVAL;
+  if (second != nullptr && (!second->x || !second->gout || second->n < 0 || (std != nullptr) != (second->std != nullptr))) return NR_EINVAL;
+  const int64_t nb1 = tiles_of(F, n), nb2 = second != nullptr ? tiles_of(F, second->n) : 0;
+  if (!bin_geom(F, log2T, n, &g) || ((uintptr_t)workspace & 15u) != 0 || nb1 + nb2 > INT_MAX) return NR_EINVAL;
+  g.nb = nb1 + nb2;
   if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
   int64_t persistent = (BinCfg<1>::M > 4096 && F == 1 ? 1 : BinCfg<1>::M < 4096 && F == 1 ? 4 : 2) * (int64_t)nr_num_cus();  // tables per CU that fit its LDS
@@ -616,17 +645,19 @@ static int launch_binned(const float* x, const float* std, const float* scalings
     head = *head_in;
     head.partials = w.partials;
   }
+  BinSegment seg2 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  if (second != nullptr) seg2 = *second;
 #define CALL(FF)                                                                                                            \
   {                                                                                                                          \
     if (head_in != nullptr)                                                                                                  \
       hipLaunchKernelGGL((bin_kernel<FF, true>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, 0,      \
                          log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg, w.tile_exp, \
-                         head);                                                                                              \
+                         head, seg2, nb1);                                                                                   \
     else                                                                                                                     \
       for (int l0 = 0; l0 < L; l0 += kLevelChunk)                                                                            \
         hipLaunchKernelGGL((bin_kernel<FF, false>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, l0,  \
                            log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg,           \
-                           w.tile_exp, head);                                                                                \
+                           w.tile_exp, head, seg2, nb1);                                                                     \
     hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, w.rsum, w.cntg, w.tile_exp,    \
                        g.nb, g.ns, g.shift, g.cap_log2, log2T, gtable, head_in != nullptr ? w.partials : nullptr,            \
                        (int)blocks, L * FF, g_w);                                                                            \
@@ -657,6 +688,20 @@ extern "C" int nr_prop_density_scatter_binned(const float* x, const float* std, 
     return NR_EINVAL;
   const DensityHead head = {w, g_density, nullptr, n_samples, rows_sample_major};
   return launch_binned(x, std, scalings, L, F, log2T, feats, sn, sl, gtable, n, workspace, stream, &head, g_w);
+}
+
+extern "C" int nr_prop_density_scatter_binned2(const float* x1, const float* std1, const float* feats1, const float* g_density1,
+                                               int n_samples1, int64_t n1, const float* x2, const float* std2, const float* feats2,
+                                               const float* g_density2, int n_samples2, int64_t n2, int64_t rows_sample_major,
+                                               const float* scalings, int L, int F, int log2T, int64_t sn, const float* w,
+                                               float* gtable, float* g_w, void* workspace, nr_stream_t stream) {
+  if (n1 == 0 && n2 == 0) return 0;
+  if (n1 <= 0 || n2 <= 0 || n_samples1 < 1 || n_samples2 < 1 || n1 % n_samples1 != 0 || n2 % n_samples2 != 0 ||
+      n1 / n_samples1 != n2 / n_samples2 || rows_sample_major < 0 || rows_sample_major > n1 / n_samples1 || !g_density2)
+    return NR_EINVAL;
+  const DensityHead head = {w, g_density1, nullptr, n_samples1, rows_sample_major};
+  const BinSegment second = {x2, std2, feats2, g_density2, n2, n2 * F, rows_sample_major, n_samples2};
+  return launch_binned(x1, std1, scalings, L, F, log2T, feats1, sn, n1 * F, gtable, n1, workspace, stream, &head, g_w, &second);
 }
 
 #ifdef NR_BIN_CLOCKS

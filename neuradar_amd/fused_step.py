@@ -146,6 +146,21 @@ class FusedTrainStep:
                                                                           grid.log2_hashmap_size, (B - self.binned_from) * S)
                 if need > 0:
                     self.binned_ws[lvl] = torch.empty(need, device=dev, dtype=torch.uint8)
+        # both proposal rounds scatter into the same table (proposal_fields[1]): ONE bin + ONE apply pass for the two
+        # (nr_prop_density_scatter_binned2) when the density head rides inside the scatter for both -- NR_MERGE_PROP_SCATTER=1.
+        # Measured SLOWER (same call, graph replay: 2.75 vs 2.55 ms fresh, 3.30 vs 3.00 ms after 1 500 steps,
+        # profiles/r03_ab_runs.txt): the saved apply pass is worth less than the two rounds' bin passes sharing the CUs'
+        # LDS from two streams, and the heads of both chains then sit in front of the one launch.  Default: a pair per round.
+        self.merged_ws = None
+        if (self.binned_ws[0] is not None and self.binned_ws[1] is not None and self.binned_from == 0 and not self.n_actors
+                and self.pgrid.num_levels <= 8 and os.environ.get("NR_FUSE_DENSITY_BWD", "1") != "0"
+                and os.environ.get("NR_MERGE_PROP_SCATTER", "0") == "1"):
+            up = lambda v: (v + 511) // 512 * 512  # noqa: E731
+            need = self.lib.nr_hash_encode_bwd_binned_workspace_bytes(self.pgrid.num_levels, self.pgrid.features_per_level,
+                                                                      self.pgrid.log2_hashmap_size, up(B * self.S[0]) + up(B * self.S[1]))
+            if need > 0:
+                self.merged_ws = torch.empty(need, device=dev, dtype=torch.uint8)
+                self.binned_ws[0] = self.binned_ws[1] = self.merged_ws  # (the per-round workspaces are not needed)
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
 
     def set_lidar(self, is_lidar: Tensor, did_return: Tensor, lidar_range: Tensor, row0: int, n_lidar: int,
@@ -538,6 +553,20 @@ class FusedTrainStep:
         def chain_scatter(lvl):
             scatter(lvl, pg, "prop")
 
+        merged = self.merged_ws is not None and all(head_in_scatter)
+        if merged:
+            split_reduce = False  # (schedules 3 / 4 park the weight-gradient reduce on side[0] in front of round 1's head)
+
+        def merged_scatter():
+            """Both proposal rounds' scatters (density-head backward inside) as one bin pass + one apply pass."""
+            S0_, S1_ = self.S[0], self.S[1]
+            n0_, n1_ = B * S0_, B * S1_
+            check(self._timed(f"hash_encode_bwd[prop_s{S0_}+s{S1_}]", lambda: lib.nr_prop_density_scatter_binned2(
+                p(self.x01[0]), p(self.std[0]), p(self.feats[0]), p(self.g_dens[0]), S0_, n0_,
+                p(self.x01[1]), p(self.std[1]), p(self.feats[1]), p(self.g_dens[1]), S1_, n1_, self.sm,
+                p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size, Fp, p(w_dec), p(pg.hash_table.grad), p(w_dec.grad),
+                p(self.merged_ws), ops._stream())), "hash_bwd")
+
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
         # (both proposal chains on one side stream, or on the main stream in front of the main scatter: +6 % / +8 % per
         # step on the mixed batch -- the three scatters and the main table's Adam do share the chip productively)
@@ -545,10 +574,18 @@ class FusedTrainStep:
         for i_ in before:
             if side[i_] is not main:
                 side[i_].wait_stream(main)
+        if merged and before:
+            before = (0, 1)  # (a merged scatter needs both heads: the early-fork schedules start both chains early)
         for i_ in before:
-            with torch.cuda.stream(side[i_]):
+            # (merged: both heads and the scatter on ONE side stream -- a capture in which the two side streams wait for each
+            # other in turn crashed hipStreamEndCapture on this ROCm build; the heads are ~80 us each)
+            with torch.cuda.stream(side[1] if merged else side[i_]):
                 chain_head(chains[i_][0])
-                chain_scatter(chains[i_][0])
+                if not merged:
+                    chain_scatter(chains[i_][0])
+        if merged and before:
+            with torch.cuda.stream(side[1]):
+                merged_scatter()
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
             byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
             p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
@@ -556,6 +593,8 @@ class FusedTrainStep:
             late = i_ not in before
             if not (late or (split_reduce and i_ == 0)):
                 continue
+            if merged and not (split_reduce and i_ == 0):
+                stream = side[1]
             if stream is not main:
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
@@ -564,12 +603,20 @@ class FusedTrainStep:
                                                    ops._stream()), "field_grad_reduce")
                 if late:
                     chain_head(lvl)
-                    if order != "main_first":
+                    if order != "main_first" and not merged:
                         chain_scatter(lvl)
+        if merged and not before and order != "main_first":
+            with torch.cuda.stream(side[1]):
+                merged_scatter()
         scatter(2, mg, "main")
         if order == "main_first":
+            if merged and not before:
+                if side[1] is not main:
+                    side[1].wait_stream(main)
+                with torch.cuda.stream(side[1]):
+                    merged_scatter()
             for i_, (lvl, stream) in enumerate(chains):
-                if i_ in before:
+                if i_ in before or merged:
                     continue
                 if stream is not main:
                     stream.wait_stream(main)
