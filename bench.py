@@ -535,9 +535,17 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                              max_steps=20001, warmup_steps=2500))
         opts.append(FlatAdam(groups["transformer"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-7 * lr_scale,
                              max_steps=10001, warmup_steps=5000, skip=list(model.radar_angle_head.parameters())))
+    # the main table's gradient exchange: row lists where a step touches ~1 % of the rows (camera-only
+    # batches), reduce-scatter -> Adam on 1/world of the rows -> all-gather where the union over the ranks is most of the table
+    # (mixed batches: 9-22 % of the rows per rank)
+    mode = args.table_exchange
+    if mode == "auto":
+        mode = "dense" if (args.dense_allreduce or args.autograd) else ("shard" if "cam_rays" in wl else "sparse")
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
-                             table_dtype=torch.bfloat16 if args.bf16_allreduce else None,
-                             sparse_tables=not args.dense_allreduce and not args.autograd)
+                             table_dtype=torch.bfloat16 if args.bf16_allreduce else None, table_mode=mode)
+    if mode == "shard" and world > 1:
+        if opts[0].shard_buffer(opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table), rank, world) is None:
+            reducer.table_mode, reducer.sparse_tables = "dense", False
     scene = SyntheticScene(device, seed=1000 + rank, radar=wl.get("radar", "zod"))  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
     targets = (0.1 * torch.randn(n_rays, 32, device=device), 5.0 + 50.0 * torch.rand(n_rays, 1, device=device))
@@ -674,6 +682,21 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             print(f"[bench] replicas identical on {world} ranks; fraction of main-table entries moved by training: {moved:.4f}", file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_rays * args.steps / elapsed
+    exchange = None
+    if world > 1 and stepper is not None:
+        # what the gradient exchange costs the step: the same K steps once more with the exchange switched off (every rank
+        # steps on its own gradient -- AFTER the timed region and the replica check; the run ends here)
+        keep, reducer_off = reducer.world, None
+        reducer.world = 1  # make_step's closure passes `reducer` only while reducer.world > 1
+        for _ in range(4):
+            step()
+        t_off, _ = timed_block()
+        reducer.world = keep
+        ms_off = t_off / args.steps * 1e3
+        exchange = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                    "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.get_backend() == "nccl" else None,
+                    "main_table_mode": reducer.table_mode, "ms_per_step_without_exchange": round(ms_off, 4),
+                    "exposed_ms_per_step": round(ms_per_step - ms_off, 4)}
 
     roof, cpu = None, None
     mlp_times = {}
@@ -760,7 +783,8 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
               "blocks": n_blocks, "ms_min": per_block[0] / args.steps * 1e3, "ms_max": per_block[-1] / args.steps * 1e3,
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                              if reducer.last_sparse.get("mode") == "sparse" else 0)) if world > 1 else 0,
-              "exchange": (reducer.last_sparse or "dense") if world > 1 else None, "decoders_us": decoders_us, "mlp_dtype": mlp_dtype}
+              "exchange": (reducer.last_sparse or "dense") if world > 1 else None, "decoders_us": decoders_us, "mlp_dtype": mlp_dtype,
+              "exchange_cost": exchange}
     del graphs, stepper, fwd_bwd, optim, model, opts, reducer, scene
     torch.cuda.empty_cache()
     return result
@@ -793,6 +817,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (intra-op scaling of "
                     "the oracle saturates well below the host's core count)")
     ap.add_argument("--bf16-allreduce", action="store_true", help="all-reduce the table gradients in bf16")
+    ap.add_argument("--table-exchange", default="auto", choices=["auto", "sparse", "dense", "shard"],
+                    help="main table's gradient exchange for world > 1: row lists | dense all-reduce | reduce-scatter + sharded Adam + "
+                    "all-gather (auto: shard for mixed batches, sparse for camera-only ones)")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the main table's gradient densely instead of exchanging its non-zero rows")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' + "
@@ -864,7 +891,8 @@ def main():
                        "timed_blocks": r["blocks"], "ms_per_step_min": round(r["ms_min"], 4), "ms_per_step_max": round(r["ms_max"], 4),
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"]},
+                       "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"],
+                       "gradient_exchange": r["exchange_cost"]},
             "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,
         }
         print(json.dumps(line), flush=True)

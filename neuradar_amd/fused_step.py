@@ -631,13 +631,17 @@ class FusedTrainStep:
             # main table first: its list exchange holds the step's only host read, and issuing it before the
             # proposal table's all-reduce keeps the CPU from parking behind the proposal chains
             if not shared:
-                if reducer is not None:
-                    if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
-                        reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
-                    else:
-                        reducer.start(table_opt.buffers[i_main][1])
-                        reducer.wait_all()
-                table_opt.step_buffer(i_main, scale)
+                if reducer is not None and reducer.table_mode == "shard" and i_main in getattr(table_opt, "shards", {}):
+                    # reduce-scatter -> Adam on this rank's 1/world of the rows -> all-gather (parallel.shard_step)
+                    reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype)
+                else:
+                    if reducer is not None:
+                        if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
+                            reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
+                        else:
+                            reducer.start(table_opt.buffers[i_main][1])
+                            reducer.wait_all()
+                    table_opt.step_buffer(i_main, scale)
             if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
                 side[0].wait_stream(side[1])
                 if shared:

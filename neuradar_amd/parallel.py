@@ -47,7 +47,8 @@ class GradAllReducer:
     """Mean all-reduce of `.grad` over the world: big tensors in place, small ones via one flat bucket."""
 
     def __init__(self, params: Optional[Iterable[nn.Parameter]], group=None, table_dtype: Optional[torch.dtype] = None,
-                 buffers: Optional[List[torch.Tensor]] = None, sparse_tables: bool = True, separate_sparse_group: bool = False):
+                 buffers: Optional[List[torch.Tensor]] = None, sparse_tables: bool = True, separate_sparse_group: bool = False,
+                 table_mode: Optional[str] = None):
         """`params`: parameters whose .grad is reduced; or `buffers`: ready-made flat gradient buffers
         (FlatAdam.grad_buffers(): one per hash table + one holding every small parameter).
         sparse_tables: the fused step exchanges the main table's gradient as (row, value) lists
@@ -58,6 +59,14 @@ class GradAllReducer:
         order, and the fused step issues the main table's exchange first."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # how the fused step exchanges the MAIN table's gradient: "sparse" (row lists, reduce_sparse), "dense" (all-reduce),
+        # "shard" (reduce-scatter -> Adam on 1/world of the rows -> all-gather, shard_step)
+        # world == 1 normally skips every collective; force_collectives issues them anyway (a one-rank RCCL group executes the
+        # same all_gather_into_tensor / reduce_scatter_tensor calls: how the GPU tests reach the "nccl" branches on a one-GPU box)
+        self.force_collectives = False
+        self.table_mode = table_mode if table_mode is not None else ("sparse" if sparse_tables else "dense")
+        assert self.table_mode in ("sparse", "dense", "shard")
+        sparse_tables = self.table_mode == "sparse"
         self.sparse_tables = sparse_tables
         self.last_sparse: dict = {}
         self.sparse_group = dist.new_group() if (self.world > 1 and sparse_tables and separate_sparse_group) else group
@@ -74,7 +83,7 @@ class GradAllReducer:
     # ---- fine-grained interface used by FusedTrainStep: issue early, overlap, wait late -------------
     def start(self, grad: torch.Tensor) -> None:
         """Asynchronous SUM all-reduce of one gradient buffer, ordered after the current stream's work."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         if not hasattr(self, "_pending"):
             self._pending = []
@@ -92,6 +101,70 @@ class GradAllReducer:
                 grad.copy_(low)
         self._pending = []
 
+    # ---- sharded table step: reduce-scatter -> Adam on the owned rows -> all-gather ------------------
+    def shard_step(self, opt, i: int, grad_scale: float, transport: Optional[torch.dtype] = None, chunks: int = 1) -> dict:
+        """The data-parallel step of ONE big table whose gradient is dense across the ranks (the mixed batch touches 9-22 % of
+        the main table's rows per rank: the union over 8 ranks is most of the table, so row lists no longer pay).  Instead of
+        all-reduce + a replicated Adam over the whole table on every GPU:
+          1. reduce-scatter (SUM) of the gradient: rank r receives the reduced rows [lo, hi) = its 1/world of the table
+             (`transport`: optionally carried in bf16 -- half the bytes of the step's largest exchange);
+          2. Adam on those rows only (opt.shard_buffer: moments exist for the shard only; the dense 4.3 GB stream of the
+             replicated step becomes 1/world of it on every GPU);
+          3. all-gather of the updated rows into every replica (fp32, in place: replicas stay bit-identical by construction --
+             everybody receives the owner's result);
+          4. the gradient outside the shard is cleared (the owner's Adam kernel clears its own rows).
+        The same bytes on the wire as a ring all-reduce of the table (reduce-scatter + all-gather IS that all-reduce), but the
+        optimizer sits between the halves.  `chunks`: the shard is exchanged in that many pieces so that Adam of piece k runs
+        while piece k+1 is still being reduced (collectives execute in issue order on the communicator).
+        No host read, no allocation after the first call.  opt: step.FlatAdam with shard_buffer(i) applied."""
+        p, g = opt.buffers[i]
+        if self.world == 1 and not self.force_collectives:
+            opt.step_buffer(i, grad_scale)
+            return {"mode": "single"}
+        lo, hi = opt.shards[i]
+        n, per = p.numel(), hi - lo
+        nccl = dist.get_backend(self.group) == "nccl"
+        key = ("shard", g.data_ptr(), transport)
+        st = self.__dict__.setdefault("_shard_state", {}).get(key)
+        if st is None:
+            st = {}
+            if transport is not None:
+                st["low"] = torch.empty(n, device=g.device, dtype=transport)
+                st["low_out"] = torch.empty(per, device=g.device, dtype=transport)
+            if not nccl:  # gloo (CPU / one-GPU tests) has neither reduce_scatter nor in-place all_gather
+                st["mine"] = torch.empty(per, device=g.device, dtype=torch.float32)
+            self._shard_state[key] = st
+        # 1. reduce-scatter
+        if transport is not None:
+            st["low"].copy_(g)
+            if nccl:
+                dist.reduce_scatter_tensor(st["low_out"], st["low"], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(st["low"], op=dist.ReduceOp.SUM, group=self.group)
+                st["low_out"].copy_(st["low"][lo:hi])
+            g[lo:hi].copy_(st["low_out"])
+        elif nccl:
+            dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM, group=self.group)  # in place: output = input's own slice
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)  # (test backends: same result on the shard)
+        # 2. the owner's Adam (zeroes g[lo:hi])
+        opt.step_buffer(i, grad_scale)
+        # 3. all-gather of the updated rows
+        if nccl:
+            dist.all_gather_into_tensor(p, p[lo:hi], group=self.group)  # in place: input = output's own slice
+        else:
+            st["mine"].copy_(p[lo:hi])
+            dist.all_gather([p[r * per:(r + 1) * per] for r in range(self.world)], st["mine"], group=self.group)
+        # 4. the rest of the local gradient
+        if lo > 0:
+            g[:lo].zero_()
+        if hi < n:
+            g[hi:].zero_()
+        esz = 4 if transport is None else torch.empty((), dtype=transport).element_size()
+        self.last_sparse = {"mode": "shard", "rows": [per] * self.world,
+                            "bytes": int((self.world - 1) / self.world * n * (esz + 4))}
+        return self.last_sparse
+
     # ---- sparse table exchange ---------------------------------------------------------------------
     def reduce_sparse(self, grad: torch.Tensor, row_width: int, cap_rows: Optional[int] = None, ops=None) -> dict:
         """SUM of `grad` (flat view of a [rows, row_width] table gradient) over the ranks by exchanging the
@@ -103,7 +176,7 @@ class GradAllReducer:
         22 % after 600 steps.  Synchronous
         with respect to the current stream; one small host read (the ranks' row counts) per call.
         `ops`: (compact, apply) callables; default = the HIP kernels (neuradar_amd.ops)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return {"mode": "single"}
         if ops is None:
             from . import ops as hip_ops

@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--log2t", type=int, default=20)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--shard", action="store_true", help="main table: reduce-scatter -> Adam on this rank's rows -> all-gather")
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--force-collectives", action="store_true", help="world 1: issue the collectives anyway (one-rank RCCL group)")
     args = ap.parse_args()
     from neuradar_amd.fused_step import FusedTrainStep
     from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
@@ -24,7 +27,14 @@ def main():
     from neuradar_amd.parallel import GradAllReducer, broadcast_parameters, init_distributed
     from neuradar_amd.step import FlatAdam, HotPathConfig, NeuRadarHotPath
 
-    rank, world, _ = init_distributed(backend="gloo")
+    if args.force_collectives and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend=args.backend, init_method=f"tcp://127.0.0.1:{os.environ.get('MASTER_PORT', '29533')}", rank=0, world_size=1)
+        rank, world = 0, 1
+    else:
+        rank, world, _ = init_distributed(backend=args.backend)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=args.log2t))))
@@ -40,7 +50,23 @@ def main():
     unused = list(model.proposal_fields[0].parameters())
     opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, skip=unused),
             FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, skip=unused)]
-    reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()], sparse_tables=not args.dense)
+    reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
+                             table_mode="shard" if args.shard else ("dense" if args.dense else "sparse"))
+    reducer.force_collectives = args.force_collectives
+    shard = None
+    if args.shard and (world > 1 or args.force_collectives):
+        i_main = opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)
+        if args.force_collectives and world == 1:
+            reducer.world = 1
+            pb, gb = opts[0].buffers[i_main]
+            opts[0].buffers[i_main] = (pb.view(-1), gb.view(-1))
+            mb, vb = opts[0].state[i_main]
+            opts[0].state[i_main] = (mb.view(-1), vb.view(-1))
+            opts[0].shards = {i_main: (0, pb.numel())}  # one rank owns everything
+            shard = opts[0].shards[i_main]
+        else:
+            shard = opts[0].shard_buffer(i_main, rank, world)
+            assert shard is not None
     B = args.rays
     g = torch.Generator().manual_seed(42)  # the GLOBAL batch, identical in every process
     o = torch.cat([-50 + 100 * torch.rand(B, 1, generator=g), torch.randn(B, 1, generator=g), torch.full((B, 1), 1.6)], -1)
@@ -56,14 +82,15 @@ def main():
     for k in range(args.steps):
         tr, j1, j2 = draws[k]
         step.forward_backward(sl(o), sl(d), sl(area), fars, sl(tf), sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts),
-                              reducer=reducer if world > 1 else None)
+                              reducer=reducer if (world > 1 or args.force_collectives) else None)
         torch.cuda.synchronize()
         info.append(dict(reducer.last_sparse))
     out = {"rank": rank, "world": world, "exchange": info,
            "params": {n: p.detach().cpu() for n, p in model.named_parameters()},
-           "exp_avg": [m.cpu() for o_ in opts for m, _ in o_.state]}
+           "exp_avg": [m.cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
+           "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)}
     torch.save(out, f"{args.out}.rank{rank}")
-    if world > 1:
+    if world > 1 or args.force_collectives:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

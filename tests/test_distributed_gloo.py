@@ -105,6 +105,61 @@ def _sparse_worker(rank, world, port):
     dist.destroy_process_group()
 
 
+class _StubOpt:
+    """What GradAllReducer.shard_step needs of step.FlatAdam (whose Adam kernel needs a GPU): buffers, shards, step_buffer --
+    here plain SGD on the rank's rows, which also clears their gradient like the fused Adam does."""
+
+    def __init__(self, p, g, rank, world):
+        self.buffers = [(p, g)]
+        per = p.numel() // world
+        self.shards = {0: (rank * per, (rank + 1) * per)}
+
+    def step_buffer(self, i, grad_scale):
+        (p, g), (lo, hi) = self.buffers[i], self.shards[i]
+        p[lo:hi] -= 0.1 * grad_scale * g[lo:hi]
+        g[lo:hi] = 0
+
+
+def _shard_worker(rank, world, port, bf16):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from neuradar_amd.parallel import GradAllReducer, init_distributed
+
+    init_distributed(backend="gloo")
+    n = 1 << 14
+    p = torch.linspace(-1, 1, n).clone()  # identical replicas
+    p0 = p.clone()
+    red = GradAllReducer(None, buffers=[], table_mode="shard")
+    opt = None
+    for stepno in range(3):
+        g = torch.Generator().manual_seed(10 * stepno + rank)
+        grad = torch.where(torch.rand(n, generator=g) < 0.3, torch.randn(n, generator=g), torch.zeros(n))
+        total = grad.clone()
+        dist.all_reduce(total)
+        if opt is None:
+            opt = _StubOpt(p, grad, rank, world)
+        opt.buffers[0] = (p, grad)
+        info = red.shard_step(opt, 0, 1.0 / world, transport=torch.bfloat16 if bf16 else None)
+        assert info["mode"] == "shard" and info["bytes"] > 0
+        p0 -= 0.1 / world * (total.bfloat16().float() if False else total)  # the replicated step on the summed gradient
+        assert float(grad.abs().max()) == 0.0, "the local gradient must be cleared everywhere"
+        gathered = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(gathered, p)
+        assert all(torch.equal(t, gathered[0]) for t in gathered), "replicas differ after the sharded step"
+        assert torch.allclose(p, p0, rtol=2e-2 if bf16 else 1e-6, atol=2e-2 if bf16 else 1e-6), float((p - p0).abs().max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_table_step_fp32():
+    mp.spawn(_shard_worker, args=(2, _free_port(), False), nprocs=2, join=True)
+
+
+def test_two_rank_sharded_table_step_bf16_transport():
+    mp.spawn(_shard_worker, args=(2, _free_port(), True), nprocs=2, join=True)
+
+
 def test_two_rank_sparse_table_exchange():
     mp.spawn(_sparse_worker, args=(2, _free_port()), nprocs=2, join=True)
 

@@ -48,7 +48,8 @@ def _run(tmp, tag, world, extra):
 
 
 @pytest.mark.parametrize("path,extra", [("sparse", ["--log2t", "20", "--rays", "256"]), ("dense_fallback", ["--log2t", "14", "--rays", "512"]),
-                                        ("dense", ["--log2t", "16", "--rays", "512", "--dense"])])
+                                        ("dense", ["--log2t", "16", "--rays", "512", "--dense"]),
+                                        ("shard", ["--log2t", "16", "--rays", "512", "--shard"])])
 def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
     dp = _run(str(tmp_path), "dp", 2, extra)
     single = _run(str(tmp_path), "single", 1, extra + ["--steps", "1"])[0]
@@ -58,10 +59,36 @@ def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
         assert torch.equal(p, dp[1]["params"][n]), f"{path}: parameter {n} differs between the ranks after 3 steps"
     # (3) the exchange path that was meant to run did run
     modes = {e.get("mode") for e in dp[0]["exchange"]}
-    want = {"sparse": {"sparse"}, "dense_fallback": {"dense"}, "dense": {None}}[path]
+    want = {"sparse": {"sparse"}, "dense_fallback": {"dense"}, "dense": {None}, "shard": {"shard"}}[path]
     assert modes == want, f"{path}: main-table exchange modes {modes}"
     # (2) the reduced gradient of step 1 == the single-process gradient on the whole batch
     for i, (a, b) in enumerate(zip(first[0]["exp_avg"], single["exp_avg"])):
+        if path == "shard" and i == first[0]["main_buffer"]:
+            # the sharded table: every rank holds the moments of ITS rows only; together they are the single-process moments
+            (lo0, hi0), (lo1, hi1) = first[0]["shard"], first[1]["shard"]
+            assert (lo0, hi1) == (0, b.numel()) and hi0 == lo1 and a.numel() == hi0 - lo0
+            both = torch.cat([a, first[1]["exp_avg"][i]])
+            err = float((both - b.reshape(-1)).norm() / b.norm().clamp_min(1e-30))
+            assert err < 1e-4, f"shard: Adam first moment of the main table: relative L2 error {err:.3e} against the single-process run"
+            continue
         err = float((a - b).norm() / b.norm().clamp_min(1e-30))
         assert err < 1e-4, f"{path}: Adam first moment of buffer {i}: relative L2 error {err:.3e} against the single-process run"
         assert torch.equal(a, first[1]["exp_avg"][i])
+
+
+def test_rccl_branches_in_a_one_rank_group(tmp_path):
+    """The "nccl" (= RCCL) code paths that two ranks on one GPU cannot reach through gloo -- all_gather_into_tensor of the
+    row lists, the in-place reduce_scatter_tensor / all_gather_into_tensor of the sharded table step -- executed for real in a
+    one-rank RCCL group (force_collectives): same result as the step without any collective."""
+    base = ["--log2t", "16", "--rays", "256", "--steps", "2"]
+    plain = _run(str(tmp_path), "plain", 1, base)[0]
+    env_port = str(_free_port())
+    os.environ["MASTER_PORT"] = env_port
+    try:
+        for tag, extra in (("rccl_sparse", []), ("rccl_shard", ["--shard"])):
+            got = _run(str(tmp_path), tag, 1, base + extra + ["--backend", "nccl", "--force-collectives"])[0]
+            assert {e.get("mode") for e in got["exchange"]} == ({"shard"} if extra else {"sparse"}), got["exchange"]
+            for n, p in plain["params"].items():  # (float atomics: two runs agree to rounding, not bitwise)
+                torch.testing.assert_close(got["params"][n], p, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{tag}: parameter {n}: {m}")
+    finally:
+        os.environ.pop("MASTER_PORT", None)
