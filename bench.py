@@ -784,7 +784,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                              if reducer.last_sparse.get("mode") == "sparse" else 0)) if world > 1 else 0,
               "exchange": (reducer.last_sparse or "dense") if world > 1 else None, "decoders_us": decoders_us, "mlp_dtype": mlp_dtype,
-              "exchange_cost": exchange}
+              "exchange_cost": exchange, "loss": float(stepper.loss.sum()) if stepper is not None else None}
     del graphs, stepper, fwd_bwd, optim, model, opts, reducer, scene
     torch.cuda.empty_cache()
     return result
@@ -863,6 +863,7 @@ def main():
                                "radar_loss": fr["wl"].get("radar_loss"), "radar_grid": fr["wl"].get("radar", "zod"),
                                "mlp_operands": fr["mlp_dtype"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
+                               "loss_after_run": fr["loss"],
                                "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
                                            "the linear sum assignment on the device"})
     trained = None

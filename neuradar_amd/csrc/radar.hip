@@ -32,7 +32,7 @@ __device__ __forceinline__ float radar_cost(const float* __restrict__ p, const f
       c += logf(2.0f * b) + fabsf(g[a] - p[1 + a]) / b;
     }
   }
-  return isinf(c) ? kMaxCost : c;
+  return (isinf(c) || c != c) ? kMaxCost : c;  // (a NaN prediction -- a diverged fp16 run -- must not poison the search: scipy raises there)
 }
 
 // One block per (detection, scan): cost row [n] + its minimum / arg-minimum (the row duals the assignment starts from).
@@ -48,7 +48,7 @@ radar_cost_kernel(const float* __restrict__ pred, int64_t n, const float* __rest
   const float* p = pred + (int64_t)scan * n * 7;
   float* out = cost + ((int64_t)scan * m_cap + j) * n;
   float best = INFINITY;
-  int arg = 0x7fffffff;
+  int arg = 0;
   for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
     const float c = radar_cost(p + k * 7, g3, nll);
     out[k] = c;
@@ -58,7 +58,7 @@ radar_cost_kernel(const float* __restrict__ pred, int64_t n, const float* __rest
   __shared__ float sv[256];
   __shared__ int si[256];
   sv[threadIdx.x] = best;
-  si[threadIdx.x] = arg;
+  si[threadIdx.x] = best < INFINITY ? arg : 0x7fffffff;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
@@ -70,7 +70,7 @@ radar_cost_kernel(const float* __restrict__ pred, int64_t n, const float* __rest
   }
   if (threadIdx.x == 0) {
     row_min[(int64_t)scan * m_cap + j] = sv[0];
-    row_arg[(int64_t)scan * m_cap + j] = si[0];
+    row_arg[(int64_t)scan * m_cap + j] = si[0] < (int)n ? si[0] : 0;
   }
 }
 

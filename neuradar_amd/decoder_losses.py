@@ -14,6 +14,8 @@ nodes are HIP launches; it contains no host read, so it is captured into the ste
 `FusedTrainStep.set_decoders` runs it between the field forward and nr_render_train and feeds d loss / d features and
 d loss / d depth to the render backward (grad_features_extra / grad_depth_extra).
 """
+import contextlib
+import os
 from ctypes import byref
 from dataclasses import dataclass
 from typing import Dict, Optional
@@ -101,6 +103,8 @@ class DecoderLossHead:
         self.radar_ws = (torch.empty(_lib.lib().nr_radar_assign_workspace_bytes(n_scans, n_rad // max(n_scans, 1), max_detections),
                                      device=dev, dtype=torch.uint8) if n_rad else None)
         self.last: Dict[str, Tensor] = {}
+        self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"
+        self._streams = None
 
     def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
                seed_epoch: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -114,32 +118,59 @@ class DecoderLossHead:
         else:
             x = features
         out: Dict[str, Tensor] = {}
-        r0, n = self.layout["camera"]
-        if n:
-            # [P, h, w, C] -> packed NCHW (MIOpen falls back to naive kernels on the permuted, non-packed view: 28 ms per step)
-            patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2).contiguous()
-            if self.cnn_autocast is not None:
-                with torch.autocast("cuda", dtype=self.cnn_autocast):
+        # The three sensors' decoders do not depend on each other: the lidar and radar chains run on side streams beside the
+        # CNN (autograd replays every node's backward on the stream of its forward, so the backward overlaps the same way):
+        # the segment's critical path is its longest chain instead of their sum.  NR_DECODER_STREAMS=0: one stream.
+        cur = torch.cuda.current_stream()
+        if self._streams is None and self.overlap:
+            self._streams = (torch.cuda.Stream(device=features.device), torch.cuda.Stream(device=features.device))
+        s_lidar, s_radar = self._streams if self.overlap else (cur, cur)
+        for s_ in (s_lidar, s_radar):
+            if s_ is not cur:
+                s_.wait_stream(cur)
+        def side_chains():
+            r0, n = self.layout["lidar"]
+            if n:
+                with (torch.cuda.stream(s_lidar) if s_lidar is not cur else contextlib.nullcontext()):
+                    y = m.lidar_decoder(x[r0:r0 + n])
+                    out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
+                                                                                batch["target_intensity"], r0, n, c)
+                    self.last["lidar_y"] = y
+            r0, n = self.layout["radar"]
+            if n:
+                with (torch.cuda.stream(s_radar) if s_radar is not cur else contextlib.nullcontext()):
+                    ro = m.decode_radar(x[r0:r0 + n], depth[r0:r0 + n, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
+                                        seed_epoch=seed_epoch)
+                    out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, c.radar_loss_type,
+                                                              mult=c.radar_mult, training=True, workspace=self.radar_ws)
+                    self.last.update(radar_output=ro, assoc=assoc)
+
+        def camera_chain():
+            r0, n = self.layout["camera"]
+            if n:
+                # [P, h, w, C] -> packed NCHW (MIOpen falls back to naive kernels on the permuted, non-packed view: 28 ms per step)
+                patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2).contiguous()
+                if self.cnn_autocast is not None:
+                    with torch.autocast("cuda", dtype=self.cnn_autocast):
+                        rgb = m.rgb_decoder(patches)
+                    rgb = rgb.float()
+                else:
                     rgb = m.rgb_decoder(patches)
-                rgb = rgb.float()
-            else:
-                rgb = m.rgb_decoder(patches)
-            rgb = rgb.permute(0, 2, 3, 1)
-            out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
-            self.last["rgb"] = rgb
-        r0, n = self.layout["lidar"]
-        if n:
-            y = m.lidar_decoder(x[r0:r0 + n])
-            out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
-                                                                        batch["target_intensity"], r0, n, c)
-            self.last["lidar_y"] = y
-        r0, n = self.layout["radar"]
-        if n:
-            ro = m.decode_radar(x[r0:r0 + n], depth[r0:r0 + n, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
-                                seed_epoch=seed_epoch)
-            out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, c.radar_loss_type,
-                                                      mult=c.radar_mult, training=True, workspace=self.radar_ws)
-            self.last.update(radar_output=ro, assoc=assoc)
+                rgb = rgb.permute(0, 2, 3, 1)
+                out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
+                self.last["rgb"] = rgb
+
+        if self.overlap:  # the side streams' launches first, the CNN beside them
+            side_chains()
+            camera_chain()
+        else:
+            # (one stream: CNN first.  The other order -- MIOpen's convolutions behind the radar chain on ONE captured stream --
+            # ended in a GPU memory fault on graph replay on this ROCm build, eagerly it runs; not understood, avoided)
+            camera_chain()
+            side_chains()
+        for s_ in (s_lidar, s_radar):
+            if s_ is not cur:
+                cur.wait_stream(s_)
         return out
 
     def backward_into(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
