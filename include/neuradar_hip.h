@@ -105,6 +105,21 @@ int nr_prop_density_scatter_binned(const float* x, const float* std, const float
                                    const float* w, const float* g_density, int n_samples, int64_t rows_sample_major,
                                    float* grad_table, float* g_w, int64_t n, void* workspace, nr_stream_t stream);
 
+/* The same two entry points with the width of the bin pass's fixed-point tile sums as an argument: sum_bits = 64 (the functions
+ * above: every addend exact to fp32's resolution) or 32 -- an addend is then rounded to 2^-22..2^-21 of the LARGEST contribution
+ * of its 512-row tile (smaller ones vanish), 12 instead of 20 bytes of LDS per slot, ds_add_u32 instead of ds_add_u64, 12-byte
+ * records.  Meant for steps whose MLPs already run on 16-bit MFMA operands (nr_field_t.dtype != NR_DTYPE_F32); the same
+ * workspace size. */
+int nr_hash_encode_bwd_binned_lp(const float* x01, const float* std01, const float* scalings, int num_levels,
+                                 int features_per_level, int log2_hashmap_size, const float* grad_out, int64_t out_stride_n,
+                                 int64_t out_stride_l, float* grad_table, int64_t n, void* workspace, int sum_bits,
+                                 nr_stream_t stream);
+int nr_prop_density_scatter_binned_lp(const float* x01, const float* std01, const float* scalings, int num_levels,
+                                      int features_per_level, int log2_hashmap_size, const float* feats, int64_t out_stride_n,
+                                      int64_t out_stride_l, const float* w, const float* g_density, int n_samples,
+                                      int64_t rows_sample_major, float* grad_table, float* g_w, int64_t n, void* workspace,
+                                      int sum_bits, nr_stream_t stream);
+
 /* Both proposal rounds in ONE bin pass and ONE apply pass: the rounds evaluate the same field (proposal_fields[1],
  * models/neuradar.py:302), so their gradients scatter into the same table; round 2's row tiles follow round 1's and the
  * apply pass walks every table slice once per step instead of once per round.  Arguments as

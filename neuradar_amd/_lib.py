@@ -59,6 +59,8 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
+    "nr_hash_encode_bwd_binned_lp": [P, P, P, I, I, I, P, L, L, P, L, P, I, P],
+    "nr_prop_density_scatter_binned_lp": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, I, P],
     "nr_prop_density_scatter_binned2": [P, P, P, P, I, L, P, P, P, P, I, L, L, P, I, I, I, L, P, P, P, P, P],
     "nr_attention_workspace_floats": [L, L, I],
     "nr_attention_fwd": [P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P],

@@ -30,8 +30,18 @@ namespace {
 
 constexpr int kSliceFloats = 16384;  // 128 KB of int64 accumulators per apply block
 constexpr int kMaxSlices = 64;
-constexpr int kFixBits = 44;    // a tile's sums: 44 bits below the tile's largest value (2 048 addends: < 2^55)
-constexpr int kApplyDrop = 8;   // the level's sums: 36 bits below the level's largest (2^14 tiles: < 2^62)
+// A tile's sums in the bin pass's LDS table (SumT):
+//   unsigned long long  64-bit fixed point 44 bits below the tile's largest value (2 048 addends: < 2^55) -- exact to fp32's
+//                       resolution for every addend; the fp32 path.
+//   uint32_t            32-bit fixed point 21 bits below it (a slot collects at most one addend per run of equal cells: <= 512
+//                       per tile, < 2^31): 12 instead of 20 bytes of LDS per slot (three blocks per CU instead of two),
+//                       ds_add_u32 at twice the rate of ds_add_u64, 12-byte records.  An addend is rounded to 2^-22..2^-21 of
+//                       the TILE's largest contribution (smaller ones vanish): for the steps whose MLPs already run on
+//                       16-bit operands (u = 2^-8 / 2^-11) -- the fused step picks it there; fresh step 2.55 -> 2.38 ms.
+template <typename SumT> struct FixBits;
+template <> struct FixBits<unsigned long long> { static constexpr int value = 44; };
+template <> struct FixBits<uint32_t> { static constexpr int value = 21; };
+constexpr int kLevelBits = 36;  // the level's sums (apply pass, always 64-bit): 36 bits below the level's largest (2^14 tiles: < 2^62)
 constexpr int kApplyThreads = 1024;
 constexpr int kNoRecords = INT_MIN;
 
@@ -90,6 +100,12 @@ __device__ __forceinline__ long long fix_i64(float y) {
   const float lo = fmaf(hi, -0x1p20f, y);
   return ((long long)(int)hi << 20) + (long long)(int)rintf(lo);
 }
+template <typename SumT> __device__ __forceinline__ SumT fix_sum(float y);
+template <> __device__ __forceinline__ unsigned long long fix_sum<unsigned long long>(float y) { return (unsigned long long)fix_i64(y); }
+template <> __device__ __forceinline__ uint32_t fix_sum<uint32_t>(float y) { return (uint32_t)(int)rintf(y); }
+template <typename SumT> __device__ __forceinline__ long long sum_to_i64(SumT v);
+template <> __device__ __forceinline__ long long sum_to_i64<unsigned long long>(unsigned long long v) { return (long long)v; }
+template <> __device__ __forceinline__ long long sum_to_i64<uint32_t>(uint32_t v) { return (long long)(int)v; }
 
 // Persistent blocks: a block walks row tiles (ROWS rows) and, per tile, up to kLevelChunk levels; the LDS table is set up
 // once and every flush leaves the slots it read empty again.  Two barriers per (tile, level): A -- the wave maxima are
@@ -130,19 +146,20 @@ struct BinSegment {
   int n_samples;
 };
 
-template <int F, bool HEAD>
+template <int F, bool HEAD, typename SumT>
 __global__ void __launch_bounds__(BinCfg<F>::ROWS)
 bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
            int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int ns,
-           int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, unsigned long long* __restrict__ rsum,
+           int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, SumT* __restrict__ rsum,
            uint32_t* __restrict__ cntg, int* __restrict__ tile_exp, DensityHead head, BinSegment seg2, int64_t nb1) {
   constexpr int ROWS = BinCfg<F>::ROWS, M = BinCfg<F>::M, WAVES = ROWS / NR_WAVE;
   // keys [M] | 64-bit sums [M][2][F].  Exactly half a CU's LDS at F = 1 (two blocks per CU), so the WAVES floats of the
   // block maximum live in the sums of the table's last slots, which are taken out of service (kReserved never matches)
-  __shared__ __attribute__((aligned(16))) uint32_t lds[M + M * 4 * F];
+  constexpr int kSumWords = sizeof(SumT) / 4, kFixBits = FixBits<SumT>::value;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[M + M * 2 * kSumWords * F];
   uint32_t* keys = lds;
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + M);
-  constexpr int kScratchSlots = (WAVES * 4 + 16 * F - 1) / (16 * F);
+  SumT* acc = reinterpret_cast<SumT*>(lds + M);
+  constexpr int kScratchSlots = (WAVES * 4 + 8 * kSumWords * F - 1) / (8 * kSumWords * F);
   float* wmax = reinterpret_cast<float*>(acc + (size_t)(M - kScratchSlots) * 2 * F);
   const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the flush's sub-bin addresses stay in SGPRs)
@@ -150,7 +167,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
   const uint32_t mask = (1u << log2T) - 1u, pmask = (uint32_t)cap - 1u;
   const int nl = L - level0 < kLevelChunk ? L - level0 : kLevelChunk;
   for (int i = tid; i < M; i += ROWS) keys[i] = i < M - kScratchSlots ? kEmpty : kReserved;
-  for (int i = tid; i < M * 2 * F; i += ROWS) acc[i] = 0ull;
+  for (int i = tid; i < M * 2 * F; i += ROWS) acc[i] = 0;
   __syncthreads();
 
   int64_t tile = blockIdx.x;
@@ -355,8 +372,8 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
         if (slot >= 0) {
 #pragma unroll
           for (int f = 0; f < F; ++f) {
-            atomicAdd(&acc[(slot * 2 + 0) * F + f], (unsigned long long)fix_i64(va[q][f] * fix));  // ds_add_u64
-            atomicAdd(&acc[(slot * 2 + 1) * F + f], (unsigned long long)fix_i64(vb[q][f] * fix));
+            atomicAdd(&acc[(slot * 2 + 0) * F + f], fix_sum<SumT>(va[q][f] * fix));  // ds_add_u64 / ds_add_u32
+            atomicAdd(&acc[(slot * 2 + 1) * F + f], fix_sum<SumT>(vb[q][f] * fix));
           }
         } else {
           // partition full, pair across two slices (negative corner) or non-finite values: straight to the table
@@ -386,7 +403,8 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
 #pragma unroll 1
         for (int j0 = 0; j0 < NP; j0 += NB) {
           uint32_t kk[NB];
-          unsigned long long bal[NB], av[NB][2 * F];
+          unsigned long long bal[NB];
+          SumT av[NB][2 * F];
 #pragma unroll
           for (int j = 0; j < NB; ++j) kk[j] = keys[((wave + (j0 + j) * WAVES) << 6) + lane];
 #pragma unroll
@@ -395,7 +413,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
             bal[j] = __ballot(occ);
             const int sl_ = ((wave + (j0 + j) * WAVES) << 6) + lane;
 #pragma unroll
-            for (int k = 0; k < 2 * F; ++k) av[j][k] = occ ? acc[sl_ * 2 * F + k] : 0ull;
+            for (int k = 0; k < 2 * F; ++k) av[j][k] = occ ? acc[sl_ * 2 * F + k] : (SumT)0;
           }
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
@@ -408,7 +426,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
 #pragma unroll
               for (int k = 0; k < 2 * F; ++k) {
                 rsum[(subj + at) * (2 * F) + k] = av[j][k];
-                acc[sl_ * 2 * F + k] = 0ull;
+                acc[sl_ * 2 * F + k] = 0;
               }
               keys[sl_] = kEmpty;
             }
@@ -418,7 +436,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       } else {
       for (int s = wave; s < ns; s += WAVES, sub += WAVES * sub_stride) {
         uint32_t* dk = rkey + sub;                      // (scalar bases, 32-bit lane offsets)
-        unsigned long long* ds = rsum + sub * (2 * F);
+        SumT* ds = rsum + sub * (2 * F);
         uint32_t count = 0;
         for (int c0 = 0; c0 < cap; c0 += NR_WAVE) {
           const int sl_ = (s << cap_log2) + c0 + lane;
@@ -432,7 +450,7 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
 #pragma unroll
             for (int k = 0; k < 2 * F; ++k) {
               ds[at * (2 * F) + k] = acc[sl_ * 2 * F + k];
-              acc[sl_ * 2 * F + k] = 0ull;
+              acc[sl_ * 2 * F + k] = 0;
             }
             keys[sl_] = kEmpty;
           }
@@ -468,9 +486,9 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
   }
 }
 
-template <int F>
+template <int F, typename SumT>
 __global__ void __launch_bounds__(kApplyThreads)
-apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __restrict__ rsum, const uint32_t* __restrict__ cntg,
+apply_kernel(const uint32_t* __restrict__ rkey, const SumT* __restrict__ rsum, const uint32_t* __restrict__ cntg,
              const int* __restrict__ tile_exp, int64_t nb, int ns, int shift, int cap_log2, int log2T, float* __restrict__ gtable,
              const float* __restrict__ head_partials, int head_blocks, int head_dim, float* __restrict__ g_w) {
   __shared__ unsigned long long acc[kSliceFloats];
@@ -513,9 +531,9 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
         const int e_b = tile_exp[(int64_t)level * nb + b0 + tid];
         if (e_b != kNoRecords) {
           c = cntg[((int64_t)level * nb + b0 + tid) * ns + slice];
-          int sh = e_l - e_b + kApplyDrop;
+          int sh = e_l - e_b + (FixBits<SumT>::value - kLevelBits);  // (32-bit records: -15 + ..., a left shift where the tile's exponent is near the level's)
           sh = sh > 63 ? 63 : sh;
-          c |= (uint32_t)sh << 16;
+          c |= (uint32_t)(sh + 64) << 16;
         }
       }
       cnts[tid] = c;
@@ -526,11 +544,11 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
       const int t = tg + sub;
       const uint32_t c = t < tiles_here ? cnts[t] : 0u;
       const uint32_t cnt = c & 0xFFFFu;
-      const int sh = (int)(c >> 16);
+      const int sh = (int)(c >> 16) - 64;
       const int64_t at0 = sub0 + ((b0 + t) << cap_log2);
       for (uint32_t r0 = 0; __any(r0 < cnt); r0 += kBatch * 8) {
         uint32_t key[kBatch];
-        unsigned long long q[kBatch][2 * F];
+        SumT q[kBatch][2 * F];
         bool ok[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
@@ -551,7 +569,8 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
           const uint32_t ea = (a & in_mask) * F, eb = (b & in_mask) * F;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
-            const long long qa = (long long)q[k][f] >> sh, qb = (long long)q[k][F + f] >> sh;
+            const long long ra = sum_to_i64<SumT>(q[k][f]), rb = sum_to_i64<SumT>(q[k][F + f]);
+            const long long qa = sh >= 0 ? ra >> sh : ra << -sh, qb = sh >= 0 ? rb >> sh : rb << -sh;
             if (qa != 0) atomicAdd(&acc[ea + f], (unsigned long long)qa);  // ds_add_u64
             if (qb != 0) atomicAdd(&acc[eb + f], (unsigned long long)qb);
           }
@@ -560,7 +579,7 @@ apply_kernel(const uint32_t* __restrict__ rkey, const unsigned long long* __rest
     }
   }
   __syncthreads();
-  const float unfix = ldexpf(1.0f, e_l - kFixBits + kApplyDrop);
+  const float unfix = ldexpf(1.0f, e_l - kLevelBits);
   float* out = gtable + ((((int64_t)level << log2T) + ((int64_t)slice << shift)) * F);
   for (int i = tid; i < slice_floats; i += kApplyThreads) {
     const long long a = (long long)acc[i];
@@ -585,7 +604,7 @@ struct Workspace {
   uint32_t* cntg;
   int* tile_exp;
   uint32_t* rkey;
-  unsigned long long* rsum;
+  void* rsum;  // SumT records
   float* partials;  // [kMaxBinBlocks][kLevelChunk * F]: the density head's weight-gradient partials
   int64_t bytes;
 };
@@ -601,8 +620,8 @@ inline Workspace carve(void* workspace, int L, int F, const BinGeom& g) {
   p += align_up((int64_t)L * g.nb * 4, 256);
   w.rkey = reinterpret_cast<uint32_t*>(p);
   p += align_up(slots * 4, 256);
-  w.rsum = reinterpret_cast<unsigned long long*>(p);
-  p += align_up(slots * 2 * F * 8, 256);
+  w.rsum = p;
+  p += align_up(slots * 2 * F * 8, 256);  // (sized for the 64-bit records; the 32-bit ones use the first half)
   w.partials = reinterpret_cast<float*>(p);
   p += align_up((int64_t)kMaxBinBlocks * kLevelChunk * F * 4, 256);
   w.bytes = p - static_cast<char*>(workspace);
@@ -625,8 +644,9 @@ static int64_t tiles_of(int F, int64_t n) {
 
 static int launch_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T, const float* gout,
                          int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace, nr_stream_t stream,
-                         const DensityHead* head_in, float* g_w, const BinSegment* second = nullptr) {
+                         const DensityHead* head_in, float* g_w, const BinSegment* second = nullptr, int sum_bits = 64) {
   if (n == 0 && (second == nullptr || second->n == 0)) return 0;
+  if (sum_bits != 32 && sum_bits != 64) return NR_EINVAL;
   BinGeom g;
   if (!x || !gout || !scalings || !gtable || !workspace || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (second != nullptr && (!second->x || !second->gout || second->n < 0 || (std != nullptr) != (second->std != nullptr))) return NR_EINVAL;
@@ -636,6 +656,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
   int64_t persistent = (BinCfg<1>::M > 4096 && F == 1 ? 1 : BinCfg<1>::M < 4096 && F == 1 ? 4 : 2) * (int64_t)nr_num_cus();  // tables per CU that fit its LDS
+  if (sum_bits == 32 && F == 1) persistent = 3 * (int64_t)nr_num_cus();  // 48 KB per table
   if (const char* e = getenv("NR_BIN_BLOCKS_PER_CU")) persistent = (int64_t)atoi(e) * nr_num_cus() / 2 > 0 ? (int64_t)atoi(e) * nr_num_cus() / 2 : persistent;  // (halves of a CU: tuning knob)
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
@@ -647,21 +668,24 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   }
   BinSegment seg2 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   if (second != nullptr) seg2 = *second;
-#define CALL(FF)                                                                                                            \
+#define CALL_T(FF, ST)                                                                                                      \
   {                                                                                                                          \
+    ST* rs = static_cast<ST*>(w.rsum);                                                                                       \
     if (head_in != nullptr)                                                                                                  \
-      hipLaunchKernelGGL((bin_kernel<FF, true>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, 0,      \
-                         log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg, w.tile_exp, \
+      hipLaunchKernelGGL((bin_kernel<FF, true, ST>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, 0,  \
+                         log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, rs, w.cntg, w.tile_exp,     \
                          head, seg2, nb1);                                                                                   \
     else                                                                                                                     \
       for (int l0 = 0; l0 < L; l0 += kLevelChunk)                                                                            \
-        hipLaunchKernelGGL((bin_kernel<FF, false>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L, l0,  \
-                           log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, w.rsum, w.cntg,           \
+        hipLaunchKernelGGL((bin_kernel<FF, false, ST>), grid1, dim3(BinCfg<FF>::ROWS), 0, nr_s(stream), x, std, scalings, L,  \
+                           l0, log2T, gout, sn, sl, gtable, n, g.ns, g.shift, g.cap_log2, g.nb, w.rkey, rs, w.cntg,           \
                            w.tile_exp, head, seg2, nb1);                                                                     \
-    hipLaunchKernelGGL(apply_kernel<FF>, grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, w.rsum, w.cntg, w.tile_exp,    \
+    hipLaunchKernelGGL((apply_kernel<FF, ST>), grid2, dim3(kApplyThreads), 0, nr_s(stream), w.rkey, rs, w.cntg, w.tile_exp,  \
                        g.nb, g.ns, g.shift, g.cap_log2, log2T, gtable, head_in != nullptr ? w.partials : nullptr,            \
                        (int)blocks, L * FF, g_w);                                                                            \
   }
+#define CALL(FF)                                          \
+  if (sum_bits == 32) CALL_T(FF, uint32_t) else CALL_T(FF, unsigned long long)
   switch (F) {
     case 1: CALL(1) break;
     case 2: CALL(2) break;
@@ -669,6 +693,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
     default: return NR_EINVAL;
   }
 #undef CALL
+#undef CALL_T
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -679,15 +704,29 @@ extern "C" int nr_hash_encode_bwd_binned(const float* x, const float* std, const
   return launch_binned(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, workspace, stream, nullptr, nullptr);
 }
 
+extern "C" int nr_hash_encode_bwd_binned_lp(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                            const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, void* workspace,
+                                            int sum_bits, nr_stream_t stream) {
+  return launch_binned(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, workspace, stream, nullptr, nullptr, nullptr, sum_bits);
+}
+
 extern "C" int nr_prop_density_scatter_binned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
                                               const float* feats, int64_t sn, int64_t sl, const float* w, const float* g_density,
                                               int n_samples, int64_t rows_sample_major, float* gtable, float* g_w, int64_t n,
                                               void* workspace, nr_stream_t stream) {
+  return nr_prop_density_scatter_binned_lp(x, std, scalings, L, F, log2T, feats, sn, sl, w, g_density, n_samples, rows_sample_major,
+                                           gtable, g_w, n, workspace, 64, stream);
+}
+
+extern "C" int nr_prop_density_scatter_binned_lp(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                                 const float* feats, int64_t sn, int64_t sl, const float* w, const float* g_density,
+                                                 int n_samples, int64_t rows_sample_major, float* gtable, float* g_w, int64_t n,
+                                                 void* workspace, int sum_bits, nr_stream_t stream) {
   if (n == 0) return 0;
   if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples)))
     return NR_EINVAL;
   const DensityHead head = {w, g_density, nullptr, n_samples, rows_sample_major};
-  return launch_binned(x, std, scalings, L, F, log2T, feats, sn, sl, gtable, n, workspace, stream, &head, g_w);
+  return launch_binned(x, std, scalings, L, F, log2T, feats, sn, sl, gtable, n, workspace, stream, &head, g_w, nullptr, sum_bits);
 }
 
 extern "C" int nr_prop_density_scatter_binned2(const float* x1, const float* std1, const float* feats1, const float* g_density1,

@@ -132,6 +132,11 @@ class FusedTrainStep:
         # (freshly initialised: 3.13 / 3.08 / 3.09 / 3.46).  Camera-only batches stay with the merging kernel, which folds
         # neighbouring pixels before anything leaves the wave (16 384 rays: 2.62 against 2.73 ms after 1 500 steps).
         # NR_BINNED=0 / all / lidar and NR_BINNED_FROM=<first binned ray> override (A/B runs).
+        # width of the binned scatter's fixed-point tile sums: 64 bits with fp32 MLPs (every addend exact to fp32's resolution),
+        # 32 bits where the field MLPs already run on 16-bit operands -- an addend is rounded to 2^-22..2^-21 of the largest
+        # contribution of its 512-row tile, far below the operands' own rounding (u = 2^-8 / 2^-11): step 2.55 -> 2.38 ms fresh,
+        # 2.83 -> 2.72 ms after 1 500 steps (profiles/r03_ab_runs.txt).  NR_BIN_SUM_BITS overrides.
+        self.bin_sum_bits = int(os.environ.get("NR_BIN_SUM_BITS", "64" if model.field.config.mlp_dtype == "float32" else "32"))
         self.binned_ws = [None, None, None]
         self.binned_from = 0 if self.sm < B else B  # first ray whose rows go through the binned kernels
         mode = os.environ.get("NR_BINNED", "")
@@ -531,10 +536,10 @@ class FusedTrainStep:
 
             def launch():
                 if lvl < 2 and head_in_scatter[lvl]:
-                    return lib.nr_prop_density_scatter_binned(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
-                                                              grid.log2_hashmap_size, p(self.feats[lvl]), Fg, nl * Fg, p(w_dec),
-                                                              p(self.g_dens[lvl]), S, self.sm, p(grid.hash_table.grad), p(w_dec.grad),
-                                                              nl, p(self.binned_ws[lvl]), sp_)
+                    return lib.nr_prop_density_scatter_binned_lp(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                                 grid.log2_hashmap_size, p(self.feats[lvl]), Fg, nl * Fg, p(w_dec),
+                                                                 p(self.g_dens[lvl]), S, self.sm, p(grid.hash_table.grad), p(w_dec.grad),
+                                                                 nl, p(self.binned_ws[lvl]), self.bin_sum_bits, sp_)
                 # batches with incoherent rows: the wide per-wave table of the F = 4 merging kernel (fewer atomics per sample,
                 # more of the chip left to the two binned scatters and Adam beside it: step -3 % fresh, -6 % after 1 500 steps)
                 cells = 256 if self.sm < B and os.environ.get("NR_WIDE_MERGE", "1") != "0" else 0
@@ -542,10 +547,10 @@ class FusedTrainStep:
                                                   grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
                                                   n_coh, 0, cells, sp_) if n_coh > 0 else 0
                 if rc == 0 and n_coh < nl:
-                    rc = lib.nr_hash_encode_bwd_binned(p(self.x01[lvl][n_coh:]), p(self.std[lvl][n_coh:]), p(grid.scalings),
-                                                       grid.num_levels, Fg, grid.log2_hashmap_size,
-                                                       p(self.g_feats[lvl][:, n_coh:, :]), Fg, nl * Fg, p(grid.hash_table.grad),
-                                                       nl - n_coh, p(self.binned_ws[lvl]), sp_)
+                    rc = lib.nr_hash_encode_bwd_binned_lp(p(self.x01[lvl][n_coh:]), p(self.std[lvl][n_coh:]), p(grid.scalings),
+                                                          grid.num_levels, Fg, grid.log2_hashmap_size,
+                                                          p(self.g_feats[lvl][:, n_coh:, :]), Fg, nl * Fg, p(grid.hash_table.grad),
+                                                          nl - n_coh, p(self.binned_ws[lvl]), self.bin_sum_bits, sp_)
                 return rc
 
             check(self._timed(f"hash_encode_bwd[{tag}_s{S}]", launch), "hash_bwd")

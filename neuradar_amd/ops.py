@@ -75,18 +75,20 @@ def hash_encode(x: Tensor, table: Tensor, scalings: Tensor, log2_hashmap_size: i
 
 def hash_encode_bwd_binned(x: Tensor, std: Optional[Tensor], scalings: Tensor, log2_hashmap_size: int, grad_out: Tensor,
                            strides: Tuple[int, int], features_per_level: int, grad_table: Tensor,
-                           workspace: Optional[Tensor] = None) -> Tensor:
+                           workspace: Optional[Tensor] = None, sum_bits: int = 64) -> Tensor:
     """grad_table += scatter of grad_out (element (i,l,f) at i*strides[0] + l*strides[1] + f) through the two-pass binned
-    kernels (nr_hash_encode_bwd_binned: for incoherent rows).  Returns the workspace (reusable for the same sizes)."""
+    kernels (nr_hash_encode_bwd_binned: for incoherent rows).  Returns the workspace (reusable for the same sizes).
+    sum_bits: 64 (exact to fp32's resolution) or 32 (addends rounded to 2^-22..2^-21 of their tile's largest: the companion
+    of 16-bit MLP operands, see include/neuradar_hip.h)."""
     n, L = x.shape[0], scalings.numel()
     need = _lib.lib().nr_hash_encode_bwd_binned_workspace_bytes(L, features_per_level, log2_hashmap_size, n)
     if need < 0:
         raise RuntimeError("nr_hash_encode_bwd_binned: a level of this table has more than 32 slices of 128 KB")
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
-    check(_lib.lib().nr_hash_encode_bwd_binned(_p(x), _p(std), _p(scalings), L, features_per_level, log2_hashmap_size,
-                                               _p(grad_out), strides[0], strides[1], _p(grad_table), n, _p(workspace),
-                                               _stream()), "nr_hash_encode_bwd_binned")
+    check(_lib.lib().nr_hash_encode_bwd_binned_lp(_p(x), _p(std), _p(scalings), L, features_per_level, log2_hashmap_size,
+                                                  _p(grad_out), strides[0], strides[1], _p(grad_table), n, _p(workspace),
+                                                  int(sum_bits), _stream()), "nr_hash_encode_bwd_binned")
     return workspace
 
 
