@@ -608,7 +608,7 @@ struct Workspace {
   float* partials;  // [kMaxBinBlocks][kLevelChunk * F]: the density head's weight-gradient partials
   int64_t bytes;
 };
-constexpr int kMaxBinBlocks = 1024;
+constexpr int kMaxBinBlocks = 2048;
 
 inline Workspace carve(void* workspace, int L, int F, const BinGeom& g) {
   Workspace w;
@@ -655,8 +655,15 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   g.nb = nb1 + nb2;
   if (head_in != nullptr && (L > kLevelChunk || !head_in->w || !head_in->g_density || !g_w)) return NR_EINVAL;
   const Workspace w = carve(workspace, L, F, g);
-  int64_t persistent = (BinCfg<1>::M > 4096 && F == 1 ? 1 : BinCfg<1>::M < 4096 && F == 1 ? 4 : 2) * (int64_t)nr_num_cus();  // tables per CU that fit its LDS
-  if (sum_bits == 32 && F == 1) persistent = 3 * (int64_t)nr_num_cus();  // 48 KB per table
+  // persistent blocks: as many merge tables as fit a CU's 160 KB of LDS (20 bytes per slot with 64-bit sums at F = 1, 12 with
+  // 32-bit ones), at most 8 waves per SIMD
+  const int m_slots = F == 1 ? BinCfg<1>::M : F == 2 ? BinCfg<2>::M : BinCfg<4>::M;
+  const int rows_blk = F == 1 ? BinCfg<1>::ROWS : F == 2 ? BinCfg<2>::ROWS : BinCfg<4>::ROWS;
+  const int64_t lds_bytes = (int64_t)m_slots * (4 + 2 * F * (sum_bits / 8));
+  int64_t per_cu = (160 * 1024) / lds_bytes;
+  if (per_cu * rows_blk > 2048) per_cu = 2048 / rows_blk;
+  if (per_cu < 1) per_cu = 1;
+  int64_t persistent = per_cu * (int64_t)nr_num_cus();
   if (const char* e = getenv("NR_BIN_BLOCKS_PER_CU")) persistent = (int64_t)atoi(e) * nr_num_cus() / 2 > 0 ? (int64_t)atoi(e) * nr_num_cus() / 2 : persistent;  // (halves of a CU: tuning knob)
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
