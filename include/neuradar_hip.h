@@ -354,6 +354,17 @@ int64_t nr_field_bwd_workspace_floats(const nr_field_t* field, int64_t n);
  * (nr_field_pack) whenever the weights change, i.e. once per optimizer step. */
 int64_t nr_field_image_floats(const nr_field_t* field);
 int64_t nr_field_stash_floats(const nr_field_t* field, int64_t n);
+/* nr_hash_encode_fwd of the main grid + nr_field_fwd as ONE launch (fields/neurad_field.py:128-152 with
+ * neurad_encoding.py:277-280,309-316 in front): the per-level features go from the gather to the first layer in registers.
+ * x01 [n,3], std01 [n] (nr_contract_gaussians, the step's row order), table [L*T, F], scalings [L]; feats_out (nullable): the
+ * level-major [L, n, F] copy (level stride feat_stride_l floats) nr_field_bwd recomputes from -- the values
+ * nr_hash_encode_fwd(..., std01, ...) stores.  Other arguments and outputs as nr_field_fwd.  Built for num_levels = 8,
+ * features_per_level = 4, width 32, 16-bit operands (nr_field_t.dtype != NR_DTYPE_F32); NR_EINVAL otherwise: use the two
+ * launches. */
+int nr_field_fwd_gather(const nr_field_t* field, const float* x01, const float* std01, const float* table,
+                        const float* scalings, int num_levels, int features_per_level, int log2_hashmap_size,
+                        float* feats_out, int64_t feat_stride_l, const float* directions, int n_samples,
+                        int rows_sample_major, int64_t n, float* feature, float* sdf, float* alpha, nr_stream_t stream);
 int nr_field_pack(const nr_field_t* field, float* image, nr_stream_t stream);
 int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t feat_stride_n, int64_t feat_stride_l,
                  int feat_f, const float* directions, int n_samples, int rows_sample_major, int64_t n,

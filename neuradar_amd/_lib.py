@@ -88,6 +88,7 @@ PROTOTYPES = {
     "nr_field_image_floats": [POINTER(NrField)],
     "nr_field_pack": [POINTER(NrField), P, P],
     "nr_field_fwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P],
+    "nr_field_fwd_gather": [POINTER(NrField), P, P, P, P, I, I, I, P, L, P, I, I, L, P, P, P, P],
     "nr_field_bwd": [POINTER(NrField), P, L, L, I, P, I, I, L, P, P, P, P, POINTER(NrFieldGrads), P, P],
     "nr_field_grad_reduce": [POINTER(NrField), P, L, POINTER(NrFieldGrads), P],
     "nr_sh4_fwd": [P, L, P, P],

@@ -107,6 +107,9 @@ int64_t field_image_bytes_lp(int hid);
 int field_pack_lp(const nr_field_t* field, int hid, void* image, hipStream_t st);
 int field_fwd_lp(const nr_field_t* field, int hid, const float* feats, int64_t sn, int64_t sl, int F, const float* dirs, int S,
                  int rows_sm, int64_t n, float* feature, float* sdf, float* alpha, unsigned blocks, hipStream_t st);
+int field_fwd_gather_lp(const nr_field_t* field, int hid, const float* x01, const float* std01, const float* table,
+                        const float* scalings, int log2T, float* feats_out, int64_t sl, const float* dirs, int S, int rows_sm,
+                        int64_t n, float* feature, float* sdf, float* alpha, unsigned blocks, hipStream_t st);
 int field_bwd_lp(const nr_field_t* field, int hid, const float* feats, int64_t sn, int64_t sl, int F, const float* dirs, int S,
                  int rows_sm, int64_t n, const float* g_feature, const float* g_alpha, const float* g_sdf, float* g_feats,
                  float* ws, float* slab, unsigned blocks, hipStream_t st);

@@ -613,6 +613,29 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
 }
 
 
+extern "C" int nr_field_fwd_gather(const nr_field_t* field, const float* x01, const float* std01, const float* table,
+                                   const float* scalings, int L, int F, int log2T, float* feats_out, int64_t sl, const float* dirs,
+                                   int S, int rows_sample_major, int64_t n, float* feature, float* sdf, float* alpha,
+                                   nr_stream_t stream) {
+  if (n == 0) return 0;
+  int hid = 0;
+  if (check_field(field, &hid) != 0 || !x01 || !std01 || !table || !scalings || !dirs || !feature || !sdf || !alpha || S < 0 || n < 0 ||
+      log2T < 1 || log2T > 30)
+    return NR_EINVAL;
+  if (rows_sample_major < 0 || (rows_sample_major && (S < 1 || n % S != 0 || rows_sample_major > n / S))) return NR_EINVAL;
+  // built for NeuRadar's main grid feeding the 32-wide stack on 16-bit operands; anything else: nr_hash_encode_fwd + nr_field_fwd
+  if (L != 8 || F != 4 || hid != 32 || field->dtype == NR_DTYPE_F32) return NR_EINVAL;
+  if (feats_out != nullptr && (((uintptr_t)feats_out & 15u) != 0 || (sl & 3) != 0)) return NR_EINVAL;
+  const int64_t tiles = nr_cdiv(n, 32);
+  unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
+  if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
+  }
+  return field_fwd_gather_lp(field, hid, x01, std01, table, scalings, log2T, feats_out, sl, dirs, S, rows_sample_major, n, feature,
+                             sdf, alpha, blocks, nr_s(stream));
+}
+
 extern "C" int nr_field_bwd(const nr_field_t* field, const float* feats, int64_t sn, int64_t sl, int F,
                             const float* dirs, int S, int rows_sample_major, int64_t n, const float* g_feature,
                             const float* g_alpha, const float* g_sdf, float* g_feats, const nr_field_grads_t* grads,

@@ -12,6 +12,7 @@
 // granules, XOR-swizzled) and read back transposed with ds_read_b64_tr_b16.  The sdf row, biases, the sigmoid and all
 // reductions stay fp32.  The backward recomputes the forward (22 MFMAs per tile) instead of reading a stash.
 #include "field_common.h"
+#include "grid_dev.h"
 
 using namespace nrmlp;
 using namespace nrfield;
@@ -281,6 +282,112 @@ field_fwd_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t sn,
       const int64_t tn = tile + (int64_t)gridDim.x * 4, sn_ = tn * 32 + i;
       const bool vn = tn < tiles && sn_ < n;
       load_rows<32>(xn, feats + (vn ? sn_ * sn : 0), vn, h, foff);
+    }
+    PTile xp[1] = {to_ptile<T>(x0[0])};
+    dense_lp<T, 2, HT>(xp, h1, lds + I::oG1f, fb + I::bG1, lane, h);
+    PTile h1p[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) { relu_tile(h1[t]); h1p[t] = to_ptile<T>(h1[t]); }
+    const float sdf = sdf_row_lp<HID>(h1, fb + I::wSdf, h);
+    dense_lp<T, HS, 1>(h1p, e, lds + I::oG2f, fb + I::bG2, lane, h);
+    const NrRowMap rm = nr_row_map(valid ? smp : 0, n, S, rows_sm);
+    PTile cat[2] = {to_ptile<T>(e[0]), (fld.sample_dirs != nullptr ? sh_ptile<T>(fld.sample_dirs, rm.out, h) : sh_ptile<T>(dirs, rm.ray, h))};
+    dense_lp<T, 3, HT>(cat, f1, lds + I::oF1f, fb + I::bF1, lane, h);
+    PTile f1p[HT], f2p[HT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) { relu_tile(f1[t]); f1p[t] = to_ptile<T>(f1[t]); }
+    dense_lp<T, HS, HT>(f1p, f2, lds + I::oF2f, fb + I::bF2, lane, h);
+#pragma unroll
+    for (int t = 0; t < HT; ++t) { relu_tile(f2[t]); f2p[t] = to_ptile<T>(f2[t]); }
+    dense_lp<T, HS, 1>(f2p, o, lds + I::oF3f, fb + I::bF3, lane, h);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(e[0][4 * q] + o[0][4 * q], e[0][4 * q + 1] + o[0][4 * q + 1],
+                               e[0][4 * q + 2] + o[0][4 * q + 2], e[0][4 * q + 3] + o[0][4 * q + 3]);
+        *reinterpret_cast<float4*>(feature + rm.out * kC + 8 * q + 4 * h) = v;
+      }
+      if (h == 0) {
+        sdf_out[rm.out] = sdf;
+        alpha_out[rm.out] = 1.0f / (1.0f + expf(sdf * beta));
+      }
+    }
+  }
+}
+
+// ---- forward with the main grid's gather inside (SURVEY north star: "LDS-staged per-level features" -- here they never
+// leave the registers).  NeuRadar's main grid: L = 8 levels x F = 4 features = the MLP's 32 inputs.  Lane (sample i, half h) of
+// the 32-sample tile holds input rows {0-3, 8-11, 16-19, 24-27} + 4 h in the MFMA layout = levels {h, h + 2, h + 4, h + 6}:
+// it gathers exactly those four levels of its sample (4 x 8 corners x 16 bytes), interpolates them with encode_level's
+// arithmetic -- the same values nr_hash_encode_fwd would store -- and feeds the chain of five layers directly; the level-major
+// [L, n, F] copy the backward recomputes from is written on the way (16 bytes per lane and level) instead of being written by
+// one launch and read back by the next.
+template <typename T, int HID>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+field_fwd_gather_lp_kernel(nr_field_t fld, const float* __restrict__ x01, const float* __restrict__ std01,
+                           const float* __restrict__ table, const float* __restrict__ scalings, int log2T,
+                           float* __restrict__ feats_out, int64_t sl, const float* __restrict__ dirs, int S, int rows_sm, int64_t n,
+                           float* __restrict__ feature, float* __restrict__ sdf_out, float* __restrict__ alpha_out) {
+  using I = LpImage<HID>;
+  constexpr int HT = I::HT, HS = I::HS;
+  constexpr int oF32 = I::oF1t;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[oF32 + I::nF32 * 4];
+  const unsigned char* image = reinterpret_cast<const unsigned char*>(fld.packed);
+  copy_bytes<I::oF1t>(lds, image);
+  copy_bytes<I::nF32 * 4>(lds + oF32, image + I::oF32);
+  __syncthreads();
+  const float* fb = reinterpret_cast<const float*>(lds + oF32);
+  const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const float beta = fabsf(fld.beta[0]) + kBetaMin;
+  const int64_t tiles = nr_cdiv_dev(n, 32);
+  float scal[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) scal[j] = scalings[2 * j + h];
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t smp = tile * 32 + i;
+    const bool valid = smp < n;
+    f32x16 x0[1], h1[HT], e[1], f1[HT], f2[HT], o[1];
+    {
+      // all 32 corner loads of the lane's four levels are requested before the first is used (written level by level the
+      // compiler waits for each level's eight loads and its store before requesting the next: four exposed round trips per
+      // tile at two waves per SIMD); the arithmetic is encode_level's, in its order
+      const uint32_t mask = (1u << log2T) - 1u;
+      const int64_t sq = valid ? smp : 0;
+      nrgrid::Corner cr[4];
+      float4 cv[4][8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cr[j] = nrgrid::make_corner(x01, sq, scal[j]);
+        const float* base = table + (((int64_t)(2 * j + h) << log2T) * 4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {  // q = zs * 4 + ys * 2 + xs; s = 0: ceil corner, 1: floor corner (encode_level's loops)
+          const int iz = (q & 4) ? cr[j].lo[2] : cr[j].hi[2], iy = (q & 2) ? cr[j].lo[1] : cr[j].hi[1];
+          const int ix = (q & 1) ? cr[j].lo[0] : cr[j].hi[0];
+          cv[j][q] = *reinterpret_cast<const float4*>(base + (int64_t)nr_hash3(ix, iy, iz, mask) * 4);
+        }
+      }
+      const float sd = std01[sq];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float wx = cr[j].w[0], wy = cr[j].w[1], wz = cr[j].w[2];
+        float feat[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          auto el = [&](int q) { const float4 t = cv[j][q]; return f == 0 ? t.x : f == 1 ? t.y : f == 2 ? t.z : t.w; };
+          float az[2];
+#pragma unroll
+          for (int zs = 0; zs < 2; ++zs) {
+            const float ay0 = el(zs * 4 + 0) * wx + el(zs * 4 + 1) * (1.0f - wx);  // ys = 0 (ceil y): x ceil * w + x floor * (1 - w)
+            const float ay1 = el(zs * 4 + 2) * wx + el(zs * 4 + 3) * (1.0f - wx);
+            az[zs] = ay0 * wy + ay1 * (1.0f - wy);
+          }
+          const float r = 1.0f / fmaxf(scal[j] * 2.0f * sd, 1.0f);  // neurad_encoding.py:314
+          feat[f] = valid ? (az[0] * wz + az[1] * (1.0f - wz)) * r : 0.0f;
+          x0[0][4 * j + f] = feat[f];
+        }
+        if (valid && feats_out != nullptr)
+          *reinterpret_cast<float4*>(feats_out + (int64_t)(2 * j + h) * sl + smp * 4) = make_float4(feat[0], feat[1], feat[2], feat[3]);
+      }
     }
     PTile xp[1] = {to_ptile<T>(x0[0])};
     dense_lp<T, 2, HT>(xp, h1, lds + I::oG1f, fb + I::bG1, lane, h);
@@ -677,6 +784,20 @@ int field_fwd_lp(const nr_field_t* field, int hid, const float* feats, int64_t s
                      : launch_fwd<Bf16, 64>(field, feats, sn, sl, F, dirs, S, rows_sm, n, feature, sdf, alpha, blocks, st);
   return hid == 32 ? launch_fwd<Fp16, 32>(field, feats, sn, sl, F, dirs, S, rows_sm, n, feature, sdf, alpha, blocks, st)
                    : launch_fwd<Fp16, 64>(field, feats, sn, sl, F, dirs, S, rows_sm, n, feature, sdf, alpha, blocks, st);
+}
+
+int field_fwd_gather_lp(const nr_field_t* field, int hid, const float* x01, const float* std01, const float* table,
+                        const float* scalings, int log2T, float* feats_out, int64_t sl, const float* dirs, int S, int rows_sm,
+                        int64_t n, float* feature, float* sdf, float* alpha, unsigned blocks, hipStream_t st) {
+  if (hid != 32) return NR_EINVAL;
+  if (field->dtype == NR_DTYPE_BF16)
+    hipLaunchKernelGGL((field_fwd_gather_lp_kernel<Bf16, 32>), dim3(blocks), dim3(256), 0, st, *field, x01, std01, table, scalings, log2T,
+                       feats_out, sl, dirs, S, rows_sm, n, feature, sdf, alpha);
+  else
+    hipLaunchKernelGGL((field_fwd_gather_lp_kernel<Fp16, 32>), dim3(blocks), dim3(256), 0, st, *field, x01, std01, table, scalings, log2T,
+                       feats_out, sl, dirs, S, rows_sm, n, feature, sdf, alpha);
+  NR_LAUNCH_CHECK();
+  return 0;
 }
 
 int field_bwd_lp(const nr_field_t* field, int hid, const float* feats, int64_t sn, int64_t sl, int F, const float* dirs, int S,

@@ -423,9 +423,15 @@ class FusedTrainStep:
         mg, Sm = self.mgrid, self.S[2]
         n = B * Sm
         F = mg.features_per_level
-        check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
-            p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
-            p(self.feats[2]), F, n * F, n, 0, st)), "hash_fwd")
+        # the main grid's gather inside the field forward (nr_field_fwd_gather: the per-level features go to the first layer in
+        # registers; the [L, n, F] copy the backward recomputes from is written on the way): NeuRadar's grid (8 x 4) into the
+        # 32-wide stack on 16-bit operands, no actor rows to patch in between.  NR_FUSE_MAIN_GATHER=0: two launches.
+        fuse_gather = (mg.num_levels == 8 and F == 4 and self.field_struct.dtype != 0 and self.model.field.config.geo_hidden_dim == 32
+                       and not self.n_actors and os.environ.get("NR_FUSE_MAIN_GATHER", "1") != "0")
+        if not fuse_gather:
+            check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
+                p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
+                p(self.feats[2]), F, n * F, n, 0, st)), "hash_fwd")
         if self.n_actors:
             actor_overwrite(2, mg)
         if side[0] is not main:
@@ -435,8 +441,14 @@ class FusedTrainStep:
                 side[1].wait_stream(main)
             with torch.cuda.stream(side[1]):
                 after_sampling()
-        check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n,
-                                                                 p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
+        if fuse_gather:
+            check(self._timed(f"field_fwd+gather[main_s{Sm}]", lambda: lib.nr_field_fwd_gather(
+                byref(self.field_struct), p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F,
+                mg.log2_hashmap_size, p(self.feats[2]), n * F, d, Sm, self.sm, n, p(self.feature), p(self.sdf), p(self.alpha), st)),
+                  "field_fwd_gather")
+        else:
+            check(self._timed("field_fwd", lambda: lib.nr_field_fwd(byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n,
+                                                                     p(self.feature), p(self.sdf), p(self.alpha), st)), "field_fwd")
         # composite + supervision + distortion + composite backward of the main level: one launch
         lid = self.lidar[slot] if isinstance(self.lidar, list) else self.lidar
         if lid is not None and lid["decoder"]:

@@ -176,3 +176,55 @@ def test_field_lp_vs_reference_autocast_golden(tag, hidden, dtype):
         assert err < grad_bound, f"{tag} {dtype} grad {k}: relative L2 error {err:.3e} vs the autocast reference"
         ours, theirs = float((got - fp32).norm() / fp32.norm()), float((want - fp32).norm() / fp32.norm())
         assert ours < 3 * theirs + u, f"{tag} {dtype} grad {k}: {ours:.3e} from fp32, the reference's autocast {theirs:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n_rays,S,sm", [(96, 32, 64), (33, 32, 0), (7, 5, 7)])
+def test_field_forward_with_the_gather_inside_equals_the_two_launches(dtype, n_rays, S, sm):
+    """nr_field_fwd_gather == nr_hash_encode_fwd -> nr_field_fwd, bit for bit (the same gather arithmetic, the same rounding
+    points): outputs AND the level-major feature copy the backward recomputes from; ragged tile counts, sample-major and
+    ray-major rows."""
+    from ctypes import byref
+
+    from neuradar_amd import _lib, ops
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+
+    torch.manual_seed(n_rays + S)
+    fld = NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=15)), mlp_dtype=dtype).setup(
+        actors=None, static_scale=100.0).to(DEV)
+    g = fld.hashgrid.static_grid
+    with torch.no_grad():
+        g.hash_table.mul_(300.0)
+    n = n_rays * S
+    x01, std = torch.rand(n, 3, device=DEV), 0.01 * torch.rand(n, device=DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=DEV), dim=-1)
+    lib, p, st = _lib.lib(), ops._p, ops._stream
+    gw, gb = fld.mlp_geo.weights()
+    fw, fb = fld.mlp_feature.weights()
+    fs = _lib.NrField()
+    fs.geo, fs.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
+    fs.beta, fs.dtype, fs.grad_scale = fld.sdf_to_density.beta.data_ptr(), _lib.NR_DTYPES[dtype], 1.0
+    image = torch.empty(lib.nr_field_image_floats(byref(fs)), device=DEV)
+    fs.packed = image.data_ptr()
+    _lib.check(lib.nr_field_pack(byref(fs), p(image), st()), "pack")
+    L, F = g.num_levels, g.features_per_level
+    outs = []
+    for fused in (False, True):
+        feats = torch.full((L, n, F), float("nan"), device=DEV)
+        feature, sdf, alpha = torch.empty(n, 32, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        if fused:
+            _lib.check(lib.nr_field_fwd_gather(byref(fs), p(x01), p(std), p(g.hash_table), p(g.scalings), L, F, g.log2_hashmap_size,
+                                               p(feats), n * F, p(dirs), S, sm, n, p(feature), p(sdf), p(alpha), st()), "fused")
+        else:
+            _lib.check(lib.nr_hash_encode_fwd(p(x01), p(std), p(g.hash_table), p(g.scalings), L, F, g.log2_hashmap_size, p(feats), F,
+                                              n * F, n, 0, st()), "gather")
+            _lib.check(lib.nr_field_fwd(byref(fs), p(feats), F, n * F, F, p(dirs), S, sm, n, p(feature), p(sdf), p(alpha), st()), "fwd")
+        outs.append((feats, feature, sdf, alpha))
+    for a, b, what in zip(outs[0], outs[1], ("level-major features", "feature", "sdf", "alpha")):
+        assert torch.equal(a, b), f"{what}: the fused launch differs from the two launches (max |d| = {float((a - b).abs().max()):.3e})"
+    # and the configurations it is not built for are refused, not approximated
+    fs32 = _lib.NrField()
+    fs32.geo, fs32.feat, fs32.beta, fs32.dtype = fs.geo, fs.feat, fs.beta, 0
+    assert lib.nr_field_fwd_gather(byref(fs32), p(x01), p(std), p(g.hash_table), p(g.scalings), L, F, g.log2_hashmap_size, None, n * F,
+                                   p(dirs), S, sm, n, p(outs[0][1]), p(outs[0][2]), p(outs[0][3]), st()) == _lib.NR_EINVAL
