@@ -802,6 +802,9 @@ def main():
                     "default: BASELINE.json configs[1]")
     ap.add_argument("--full-model", default="mixed16384_neuradar_full,mixed8192_vod_nll,mixed16384_neuradar_full_fp16",
                     help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
+    ap.add_argument("--regime", default="fresh", choices=["fresh", "trained"], help="trained: the MAIN measurement itself runs in the "
+                    "trained regime (--trained-steps steps on scene-consistent targets first; no separate `trained` block) -- for "
+                    "profiling that regime by itself")
     ap.add_argument("--trained-steps", type=int, default=1000, help="report the headline workload again after this many training "
                     "steps on scene-consistent targets (block `trained`); 0 = skip")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed K-step block until this much has been timed")
@@ -840,7 +843,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     main_res = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, not args.no_cpu_baseline,
-                       args.min_seconds)
+                       args.min_seconds, trained_steps=args.trained_steps if args.regime == "trained" else 0)
     secondary = None
     if args.secondary and args.secondary != args.workload and not args.autograd:
         # BASELINE.json configs[1] (the configuration the north star's >= 2 M rays/s target is phrased on) beside the
@@ -867,7 +870,7 @@ def main():
                                "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
                                            "the linear sum assignment on the device"})
     trained = None
-    if args.trained_steps > 0 and not args.autograd:
+    if args.trained_steps > 0 and not args.autograd and args.regime != "trained":
         # the headline workload in the TRAINED regime: scene-consistent targets, args.trained_steps training steps, then the same
         # timing rules (the resampled rounds spread along the rays and every row carries a gradient: DESIGN.md section 5)
         tr = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, False, min(args.min_seconds, 0.5),
@@ -891,7 +894,7 @@ def main():
                        "graph": r["use_graph"], "steps_per_graph_replay": r["unroll"], "host_ms_per_step": round(r["host_ms"], 4),
                        "timed_blocks": r["blocks"], "ms_per_step_min": round(r["ms_min"], 4), "ms_per_step_max": round(r["ms_max"], 4),
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
-                       "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}",
+                       "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}", "regime": args.regime,
                        "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"],
                        "gradient_exchange": r["exchange_cost"]},
             "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,

@@ -8,5 +8,5 @@ WL=${1:-mixed16384_neuradar}
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_bench_$i -o out --output-format csv -- python3 $R/bench.py --workload $WL --steps 10 --warmup 3 --no-graph --secondary '' --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_bench_$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/pmc_bench_$i -o out --output-format csv -- python3 $R/bench.py --workload $WL --steps 10 --warmup 3 --no-graph --secondary= --full-model= --trained-steps 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_bench_$i.log 2>&1
 done

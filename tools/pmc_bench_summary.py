@@ -16,7 +16,7 @@ import sys
 prefix, out_path = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "cam4096_l16f2_w64"
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-WANT = ("hash_encode", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel")
+WANT = ("hash_encode", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel", "adam_kernel")
 
 
 def short(name):
@@ -62,6 +62,7 @@ unknown = collections.Counter()
 for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     last_bwd = None
+    last_kind = None
     # the proposal chains: (inter-level loss, prop_density_bwd, scatter) are launched back to back per chain, so a
     # scatter kernel belongs to the chain of the prop_density_bwd dispatched last before it (larger grid = the 128-sample round)
     for r in rows:
@@ -71,9 +72,16 @@ for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
             continue
         if not k.startswith(WANT):
             continue
-        if k.startswith("hash_encode_bwd"):
+        if k.startswith("adam_kernel"):
+            # the main table's Adam is launched right behind the main grid's scatter, the proposal table's behind the apply
+            # passes, the small parameters' (and any other buffer's) after those
+            t = {"hash_encode_bwd": "main_table", "apply_kernel": "proposal_table"}.get(last_kind, "small_parameters")
+            last_kind = "adam"
+        elif k.startswith("hash_encode_bwd"):
+            last_kind = "hash_encode_bwd"
             t = bwd_tag(k, g, rows_full) or bwd_tag(k, g, rows_coh) or ("main_s32" if "kernel<4," in k or "kernel<2," in k else last_bwd)
         elif k.startswith(("bin_kernel", "apply_kernel")):
+            last_kind = "apply_kernel" if k.startswith("apply_kernel") else last_kind
             t = last_bwd
         else:
             t = tag_of(k, g)
