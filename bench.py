@@ -229,8 +229,10 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                    order=("camera", "radar", "lidar") if radar_coherent or mixed is None else ("camera", "lidar", "radar"))
         assert asm.n == n_rays, "workload: ray counts must add up"
         if n_lidar and os.environ.get("NR_BENCH_LIDAR_SUP", "1") != "0":
-            # the lidar rays of the batch are supervised the reference's way: carving masks on the weights of all three
-            # levels (neuradar.py:529-541,637-650) from the measured ranges / did_return flags the assembler writes
+            # the lidar rays of the batch carry the reference's CARVING terms: masks on the weights of all three levels
+            # (neuradar.py:529-541,637-650) from the measured ranges / did_return flags the assembler writes.  The headline's
+            # depth / feature supervision stays the bench loss on every ray; the reference's full lidar loss (quantile-masked
+            # depth L1, intensity, ray drop, per-proposal depth terms) is what the decoder workloads add (prop_depth_loss + set_decoders)
             is_l = asm.is_lidar[:, 0].to(torch.uint8).contiguous()
             for k_ in range(2):
                 stepper.set_lidar(is_l, asm.slots[k_]["did_return"], asm.slots[k_]["directions_norm"], asm.offset["lidar"], n_lidar,

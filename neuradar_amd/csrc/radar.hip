@@ -3,7 +3,7 @@
 // assembles the loss from boolean-mask indexing -- a host round trip in the middle of every step.  Here:
 //   radar_cost_kernel   cost[m detections][n predictions] of one scan (+ every detection's cheapest prediction)
 //   lsa_kernel          the rectangular linear sum assignment (shortest augmenting paths with dual variables, Crouse 2016 -- the
-//                       algorithm scipy implements), ONE workgroup per scan, duals and path state in registers / LDS, float64
+//                       algorithm scipy implements), ONE workgroup (512 threads) per scan, duals and path state in registers / LDS, float64
 //   radar_loss_kernel   Hungarian-matched loss ("euclidean" | "nll") and its gradient w.r.t. the 7 outputs per prediction
 // so the whole chain is three launches with no host read and can sit inside a captured graph.
 #include "nr_common.h"
@@ -11,7 +11,7 @@
 namespace {
 
 constexpr float kEps = 1e-6f, kMinVar = 1e-3f, kMaxCost = 1e9f;  // radar_utils.py:30-32
-constexpr int kLsaThreads = 1024, kLsaWaves = kLsaThreads / NR_WAVE;
+constexpr int kLsaThreads = 512, kLsaWaves = kLsaThreads / NR_WAVE;
 constexpr int kLsaMaxCols = 8192, kLsaMaxRows = 1024, kLsaColsPerThread = kLsaMaxCols / kLsaThreads;
 
 __device__ __forceinline__ float clamp_ep(float r) { return fminf(fmaxf(r, kEps), 1.0f - kEps); }
@@ -90,6 +90,26 @@ __device__ __forceinline__ LsaKey lsa_shfl_xor(const LsaKey& a, int o) {
   r.k = (unsigned)__shfl_xor((int)a.k, o, NR_WAVE);
   return r;
 }
+// one step of the wave arg-min on DPP operands (VALU only: a ds_bpermute round trip per dword and step made the reduction a
+// third of an iteration): lanes without a source keep their own value
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ LsaKey lsa_dpp_min(const LsaKey& a) {
+  const int hi = __double2hiint(a.v), lo = __double2loint(a.v);
+  LsaKey o;
+  o.v = __hiloint2double(nr_dpp_i<CTRL, ROWMASK>(hi, hi), nr_dpp_i<CTRL, ROWMASK>(lo, lo));
+  o.k = (unsigned)nr_dpp_i<CTRL, ROWMASK>((int)a.k, (int)a.k);
+  return lsa_less(o, a) ? o : a;
+}
+// arg-min over the wave, valid in lane 63 (prefix minima inside the rows of 16, then the two row broadcasts)
+__device__ __forceinline__ LsaKey lsa_wave_min_to_lane63(LsaKey a) {
+  a = lsa_dpp_min<NR_DPP_ROW_SHR + 1, 0xF>(a);
+  a = lsa_dpp_min<NR_DPP_ROW_SHR + 2, 0xF>(a);
+  a = lsa_dpp_min<NR_DPP_ROW_SHR + 4, 0xF>(a);
+  a = lsa_dpp_min<NR_DPP_ROW_SHR + 8, 0xF>(a);
+  a = lsa_dpp_min<NR_DPP_ROW_BCAST15, 0xA>(a);
+  a = lsa_dpp_min<NR_DPP_ROW_BCAST31, 0xC>(a);
+  return a;
+}
 
 __global__ void __launch_bounds__(kLsaThreads)
 lsa_kernel(const float* __restrict__ cost_all, const float* __restrict__ row_min_all, const int* __restrict__ row_arg_all,
@@ -167,12 +187,8 @@ lsa_kernel(const float* __restrict__ cost_all, const float* __restrict__ row_min
           if (lsa_less(cand, best)) best = cand;
         }
       }
-#pragma unroll
-      for (int o = 1; o < NR_WAVE; o <<= 1) {
-        const LsaKey other = lsa_shfl_xor(best, o);
-        if (lsa_less(other, best)) best = other;
-      }
-      if (lane == 0) {
+      best = lsa_wave_min_to_lane63(best);
+      if (lane == NR_WAVE - 1) {
         red_v[parity][wave] = best.v;
         red_k[parity][wave] = best.k;
       }

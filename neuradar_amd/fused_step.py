@@ -330,6 +330,11 @@ class FusedTrainStep:
         lib, p, c, B = self.lib, ops._p, self.cfg, self.B
         st = ops._stream()
         assert self.C <= 32 and (target_features is None or target_features.shape[1] == self.C)
+        if c.appearance_dim > 0 and self.dec is None and not any(
+                l_ is not None and l_["decoder"] for l_ in (self.lidar if isinstance(self.lidar, list) else [self.lidar])):
+            raise NotImplementedError("the model has an appearance embedding but the step has no consumer for it: configure the "
+                                      "decoders (set_decoders) or the lidar decoder segment (set_lidar(..., target_intensity=...)); "
+                                      "the bench loss on the rendered features would silently ignore the embedding")
         main = torch.cuda.current_stream()
         side = self._side_streams() if self.overlap else [main, main]
         lam, scal = c.power_lambda, c.power_scaling
