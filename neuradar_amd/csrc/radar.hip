@@ -1,9 +1,10 @@
 // Radar point-set loss of the training step on the device (model_components/radar_utils.py:54-168): the reference builds the
 // detection-to-prediction cost matrix with torch ops, copies it to the host, runs scipy's linear_sum_assignment per scan and
 // assembles the loss from boolean-mask indexing -- a host round trip in the middle of every step.  Here:
-//   radar_cost_kernel   cost[m detections][n predictions] of one scan (+ every detection's cheapest prediction)
+//   radar_cost_sort_kernel  cost[rows][columns] of one scan + every row's cheapest columns in cost order
 //   lsa_kernel          the rectangular linear sum assignment (shortest augmenting paths with dual variables, Crouse 2016 -- the
-//                       algorithm scipy implements), ONE workgroup (512 threads) per scan, duals and path state in registers / LDS, float64
+//                       algorithm scipy implements), ONE wave per scan over the assigned columns only, duals and path state in
+//                       registers / LDS, float64
 //   radar_loss_kernel   Hungarian-matched loss ("euclidean" | "nll") and its gradient w.r.t. the 7 outputs per prediction
 // so the whole chain is three launches with no host read and can sit inside a captured graph.
 #include "nr_common.h"
@@ -11,8 +12,7 @@
 namespace {
 
 constexpr float kEps = 1e-6f, kMinVar = 1e-3f, kMaxCost = 1e9f;  // radar_utils.py:30-32
-constexpr int kLsaThreads = 512, kLsaWaves = kLsaThreads / NR_WAVE;
-constexpr int kLsaMaxCols = 8192, kLsaMaxRows = 1024, kLsaColsPerThread = kLsaMaxCols / kLsaThreads;
+constexpr int kLsaMaxCols = 8192, kLsaMaxRows = 1024;
 
 __device__ __forceinline__ float clamp_ep(float r) { return fminf(fmaxf(r, kEps), 1.0f - kEps); }
 
@@ -35,206 +35,469 @@ __device__ __forceinline__ float radar_cost(const float* __restrict__ p, const f
   return (isinf(c) || c != c) ? kMaxCost : c;  // (a NaN prediction -- a diverged fp16 run -- must not poison the search: scipy raises there)
 }
 
-// One block per (detection, scan): cost row [n] + its minimum / arg-minimum (the row duals the assignment starts from).
-__global__ void __launch_bounds__(256)
-radar_cost_kernel(const float* __restrict__ pred, int64_t n, const float* __restrict__ gt, int gt_stride,
-                  const int* __restrict__ seg, int m_cap, int nll, float* __restrict__ cost, float* __restrict__ row_min,
-                  int* __restrict__ row_arg) {
-  const int scan = blockIdx.y, j = blockIdx.x;
+// ---- linear sum assignment ----------------------------------------------------------------------------------------
+// Orientation per scan: rows = the smaller side (nr <= nc; detections when there are fewer detections than rays -- the usual
+// case).  Workspace per scan: sorted keys [small][small] u64, cost [small][large] float, row-by-slot costs [small][64 Q] float
+// (only when they do not fit the LDS); small / large = min / max of (max_detections, n_pred).
+//
+// The search never needs more than a row's CHEAPEST FREE column: free columns keep the dual v = 0 (v only changes on scanned
+// columns, and a free column is scanned only as the sink), so through row i the best free column is the first free entry of the
+// row's columns in cost order, and at most nr - 1 columns are ever assigned -- the row's nr cheapest columns are enough.  The
+// shortest-path tree is therefore kept over the ASSIGNED columns only ("slots", <= nr of them, numbered as they are assigned)
+// plus one running best free candidate: an iteration relaxes <= nr slots instead of nc columns (3 531 -> <= 200 on a
+// neuradar radar scan), which one wave does without a barrier.  Same iterations, duals and result as the full-width search.
+constexpr int kSortThreads = 512, kSortWaves = kSortThreads / NR_WAVE, kSortPerThread = kLsaMaxCols / kSortThreads;
+
+__device__ __forceinline__ unsigned lsa_ord(float f) {  // float -> unsigned with the same order
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float lsa_unord(unsigned o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu)); }
+
+// One block per (row, scan): the row's costs -> cost[row][:] and its nr cheapest columns in (cost, column) order ->
+// sorted[row][:nr].  The nr-th smallest cost is found by bisection on the ordered bit patterns (32 counting rounds over the
+// thread's registers), the columns up to it are compacted in column order and only those (P2 = nr rounded up to a power of two,
+// <= 1 024) go through a bitonic sort in LDS -- a full sort of the 3 531-column row was LDS-bandwidth-bound at 52 us.
+__global__ void __launch_bounds__(kSortThreads)
+radar_cost_sort_kernel(const float* __restrict__ pred, int n_pred, const float* __restrict__ gt, int gt_stride,
+                       const int* __restrict__ seg, int nll, int small, int large, float* __restrict__ cost_all,
+                       unsigned long long* __restrict__ sorted_all) {
+  __shared__ unsigned long long keys[kLsaMaxRows];
+  __shared__ int part[2][kSortWaves];
+  __shared__ int tot[kSortPerThread][kSortWaves];  // per (register slot, wave): taken below the threshold | at it << 16
+  const int scan = blockIdx.y, r = blockIdx.x, tid = threadIdx.x, lane = tid & (NR_WAVE - 1), wave = tid / NR_WAVE;
   const int m = seg[scan + 1] - seg[scan];
-  if (j >= m) return;
-  const float* g = gt + (int64_t)(seg[scan] + j) * gt_stride;
-  const float g3[3] = {g[0], g[1], g[2]};
-  const float* p = pred + (int64_t)scan * n * 7;
-  float* out = cost + ((int64_t)scan * m_cap + j) * n;
-  float best = INFINITY;
-  int arg = 0;
-  for (int64_t k = threadIdx.x; k < n; k += blockDim.x) {
-    const float c = radar_cost(p + k * 7, g3, nll);
-    out[k] = c;
-    if (c < best) { best = c; arg = (int)k; }
-  }
-  // block arg-min (smallest index among equal minima)
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = best < INFINITY ? arg : 0x7fffffff;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const float v2 = sv[threadIdx.x + o];
-      const int i2 = si[threadIdx.x + o];
-      if (v2 < sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
+  const bool tr = m > n_pred;
+  const int nr = tr ? n_pred : m, nc = tr ? m : n_pred;
+  if (r >= nr || nr > small || nc > large) return;
+  const float* p0 = pred + (int64_t)scan * n_pred * 7;
+  const float* g0 = gt + (int64_t)seg[scan] * gt_stride;
+  float* out = cost_all + ((int64_t)scan * small + r) * large;
+  unsigned key[kSortPerThread];  // column c = tid + q * kSortThreads; 0xffffffff past the row (no cost maps there: NaN -> MAX_COST)
+#pragma unroll
+  for (int q = 0; q < kSortPerThread; ++q) {
+    const int c = tid + q * kSortThreads;
+    key[q] = 0xffffffffu;
+    if (c < nc) {
+      const float* g = g0 + (int64_t)(tr ? c : r) * gt_stride;
+      const float g3[3] = {g[0], g[1], g[2]};
+      const float cst = radar_cost(p0 + (int64_t)(tr ? r : c) * 7, g3, nll);
+      out[c] = cst;
+      key[q] = lsa_ord(cst);
     }
+  }
+  // the smallest T with #(key <= T) >= nr
+  unsigned lo = 0u, hi = 0xfffffffeu;
+  for (int it = 0; lo < hi; ++it) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < kSortPerThread; ++q) cnt += key[q] <= mid ? 1 : 0;
+    cnt = (int)nr_wave_sum((float)cnt);  // (<= 8 192: exact in float)
+    if (lane == 0) part[it & 1][wave] = cnt;
     __syncthreads();
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) all += part[it & 1][w];
+    if (all >= nr) hi = mid; else lo = mid + 1;
   }
-  if (threadIdx.x == 0) {
-    row_min[(int64_t)scan * m_cap + j] = sv[0];
-    row_arg[(int64_t)scan * m_cap + j] = si[0] < (int)n ? si[0] : 0;
+  const unsigned T = lo;
+  // ordered compaction (column order = register slot, then thread): everything below T, then the first columns AT T
+#pragma unroll
+  for (int q = 0; q < kSortPerThread; ++q) {
+    const unsigned long long below = __ballot(key[q] < T), at = __ballot(key[q] == T);
+    if (lane == 0) tot[q][wave] = __popcll(below) | (__popcll(at) << 16);
   }
+  __syncthreads();
+  int n_below = 0;
+#pragma unroll
+  for (int q = 0; q < kSortPerThread; ++q)
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) n_below += tot[q][w] & 0xffff;
+  const int need_at = nr - n_below;  // >= 1
+  int P2 = 2;
+  while (P2 < nr) P2 <<= 1;
+  for (int k = nr + tid; k < P2; k += kSortThreads) keys[k] = ~0ull;
+  int base_below = 0, base_at = 0;
+#pragma unroll
+  for (int q = 0; q < kSortPerThread; ++q) {
+    const unsigned long long below = __ballot(key[q] < T), at = __ballot(key[q] == T);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int b0 = base_below, a0 = base_at;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; ++w) {
+      const int t = tot[q][w];
+      if (w < wave) {
+        b0 += t & 0xffff;
+        a0 += t >> 16;
+      }
+      base_below += t & 0xffff;
+      base_at += t >> 16;
+    }
+    const unsigned long long full = ((unsigned long long)key[q] << 32) | (unsigned)(tid + q * kSortThreads);
+    if (key[q] < T) {
+      keys[b0 + __popcll(below & lt)] = full;
+    } else if (key[q] == T) {
+      const int rank = a0 + __popcll(at & lt);
+      if (rank < need_at) keys[n_below + rank] = full;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P2 >> 1); t += kSortThreads) {
+        const int l2 = ((t & ~(j - 1)) << 1) | (t & (j - 1)), h2 = l2 | j;
+        const unsigned long long a = keys[l2], b = keys[h2];
+        if ((a > b) == ((l2 & k) == 0)) {
+          keys[l2] = b;
+          keys[h2] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  unsigned long long* dst = sorted_all + ((int64_t)scan * small + r) * small;
+  for (int k = tid; k < nr; k += kSortThreads) dst[k] = keys[k];
 }
 
-// ---- linear sum assignment ----------------------------------------------------------------------------------------
-// Rows = the smaller side (nr <= nc).  Thread t owns columns t, t + 1024, ...: their dual v, shortest-path cost and
-// "scanned" flag live in its registers; row4col / path (who reaches the column) in LDS for the augmentation walk.
-// Every iteration of the shortest-path search: all threads relax their columns against the current row and the block
-// takes the arg-min over (cost, assigned?, column) -- free columns win ties like in scipy, then the lower index.
-struct LsaKey {
-  double v;
-  unsigned k;  // bit 31: column already assigned, low bits: column
-};
-__device__ __forceinline__ bool lsa_less(const LsaKey& a, const LsaKey& b) { return a.v < b.v || (a.v == b.v && a.k < b.k); }
-__device__ __forceinline__ LsaKey lsa_shfl_xor(const LsaKey& a, int o) {
-  LsaKey r;
-  r.v = __shfl_xor(a.v, o, NR_WAVE);
-  r.k = (unsigned)__shfl_xor((int)a.k, o, NR_WAVE);
-  return r;
-}
-// one step of the wave arg-min on DPP operands (VALU only: a ds_bpermute round trip per dword and step made the reduction a
-// third of an iteration): lanes without a source keep their own value
+// minimum of a double over the wave, in every lane (DPP operands: VALU only)
 template <int CTRL, int ROWMASK>
-__device__ __forceinline__ LsaKey lsa_dpp_min(const LsaKey& a) {
-  const int hi = __double2hiint(a.v), lo = __double2loint(a.v);
-  LsaKey o;
-  o.v = __hiloint2double(nr_dpp_i<CTRL, ROWMASK>(hi, hi), nr_dpp_i<CTRL, ROWMASK>(lo, lo));
-  o.k = (unsigned)nr_dpp_i<CTRL, ROWMASK>((int)a.k, (int)a.k);
-  return lsa_less(o, a) ? o : a;
+__device__ __forceinline__ double lsa_dpp_min(double a) {
+  const int hi = __double2hiint(a), lo = __double2loint(a);
+  return fmin(a, __hiloint2double(nr_dpp_i<CTRL, ROWMASK>(hi, hi), nr_dpp_i<CTRL, ROWMASK>(lo, lo)));
 }
-// arg-min over the wave, valid in lane 63 (prefix minima inside the rows of 16, then the two row broadcasts)
-__device__ __forceinline__ LsaKey lsa_wave_min_to_lane63(LsaKey a) {
+__device__ __forceinline__ double lsa_wave_min(double a) {
   a = lsa_dpp_min<NR_DPP_ROW_SHR + 1, 0xF>(a);
   a = lsa_dpp_min<NR_DPP_ROW_SHR + 2, 0xF>(a);
   a = lsa_dpp_min<NR_DPP_ROW_SHR + 4, 0xF>(a);
   a = lsa_dpp_min<NR_DPP_ROW_SHR + 8, 0xF>(a);
   a = lsa_dpp_min<NR_DPP_ROW_BCAST15, 0xA>(a);
   a = lsa_dpp_min<NR_DPP_ROW_BCAST31, 0xC>(a);
-  return a;
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63));
 }
 
-__global__ void __launch_bounds__(kLsaThreads)
-lsa_kernel(const float* __restrict__ cost_all, const float* __restrict__ row_min_all, const int* __restrict__ row_arg_all,
-           const int* __restrict__ seg, int m_cap, int n_pred, int* __restrict__ assoc_all, int* __restrict__ status) {
-  const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Per-slot state lives in registers: entry x of such an array belongs to lane (x & 63), register (x >> 6).
+// A lane's own entry by a per-lane register index / predicated write of it (VALU selects: no branches):
+template <int Q, typename T>
+__device__ __forceinline__ T lsa_pick(const T (&a)[Q], int q) {
+  // (every element passes through an empty asm: left alone, the compiler folds the select chain over the array into ONE
+  // dynamically indexed load, which puts the array -- all the per-slot state -- into scratch memory: 2 100 cycles per iteration)
+  T r = a[0];
+  asm("" : "+v"(r));
+#pragma unroll
+  for (int k = 1; k < Q; ++k) {
+    T t = a[k];
+    asm("" : "+v"(t));
+    r = q == k ? t : r;
+  }
+  return r;
+}
+template <int Q, typename T>
+__device__ __forceinline__ void lsa_put(T (&a)[Q], int q, T val, bool pred) {
+#pragma unroll
+  for (int k = 0; k < Q; ++k) a[k] = (pred && q == k) ? val : a[k];
+}
+__device__ __forceinline__ int lsa_lane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double lsa_lane(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+// read of entry x for a wave-uniform x
+template <int Q, typename T>
+__device__ __forceinline__ T lsa_rd(const T (&a)[Q], int x) { return lsa_lane(lsa_pick<Q, T>(a, x >> 6), x & 63); }
+
+// One wave per scan (shortest augmenting paths with dual variables, Crouse 2016 -- the algorithm scipy implements; float64
+// duals).  All state of the search is per SLOT and in registers: the slot's column and dual v, and -- moving with it along an
+// augmenting path -- the row matched to it with that row's dual u, its cached cheapest free column (and where in its sorted
+// columns that was found) and two flags; an unmatched row exists only as the root of its own search (wave-uniform values).
+// cm[row][slot]: the cost of (row, the slot's column) -- in LDS when small * small floats fit beside the assigned-columns
+// bitmap (<= 200 rows), else in the workspace through L2-coherent accesses (a plain store followed by a plain load of the same
+// address by the same wave returned stale L1 data on gfx950) -- filled for a row when it first enters a tree and extended for
+// all such rows when a column becomes a slot: an iteration of the search touches no global memory and is ~150 instructions.
+template <int Q, bool LDS_CM>
+__global__ void __launch_bounds__(NR_WAVE)
+lsa_kernel(const float* __restrict__ cost_all, const unsigned long long* __restrict__ sorted_all, float* cm_all,
+           const int* __restrict__ seg, int small, int large, int n_pred, int* __restrict__ assoc_all, int* __restrict__ status) {
+  extern __shared__ unsigned lsa_lds[];
+  unsigned* abits = lsa_lds;                                           // [kLsaMaxCols / 32] column is assigned
+  int* claim = reinterpret_cast<int*>(lsa_lds + kLsaMaxCols / 32);     // start only: [nc] lowest row whose minimum it is
+  int* start_col = claim + kLsaMaxCols;                                // start only: [Q * 64] per slot: column, row, minimum
+  int* start_row = start_col + Q * NR_WAVE;
+  int* start_min = start_row + Q * NR_WAVE;
+  float* cm_l = reinterpret_cast<float*>(lsa_lds + kLsaMaxCols / 32);  // afterwards (LDS_CM): [small][small]
+  const int scan = blockIdx.x, lane = threadIdx.x;
   const int m = seg[scan + 1] - seg[scan];
-  const float* C = cost_all + (int64_t)scan * m_cap * n_pred;  // [m][n_pred]
-  int* assoc = assoc_all + (int64_t)scan * n_pred;             // per prediction: detection index or -1
-  // orientation: rows = detections when m <= n_pred (the usual case: a few hundred detections, thousands of rays)
+  int* assoc = assoc_all + (int64_t)scan * n_pred;  // per prediction: detection index or -1
   const bool tr = m > n_pred;
   const int nr = tr ? n_pred : m, nc = tr ? m : n_pred;
-  for (int k = tid; k < n_pred; k += kLsaThreads) assoc[k] = -1;
+  for (int k = lane; k < n_pred; k += NR_WAVE) assoc[k] = -1;
   if (nr == 0) return;
-  if (nr > kLsaMaxRows || nc > kLsaMaxCols) {
-    if (tid == 0) status[scan] = 2;  // beyond the kernel's static limits
+  if (nr > Q * NR_WAVE || nc > kLsaMaxCols || nr > small || nc > large) {
+    if (lane == 0) status[scan] = 2;  // beyond the kernel's static limits / more detections than max_detections
     return;
   }
-  auto c_at = [&](int i, int j) -> double { return (double)(tr ? C[(int64_t)j * n_pred + i] : C[(int64_t)i * n_pred + j]); };
+  const float* C = cost_all + (int64_t)scan * small * large;
+  const unsigned long long* S = sorted_all + (int64_t)scan * small * small;
+  float* cm_g = cm_all + (int64_t)scan * small * (Q * NR_WAVE);
+  auto cm_at = [&](int row, int s) -> float* { return LDS_CM ? cm_l + row * small + s : cm_g + (int64_t)row * (Q * NR_WAVE) + s; };
+  auto cm_store = [&](int row, int s, float x) {
+    if (LDS_CM) *cm_at(row, s) = x; else __hip_atomic_store(cm_at(row, s), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto cm_load = [&](int row, int s) -> float {
+    return LDS_CM ? *cm_at(row, s) : __hip_atomic_load(cm_at(row, s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto is_assigned = [&](unsigned c) -> bool { return (abits[c >> 5] >> (c & 31)) & 1u; };
+  constexpr int kActive = 1, kHasFree = 2;  // flags: the row has its cm row | its cheapest free column is cached
 
-  __shared__ int row4col[kLsaMaxCols];
-  __shared__ int path[kLsaMaxCols];
-  __shared__ double u[kLsaMaxRows];
-  __shared__ int col4row[kLsaMaxRows];
-  __shared__ int sr_row[kLsaMaxRows + 1];
-  __shared__ double sr_val[kLsaMaxRows + 1];
-  __shared__ double red_v[2][kLsaWaves];
-  __shared__ unsigned red_k[2][kLsaWaves];
-
-  double v[kLsaColsPerThread], spc[kLsaColsPerThread];
+  for (int w = lane; w < kLsaMaxCols / 32; w += NR_WAVE) abits[w] = 0u;
+  for (int j = lane; j < nc; j += NR_WAVE) claim[j] = -1;
+  __syncthreads();
+  // start from the duals u_i = min_j c_ij, v = 0 (feasible; the edge (i, argmin_i) is tight): every column that is some row's
+  // minimum is assigned at once -- the lowest row wins a contested column -- and only the losers need a search
+  int c0[Q], min0[Q];  // per row (lane + 64 q): its cheapest column and that cost's ordered bits
 #pragma unroll
-  for (int q = 0; q < kLsaColsPerThread; ++q) v[q] = 0.0;
-  for (int j = tid; j < nc; j += kLsaThreads) row4col[j] = -1;
-  for (int i = tid; i < nr; i += kLsaThreads) {
-    col4row[i] = -1;
-    u[i] = tr ? 0.0 : (double)row_min_all[(int64_t)scan * m_cap + i];
+  for (int q = 0; q < Q; ++q) {
+    const int i = lane + q * NR_WAVE;
+    c0[q] = min0[q] = 0;
+    if (i < nr) {
+      const unsigned long long k0 = S[(int64_t)i * small];
+      min0[q] = (int)(unsigned)(k0 >> 32);
+      c0[q] = (int)(unsigned)k0;
+      atomicMin(reinterpret_cast<unsigned*>(&claim[c0[q]]), (unsigned)i);  // (-1 is the largest unsigned value)
+    }
   }
   __syncthreads();
-  if (!tr) {
-    // start from the duals u_i = min_j c_ij, v = 0 (feasible; an edge (i, argmin_i) is tight): every column claimed by exactly
-    // one row's minimum is assigned at once -- the lowest row wins a contested column -- and only the losers need a search
-    for (int i = tid; i < nr; i += kLsaThreads)  // (-1 is the largest unsigned value: any row index replaces it)
-      atomicMin(reinterpret_cast<unsigned*>(&row4col[row_arg_all[(int64_t)scan * m_cap + i]]), (unsigned)i);
-    __syncthreads();
-    for (int j = tid; j < nc; j += kLsaThreads)
-      if (row4col[j] != -1) col4row[row4col[j]] = j;
-    __syncthreads();
+  int n_slots = 0;
+  unsigned unmatched = 0;  // bit q: my row q needs a search
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {  // (slots are numbered in row order)
+    const int i = lane + q * NR_WAVE;
+    const bool win = i < nr && claim[c0[q]] == i;
+    const unsigned long long mask = __ballot(win);
+    if (win) {
+      const int s = n_slots + __popcll(mask & ((1ull << lane) - 1ull));
+      start_col[s] = c0[q];
+      start_row[s] = i;
+      start_min[s] = min0[q];
+      atomicOr(&abits[(unsigned)c0[q] >> 5], 1u << (c0[q] & 31));
+    } else if (i < nr) {
+      unmatched |= 1u << q;
+    }
+    n_slots += __popcll(mask);
   }
+  __syncthreads();
+  // slots (entry s: lane s & 63, register s >> 6)
+  double u_s[Q], v[Q], vw[Q], spc[Q], cand[Q];  // u of the slot's row; v of its column; per search: v or -inf (closed), path cost, open path cost
+  int col[Q], row_of[Q], path[Q], bf_cost[Q], bf_col[Q], bf_ptr[Q], flags[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int s = lane + q * NR_WAVE;
+    col[q] = s < n_slots ? start_col[s] : 0;
+    row_of[q] = s < n_slots ? start_row[s] : 0;
+    u_s[q] = s < n_slots ? (double)lsa_unord((unsigned)start_min[s]) : 0.0;
+    path[q] = bf_cost[q] = bf_col[q] = bf_ptr[q] = flags[q] = 0;
+    v[q] = 0.0;
+  }
+  __syncthreads();  // (the start arrays' LDS becomes cm)
 
-  int parity = 0;
   for (int cur = 0; cur < nr; ++cur) {
-    if (col4row[cur] != -1) continue;  // (uniform: LDS value read by every thread after a barrier)
-    unsigned scanned = 0;              // bit q: my column q is in SC
+    if (!((lsa_lane((int)unmatched, cur & 63) >> (cur >> 6)) & 1)) continue;
+    // the root: an unmatched row (never in a tree before)
+    double cur_u = (double)lsa_unord((unsigned)lsa_rd<Q, int>(min0, cur));
+    int cur_bf_cost = 0, cur_bf_col = 0, cur_bf_ptr = 0, cur_flags = 0;
+    unsigned scanned = 0;  // bit q: my slot q is in the tree
 #pragma unroll
-    for (int q = 0; q < kLsaColsPerThread; ++q) spc[q] = INFINITY;
-    double min_val = 0.0;
-    int i = cur, n_sr = 0, sink = -1;
-    while (sink == -1) {
-      if (tid == 0) {
-        sr_row[n_sr] = i;
-        sr_val[n_sr] = min_val;
+    for (int q = 0; q < Q; ++q) {
+      vw[q] = (lane + q * NR_WAVE) < n_slots ? v[q] : -INFINITY;
+      spc[q] = cand[q] = INFINITY;
+    }
+    double min_val = 0.0, free_val = INFINITY;  // free_val: cheapest way to a free column so far ...
+    unsigned free_col = 0xffffffffu;            // ... the column ...
+    int free_via = -1;                          // ... and the slot of the row it is reached from (-1: the root)
+    // the row being scanned (wave-uniform): its slot (-1: the root), dual, cached free column, flags
+    int i = cur, i_slot = -1, r_bf_cost = 0, r_bf_col = 0, r_flags = 0;
+    double ui = cur_u;
+    while (true) {
+      const bool mine = i_slot >= 0 && lane == (i_slot & 63);
+      if (!(r_flags & kActive)) {  // first time in a tree: the row's costs of all slots so far
+        const float* Ci = C + (int64_t)i * large;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int s = lane + q * NR_WAVE;
+          if (s < n_slots) cm_store(i, s, Ci[col[q]]);
+        }
+        r_flags |= kActive;
+        if (i_slot < 0) cur_flags = r_flags; else lsa_put<Q, int>(flags, i_slot >> 6, r_flags, mine);
       }
-      ++n_sr;
-      const double ui = u[i];
-      LsaKey best = {INFINITY, 0xffffffffu};
+      float cq[Q];  // (slots past n_slots: any value -- their vw is -inf)
 #pragma unroll
-      for (int q = 0; q < kLsaColsPerThread; ++q) {
-        const int j = tid + q * kLsaThreads;
-        if (j < nc && !((scanned >> q) & 1u)) {
-          const double r = min_val + c_at(i, j) - ui - v[q];
-          if (r < spc[q]) {
-            spc[q] = r;
-            path[j] = i;
+      for (int q = 0; q < Q; ++q) cq[q] = cm_load(i, LDS_CM ? min(lane + q * NR_WAVE, small - 1) : lane + q * NR_WAVE);
+      if (!(r_flags & kHasFree)) {  // the first free entry of the row's sorted columns
+        const unsigned long long* Si = S + (int64_t)i * small;
+        int p = 0;
+        while (true) {
+          const unsigned long long key = (p + lane) < nr ? Si[p + lane] : ~0ull;
+          const bool is_free = (p + lane) < nr && !is_assigned((unsigned)key);
+          const unsigned long long mask = __ballot(is_free);
+          if (mask) {
+            const int first = __builtin_ctzll(mask);
+            r_bf_cost = lsa_lane((int)(key >> 32), first);
+            r_bf_col = lsa_lane((int)(unsigned)key, first);
+            p += first;
+            break;
           }
-          const LsaKey cand = {spc[q], (unsigned)j | (row4col[j] != -1 ? 0x80000000u : 0u)};
-          if (lsa_less(cand, best)) best = cand;
+          p += NR_WAVE;
+          if (p >= nr) {  // cannot happen: fewer than nr columns are assigned
+            if (lane == 0) status[scan] = 1;
+            return;
+          }
+        }
+        r_flags |= kHasFree;
+        if (i_slot < 0) {
+          cur_bf_cost = r_bf_cost;
+          cur_bf_col = r_bf_col;
+          cur_bf_ptr = p;
+        } else {
+          lsa_put<Q, int>(bf_cost, i_slot >> 6, r_bf_cost, mine);
+          lsa_put<Q, int>(bf_col, i_slot >> 6, r_bf_col, mine);
+          lsa_put<Q, int>(bf_ptr, i_slot >> 6, p, mine);
+        }
+        if (i_slot < 0) cur_flags = r_flags; else lsa_put<Q, int>(flags, i_slot >> 6, r_flags, mine);
+      }
+      {
+        const double r = min_val + (double)lsa_unord((unsigned)r_bf_cost) - ui;
+        if (r < free_val || (r == free_val && (unsigned)r_bf_col < free_col)) {
+          free_val = r;
+          free_col = (unsigned)r_bf_col;
+          free_via = i_slot;
         }
       }
-      best = lsa_wave_min_to_lane63(best);
-      if (lane == NR_WAVE - 1) {
-        red_v[parity][wave] = best.v;
-        red_k[parity][wave] = best.k;
-      }
-      __syncthreads();
-      best.v = red_v[parity][0];
-      best.k = red_k[parity][0];
+      double best = INFINITY;
+      int best_q = 0;
 #pragma unroll
-      for (int w = 1; w < kLsaWaves; ++w) {
-        const LsaKey other = {red_v[parity][w], red_k[parity][w]};
-        if (lsa_less(other, best)) best = other;
+      for (int q = 0; q < Q; ++q) {
+        const double r = min_val + (double)cq[q] - ui - vw[q];  // (+inf on closed slots)
+        const bool upd = r < spc[q];
+        spc[q] = upd ? r : spc[q];
+        cand[q] = upd ? r : cand[q];
+        path[q] = upd ? i_slot : path[q];
+        if (cand[q] < best) {
+          best = cand[q];
+          best_q = q;
+        }
       }
-      parity ^= 1;
-      if (!(best.v < INFINITY)) {  // infeasible (cannot happen with finite costs)
-        if (tid == 0) status[scan] = 1;
-        return;
+      const double wmin = lsa_wave_min(best);
+      if (!(wmin < free_val)) {  // a free column is at least as near as every open assigned one: the sink (free wins ties)
+        min_val = free_val;
+        break;
       }
-      min_val = best.v;
-      const int j = (int)(best.k & 0x7fffffffu);
-      if ((j & (kLsaThreads - 1)) == tid) scanned |= 1u << (j / kLsaThreads);
-      if (best.k & 0x80000000u) i = row4col[j]; else sink = j;
+      min_val = wmin;
+      // the owner of the minimum: the lowest lane holding it (its lowest slot); its row is scanned next
+      const int owner = __builtin_ctzll(__ballot(best == wmin));
+      const int sel_row = lsa_pick<Q, int>(row_of, best_q), sel_cost = lsa_pick<Q, int>(bf_cost, best_q),
+                sel_col = lsa_pick<Q, int>(bf_col, best_q), sel_flags = lsa_pick<Q, int>(flags, best_q);
+      const double sel_u = lsa_pick<Q, double>(u_s, best_q);
+      const bool own = lane == owner;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const bool hit = own && q == best_q;
+        cand[q] = hit ? INFINITY : cand[q];
+        vw[q] = hit ? -INFINITY : vw[q];
+      }
+      scanned |= own ? (1u << best_q) : 0u;
+      i_slot = owner + NR_WAVE * lsa_lane(best_q, owner);
+      i = lsa_lane(sel_row, owner);
+      ui = lsa_lane(sel_u, owner);
+      r_bf_cost = lsa_lane(sel_cost, owner);
+      r_bf_col = lsa_lane(sel_col, owner);
+      r_flags = lsa_lane(sel_flags, owner);
+    }
+    if (!(min_val < INFINITY)) {  // infeasible (cannot happen with finite costs)
+      if (lane == 0) status[scan] = 1;
+      return;
     }
     // dual updates (scipy: u[cur] += minVal; u[i] += minVal - spc[col4row[i]] for the other rows of SR; v[j] -= minVal - spc[j] on SC)
-    __syncthreads();  // sr_row / sr_val of the last iteration are visible
-    for (int t = tid; t < n_sr; t += kLsaThreads) u[sr_row[t]] += min_val - sr_val[t];
+    const int s_new = n_slots;
+    const unsigned sink = free_col;
+    cur_u += min_val;
 #pragma unroll
-    for (int q = 0; q < kLsaColsPerThread; ++q)
-      if ((scanned >> q) & 1u) v[q] -= min_val - spc[q];
-    // the sink itself was added to SC last with spc = min_val: its v is unchanged (min_val - spc = 0)
-    if (tid == 0) {  // augment along the alternating path
-      int j = sink;
+    for (int q = 0; q < Q; ++q) {
+      if ((scanned >> q) & 1u) {
+        const double d = min_val - spc[q];
+        u_s[q] += d;
+        v[q] -= d;
+      }
+      if (lane + q * NR_WAVE == s_new) {  // the sink becomes a slot (its v stays 0)
+        col[q] = (int)sink;
+        v[q] = 0.0;
+      }
+    }
+    if (lane == 0) abits[sink >> 5] |= 1u << (sink & 31);
+    {  // augment: along the alternating path every row moves to the slot it reached (the root ends in the last one)
+      int js = s_new, src = free_via;
       while (true) {
-        const int i2 = path[j];
-        row4col[j] = i2;
-        const int prev = col4row[i2];
-        col4row[i2] = j;
-        j = prev;
-        if (i2 == cur) break;
+        int m_row = cur, m_cost = cur_bf_cost, m_col = cur_bf_col, m_ptr = cur_bf_ptr, m_flags = cur_flags;
+        double m_u = cur_u;
+        if (src >= 0) {
+          m_row = lsa_rd<Q, int>(row_of, src);
+          m_cost = lsa_rd<Q, int>(bf_cost, src);
+          m_col = lsa_rd<Q, int>(bf_col, src);
+          m_ptr = lsa_rd<Q, int>(bf_ptr, src);
+          m_flags = lsa_rd<Q, int>(flags, src);
+          m_u = lsa_rd<Q, double>(u_s, src);
+        }
+        const bool dst = lane == (js & 63);
+        lsa_put<Q, int>(row_of, js >> 6, m_row, dst);
+        lsa_put<Q, int>(bf_cost, js >> 6, m_cost, dst);
+        lsa_put<Q, int>(bf_col, js >> 6, m_col, dst);
+        lsa_put<Q, int>(bf_ptr, js >> 6, m_ptr, dst);
+        lsa_put<Q, int>(flags, js >> 6, m_flags, dst);
+        lsa_put<Q, double>(u_s, js >> 6, m_u, dst);
+        if (src < 0) break;
+        js = src;
+        src = lsa_rd<Q, int>(path, src);
+      }
+    }
+    ++n_slots;
+    __syncthreads();  // (the bitmap's new bit)
+    // rows that have been in a tree: their cost of the new slot; rows whose cached cheapest free column was the sink: the next one
+    // (both loads requested before either is used)
+    float c_new[Q];
+    unsigned long long k_new[Q];
+    bool refresh[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool live = (lane + q * NR_WAVE) < n_slots;
+      c_new[q] = 0.0f;
+      k_new[q] = 0ull;
+      refresh[q] = live && (flags[q] & kHasFree) && (unsigned)bf_col[q] == sink;
+      if (live && (flags[q] & kActive)) c_new[q] = C[(int64_t)row_of[q] * large + sink];
+      if (refresh[q]) k_new[q] = S[(int64_t)row_of[q] * small + bf_ptr[q] + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool live = (lane + q * NR_WAVE) < n_slots;
+      if (live && (flags[q] & kActive)) cm_store(row_of[q], s_new, c_new[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (refresh[q]) {
+        const unsigned long long* Sr = S + (int64_t)row_of[q] * small;
+        int p = bf_ptr[q] + 1;
+        unsigned long long key = k_new[q];
+        while (is_assigned((unsigned)key)) key = Sr[++p];  // (ends before nr: fewer than nr columns are assigned)
+        bf_ptr[q] = p;
+        bf_cost[q] = (int)(key >> 32);
+        bf_col[q] = (int)(unsigned)key;
       }
     }
     __syncthreads();
   }
   // association per prediction
-  if (!tr) {
-    for (int i = tid; i < nr; i += kLsaThreads) assoc[col4row[i]] = i;
-  } else {
-    for (int i = tid; i < nr; i += kLsaThreads) assoc[i] = col4row[i];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if ((lane + q * NR_WAVE) < n_slots) {
+      if (!tr) assoc[col[q]] = row_of[q]; else assoc[row_of[q]] = col[q];
+    }
   }
 }
 
@@ -288,36 +551,74 @@ radar_loss_kernel(const float* __restrict__ pred, int64_t n, int n_scans, const 
 
 }  // namespace
 
+static int lsa_q(int64_t small) {  // slots per lane: 1, 2, 4, 8, 16
+  int q = 1;
+  while ((int64_t)q * NR_WAVE < small) q <<= 1;
+  return q;
+}
+constexpr int64_t kLsaLdsBytes = 160 * 1024, kLsaLdsFixed = kLsaMaxCols / 8;  // the CU's LDS; the assigned-columns bitmap
+static bool lsa_cm_in_lds(int64_t small) { return kLsaLdsFixed + small * small * 4 <= kLsaLdsBytes; }
+static int64_t lsa_lds_bytes(int64_t small, int Q) {
+  const int64_t start = (int64_t)kLsaMaxCols * 4 + 3 * Q * NR_WAVE * 4, cm = lsa_cm_in_lds(small) ? small * small * 4 : 0;
+  return kLsaLdsFixed + (start > cm ? start : cm);
+}
+
 extern "C" int64_t nr_radar_assign_workspace_bytes(int n_scans, int64_t n_pred, int max_detections) {
   if (n_scans < 0 || n_pred < 0 || max_detections < 0) return -1;
-  // cost [scans][m_cap][n] floats, row minima + arg-minima [scans][m_cap], status [scans]
-  return ((int64_t)n_scans * max_detections * n_pred + (int64_t)n_scans * max_detections) * 4 + (int64_t)n_scans * max_detections * 4 +
-         (int64_t)n_scans * 4 + 64;
+  const int64_t small = max_detections < n_pred ? max_detections : n_pred, large = max_detections < n_pred ? n_pred : max_detections;
+  // per scan: sorted keys [small][small] u64, cost [small][large] float, row-by-slot costs [small][64 Q] float; status [scans]
+  return (int64_t)n_scans * small * small * 8 + (int64_t)n_scans * small * (large + lsa_q(small) * NR_WAVE) * 4 + (int64_t)n_scans * 4 + 64;
+}
+
+template <int Q, bool LDS_CM>
+static int lsa_launch(const float* cost, const unsigned long long* sorted, float* cm, const int* seg, int small, int large, int n_pred,
+                      int* assoc, int* status, int n_scans, nr_stream_t stream) {
+  const int64_t lds = lsa_lds_bytes(small, Q);
+  static bool raised = false;  // (more than the default 64 KB of dynamic LDS needs the attribute once per kernel)
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel<Q, LDS_CM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kLsaLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL((lsa_kernel<Q, LDS_CM>), dim3((unsigned)n_scans), dim3(NR_WAVE), (size_t)lds, nr_s(stream), cost, sorted, cm, seg,
+                     small, large, n_pred, assoc, status);
+  NR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int nr_radar_assign(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride,
                                const int* seg, int max_detections, int cost_type, int* assoc, void* workspace, nr_stream_t stream) {
   if (n_scans == 0 || n_pred == 0) return 0;
   if (!pred || !detections || !seg || !assoc || !workspace || n_scans < 0 || n_pred < 0 || max_detections < 0 || det_stride < 3 ||
-      (cost_type != 0 && cost_type != 1) || n_pred > 0x3fffffff)
+      (cost_type != 0 && cost_type != 1) || n_pred > 0x3fffffff || ((uintptr_t)workspace & 7))
     return NR_EINVAL;
   const int64_t small = max_detections < n_pred ? max_detections : n_pred, large = max_detections < n_pred ? n_pred : max_detections;
   if (small > kLsaMaxRows || large > kLsaMaxCols) return NR_EINVAL;
-  float* cost = reinterpret_cast<float*>(workspace);
-  float* row_min = cost + (int64_t)n_scans * max_detections * n_pred;
-  int* row_arg = reinterpret_cast<int*>(row_min + (int64_t)n_scans * max_detections);
-  int* status = row_arg + (int64_t)n_scans * max_detections;
+  const int Q = lsa_q(small);
+  unsigned long long* sorted = reinterpret_cast<unsigned long long*>(workspace);
+  float* cost = reinterpret_cast<float*>(sorted + (int64_t)n_scans * small * small);
+  float* cm = cost + (int64_t)n_scans * small * large;
+  int* status = reinterpret_cast<int*>(cm + (int64_t)n_scans * small * Q * NR_WAVE);
   hipError_t e = hipMemsetAsync(status, 0, sizeof(int) * n_scans, nr_s(stream));
   if (e != hipSuccess) return (int)e;
-  if (max_detections > 0) {
-    hipLaunchKernelGGL(radar_cost_kernel, dim3((unsigned)max_detections, (unsigned)n_scans), dim3(256), 0, nr_s(stream), pred, n_pred,
-                       detections, det_stride, seg, max_detections, cost_type, cost, row_min, row_arg);
+  if (small > 0) {
+    hipLaunchKernelGGL(radar_cost_sort_kernel, dim3((unsigned)small, (unsigned)n_scans), dim3(kSortThreads), 0, nr_s(stream), pred,
+                       (int)n_pred, detections, det_stride, seg, cost_type, (int)small, (int)large, cost, sorted);
     NR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(lsa_kernel, dim3((unsigned)n_scans), dim3(kLsaThreads), 0, nr_s(stream), cost, row_min, row_arg, seg,
-                     max_detections, (int)n_pred, assoc, status);
-  NR_LAUNCH_CHECK();
-  return 0;
+#define NR_LSA_LAUNCH(QQ, IN_LDS) \
+  return lsa_launch<QQ, IN_LDS>(cost, sorted, cm, seg, (int)small, (int)large, (int)n_pred, assoc, status, n_scans, stream)
+  switch (Q) {
+    case 1: NR_LSA_LAUNCH(1, true);
+    case 2: NR_LSA_LAUNCH(2, true);
+    case 4:
+      if (lsa_cm_in_lds(small)) NR_LSA_LAUNCH(4, true);
+      NR_LSA_LAUNCH(4, false);
+    case 8: NR_LSA_LAUNCH(8, false);
+    default: NR_LSA_LAUNCH(16, false);
+  }
+#undef NR_LSA_LAUNCH
 }
 
 extern "C" int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
