@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 15
+#define NR_ABI_VERSION 16
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -172,6 +172,17 @@ int nr_radar_assign(const float* pred, int n_scans, int64_t n_pred, const float*
                     int max_detections, int cost_type, int* assoc, void* workspace, nr_stream_t stream);
 int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
                   const int* assoc, int loss_type, float mult, float* grad_pred, float* loss, nr_stream_t stream);
+
+/* Radar rays -> rendered points and their sine position embedding, the head of decode_features' radar branch
+ * (models/neuradar.py:470-476: spherical (azimuth, elevation) * depth -> xyz; detr/models/position_encoding_3d.py:56-103,
+ * evaluated under no_grad): one launch instead of ~50 elementwise ones.
+ *   depth [n], dirs_spher [n, 2] = (azimuth phi, elevation theta); xyz [n, 3] = depth * (cos phi cos theta, sin phi cos theta,
+ *   sin theta); dirs [n, 3] = d xyz / d depth (kept for the backward); pos [n, C]: channel c = sin (code[c] & 1 == 0) or cos of
+ *   xyz[code[c] >> 1] * 2 pi / dim_t[c], dim_t [C] = temperature^(2 floor(k / 2) / cdim) per axis as the reference computes it.
+ * nr_radar_points_bwd: g_depth [n] = <g_xyz, dirs>. */
+int nr_radar_points_fwd(const float* depth, const float* dirs_spher, int64_t n, const float* dim_t, const int* code, int C,
+                        float* xyz, float* dirs, float* pos, nr_stream_t stream);
+int nr_radar_points_bwd(const float* g_xyz, const float* dirs, int64_t n, float* g_depth, nr_stream_t stream);
 
 /* tiny-cuda-nn-compatible multiresolution hash grid for 3-D and 4-D inputs: what
  * `tcnn.Encoding(n_input_dims, {"otype": "HashGrid", n_levels, n_features_per_level, log2_hashmap_size, base_resolution,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 15
+NR_ABI_VERSION = 16
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -68,6 +68,8 @@ PROTOTYPES = {
     "nr_radar_assign_workspace_bytes": [I, L, I],
     "nr_radar_assign": [P, I, L, P, I, P, I, I, P, P, P],
     "nr_radar_loss": [P, I, L, P, I, P, P, I, F, P, P, P],
+    "nr_radar_points_fwd": [P, P, L, P, P, I, P, P, P, P],
+    "nr_radar_points_bwd": [P, P, L, P, P],
     "nr_tcnn_grid_param_count": [I, I, I, I, I, F],
     "nr_tcnn_grid_geometry": [I, I, I, I, F, P, P, P],
     "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],

@@ -549,6 +549,37 @@ radar_loss_kernel(const float* __restrict__ pred, int64_t n, int n_scans, const 
   if (nr_lane() == 0 && acc != 0.0f) unsafeAtomicAdd(loss + nr_loss_slot_index(), acc);
 }
 
+
+// Radar rays -> rendered points + their sine position embedding (neuradar.py:470-476, detr/models/position_encoding_3d.py:56-103)
+// in ONE launch (the torch expression of it is ~50 elementwise launches at the head of the radar chain).  Channel c of the
+// embedding: axis code[c] >> 1, sin (code & 1 == 0) or cos of  xyz[axis] * 2 pi / dim_t[c]  (dim_t from the host, in torch's
+// arithmetic).  dirs = d xyz / d depth.
+__global__ void __launch_bounds__(256)
+radar_points_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ sph, int64_t n, const float* __restrict__ dim_t,
+                        const int* __restrict__ code, int C, float* __restrict__ xyz, float* __restrict__ dirs, float* __restrict__ pos) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * C) return;
+  const int64_t r = idx / C;
+  const int c = (int)(idx - r * C);
+  const float d = depth[r], phi = sph[r * 2], theta = sph[r * 2 + 1];
+  const float cp = cosf(phi), sp = sinf(phi), ct = cosf(theta), st = sinf(theta);
+  const float p3[3] = {d * cp * ct, d * sp * ct, d * st};
+  if (c < 3) {
+    xyz[r * 3 + c] = p3[c];
+    dirs[r * 3 + c] = c == 0 ? cp * ct : (c == 1 ? sp * ct : st);
+  }
+  const int k = code[c];
+  const float a = p3[k >> 1] * 6.283185307179586f / dim_t[c];
+  pos[idx] = (k & 1) ? cosf(a) : sinf(a);
+}
+
+__global__ void __launch_bounds__(256)
+radar_points_bwd_kernel(const float* __restrict__ g_xyz, const float* __restrict__ dirs, int64_t n, float* __restrict__ g_depth) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  g_depth[r] = g_xyz[r * 3] * dirs[r * 3] + g_xyz[r * 3 + 1] * dirs[r * 3 + 1] + g_xyz[r * 3 + 2] * dirs[r * 3 + 2];
+}
+
 }  // namespace
 
 static int lsa_q(int64_t small) {  // slots per lane: 1, 2, 4, 8, 16
@@ -629,6 +660,24 @@ extern "C" int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, con
     return NR_EINVAL;
   hipLaunchKernelGGL(radar_loss_kernel, dim3((unsigned)nr_cdiv(n_pred * n_scans, 256)), dim3(256), 0, nr_s(stream), pred, n_pred,
                      n_scans, detections, det_stride, seg, assoc, loss_type, mult, grad_pred, loss);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_radar_points_fwd(const float* depth, const float* dirs_spher, int64_t n, const float* dim_t, const int* code, int C,
+                                   float* xyz, float* dirs, float* pos, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!depth || !dirs_spher || !dim_t || !code || !xyz || !dirs || !pos || n < 0 || C < 3) return NR_EINVAL;
+  hipLaunchKernelGGL(radar_points_fwd_kernel, dim3((unsigned)nr_cdiv(n * C, 256)), dim3(256), 0, nr_s(stream), depth, dirs_spher, n, dim_t,
+                     code, C, xyz, dirs, pos);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_radar_points_bwd(const float* g_xyz, const float* dirs, int64_t n, float* g_depth, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!g_xyz || !dirs || !g_depth || n < 0) return NR_EINVAL;
+  hipLaunchKernelGGL(radar_points_bwd_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), g_xyz, dirs, n, g_depth);
   NR_LAUNCH_CHECK();
   return 0;
 }

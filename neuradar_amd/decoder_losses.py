@@ -104,6 +104,7 @@ class DecoderLossHead:
                                      device=dev, dtype=torch.uint8) if n_rad else None)
         self.last: Dict[str, Tensor] = {}
         self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"
+        self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
 
     def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
@@ -130,14 +131,14 @@ class DecoderLossHead:
                 s_.wait_stream(cur)
         def side_chains():
             r0, n = self.layout["lidar"]
-            if n:
+            if n and "lidar" not in self._skip:
                 with (torch.cuda.stream(s_lidar) if s_lidar is not cur else contextlib.nullcontext()):
                     y = m.lidar_decoder(x[r0:r0 + n])
                     out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
                                                                                 batch["target_intensity"], r0, n, c)
                     self.last["lidar_y"] = y
             r0, n = self.layout["radar"]
-            if n:
+            if n and "radar" not in self._skip:
                 with (torch.cuda.stream(s_radar) if s_radar is not cur else contextlib.nullcontext()):
                     ro = m.decode_radar(x[r0:r0 + n], depth[r0:r0 + n, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
                                         seed_epoch=seed_epoch)
@@ -147,9 +148,13 @@ class DecoderLossHead:
 
         def camera_chain():
             r0, n = self.layout["camera"]
-            if n:
-                # [P, h, w, C] -> packed NCHW (MIOpen falls back to naive kernels on the permuted, non-packed view: 28 ms per step)
-                patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2).contiguous()
+            if n and "cnn" not in self._skip:
+                # [P, h, w, C] rows ARE the channels-last layout of [P, C, h, w]; the convolution weights sit channels-last in the
+                # optimizer's buffer (fused_step.flatten_parameters), so MIOpen runs NHWC kernels on both without a layout copy.
+                # (NHWC input with NCHW weights made it fall back to its naive kernels: 28 ms per step.)
+                patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2)
+                if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in m.rgb_decoder.parameters()):
+                    patches = patches.contiguous()  # (a model whose parameters were not flattened: packed NCHW for both)
                 if self.cnn_autocast is not None:
                     with torch.autocast("cuda", dtype=self.cnn_autocast):
                         rgb = m.rgb_decoder(patches)

@@ -156,13 +156,13 @@ class Decoders(nn.Module):
                      seed_epoch: Optional[Tensor] = None) -> Tensor:
         """neuradar.py:463-491: features / depth / (azimuth, elevation) of the radar rays, scan after scan ->
         radar_output [scans, n, 7] = (existence probability, x, y, z, three Laplace scales)."""
+        from . import ops
+
         C = radar_features.shape[-1]
-        depth = depth.reshape(num_radar_scans, -1, 1)
-        sph = directions_spher.reshape(num_radar_scans, -1, 2)
-        theta, phi = sph[..., 1:2], sph[..., 0:1]
-        xyz = torch.cat((depth * torch.cos(phi) * torch.cos(theta), depth * torch.sin(phi) * torch.cos(theta), depth * torch.sin(theta)), dim=2)
-        with torch.no_grad():
-            pos = sine_position_embedding(xyz.detach(), C)
+        # the rendered points and their position embedding (constant, like under the reference's no_grad): one launch
+        # (sine_position_embedding above is the same expression in torch ops: ~50 launches at the head of the chain)
+        xyz, pos = ops.radar_points(depth, directions_spher, C)
+        xyz, pos = xyz.view(num_radar_scans, -1, 3), pos.view(num_radar_scans, -1, C)
         out = self.radar_decoder(radar_features.reshape(num_radar_scans, -1, C), pos, seed_epoch)
         offset = 1.5 * self.offset_head(out)
         ep = self.existence_probability_head(out)

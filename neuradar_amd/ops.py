@@ -561,6 +561,61 @@ def radar_loss(pred: Tensor, detections: Tensor, seg: Tensor, max_detections: in
     return _RadarLoss.apply(pred, detections, seg, assoc, loss_type, float(mult)), assoc
 
 
+_POSEMB_TABLES: dict = {}
+
+
+def _posemb_tables(C: int, temperature: float, device) -> Tuple[Tensor, Tensor]:
+    """Per-channel (dim_t, axis * 2 + is_cos) of PositionEmbeddingCoordsSine for three input axes (position_encoding_3d.py:
+    66-84: C // 3 channels per axis rounded down to even, the remainder handed out two at a time from the first axis on),
+    dim_t in torch's own float32 arithmetic."""
+    key = (C, float(temperature), str(device))
+    if key not in _POSEMB_TABLES:
+        ndim = C // 3
+        ndim -= ndim % 2
+        rems = C - ndim * 3
+        dim_t, code = [], []
+        for d in range(3):
+            cdim = ndim
+            if rems > 0:
+                cdim += 2
+                rems -= 2
+            k = torch.arange(cdim, dtype=torch.float32, device=device)
+            dim_t.append(temperature ** (2 * torch.div(k, 2, rounding_mode="floor") / cdim))
+            code.append(2 * d + (torch.arange(cdim, device=device) % 2))
+        _POSEMB_TABLES[key] = (torch.cat(dim_t).contiguous(), torch.cat(code).to(torch.int32).contiguous())
+    return _POSEMB_TABLES[key]
+
+
+class _RadarPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, dirs_spher, C, temperature):
+        ctx.depth_shape = depth.shape
+        depth, dirs_spher = _f32(depth, "depth").reshape(-1), _f32(dirs_spher, "directions_spher").reshape(-1, 2)
+        n = depth.shape[0]
+        dim_t, code = _posemb_tables(C, temperature, depth.device)
+        xyz, dirs = torch.empty(n, 3, device=depth.device), torch.empty(n, 3, device=depth.device)
+        pos = torch.empty(n, C, device=depth.device)
+        check(_lib.lib().nr_radar_points_fwd(_p(depth), _p(dirs_spher), n, _p(dim_t), _p(code), C, _p(xyz), _p(dirs), _p(pos), _stream()),
+              "nr_radar_points_fwd")
+        ctx.save_for_backward(dirs)
+        ctx.mark_non_differentiable(pos)
+        return xyz, pos
+
+    @staticmethod
+    def backward(ctx, g_xyz, _g_pos):
+        (dirs,) = ctx.saved_tensors
+        g_xyz = _f32(g_xyz, "g_xyz")
+        g_depth = torch.empty(dirs.shape[0], device=dirs.device)
+        check(_lib.lib().nr_radar_points_bwd(_p(g_xyz), _p(dirs), dirs.shape[0], _p(g_depth), _stream()), "nr_radar_points_bwd")
+        return g_depth.view(ctx.depth_shape), None, None, None
+
+
+def radar_points(depth: Tensor, dirs_spher: Tensor, num_channels: int, temperature: float = 10000.0) -> Tuple[Tensor, Tensor]:
+    """nr_radar_points_fwd: depth [n], (azimuth, elevation) [n, 2] -> (xyz [n, 3], differentiable in depth; sine position
+    embedding of xyz [n, num_channels], constant) -- neuradar.py:470-476 + position_encoding_3d.py:56-103."""
+    return _RadarPoints.apply(depth, dirs_spher, int(num_channels), float(temperature))
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
               betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,

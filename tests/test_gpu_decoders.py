@@ -212,3 +212,33 @@ def test_transformer_layer_with_hip_attention(monkeypatch):
     assert_close(g_hip, g_ref, rtol=1e-3, atol_scale=1e-4, what="input gradient, hip attention")
     assert_close(y_tor, y_ref, rtol=2e-2, atol_scale=2e-3, what="encoder output, torch attention")
     assert_close(g_tor, g_ref, rtol=2e-2, atol_scale=2e-2, what="input gradient, torch attention")
+
+
+@pytest.mark.parametrize("C", [48, 52, 32])
+def test_radar_points_kernel_equals_the_torch_expression(C):
+    """nr_radar_points_fwd/bwd against the expression it replaces (neuradar.py:470-476 + sine_position_embedding, the port of
+    position_encoding_3d.py:56-103): points, embedding (channel split 16/16/16, 18/18/16, 12/10/10) and d points / d depth."""
+    import math
+
+    from neuradar_amd import ops
+    from neuradar_amd.decoders import sine_position_embedding
+
+    gen = torch.Generator().manual_seed(C)
+    n = 2 * 1177
+    depth = (torch.rand(n, generator=gen) * 120.0 + 0.5).to(DEV).requires_grad_(True)
+    sph = torch.stack([(torch.rand(n, generator=gen) - 0.5) * 2.0, (torch.rand(n, generator=gen) - 0.5) * 0.5], 1).to(DEV)
+    xyz, pos = ops.radar_points(depth, sph, C)
+    d2 = depth.detach().clone().requires_grad_(True)
+    theta, phi = sph[:, 1:2], sph[:, 0:1]
+    ref = torch.cat((d2[:, None] * torch.cos(phi) * torch.cos(theta), d2[:, None] * torch.sin(phi) * torch.cos(theta),
+                     d2[:, None] * torch.sin(theta)), dim=1)
+    ref_pos = sine_position_embedding(ref.detach()[None], C)[0]
+    assert torch.equal(xyz.detach(), ref.detach())
+    # the embedding's argument reaches ~750 rad: sin / cos of identical float arguments, up to the libraries' last-place differences
+    assert float((pos - ref_pos).abs().max()) <= 2e-6, float((pos - ref_pos).abs().max())
+    assert not pos.requires_grad
+    w = torch.randn(n, 3, generator=gen).to(DEV)
+    (xyz * w).sum().backward()
+    (ref * w).sum().backward()
+    assert_close(depth.grad.cpu(), d2.grad.cpu(), rtol=1e-6, atol_scale=1e-6, what="d points / d depth")
+    assert math.isfinite(float(pos.sum()))
