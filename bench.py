@@ -506,6 +506,59 @@ def cpu_baseline(model, stepper, fwd_bwd, targets, n_rays_sample, threads):
                       f"(host: {logical} logical / {physical} physical cores)"}
 
 
+def has_actors_wl(wl):
+    return bool(wl.get("actors"))
+
+
+def measure_render(model, scene, device, reps=5):
+    """Evaluation / rendering entry (models/neuradar.py:905-969; NeuRadarHotPath.get_outputs_for_camera_ray_bundle) with the model
+    the step has just trained: one 1920 x 1080 camera image -- rays shot at every third pixel (640 x 360 = 230 400 rays, eight
+    chunks of 32 768), eval-mode samplers, the RGB CNN once over the whole feature image -> 1920 x 1080 x 3 -- and one radar scan
+    (one chunk, transformer + heads).  Forward only, eager launches on the modular path's kernels; HIP events, median of `reps`."""
+    from neuradar_amd.sensors import scale_pixel_area
+
+    was_training = model.training
+    model.eval()
+    H, W = scene.H, scene.W
+    ys, xs = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    idx = torch.stack([torch.full_like(ys, 100), ys, xs], dim=-1).reshape(-1, 3)
+    out = {}
+    with torch.no_grad():
+        def cam():
+            bundle = scene.cameras.generate_rays(idx)
+            scale_pixel_area(bundle)
+            if model.config.appearance_dim > 0:
+                bundle.metadata["sensor_idxs"] = torch.zeros_like(bundle.pixel_area, dtype=torch.int64)
+            return model.get_outputs_for_camera_ray_bundle(bundle, image_shape=(H, W))
+
+        def radar():
+            bundle = scene.radars.generate_rays(torch.tensor([100], device=device))
+            bundle.metadata["is_radar"] = torch.ones_like(bundle.pixel_area, dtype=torch.bool)
+            if model.config.appearance_dim > 0:
+                bundle.metadata["sensor_idxs"] = torch.full_like(bundle.pixel_area, 2, dtype=torch.int64)
+            return model.get_outputs_for_camera_ray_bundle(bundle, num_radar_scans=1)
+
+        for name, fn in (("camera_image", cam), ("radar_scan", radar)):
+            res = fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                res = fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            ms = sorted(ts)[len(ts) // 2]
+            n = res["depth"].numel()
+            out[name] = {"rays": n, "ms": round(ms, 3), "rays_per_s": round(n / (ms * 1e-3), 1),
+                         "outputs": {k: list(v.shape) for k, v in res.items() if k in ("rgb", "depth", "radar_output", "intensity")}}
+    out["note"] = ("forward only, eval mode, eager launches (ray generation of the full image included); "
+                   "chunks of %d rays" % model.config.eval_num_rays_per_chunk)
+    model.train(was_training)
+    return out
+
+
 def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_cpu, min_seconds, trained_steps=0):
     """Build `workload`, warm up, time it (see timed_block) and, on request, collect the roofline / CPU-baseline blocks.
     trained_steps > 0: the "trained" regime -- scene-consistent targets (make_step), that many training steps before the timed
@@ -780,7 +833,11 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                                              "the main table's Adam (up to 32 B per parameter) streams beside them and is not counted"}
     if rank == 0 and world == 1 and want_cpu:
         cpu = cpu_baseline(model, stepper, fwd_bwd, targets, args.cpu_sample_rays, args.cpu_threads)
+    render = None
+    if rank == 0 and world == 1 and wl.get("decoders") and not args.no_render and not has_actors_wl(wl):
+        render = measure_render(model, scene, device)
     result = {"workload": workload, "wl": wl, "value": value, "ms_per_step": ms_per_step, "n_rays": n_rays, "use_graph": bool(use_graph),
+              "render": render,
               "unroll": (unroll if use_graph else 1), "host_ms": host_elapsed / args.steps * 1e3, "roof": roof, "cpu": cpu,
               "blocks": n_blocks, "ms_min": per_block[0] / args.steps * 1e3, "ms_max": per_block[-1] / args.steps * 1e3,
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
@@ -804,6 +861,7 @@ def main():
                     "default: BASELINE.json configs[1]")
     ap.add_argument("--full-model", default="mixed16384_neuradar_full,mixed8192_vod_nll,mixed16384_neuradar_full_fp16",
                     help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
+    ap.add_argument("--no-render", action="store_true", help="skip the rendering-entry block of the full-model workloads")
     ap.add_argument("--regime", default="fresh", choices=["fresh", "trained"], help="trained: the MAIN measurement itself runs in the "
                     "trained regime (--trained-steps steps on scene-consistent targets first; no separate `trained` block) -- for "
                     "profiling that regime by itself")
@@ -868,7 +926,7 @@ def main():
                                "radar_loss": fr["wl"].get("radar_loss"), "radar_grid": fr["wl"].get("radar", "zod"),
                                "mlp_operands": fr["mlp_dtype"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
-                               "loss_after_run": fr["loss"],
+                               "loss_after_run": fr["loss"], "render": fr["render"],
                                "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
                                            "the linear sum assignment on the device"})
     trained = None

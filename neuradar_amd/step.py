@@ -63,6 +63,10 @@ class HotPathConfig:
     decoders: bool = False
     radar_mult: float = 0.02
     radar_loss_type: str = "nll"  # LossSettings.radar_loss_type (:114); "euclidean" = the deterministic head
+    # rendering (get_outputs_for_camera_ray_bundle): method_configs.py:380, neurad.py:141,149
+    eval_num_rays_per_chunk: int = 1 << 15
+    rgb_upsample_factor: int = 3
+    compensate_upsampling_when_rendering: bool = True
 
 
 class NeuRadarHotPath(nn.Module):
@@ -216,6 +220,79 @@ class NeuRadarHotPath(nn.Module):
         return out
 
     forward = get_nff_outputs
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, bundle: RayBundle, image_shape: Optional[Tuple[int, int]] = None,
+                                          num_radar_scans: int = 1) -> Dict[str, Tensor]:
+        """models/neuradar.py:905-969 (evaluation / rendering entry).  `bundle` holds the rays of ONE sensor reading, row
+        major: a camera image or patch of `image_shape` = (H, W) rays, or -- image_shape None -- a lidar / radar scan marked
+        by `is_lidar` / `is_radar` in its metadata.  Camera rays are shot at 1 / rgb_upsample_factor of the resolution
+        (every `step`-th ray from `step // 2` on, both axes) because the RGB decoder upsamples; the field is evaluated in
+        chunks of eval_num_rays_per_chunk rays (a radar scan in one piece: its decoder attends over the whole scan), the
+        decoders once over the whole reading.  Outputs: features / depth / accumulation / prop_depth_i shaped [*size, -1],
+        rgb [H, W, 3] (camera), intensity and ray_drop_logits / ray_drop_prob (every ray, "intensity_for_cam"),
+        radar_output [scans, n, 7] (radar)."""
+        assert not self.training, "rendering runs in eval mode (deterministic samplers, no carving masks)"
+        n_all = len(bundle)
+        take = None
+        if image_shape is None:  # lidar or radar
+            md = bundle.metadata
+            is_lidar = torch.ones_like(bundle.pixel_area, dtype=torch.bool) if "is_lidar" in md else None
+            is_radar = torch.ones_like(bundle.pixel_area, dtype=torch.bool) if "is_radar" in md else None
+            if is_lidar is not None and is_radar is not None:
+                raise ValueError("a reading is a lidar scan or a radar scan, not both")
+            if is_radar is not None:
+                is_lidar = torch.zeros_like(is_radar)
+            elif is_lidar is not None:
+                is_radar = torch.zeros_like(is_lidar)
+            output_size, patch_size = (n_all,), (1, 1)
+        else:
+            H, W = image_shape
+            assert H * W == n_all, "image_shape does not match the bundle"
+            if self.config.compensate_upsampling_when_rendering:
+                step = self.config.rgb_upsample_factor
+                rows = torch.arange(step // 2, H, step, device=bundle.origins.device)
+                cols = torch.arange(step // 2, W, step, device=bundle.origins.device)
+                take = (rows[:, None] * W + cols[None, :]).reshape(-1)
+                H, W = rows.numel(), cols.numel()
+            output_size = patch_size = (H, W)
+            is_lidar = is_radar = None
+        pick = (lambda t: t if (t is None or take is None) else t[take])  # noqa: E731
+        rays = RayBundle(pick(bundle.origins), pick(bundle.directions), pick(bundle.pixel_area), pick(bundle.camera_indices),
+                         pick(bundle.nears), pick(bundle.fars), {k: pick(v) for k, v in bundle.metadata.items()}, pick(bundle.times))
+        n = len(rays)
+        radar = image_shape is None and "is_radar" in bundle.metadata
+        chunk = n if radar else self.config.eval_num_rays_per_chunk
+        keep = ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1")
+        lists: Dict[str, List[Tensor]] = {k: [] for k in keep}
+        for lo in range(0, n, chunk):
+            sl = slice(lo, min(lo + chunk, n))
+            cut = (lambda t: None if t is None else t[sl])  # noqa: E731
+            part = RayBundle(rays.origins[sl], rays.directions[sl], rays.pixel_area[sl], cut(rays.camera_indices), cut(rays.nears),
+                             cut(rays.fars), {k: v[sl] for k, v in rays.metadata.items()}, cut(rays.times))
+            out = self.get_nff_outputs(part)
+            for k in keep:
+                if k in out:
+                    lists[k].append(out[k])
+        outputs = {k: torch.cat(v).view(*output_size, -1) for k, v in lists.items() if v}
+        if getattr(self, "_decoders", None) is None:
+            return outputs
+        features = outputs["features"].view(-1, outputs["features"].shape[-1])
+        dec = self._decoders
+        # intensity_for_cam (neuradar.py:446-447): the lidar decoder over every ray of the reading
+        intensity, ray_drop_logit = dec.lidar_decoder(features).float().split(1, dim=-1)
+        outputs["intensity"] = intensity.sigmoid().view(*output_size, -1)
+        outputs["ray_drop_logits"] = ray_drop_logit.view(*output_size, -1)
+        outputs["ray_drop_prob"] = outputs["ray_drop_logits"].sigmoid()
+        if image_shape is not None:  # the CNN over the whole image as one patch
+            patch = features.view(1, *patch_size, features.shape[-1]).permute(0, 3, 1, 2)
+            if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in dec.rgb_decoder.parameters()):
+                patch = patch.contiguous()
+            outputs["rgb"] = dec.rgb_decoder(patch).permute(0, 2, 3, 1).squeeze(0)
+        elif radar:
+            outputs["radar_output"] = dec.decode_radar(features, outputs["depth"].reshape(-1, 1), rays.metadata["directions_spher"],
+                                                        num_radar_scans)
+        return outputs
 
     def decode_lidar(self, features: Tensor, is_lidar: Tensor):
         """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the

@@ -39,5 +39,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     fm = r["full_model"]
     assert len(fm) == 1 and fm[0]["workload"] == "mixed8192_vod_nll" and fm[0]["value"] > 0 and fm[0]["decoders_us_in_step"] > 0
     assert fm[0]["rays"] == {"camera": 2048, "lidar": 1599, "radar": 4545} and fm[0]["radar_loss"] == "nll"
+    # the rendering entry with the model the step trained: one camera image at a third of the resolution, one radar scan
+    rd = fm[0]["render"]
+    assert rd["camera_image"]["rays"] == 640 * 360 and rd["camera_image"]["outputs"]["rgb"] == [1080, 1920, 3] and rd["camera_image"]["ms"] > 0
+    assert rd["radar_scan"]["rays"] == 4545 and rd["radar_scan"]["outputs"]["radar_output"] == [1, 4545, 7]
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "rays/s" and cpu["sample"]

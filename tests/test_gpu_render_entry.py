@@ -1,0 +1,105 @@
+"""The evaluation / rendering entry (models/neuradar.py:905-969, get_outputs_for_camera_ray_bundle) on the HIP path: strided
+camera rays, ragged chunks, eval-mode samplers, one decode over the reading -- against the CPU oracle's eval pipeline and
+against the same model evaluated in one piece."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from test_gpu_fullsize import _check, _oracle_params  # noqa: E402
+
+
+def _model(chunk, decoders=True):
+    from neuradar_amd.neurad_encoding import NeuRADHashEncodingConfig, StaticSettings
+    from neuradar_amd.neurad_field import NeuRADFieldConfig
+    from neuradar_amd.step import HotPathConfig, NeuRadarHotPath
+
+    torch.manual_seed(3)
+    cfg = HotPathConfig(field=NeuRADFieldConfig(grid=NeuRADHashEncodingConfig(static=StaticSettings(log2_hashmap_size=15))),
+                        decoders=decoders, eval_num_rays_per_chunk=chunk)
+    cfg.proposal_field_1.grid.static.log2_hashmap_size = 14
+    cfg.proposal_field_2.grid.static.log2_hashmap_size = 14
+    model = NeuRadarHotPath(cfg).to(DEV).eval()
+    with torch.no_grad():  # a scene with structure: tables away from their near-zero initialisation
+        model.field.hashgrid.static_grid.hash_table.uniform_(-0.5, 0.5)
+        model.proposal_fields[1].hashgrid.static_grid.hash_table.uniform_(-0.5, 0.5)
+    return model
+
+
+def _camera_rays(H, W, gen):
+    from neuradar_amd.rays import RayBundle
+
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    d = torch.stack([(xs - W / 2) / W, (ys - H / 2) / W, torch.ones_like(xs)], -1).reshape(-1, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    o = torch.tensor([1.0, -2.0, 0.5]).expand_as(d) + 0.01 * torch.randn(H * W, 3, generator=gen)
+    area = torch.full((H * W, 1), 1e-6) * (1 + torch.rand(H * W, 1, generator=gen))
+    fars = 40.0 + 200.0 * torch.rand(H * W, 1, generator=gen)
+    return RayBundle(o.to(DEV).contiguous(), d.to(DEV).contiguous(), area.to(DEV), fars=fars.to(DEV))
+
+
+def test_camera_image_in_ragged_chunks_vs_oracle_and_one_piece():
+    from oracle import pipeline as op
+
+    gen = torch.Generator().manual_seed(0)
+    H, W = 26, 31  # not multiples of the upsampling factor: rows 1, 4, ..., 25 and columns 1, 4, ..., 28
+    model = _model(chunk=37)
+    bundle = _camera_rays(H, W, gen)
+    keep = dict(o=bundle.origins.clone(), d=bundle.directions.clone(), a=bundle.pixel_area.clone(), f=bundle.fars.clone())
+    out = model.get_outputs_for_camera_ray_bundle(bundle, image_shape=(H, W))
+    h, w = len(range(1, H, 3)), len(range(1, W, 3))
+    assert out["features"].shape == (h, w, 32) and out["depth"].shape == (h, w, 1) and out["accumulation"].shape == (h, w, 1)
+    assert out["rgb"].shape == (3 * h, 3 * w, 3) and out["intensity"].shape == (h, w, 1) and out["ray_drop_prob"].shape == (h, w, 1)
+    assert float(out["rgb"].min()) >= 0.0 and float(out["rgb"].max()) <= 1.0
+    # the strided rays through the CPU oracle's eval pipeline (bin edges at linspace, no jitter)
+    idx = (torch.arange(1, H, 3)[:, None] * W + torch.arange(1, W, 3)[None, :]).reshape(-1).to(DEV)
+    fp, pp = _oracle_params(model)
+    with torch.no_grad():
+        ref = op.nff_outputs(fp, [pp, pp], dict(origins=keep["o"][idx].cpu(), directions=keep["d"][idx].cpu(),
+                                               pixel_area=keep["a"][idx].cpu(), fars=keep["f"][idx].cpu()))
+    _check(out["features"].reshape(-1, 32).cpu(), ref["features"], "rendered features (eval)", few=5e-3)  # (2 880 values: 4 of them = 1.4e-3)
+    _check(out["depth"].reshape(-1, 1).cpu(), ref["depth"], "depth (eval)")
+    _check(out["accumulation"].reshape(-1, 1).cpu(), ref["accumulation"], "accumulation (eval)")
+    _check(out["prop_depth_1"].reshape(-1, 1).cpu(), ref["prop_depth_1"], "proposal depth (eval)", rtol=1e-3)
+    # one piece: the same numbers (every ray is independent of its chunk)
+    model.config.eval_num_rays_per_chunk = 1 << 15
+    bundle2 = _camera_rays(H, W, torch.Generator().manual_seed(0))
+    whole = model.get_outputs_for_camera_ray_bundle(bundle2, image_shape=(H, W))
+    for k in ("features", "depth", "accumulation", "rgb", "intensity"):
+        assert torch.equal(out[k], whole[k]), k
+    # without the upsampling compensation every ray is shot and the image comes out 3x as large
+    model.config.compensate_upsampling_when_rendering = False
+    full = model.get_outputs_for_camera_ray_bundle(_camera_rays(6, 5, gen), image_shape=(6, 5))
+    assert full["features"].shape == (6, 5, 32) and full["rgb"].shape == (18, 15, 3)
+
+
+def test_lidar_and_radar_readings():
+    from neuradar_amd.rays import RayBundle
+
+    gen = torch.Generator().manual_seed(1)
+    model = _model(chunk=64)
+    n = 2 * 107  # two radar scans of 107 rays
+    base = _camera_rays(n, 1, gen)
+    sph = torch.stack([(torch.rand(n, generator=gen) - 0.5) * 1.5, (torch.rand(n, generator=gen) - 0.5) * 0.4], 1).to(DEV)
+    lidar = RayBundle(base.origins, base.directions, base.pixel_area, fars=base.fars.clone(),
+                      metadata={"is_lidar": torch.ones(n, 1, dtype=torch.bool, device=DEV)})
+    out = model.get_outputs_for_camera_ray_bundle(lidar)
+    assert out["depth"].shape == (n, 1) and out["intensity"].shape == (n, 1) and "rgb" not in out and "radar_output" not in out
+    assert float(out["intensity"].min()) > 0.0 and float(out["intensity"].max()) < 1.0
+    radar = RayBundle(base.origins, base.directions, base.pixel_area, fars=base.fars.clone(),
+                      metadata={"is_radar": torch.ones(n, 1, dtype=torch.bool, device=DEV), "directions_spher": sph})
+    ro = model.get_outputs_for_camera_ray_bundle(radar, num_radar_scans=2)
+    assert ro["radar_output"].shape == (2, 107, 7) and bool(torch.isfinite(ro["radar_output"]).all())
+    assert torch.equal(ro["depth"], out["depth"])  # same rays, same field: the sensor only selects the decoder
+    # the decoded points are the rendered points plus a bounded offset (neuradar.py:486: 1.5 * tanh)
+    xyz = ro["depth"].view(2, 107, 1) * torch.stack([torch.cos(sph[:, 0]) * torch.cos(sph[:, 1]), torch.sin(sph[:, 0]) * torch.cos(sph[:, 1]),
+                                                     torch.sin(sph[:, 1])], -1).view(2, 107, 3)
+    assert float((ro["radar_output"][..., 1:4] - xyz).abs().max()) <= 1.5 + 1e-4
+    with pytest.raises(AssertionError):
+        model.train().get_outputs_for_camera_ray_bundle(lidar)
