@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 16
+#define NR_ABI_VERSION 17
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -76,6 +76,15 @@ int nr_hash_encode_bwd_tuned(const float* x, const float* std, const float* scal
                              int num_levels, int features_per_level, int log2_hashmap_size,
                              const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                              float* grad_table, int64_t n, int sample_major, int wave_cells, nr_stream_t stream);
+
+/* The same, and seen_grad[(row * F + f) / 4] = 1 (bytes, one per four floats of the table, as nr_adam_step's) wherever a sum is
+ * added: the optimizer step that follows (nr_adam_step_marked) then leaves never-marked groups alone without reading their
+ * gradient.  Single-GPU steps only: a gradient that arrives by a collective marks nothing. */
+int nr_hash_encode_bwd_marked(const float* x, const float* std, const float* scalings,
+                              int num_levels, int features_per_level, int log2_hashmap_size,
+                              const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
+                              float* grad_table, int64_t n, int sample_major, int wave_cells, unsigned char* seen_grad,
+                              nr_stream_t stream);
 
 /* The same scatter-add by TABLE SLICE OWNERSHIP, for tables a step hits densely (the proposal grids) and for incoherent rows
  * (lidar / radar rays), where the merging of nr_hash_encode_bwd finds little and the launch runs at the memory side's rate for
@@ -685,6 +694,13 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, i
 /* seen_grad: NULL, or n/4 bytes owned by the caller, zeroed when exp_avg / exp_avg_sq are zeroed.  Byte i is set
  * the first time parameters 4i..4i+3 receive a non-zero gradient; while it is 0 their moments are known to be
  * zero, and (weight_decay == 0) a zero gradient leaves them untouched without reading the moments.  Exact. */
+
+/* nr_adam_step (Adam, no weight decay) over a buffer whose seen_grad bytes are set by the SCATTER (nr_hash_encode_bwd_marked):
+ * a group whose byte is 0 has g = exp_avg = exp_avg_sq = 0 by construction and is skipped after reading the byte alone (nr_adam_step
+ * reads its gradient to notice a first arrival: 4 B per parameter of the whole table per step); n % 4 == 0.  Exact. */
+int nr_adam_step_marked(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                        float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
+                        const unsigned char* seen_grad, nr_stream_t stream);
 
 /* Advance the optimizer step counter step_t[0] (device float, 0-based scheduler step) and refresh
  * dev_hyper = {lr(step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))} with the reference's

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 16
+NR_ABI_VERSION = 17
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -56,6 +56,7 @@ PROTOTYPES = {
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
     "nr_hash_encode_bwd_tuned": [P, P, P, I, I, I, P, L, L, P, L, I, I, P],
+    "nr_hash_encode_bwd_marked": [P, P, P, I, I, I, P, L, L, P, L, I, I, P, P],
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
@@ -123,6 +124,7 @@ PROTOTYPES = {
     "nr_permutation_from_uniform": [P, I, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
     "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P],
+    "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P],
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],

@@ -112,9 +112,11 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// seen: optional, one byte per four floats of this level's table region: set where a sum is added (the optimizer then leaves
+// never-marked groups alone without reading their gradient, nr_adam_step_marked)
 template <int F, int CAP>
 __device__ __forceinline__ void flush_table(unsigned long long* keys, float* vals, int* list, float* base, uint32_t mask,
-                                            int lane, bool reset) {
+                                            int lane, bool reset, uint8_t* seen = nullptr) {
   // occupied slots first (list = the owner words, idle outside the insert phase): the flush then costs
   // occupied * 8 * F / 64 wave-instructions instead of CAP * 8 * F / 64
   int n_occ = 0;
@@ -138,7 +140,10 @@ __device__ __forceinline__ void flush_table(unsigned long long* keys, float* val
     const int cz = ((int)((uint32_t)((key >> 42) & 0x1FFFFF) << 11)) >> 11;
     const uint32_t hs = nr_hash3(cx + (corner & 1), cy + ((corner >> 1) & 1), cz + ((corner >> 2) & 1), mask);
     const float t = vals[slot * 8 * F + r];
-    if (t != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
+    if (t != 0.0f) {
+      unsafeAtomicAdd(base + (int64_t)hs * F + f, t);
+      if (seen != nullptr) seen[((int64_t)hs * F + f) >> 2] = 1;
+    }
     if (reset) vals[slot * 8 * F + r] = 0.0f;
   }
   if (reset) {
@@ -151,7 +156,8 @@ __device__ __forceinline__ void flush_table(unsigned long long* keys, float* val
 template <int F, int CHUNK, int CAP, int W>
 __global__ void __launch_bounds__(W * 64)
 hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int log2T,
-           const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int S) {
+           const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int S,
+           uint8_t* __restrict__ seen_all) {
   constexpr int NV = 8 * F;
   __shared__ unsigned long long s_key[W][CAP];
   __shared__ float s_val[W][CAP * NV];
@@ -164,6 +170,7 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
   const float scale = scalings[level];
   const uint32_t mask = (1u << log2T) - 1u;
   float* base = gtable + (((int64_t)level << log2T) * F);
+  uint8_t* seen = seen_all != nullptr ? seen_all + ((((int64_t)level << log2T) * F) >> 2) : nullptr;
   for (int k = lane; k < CAP; k += NR_WAVE) keys[k] = kEmptyKey;
   for (int k = lane; k < CAP * NV; k += NR_WAVE) vals[k] = 0.0f;
   wave_fence();
@@ -306,7 +313,7 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
     {  // make room BEFORE inserting: with <= 3/4 load the probes (almost) always succeed
       const int need = __popcll(__ballot(want));
       if (fill + need > CAP * 3 / 4 && fill > 0) {
-        flush_table<F, CAP>(keys, vals, owner, base, mask, lane, true);
+        flush_table<F, CAP>(keys, vals, owner, base, mask, lane, true, seen);
         fill = 0;
       }
     }
@@ -350,14 +357,17 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
           const uint32_t hs = nr_hash3(lo[0] + (corner & 1), lo[1] + ((corner >> 1) & 1), lo[2] + ((corner >> 2) & 1), mask);
 #pragma unroll
           for (int f = 0; f < F; ++f)
-            if (v[corner][f] != 0.0f) unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
+            if (v[corner][f] != 0.0f) {
+              unsafeAtomicAdd(base + (int64_t)hs * F + f, v[corner][f]);
+              if (seen != nullptr) seen[((int64_t)hs * F + f) >> 2] = 1;
+            }
         }
       }
       fill = CAP;  // crowded around some hash: make room
     }
   }
   wave_fence();
-  flush_table<F, CAP>(keys, vals, owner, base, mask, lane, false);
+  flush_table<F, CAP>(keys, vals, owner, base, mask, lane, false, seen);
 }
 
 // Gradient w.r.t. the input positions (needed only where positions depend on parameters: samples
@@ -467,9 +477,9 @@ extern "C" int nr_prop_field_fwd(const float* x, const float* std, const float* 
 // configuration (512 samples per wave, 256 cells, one wave per block) for batches with incoherent rows: it issues fewer
 // atomics per sample and leaves more of the chip to the kernels that run beside it (mixed batch: step -3 % fresh, -6 %
 // after 1 500 steps; camera-only 16 384 rays +3 %, which is why it is the caller's choice).
-extern "C" int nr_hash_encode_bwd_tuned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
-                                        const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
-                                        int sample_major, int wave_cells, nr_stream_t stream) {
+static int hash_encode_bwd_launch(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                  const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, int sample_major,
+                                  int wave_cells, uint8_t* seen, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!x || !gout || !scalings || !gtable || L < 1 || log2T < 1 || log2T > 30 || n < 0) return NR_EINVAL;
   if (sample_major > 0 && n % sample_major != 0) return NR_EINVAL;
@@ -478,7 +488,7 @@ extern "C" int nr_hash_encode_bwd_tuned(const float* x, const float* std, const 
   {                                                                                                               \
     dim3 grid((unsigned)nr_cdiv(n, (int64_t)(W) * (CHUNK)), (unsigned)L), block((W) * 64);                         \
     hipLaunchKernelGGL((hash_encode_bwd_kernel<FF, CHUNK, CAP, W>), grid, block, 0, nr_s(stream), x, std, scalings, \
-                       log2T, gout, sn, sl, gtable, n, sample_major);                                             \
+                       log2T, gout, sn, sl, gtable, n, sample_major, seen);                                       \
   }
 #define LAUNCH_X(...) LAUNCH(__VA_ARGS__)
 #define CALL(FF) LAUNCH(FF, BwdCfg<FF>::CHUNK, BwdCfg<FF>::CAP, BwdCfg<FF>::W)
@@ -496,6 +506,19 @@ extern "C" int nr_hash_encode_bwd_tuned(const float* x, const float* std, const 
 #undef LAUNCH
   NR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int nr_hash_encode_bwd_tuned(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                        const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n,
+                                        int sample_major, int wave_cells, nr_stream_t stream) {
+  return hash_encode_bwd_launch(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, sample_major, wave_cells, nullptr, stream);
+}
+
+extern "C" int nr_hash_encode_bwd_marked(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                         const float* gout, int64_t sn, int64_t sl, float* gtable, int64_t n, int sample_major,
+                                         int wave_cells, unsigned char* seen_grad, nr_stream_t stream) {
+  if (!seen_grad) return NR_EINVAL;
+  return hash_encode_bwd_launch(x, std, scalings, L, F, log2T, gout, sn, sl, gtable, n, sample_major, wave_cells, seen_grad, stream);
 }
 
 extern "C" int nr_hash_encode_bwd(const float* x, const float* std, const float* scalings, int L, int F, int log2T,

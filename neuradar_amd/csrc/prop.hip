@@ -173,6 +173,77 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) upd(param[i], grad[i], m[i], v[i]);
 }
 
+// The same update where the SCATTER marks `seen_grad` (nr_hash_encode_bwd_marked: a byte is set wherever a gradient sum is
+// added): a never-marked group has g = m = v = 0 by construction, so it is left alone after reading its byte alone -- adam_kernel
+// above still reads the group's gradient (4 B/param: 537 MB of the NeuRadar table per step) to notice a first arrival.  The
+// thread's next byte is requested one trip ahead, and a marked group's g, m, v and p in ONE trip (adam_kernel: g, then m / v / p).
+// No weight decay (a decayed parameter moves without a gradient).  Bit-identical to the dense update.
+__global__ void __launch_bounds__(256)
+adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float grad_scale, int zero_grad,
+                   const float* __restrict__ dev_hyper, const uint8_t* __restrict__ seen_grad) {
+  if (dev_hyper != nullptr) {
+    lr = dev_hyper[0];
+    bc1 = dev_hyper[1];
+    bc2_sqrt = dev_hyper[2];
+  }
+  const int64_t n4 = n / 4;
+  float4* p4 = reinterpret_cast<float4*>(param);
+  float4* g4 = reinterpret_cast<float4*>(grad);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  const float step_size = lr / bc1;
+  auto upd = [&](float& p, float& g, float& mm, float& vv) {
+    const float gr = g * grad_scale;
+    mm = mm + (gr - mm) * (1.0f - beta1);
+    vv = vv * beta2 + (1.0f - beta2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p = p - step_size * (mm / denom);
+    if (zero_grad) g = 0.0f;
+  };
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto ld = [](const float4* q) { f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(q)); return make_float4(t.x, t.y, t.z, t.w); };
+  auto stv = [](float4* q, float4 x) { f4 t = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4*>(q)); };
+#ifndef NR_ADAMM_U
+#define NR_ADAMM_U 1
+#endif
+  constexpr int kU = NR_ADAMM_U;  // groups per trip: their four loads each are requested together
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint8_t mark[kU];
+#pragma unroll
+  for (int k = 0; k < kU; ++k) mark[k] = (i0 + k * stride) < n4 ? seen_grad[i0 + k * stride] : (uint8_t)0;
+  for (; i0 < n4; i0 += stride * kU) {
+    uint8_t cur[kU];
+    float4 g[kU], mm[kU], vv[kU], pp[kU];
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      const int64_t i = i0 + k * stride, nx = i + stride * kU;
+      cur[k] = mark[k];
+      mark[k] = nx < n4 ? seen_grad[nx] : (uint8_t)0;
+      if (cur[k] != 0) {
+        g[k] = ld(g4 + i);
+        mm[k] = ld(m4 + i);
+        vv[k] = ld(v4 + i);
+        pp[k] = ld(p4 + i);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kU; ++k) {
+      if (cur[k] == 0) continue;
+      const int64_t i = i0 + k * stride;
+      const bool had = g[k].x != 0.0f || g[k].y != 0.0f || g[k].z != 0.0f || g[k].w != 0.0f;
+      if (!had && mm[k].x == 0.0f && mm[k].y == 0.0f && mm[k].z == 0.0f && mm[k].w == 0.0f && vv[k].x == 0.0f && vv[k].y == 0.0f &&
+          vv[k].z == 0.0f && vv[k].w == 0.0f)
+        continue;  // fixed point: no stores
+      upd(pp[k].x, g[k].x, mm[k].x, vv[k].x); upd(pp[k].y, g[k].y, mm[k].y, vv[k].y);
+      upd(pp[k].z, g[k].z, mm[k].z, vv[k].z); upd(pp[k].w, g[k].w, mm[k].w, vv[k].w);
+      stv(p4 + i, pp[k]); stv(m4 + i, mm[k]); stv(v4 + i, vv[k]);
+      if (zero_grad && had) stv(g4 + i, g[k]);
+    }
+  }
+}
+
 // One-thread kernel: advances the optimizer step counter and refreshes {lr, 1-beta1^t, sqrt(1-beta2^t)}
 // (ExponentialDecayScheduler, engine/schedulers.py:112-143; LambdaLR applies func(k-1) to step k).
 __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict__ hyper, float lr, float lr_final,
@@ -371,6 +442,24 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
                      wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                   float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
+                                   const uint8_t* seen_grad, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!param || !grad || !m || !v || !seen_grad || n < 0 || step < 1 || (n & 3) != 0) return NR_EINVAL;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  int64_t cap = 4096;
+  if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
+  hipLaunchKernelGGL(adam_marked_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps, bc1,
+                     bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad);
   NR_LAUNCH_CHECK();
   return 0;
 }

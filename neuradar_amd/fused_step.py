@@ -549,6 +549,22 @@ class FusedTrainStep:
                 check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 
+        # The main table's `seen` bytes set by its scatter (single GPU, fused optimizer, every row through the merging kernel, no
+        # actors writing into other tables of the same buffer): NR_ADAM_MARKED=0 disables
+        mark_seen = None
+        if (optimizers is not None and reducer is None and not self.n_actors and self.binned_ws[2] is None
+                and os.environ.get("NR_ADAM_MARKED", "1") != "0"):
+            t_opt = optimizers[0]
+            i_m = t_opt.buffer_of(mg.hash_table)
+            if (t_opt.seen[i_m] is not None and t_opt.buffers[i_m][0].data_ptr() == mg.hash_table.data_ptr()
+                    and t_opt.buffers[i_m][0].numel() == mg.hash_table.numel() and i_m not in getattr(t_opt, "shards", {})):
+                mark_seen = t_opt.seen[i_m]
+                if not hasattr(t_opt, "marked"):
+                    t_opt.marked = {}
+                t_opt.marked[i_m] = True
+        if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
+            optimizers[0].marked.clear()
+
         def scatter(lvl, grid, tag):
             """grad_table += scatter of g_feats[lvl] on the current stream: the merging kernel on the coherent rows, the
             binned one on the rows behind them (when a workspace was set up for this level)."""
@@ -568,6 +584,13 @@ class FusedTrainStep:
                 # batches with incoherent rows: the wide per-wave table of the F = 4 merging kernel (fewer atomics per sample,
                 # more of the chip left to the two binned scatters and Adam beside it: step -3 % fresh, -6 % after 1 500 steps)
                 cells = 256 if self.sm < B and os.environ.get("NR_WIDE_MERGE", "1") != "0" else 0
+                if mark_seen is not None and lvl == 2:
+                    # the main table's scatter sets the optimizer's `seen` bytes itself: Adam then skips never-touched groups
+                    # on the byte alone instead of reading 4 B of gradient per parameter of the whole table (FlatAdam.marked)
+                    rc = lib.nr_hash_encode_bwd_marked(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                       grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
+                                                       p(grid.hash_table.grad), n_coh, 0, cells, p(mark_seen), sp_)
+                    return rc
                 rc = lib.nr_hash_encode_bwd_tuned(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
                                                   grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg, p(grid.hash_table.grad),
                                                   n_coh, 0, cells, sp_) if n_coh > 0 else 0

@@ -457,8 +457,11 @@ class FlatAdam:
         lo_hi = getattr(self, "shards", {}).get(i)
         if lo_hi is not None:  # this rank's rows only (the rest of the gradient buffer is cleared by the exchange)
             p, g = p[lo_hi[0]:lo_hi[1]], g[lo_hi[0]:lo_hi[1]]
+        # marked[i]: this step's scatter set the buffer's `seen` bytes itself (FusedTrainStep, single GPU): groups that never had
+        # a gradient are skipped on their byte alone
+        marked = bool(getattr(self, "marked", {}).get(i)) and lo_hi is None and self.seen[i] is not None
         ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
-                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i])
+                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked)
 
     def state_dict(self) -> Dict[str, object]:
         """Moments, the device-side step counter / schedule triple and the `seen` flags (what the reference's

@@ -585,7 +585,11 @@ def test_adam_sparse_gradients_are_exact():
     opt = torch.optim.Adam([ref], lr=1e-2, eps=1e-15)
     runs = [dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV), seen=None),
             dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
-                 seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV))]
+                 seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV)),
+            # nr_adam_step_marked: the bytes are set by whoever writes the gradient (here the test, in the step the scatter
+            # kernel of the fused step): never-marked groups are skipped without reading their gradient
+            dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
+                 seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV), marked=True)]
     ever = torch.zeros(n, dtype=torch.bool, device=DEV)
     for step in range(1, 7):
         g = torch.zeros(n, device=DEV)
@@ -597,16 +601,52 @@ def test_adam_sparse_gradients_are_exact():
         opt.step()
         for r in runs:
             gbuf = g.clone()
-            ops.adam_step(r["p"], gbuf, r["m"], r["v"], 1e-2, step, eps=1e-15, seen_grad=r["seen"])
+            if r.get("marked"):
+                r["seen"] |= (g != 0).view(-1, 4).any(1).to(torch.uint8)
+            ops.adam_step(r["p"], gbuf, r["m"], r["v"], 1e-2, step, eps=1e-15, seen_grad=r["seen"], marked=bool(r.get("marked")))
             assert float(gbuf.abs().max()) == 0.0
-    a_, b_ = runs
+    a_, b_, c_ = runs
     assert torch.equal(a_["p"], b_["p"]) and torch.equal(a_["m"], b_["m"]) and torch.equal(a_["v"], b_["v"])
+    assert torch.equal(a_["p"], c_["p"]) and torch.equal(a_["m"], c_["m"]) and torch.equal(a_["v"], c_["v"])
+    assert torch.equal(b_["seen"], c_["seen"])
     st = opt.state[ref]
     torch.testing.assert_close(a_["p"], ref.data, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(a_["m"], st["exp_avg"], rtol=1e-4, atol=1e-9)
     torch.testing.assert_close(a_["v"], st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
     assert torch.equal(a_["p"][~ever], p0[~ever]) and float(a_["m"][~ever].abs().max()) == 0.0
     assert torch.equal(b_["seen"].bool(), ever.view(-1, 4).any(1))
+
+
+@pytest.mark.parametrize("F,cells", [(4, 256), (4, 0), (2, 0), (1, 0), (8, 0)])
+def test_marked_scatter_sets_the_bytes_of_every_group_it_adds_to(F, cells):
+    """nr_hash_encode_bwd_marked: the same gradient as nr_hash_encode_bwd_tuned, and seen_grad byte (row * F + f) / 4 is set for
+    every group that received a non-zero sum and for no group outside the cells the samples touch."""
+    from neuradar_amd import _lib, ops
+
+    torch.manual_seed(F + cells)
+    L, log2T, n, S = 3, 12, 64 * 40, 8
+    T = 1 << log2T
+    x = torch.rand(n, 3, device=DEV)
+    scal = torch.tensor([4.0, 9.0, 23.0], device=DEV)
+    gout = torch.randn(L, n, F, device=DEV)
+    gout[:, ::3] = 0.0  # rows without a gradient mark nothing
+    lib, p = _lib.lib(), ops._p
+    g_ref = torch.zeros(L * T, F, device=DEV)
+    g_mk = torch.zeros_like(g_ref)
+    seen = torch.zeros(L * T * F // 4, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.nr_hash_encode_bwd_tuned(p(x), None, p(scal), L, F, log2T, p(gout), F, n * F, p(g_ref), n, S, cells, ops._stream()), "tuned")
+    _lib.check(lib.nr_hash_encode_bwd_marked(p(x), None, p(scal), L, F, log2T, p(gout), F, n * F, p(g_mk), n, S, cells, p(seen),
+                                             ops._stream()), "marked")
+    torch.testing.assert_close(g_mk, g_ref, rtol=1e-5, atol=1e-6)  # (float atomics: the order of the sums differs per launch)
+    nonzero = (g_mk.view(-1, 4) != 0).any(1)
+    assert bool((seen.bool() | ~nonzero).all()), "a group with a gradient was not marked"
+    # marks only where a corner of a row WITH a gradient lands: the same scatter of ones
+    ones = torch.zeros_like(g_ref)
+    _lib.check(lib.nr_hash_encode_bwd_tuned(p(x), None, p(scal), L, F, log2T, p((gout != 0).float().contiguous()), F, n * F, p(ones), n,
+                                            S, cells, ops._stream()), "tuned")
+    touched = (ones.view(-1, 4) != 0).any(1)
+    assert bool((touched | ~seen.bool()).all()), "a group no sample touches was marked"
+    assert int(seen.sum()) > 0
 
 
 # ------------------------------------------------------------------------------------------------ f-3 loss kernels
