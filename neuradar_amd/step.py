@@ -501,5 +501,7 @@ class FlatAdam:
     @torch.no_grad()
     def step(self) -> None:
         self.advance()
+        if hasattr(self, "marked"):  # whoever calls step() wrote the gradients without marking `seen` (modular backward, a
+            self.marked.clear()      # collective): only FusedTrainStep pairs its marking scatter with step_buffer()
         for i in range(len(self.buffers)):
             self.step_buffer(i)

@@ -26,7 +26,7 @@ def test_binned_scatter_with_32_bit_tile_sums_stays_within_its_stated_bound(F, L
     of two above the largest contribution of its 512-row tile -- at most 2^-21 of the tile's largest per addend, half of that
     on average.  Checked against the 64-bit path on the same rows: the difference of an entry stays below
     (addends into it) x 2^-21 x (largest single contribution anywhere), 2^-21 being 4.8e-7; in relative L2 the two gradients
-    agree to 1e-5.  No entry is written that the exact path does not write."""
+    agree to 1e-5.  No entry is written that no row touches."""
     from oracle import hashgrid
 
     torch.manual_seed(F + L + n)
@@ -44,7 +44,11 @@ def test_binned_scatter_with_32_bit_tile_sums_stays_within_its_stated_bound(F, L
     assert bool((err <= bound).all()), f"worst excess {float((err - bound).max()):.3e}"
     rel = float((lp - exact).norm() / exact.norm())
     assert rel < 1e-5, rel
-    assert not bool(((lp != 0) & (exact == 0)).any())
+    # No entry is written that no row touches.  (Not "that the 64-bit path leaves at zero": the two launches are not bit-reproducible
+    # from run to run -- which contributions find a slot in a block's LDS table and which overflow to direct float atomics depends
+    # on timing -- and a contribution of 1.6e-7 beside ones of 3e4 is below the fixed-point resolution of its tile in one run and
+    # added directly in the next, in EITHER path: measured, 1 run in ~4 had such an entry.)
+    assert not bool(((lp != 0) & (counts == 0)).any())
 
 
 @pytest.mark.parametrize("F", [1, 2, 4])

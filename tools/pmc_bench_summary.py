@@ -16,7 +16,7 @@ import sys
 prefix, out_path = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "cam4096_l16f2_w64"
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-WANT = ("hash_encode", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel", "adam_kernel")
+WANT = ("hash_encode", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel", "adam_kernel", "adam_marked_kernel")
 
 
 def short(name):
@@ -72,7 +72,7 @@ for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
             continue
         if not k.startswith(WANT):
             continue
-        if k.startswith("adam_kernel"):
+        if k.startswith(("adam_kernel", "adam_marked_kernel")):
             # the main table's Adam is launched right behind the main grid's scatter, the proposal table's behind the apply
             # passes, the small parameters' (and any other buffer's) after those
             t = {"hash_encode_bwd": "main_table", "apply_kernel": "proposal_table"}.get(last_kind, "small_parameters")
