@@ -187,7 +187,8 @@ class DecoderLossHead:
         with torch.enable_grad():
             terms = self.losses(f, d, times, sensor_idx, batch, seed_epoch)
             total = sum(terms.values())
-        total.backward()
+        with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
+            total.backward()
         loss_slots[0:1].add_(total.detach().reshape(1))
         self.last["terms"] = {k: v.detach() for k, v in terms.items()}
         g_d = d.grad if d.grad is not None else torch.zeros_like(depth)

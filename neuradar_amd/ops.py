@@ -130,6 +130,24 @@ def _mlp_grads_struct(gw: Sequence[Tensor], gb: Sequence[Tensor]) -> NrMlpGrads:
     return g
 
 
+_DIRECT_PARAM_GRADS = False  # (a plain global, not thread-local: autograd runs GPU nodes on its own device threads)
+
+
+class direct_param_grads:
+    """Inside this context, `mlp`'s backward adds the parameter gradients straight into the parameters' `.grad` buffers (the
+    ABI's grads are "+=") and hands autograd None for them: no zero-filled temporaries, no AccumulateGrad adds -- 13 launches
+    less per MLP backward.  For callers that want exactly `loss.backward()`'s accumulation into preallocated `.grad`s (the
+    decoder-loss segment of the fused step); `torch.autograd.grad(...)` over those parameters would see None."""
+
+    def __enter__(self):
+        global _DIRECT_PARAM_GRADS
+        self._prev, _DIRECT_PARAM_GRADS = _DIRECT_PARAM_GRADS, True
+
+    def __exit__(self, *exc):
+        global _DIRECT_PARAM_GRADS
+        _DIRECT_PARAM_GRADS = self._prev
+
+
 class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_layers, *params):
@@ -141,6 +159,7 @@ class _Mlp(torch.autograd.Function):
         check(_lib.lib().nr_mlp_fwd(byref(m), _p(x), x.shape[0], _p(y), _stream()), "nr_mlp_fwd")
         ctx.save_for_backward(x, *ws, *bs)
         ctx.n_layers = n_layers
+        ctx.param_refs = params  # the caller's tensors (their .grad, for direct_param_grads)
         return y
 
     @staticmethod
@@ -149,11 +168,20 @@ class _Mlp(torch.autograd.Function):
         nl = ctx.n_layers
         ws, bs = params[:nl], params[nl:]
         m = _mlp_struct(ws, bs)
-        gws, gbs = [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs]
+        refs = ctx.param_refs
+        direct = _DIRECT_PARAM_GRADS and all(
+            isinstance(p, Tensor) and p.is_leaf and p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+            and p.grad.is_contiguous() and p.dtype == torch.float32 and p.is_contiguous() for p in refs)
+        if direct:
+            gws, gbs = [p.grad for p in refs[:nl]], [p.grad for p in refs[nl:]]
+        else:
+            gws, gbs = [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs]
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         g = _mlp_grads_struct(gws, gbs)
         check(_lib.lib().nr_mlp_bwd(byref(m), _p(x), _p(gy.contiguous()), x.shape[0], _p(gx), byref(g), _stream()),
               "nr_mlp_bwd")
+        if direct:
+            return (gx, None, *([None] * len(refs)))
         return (gx, None, *gws, *gbs)
 
 
