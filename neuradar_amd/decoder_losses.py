@@ -181,7 +181,7 @@ class DecoderLossHead:
     def backward_into(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
                       loss_slots: Tensor, seed_epoch: Optional[Tensor] = None):
         """Run the segment on detached leaves of (features, depth), accumulate the parameter gradients into their .grad
-        buffers and the loss value into loss_slots[0]; returns (d loss / d features [B,C], d loss / d depth [B])."""
+        buffers and the loss value into loss_slots[-1]; returns (d loss / d features [B,C], d loss / d depth [B])."""
         f = features.detach().requires_grad_(True)
         d = depth.detach().requires_grad_(True)
         with torch.enable_grad():
@@ -189,7 +189,7 @@ class DecoderLossHead:
             total = sum(terms.values())
         with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
             total.backward()
-        loss_slots[0:1].add_(total.detach().reshape(1))
+        loss_slots[-1:].add_(total.detach().reshape(1))  # (the LAST entry: FusedTrainStep keeps it free of the kernels' atomics)
         self.last["terms"] = {k: v.detach() for k, v in terms.items()}
         g_d = d.grad if d.grad is not None else torch.zeros_like(depth)
         return f.grad, g_d

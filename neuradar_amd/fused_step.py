@@ -106,7 +106,9 @@ class FusedTrainStep:
         self.acc = torch.empty(B, **f32)
         self.features = torch.empty(B, C, **f32)
         self.depth = torch.empty(B, **f32)
-        self.loss = torch.zeros(_lib.NR_LOSS_SLOTS, **f32)  # partial sums; loss value = self.loss.sum()
+        # partial sums; loss value = self.loss.sum().  The kernels add into the first NR_LOSS_SLOTS entries with atomics; the last
+        # entry belongs to the decoder segment's plain torch add (it runs beside the proposal chains' loss kernels)
+        self.loss = torch.zeros(_lib.NR_LOSS_SLOTS + 1, **f32)
         self.g_features = torch.zeros(B, C, **f32)
         self.g_depth = torch.empty(B, **f32)
         self.g_alpha = torch.empty(B * Sm, **f32)
@@ -483,24 +485,6 @@ class FusedTrainStep:
                   "lidar_decoder_bwd")
             check(lib.nr_appearance_concat_bwd(p(lid["g_x"]), self.C, emb.shape[1], p(times), p(lid["sensor_idx"]), c.duration, E,
                                                r0, nl_, p(self.g_features_extra), p(emb.grad), emb.shape[0], st), "appearance_bwd")
-        g_f_extra = self.g_features_extra if (lid is not None and lid["decoder"]) else None
-        g_d_extra, rgb_mult, depth_mult = None, c.rgb_mult, c.depth_mult
-        if self.dec is not None:
-            # the decoders' losses replace the direct supervision: composite -> decoder segment (autograd over HIP launches)
-            # -> gradients on the rendered features / depth, which re-enter the render backward below
-            assert times is not None, "the decoders need the rays' times (appearance embedding)"
-            check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
-                                       p(self.features), p(self.depth), st), "composite_fwd")
-            epoch = optimizers[0].step_t if optimizers is not None else None
-            g_f_extra, g_d_extra = self._timed("decoders", lambda: self.dec["head"].backward_into(
-                self.features, self.depth, times, self.dec["sensor_idx"], self.dec["batches"][slot], self.loss, seed_epoch=epoch))
-            rgb_mult = depth_mult = 0.0
-            target_features = target_depth = None
-        check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
-                                  p(target_depth), B, Sm, self.C, rgb_mult, depth_mult, c.distortion_loss_mult,
-                                  p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
-                                  p(self.g_feature), p(self.loss), p(g_f_extra), p(g_d_extra),
-                                  byref(lid["main"]) if lid is not None else None, st), "render_train")
         # ---- backward.  The field's MFMA backward needs 1 wave/SIMD worth of registers and ~127 KB of LDS per
         #      workgroup, so LDS-heavy kernels sharing the CUs with it (and it with them) crawl: forking all three
         #      chains (main grid scatter + Adam / proposal round 1 / proposal round 0) right after the render launch
@@ -524,6 +508,12 @@ class FusedTrainStep:
             # data parallel: both proposal chains before field_bwd for camera-only batches (the 25-MB proposal table's
             # all-reduce starts earlier); mixed batches run the main grid's scatter and exchange first instead (`order`)
             early = 1 if reducer is not None and self.sm >= B else 0
+            # with the decoders in the step: both proposal chains BEFORE the decoder segment.  Their inputs (the three levels'
+            # weights, spacings and densities) exist once the forward has composited -- the inter-level loss does not see the
+            # decoders -- and the segment is ~560 small dependent launches that leave the chip idle: the two bin + apply pairs
+            # (0.73 ms of kernel time) run beside it instead of beside the main table's scatter and Adam afterwards.
+            if self.dec is not None and reducer is None and os.environ.get("NR_PROP_BESIDE_DECODERS", "1") != "0":
+                early = 5
         split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
         # Order of the three table scatters.  "concurrent" (single process): all at once -- 2.5 % faster than either serial
         # order on one GPU.  "main_first" (data parallel): the main grid's scatter by itself, the proposal scatters after
@@ -619,26 +609,51 @@ class FusedTrainStep:
                 p(self.x01[1]), p(self.std[1]), p(self.feats[1]), p(self.g_dens[1]), S1_, n1_, self.sm,
                 p(pg.scalings), pg.num_levels, Fp, pg.log2_hashmap_size, Fp, p(w_dec), p(pg.hash_table.grad), p(w_dec.grad),
                 p(self.merged_ws), ops._stream())), "hash_bwd")
-
         chains = list(zip((1, 0), side))  # (level, stream): side[0] runs round 1 (s64), side[1] round 0 (s128)
         # (both proposal chains on one side stream, or on the main stream in front of the main scatter: +6 % / +8 % per
         # step on the mixed batch -- the three scatters and the main table's Adam do share the chip productively)
-        before = {0: (), 1: (0, 1), 2: (1,), 3: (), 4: (1,)}[early]  # side indices whose chain starts before field_bwd
-        for i_ in before:
-            if side[i_] is not main:
-                side[i_].wait_stream(main)
+        before = {0: (), 1: (0, 1), 2: (1,), 3: (), 4: (1,), 5: (0, 1)}[early]  # side indices whose chain starts before field_bwd
         if merged and before:
             before = (0, 1)  # (a merged scatter needs both heads: the early-fork schedules start both chains early)
-        for i_ in before:
-            # (merged: both heads and the scatter on ONE side stream -- a capture in which the two side streams wait for each
-            # other in turn crashed hipStreamEndCapture on this ROCm build; the heads are ~80 us each)
-            with torch.cuda.stream(side[1] if merged else side[i_]):
-                chain_head(chains[i_][0])
-                if not merged:
-                    chain_scatter(chains[i_][0])
-        if merged and before:
-            with torch.cuda.stream(side[1]):
-                merged_scatter()
+
+        def start_chains_before():
+            """The proposal chains the schedule starts early: before nr_field_bwd, or (5) before the decoder segment."""
+            for i_ in before:
+                if side[i_] is not main:
+                    side[i_].wait_stream(main)
+            for i_ in before:
+                # (merged: both heads and the scatter on ONE side stream -- a capture in which the two side streams wait for each
+                # other in turn crashed hipStreamEndCapture on this ROCm build; the heads are ~80 us each)
+                with torch.cuda.stream(side[1] if merged else side[i_]):
+                    chain_head(chains[i_][0])
+                    if not merged:
+                        chain_scatter(chains[i_][0])
+            if merged and before:
+                with torch.cuda.stream(side[1]):
+                    merged_scatter()
+
+        g_f_extra = self.g_features_extra if (lid is not None and lid["decoder"]) else None
+        g_d_extra, rgb_mult, depth_mult = None, c.rgb_mult, c.depth_mult
+        if self.dec is not None:
+            # the decoders' losses replace the direct supervision: composite -> decoder segment (autograd over HIP launches)
+            # -> gradients on the rendered features / depth, which re-enter the render backward below
+            assert times is not None, "the decoders need the rays' times (appearance embedding)"
+            check(lib.nr_composite_fwd(p(self.alpha), p(self.feature), p(self.eu[2]), B, Sm, self.C, p(self.w[2]), p(self.acc),
+                                       p(self.features), p(self.depth), st), "composite_fwd")
+            if early == 5:
+                start_chains_before()
+            epoch = optimizers[0].step_t if optimizers is not None else None
+            g_f_extra, g_d_extra = self._timed("decoders", lambda: self.dec["head"].backward_into(
+                self.features, self.depth, times, self.dec["sensor_idx"], self.dec["batches"][slot], self.loss, seed_epoch=epoch))
+            rgb_mult = depth_mult = 0.0
+            target_features = target_depth = None
+        check(lib.nr_render_train(p(self.alpha), p(self.feature), p(self.eu[2]), p(self.sp[2]), p(target_features),
+                                  p(target_depth), B, Sm, self.C, rgb_mult, depth_mult, c.distortion_loss_mult,
+                                  p(self.w[2]), p(self.acc), p(self.features), p(self.depth), p(self.g_alpha),
+                                  p(self.g_feature), p(self.loss), p(g_f_extra), p(g_d_extra),
+                                  byref(lid["main"]) if lid is not None else None, st), "render_train")
+        if early != 5:
+            start_chains_before()
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
             byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
             p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
