@@ -103,9 +103,44 @@ class DecoderLossHead:
         self.radar_ws = (torch.empty(_lib.lib().nr_radar_assign_workspace_bytes(n_scans, n_rad // max(n_scans, 1), max_detections),
                                      device=dev, dtype=torch.uint8) if n_rad else None)
         self.last: Dict[str, Tensor] = {}
+        self._shadow = None  # 16-bit copies of the CNN's convolution parameters (see _cnn_shadow)
         self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"
         self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
+
+    def _cnn_shadow(self):
+        """16-bit working copies of the RGB CNN's convolution weights / biases, instead of torch.autocast's per-parameter casts:
+        autocast launches one cast per parameter in the forward (24) and one per gradient in the backward (24).  Here the 16-bit
+        copies are leaves of their own whose storage mirrors the fp32 parameters' flat buffer element for element (same
+        offsets and channels-last strides), so ONE copy refreshes all of them before the forward and ONE mixed-precision add
+        folds their gradients into the fp32 gradient buffer after the backward (the same values: autocast's backward casts the
+        16-bit gradient to fp32 and adds it to a zeroed buffer).  Batch-norm parameters stay fp32, as under autocast.  Needs the
+        parameters in one flat buffer (FlatAdam / flatten_parameters); otherwise None -> torch.autocast."""
+        if self._shadow is not None or self.cnn_autocast is None or os.environ.get("NR_CNN_SHADOW", "1") == "0":
+            return self._shadow or None
+        mod = self.model.rgb_decoder
+        conv = [(n, p_) for n, p_ in mod.named_parameters() if n.rsplit(".", 1)[0] in
+                {k for k, m_ in mod.named_modules() if isinstance(m_, (torch.nn.Conv2d, torch.nn.ConvTranspose2d))}]
+        ps = [p_ for _, p_ in conv]
+        ok = ps and all(p_.grad is not None and p_.dtype == torch.float32 and p_.grad.dtype == torch.float32
+                        and p_.untyped_storage().data_ptr() == ps[0].untyped_storage().data_ptr()
+                        and p_.grad.untyped_storage().data_ptr() == ps[0].grad.untyped_storage().data_ptr()
+                        and p_.grad.storage_offset() == p_.storage_offset() and p_.grad.stride() == p_.stride() for p_ in ps)
+        if not ok:
+            self._shadow = False
+            return None
+        n_all = ps[0].untyped_storage().nbytes() // 4
+        flat32 = torch.empty(0, device=ps[0].device, dtype=torch.float32).set_(ps[0].untyped_storage(), 0, (n_all,))
+        gflat32 = torch.empty(0, device=ps[0].device, dtype=torch.float32).set_(ps[0].grad.untyped_storage(), 0, (n_all,))
+        flat16 = torch.zeros(n_all, device=ps[0].device, dtype=self.cnn_autocast)
+        gflat16 = torch.zeros_like(flat16)
+        params = {}
+        for n, p_ in conv:
+            sp = flat16.as_strided(p_.size(), p_.stride(), p_.storage_offset()).detach().requires_grad_(True)
+            sp.grad = gflat16.as_strided(p_.size(), p_.stride(), p_.storage_offset())
+            params[n] = sp
+        self._shadow = dict(flat32=flat32, gflat32=gflat32, flat16=flat16, gflat16=gflat16, params=params)
+        return self._shadow
 
     def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
                seed_epoch: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -155,7 +190,13 @@ class DecoderLossHead:
                 patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2)
                 if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in m.rgb_decoder.parameters()):
                     patches = patches.contiguous()  # (a model whose parameters were not flattened: packed NCHW for both)
-                if self.cnn_autocast is not None:
+                sh = self._cnn_shadow()
+                if sh:
+                    with torch.no_grad():
+                        sh["flat16"].copy_(sh["flat32"])
+                    rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
+                    self._shadow_used = True
+                elif self.cnn_autocast is not None:
                     with torch.autocast("cuda", dtype=self.cnn_autocast):
                         rgb = m.rgb_decoder(patches)
                     rgb = rgb.float()
@@ -189,6 +230,10 @@ class DecoderLossHead:
             total = sum(terms.values())
         with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
             total.backward()
+        if self._shadow and getattr(self, "_shadow_used", False):  # the CNN's 16-bit gradients into the fp32 gradient buffer
+            self._shadow["gflat32"].add_(self._shadow["gflat16"])
+            self._shadow["gflat16"].zero_()
+            self._shadow_used = False
         loss_slots[-1:].add_(total.detach().reshape(1))  # (the LAST entry: FusedTrainStep keeps it free of the kernels' atomics)
         self.last["terms"] = {k: v.detach() for k, v in terms.items()}
         g_d = d.grad if d.grad is not None else torch.zeros_like(depth)

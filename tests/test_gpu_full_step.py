@@ -254,3 +254,48 @@ def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type):
                  "field.hashgrid.static_grid.hash_table", "proposal_fields.1.hashgrid.static_grid.hash_table"):
         assert ref[must] is not None and float(ref[must].abs().max()) > 0, must
     assert checked > 50
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cnn_16_bit_working_copies_equal_autocast(dtype, monkeypatch):
+    """DecoderLossHead runs the RGB CNN on 16-bit working copies of its convolution parameters (one copy before the forward,
+    one mixed-precision add of the gradients after the backward) instead of torch.autocast's per-parameter casts: bit-identical
+    output, loss and batch-norm statistics; gradients as close to the fp32 CNN's as autocast's are (the backward runs the same
+    operations on the same 16-bit operands, but MIOpen's benchmark mode picks the algorithms of every head independently and
+    the gradients sit at 1e-4 ... 1e-8 -- fp16's subnormal range -- so two 16-bit runs differ by ~2 % in relative L2)."""
+    from neuradar_amd.decoder_losses import DecoderLossHead
+    from neuradar_amd.fused_step import flatten_parameters
+
+    g = load_golden("model_train")
+    n_cam = int(g["n_patch"]) * int(g["patch"]) ** 2
+    layout = {"camera": (0, n_cam), "lidar": (n_cam, 0), "radar": (n_cam, 0)}
+    feats = g["features"][:n_cam].to(DEV)
+    image = g["image"].to(DEV)
+    res = {}
+    for mode in ("copies", "autocast", "fp32"):
+        monkeypatch.setenv("NR_CNN_SHADOW", "1" if mode == "copies" else "0")
+        torch.manual_seed(0)
+        dec, m = _decoder_model(48)
+        _load_reference_parameters(dec)
+        flatten_parameters(list(dec.rgb_decoder.parameters()))
+        head = DecoderLossHead(m, layout, int(g["patch"]), 0, 0, cnn_autocast=None if mode == "fp32" else dtype)
+        slots = torch.zeros(1025, device=DEV)
+        for _ in range(2):  # twice: the working copies' gradient buffer is cleared and reused
+            for p_ in dec.rgb_decoder.parameters():
+                p_.grad.zero_()
+            g_f, _ = head.backward_into(feats, torch.ones(n_cam, device=DEV), None, None, {"image": image}, slots)
+        assert bool(head._shadow) == (mode == "copies")
+        res[mode] = (head.last["rgb"].detach().clone(), float(slots.sum()), g_f.clone(),
+                     {k: v.grad.clone() for k, v in dec.rgb_decoder.named_parameters()},
+                     {k: v.clone() for k, v in dec.rgb_decoder.named_buffers()})
+    a, b, f = res["copies"], res["autocast"], res["fp32"]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1], "rgb / loss"
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), "batch-norm statistics " + k
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
+    rows = {"d loss / d features": (a[2], b[2], f[2])}
+    rows.update({k: (a[3][k], b[3][k], f[3][k]) for k in a[3] if not k.endswith(("main_branch.0.bias", "main_branch.3.bias"))})
+    for k, (x, y, z) in rows.items():  # (a convolution bias in front of a batch norm has no gradient: rounding noise only)
+        e_copies, e_autocast = rel(x, z), rel(y, z)
+        assert e_copies <= 1.5 * e_autocast + 2e-3, (k, e_copies, e_autocast)
+        assert rel(x, y) < 0.05, (k, rel(x, y))
