@@ -150,7 +150,8 @@ class DecoderLossHead:
         m, c = self.model, self.c
         B = features.shape[0]
         if m.config.appearance_dim > 0:  # neuradar.py:518-520: every ray's features are extended by its appearance embedding
-            x = torch.cat([features, m.appearance_of(times, sensor_idx)], dim=-1)
+            x = ops.appearance_concat(features, m.appearance_embedding.weight, times, sensor_idx, m.config.duration,
+                                      m._num_embeds_per_sensor)
         else:
             x = features
         out: Dict[str, Tensor] = {}

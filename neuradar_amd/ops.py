@@ -589,6 +589,46 @@ def radar_loss(pred: Tensor, detections: Tensor, seg: Tensor, max_detections: in
     return _RadarLoss.apply(pred, detections, seg, assoc, loss_type, float(mult)), assoc
 
 
+class _AppearanceConcat(torch.autograd.Function):
+    """nr_appearance_concat_fwd/bwd: [features | temporal appearance embedding] of every ray (neuradar.py:510-512,550-568)."""
+
+    @staticmethod
+    def forward(ctx, features, table, times, sensor_idx, duration, embeds_per_sensor):
+        features, table, times = _f32(features, "features"), _f32(table, "appearance table"), _f32(times, "times").reshape(-1)
+        sensor_idx = sensor_idx.reshape(-1).contiguous()
+        assert sensor_idx.dtype == torch.int64 and sensor_idx.is_cuda and times.numel() == features.shape[0] == sensor_idx.numel()
+        n, C = features.shape
+        A = table.shape[1]
+        out = torch.empty(n, C + A, device=features.device, dtype=torch.float32)
+        check(_lib.lib().nr_appearance_concat_fwd(_p(features), C, _p(table), A, _p(times), _p(sensor_idx), float(duration),
+                                                  int(embeds_per_sensor), 0, n, _p(out), _stream()), "nr_appearance_concat_fwd")
+        ctx.save_for_backward(times, sensor_idx)
+        ctx.dims = (n, C, A, float(duration), int(embeds_per_sensor), table.shape[0])
+        ctx.table_ref = table
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        times, sensor_idx = ctx.saved_tensors
+        n, C, A, duration, E, rows = ctx.dims
+        g_out = _f32(g_out, "g_out")
+        g_features = torch.empty(n, C, device=g_out.device, dtype=torch.float32)
+        table = ctx.table_ref
+        direct = (_DIRECT_PARAM_GRADS and table.is_leaf and table.requires_grad and table.grad is not None
+                  and table.grad.dtype == torch.float32 and table.grad.is_contiguous())
+        g_table = table.grad if direct else torch.zeros(rows, A, device=g_out.device, dtype=torch.float32)
+        check(_lib.lib().nr_appearance_concat_bwd(_p(g_out), C, A, _p(times), _p(sensor_idx), duration, E, 0, n, _p(g_features),
+                                                  _p(g_table), rows, _stream()), "nr_appearance_concat_bwd")
+        return g_features, (None if direct else g_table), None, None, None, None
+
+
+def appearance_concat(features: Tensor, table: Tensor, times: Tensor, sensor_idx: Tensor, duration: float, embeds_per_sensor: int) -> Tensor:
+    """[B, C] rendered features -> [B, C + A]: every ray's features extended by the linear interpolation of its sensor's two
+    nearest appearance embeddings in time (table [sensors * embeds_per_sensor, A]; neuradar.py:518-520,550-568) -- one launch
+    each way instead of the ~25 elementwise / gather launches of the torch expression and the sort-based embedding backward."""
+    return _AppearanceConcat.apply(features, table, times, sensor_idx, duration, embeds_per_sensor)
+
+
 _POSEMB_TABLES: dict = {}
 
 
