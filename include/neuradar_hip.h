@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 17
+#define NR_ABI_VERSION 18
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -192,6 +192,25 @@ int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* d
 int nr_radar_points_fwd(const float* depth, const float* dirs_spher, int64_t n, const float* dim_t, const int* code, int C,
                         float* xyz, float* dirs, float* pos, nr_stream_t stream);
 int nr_radar_points_bwd(const float* g_xyz, const float* dirs, int64_t n, float* g_depth, nr_stream_t stream);
+
+/* Training-mode batch normalisation of a channels-last activation x [M, C] (M = batch * height * width pixels, C = 8, 16, 32
+ * or 64; x 16-byte aligned) with the residual add and the ReLU behind it, as the RGB decoder's BasicBlock chains them
+ * (model_components/cnns.py:21-47; torch.nn.BatchNorm2d, train mode):
+ *   y = act(gamma * (x - mean) / sqrt(var + eps) + beta + residual),  act = ReLU (relu != 0) or identity; residual nullable
+ *   mean / var over the M pixels (biased variance); running_mean / running_var (nullable pair) <- (1 - momentum) * running +
+ *   momentum * (mean | unbiased variance); save_mean / save_rstd [C] for the backward.
+ * nr_bn_act_bwd: from grad_y, with g' = grad_y where y > 0 (relu) -- grad_x = gamma * rstd * (g' - mean(g') - xhat * mean(g' xhat)),
+ * grad_residual = g' (nullable), grad_gamma += sum g' xhat, grad_beta += sum g'.
+ * dtype of x / residual / y / the gradients: NR_DTYPE_F32 | NR_DTYPE_BF16 | NR_DTYPE_F16; parameters, statistics, sums: float.
+ * workspace: nr_bn_act_workspace_floats(M, C) floats, reusable by launches on one stream.  Two launches each way (torch: three
+ * MIOpen kernels per normalisation each way + clamp + add + their backwards). */
+int64_t nr_bn_act_workspace_floats(int64_t M, int C);
+int nr_bn_act_fwd(const void* x, const void* residual, int64_t M, int C, int dtype, const float* gamma, const float* beta, float eps,
+                  float momentum, float* running_mean, float* running_var, int relu, void* y, float* save_mean, float* save_rstd,
+                  float* workspace, nr_stream_t stream);
+int nr_bn_act_bwd(const void* grad_y, const void* y, const void* x, int64_t M, int C, int dtype, const float* gamma,
+                  const float* save_mean, const float* save_rstd, int relu, void* grad_x, void* grad_residual, float* grad_gamma,
+                  float* grad_beta, float* workspace, nr_stream_t stream);
 
 /* tiny-cuda-nn-compatible multiresolution hash grid for 3-D and 4-D inputs: what
  * `tcnn.Encoding(n_input_dims, {"otype": "HashGrid", n_levels, n_features_per_level, log2_hashmap_size, base_resolution,

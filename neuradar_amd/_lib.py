@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 17
+NR_ABI_VERSION = 18
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -71,6 +71,9 @@ PROTOTYPES = {
     "nr_radar_loss": [P, I, L, P, I, P, P, I, F, P, P, P],
     "nr_radar_points_fwd": [P, P, L, P, P, I, P, P, P, P],
     "nr_radar_points_bwd": [P, P, L, P, P],
+    "nr_bn_act_workspace_floats": [L, I],
+    "nr_bn_act_fwd": [P, P, L, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
+    "nr_bn_act_bwd": [P, P, P, L, I, I, P, P, P, I, P, P, P, P, P, P],
     "nr_tcnn_grid_param_count": [I, I, I, I, I, F],
     "nr_tcnn_grid_geometry": [I, I, I, I, F, P, P, P],
     "nr_tcnn_grid_fwd": [P, P, I, I, I, I, I, F, P, L, P],
@@ -138,7 +141,7 @@ PROTOTYPES = {
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
-             "nr_radar_assign_workspace_bytes": c_int64}
+             "nr_radar_assign_workspace_bytes": c_int64, "nr_bn_act_workspace_floats": c_int64}
 
 _lib = None
 

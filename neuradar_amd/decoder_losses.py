@@ -104,6 +104,14 @@ class DecoderLossHead:
                                      device=dev, dtype=torch.uint8) if n_rad else None)
         self.last: Dict[str, Tensor] = {}
         self._shadow = None  # 16-bit copies of the CNN's convolution parameters (see _cnn_shadow)
+        # the BasicBlocks' batch norm + ReLU (+ residual) on nr_bn_act_fwd/bwd; their step counters advance in one launch
+        self._bn_counters = []
+        if os.environ.get("NR_FUSED_BN", "1") != "0" and hasattr(model, "rgb_decoder"):
+            for blk in model.rgb_decoder.modules():
+                if hasattr(blk, "fused_bn"):
+                    blk.fused_bn = True
+                    self._bn_counters += [b.num_batches_tracked for b in blk.modules()
+                                          if isinstance(b, torch.nn.BatchNorm2d) and b.num_batches_tracked is not None]
         self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"
         self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
@@ -203,6 +211,8 @@ class DecoderLossHead:
                     rgb = rgb.float()
                 else:
                     rgb = m.rgb_decoder(patches)
+                if self._bn_counters and m.rgb_decoder.training:  # BatchNorm2d.forward's `num_batches_tracked += 1`
+                    torch._foreach_add_(self._bn_counters, 1)
                 rgb = rgb.permute(0, 2, 3, 1)
                 out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
                 self.last["rgb"] = rgb

@@ -126,7 +126,24 @@ class BasicBlock(nn.Module):
                                          nn.Conv2d(dim, dim, kernel_size, padding=padding), nn.BatchNorm2d(dim))
         self.final_activation = nn.ReLU(inplace=True)
 
+    fused_bn = False  # set by the training step (DecoderLossHead): batch norm + ReLU (+ residual) as nr_bn_act_fwd/bwd
+
     def forward(self, x: Tensor) -> Tensor:
+        if (self.fused_bn and self.training and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
+                and x.shape[1] in (8, 16, 32, 64)):
+            # conv -> [BN + ReLU] -> conv -> [BN + residual + ReLU]: two launches per bracket each way instead of torch's
+            # three MIOpen kernels per normalisation each way + clamp + add + their backwards
+            from . import ops
+
+            conv1, bn1, _, conv2, bn2 = self.main_branch
+            h = conv1(x)
+            if not h.is_contiguous(memory_format=torch.channels_last):
+                h = h.contiguous(memory_format=torch.channels_last)
+            h = ops.bn_act(h, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, None, bn1.momentum, bn1.eps, True)
+            h = conv2(h)
+            if not h.is_contiguous(memory_format=torch.channels_last):
+                h = h.contiguous(memory_format=torch.channels_last)
+            return ops.bn_act(h, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, x, bn2.momentum, bn2.eps, True)
         return self.final_activation(self.res_branch(x) + self.main_branch(x))
 
 

@@ -629,6 +629,67 @@ def appearance_concat(features: Tensor, table: Tensor, times: Tensor, sensor_idx
     return _AppearanceConcat.apply(features, table, times, sensor_idx, duration, embeds_per_sensor)
 
 
+_BN_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_BN_WS: dict = {}
+
+
+def _bn_workspace(device) -> Tensor:
+    key = str(device)
+    if key not in _BN_WS:
+        _BN_WS[key] = torch.empty(int(_lib.lib().nr_bn_act_workspace_floats(1, 64)), device=device, dtype=torch.float32)
+    return _BN_WS[key]
+
+
+class _BnAct(torch.autograd.Function):
+    """nr_bn_act_fwd/bwd on a channels-last [N, C, H, W] activation: y = act(batch_norm_train(x) + residual)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, momentum, eps, relu):
+        if not x.is_cuda:
+            raise RuntimeError("x must be a GPU tensor: neuradar_amd has no CPU path (the oracle is test-only)")
+        N, C, H, W = x.shape
+        assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype in _BN_DTYPES, "channels-last fp32 / bf16 / fp16 activations"
+        assert residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
+                                    and residual.is_contiguous(memory_format=torch.channels_last))
+        gamma, beta = _f32(gamma, "weight"), _f32(beta, "bias")
+        M = N * H * W
+        y = torch.empty_like(x)  # (keeps the channels-last strides)
+        mean, rstd = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+        ws = _bn_workspace(x.device)
+        check(_lib.lib().nr_bn_act_fwd(_p(x), _p(residual), M, C, _BN_DTYPES[x.dtype], _p(gamma), _p(beta), float(eps), float(momentum),
+                                       _p(running_mean), _p(running_var), int(relu), _p(y), _p(mean), _p(rstd), _p(ws), _stream()),
+              "nr_bn_act_fwd")
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        ctx.relu, ctx.has_res = int(relu), residual is not None
+        ctx.param_refs = (gamma, beta)
+        ctx.mark_non_differentiable(mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = g.contiguous(memory_format=torch.channels_last)
+        if g.dtype != x.dtype:
+            g = g.to(x.dtype)
+        dx = torch.empty_like(x)
+        d_res = torch.empty_like(x) if ctx.has_res else None
+        refs = ctx.param_refs
+        direct = _DIRECT_PARAM_GRADS and all(p.is_leaf and p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+                                             and p.grad.is_contiguous() for p in refs)
+        gg, gb = (refs[0].grad, refs[1].grad) if direct else (torch.zeros(C, device=x.device), torch.zeros(C, device=x.device))
+        check(_lib.lib().nr_bn_act_bwd(_p(g), _p(y), _p(x), N * H * W, C, _BN_DTYPES[x.dtype], _p(gamma), _p(mean), _p(rstd), ctx.relu,
+                                       _p(dx), _p(d_res), _p(gg), _p(gb), _p(_bn_workspace(x.device)), _stream()), "nr_bn_act_bwd")
+        return dx, (None if direct else gg), (None if direct else gb), None, None, d_res, None, None, None
+
+
+def bn_act(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+           residual: Optional[Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, relu: bool = True) -> Tensor:
+    """act(BatchNorm2d_train(x) + residual) on a channels-last activation in two launches each way (nr_bn_act_fwd/bwd); updates
+    the running statistics in place like the module does."""
+    return _BnAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
+
+
 _POSEMB_TABLES: dict = {}
 
 

@@ -242,3 +242,48 @@ def test_radar_points_kernel_equals_the_torch_expression(C):
     (ref * w).sum().backward()
     assert_close(depth.grad.cpu(), d2.grad.cpu(), rtol=1e-6, atol_scale=1e-6, what="d points / d depth")
     assert math.isfinite(float(pos.sum()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("with_residual,relu", [(True, True), (False, True), (False, False)])
+def test_bn_act_kernels_vs_torch_batch_norm(dtype, tol, with_residual, relu):
+    """nr_bn_act_fwd/bwd (batch norm in training mode + residual + ReLU, channels-last) against torch.nn.functional.batch_norm
+    + add + relu on the same tensors: output, running statistics, and the gradients w.r.t. input, residual, weight, bias.
+    Odd pixel count (ragged last block), C = 32 like the decoder and C = 8."""
+    import torch.nn.functional as F
+
+    from neuradar_amd import ops
+
+    for C, shape in ((32, (3, 32, 17, 19)), (8, (2, 8, 5, 7))):
+        gen = torch.Generator().manual_seed(C)
+        x = (torch.randn(shape, generator=gen) * 1.7 + 0.3).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        res = torch.randn(shape, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last) if with_residual else None
+        w = (torch.rand(C, generator=gen) + 0.5).to(DEV)
+        b = torch.randn(C, generator=gen).to(DEV)
+        gy = torch.randn(shape, generator=gen).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+        outs = []
+        for which in ("hip", "torch"):
+            xi = x.clone().requires_grad_(True)
+            ri = res.clone().requires_grad_(True) if res is not None else None
+            wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
+            if which == "hip":
+                y = ops.bn_act(xi, wi, bi, rm, rv, ri, 0.1, 1e-5, relu)
+            else:  # the reference in fp32 on the same (16-bit representable) inputs
+                y = F.batch_norm(xi.float(), rm, rv, wi, bi, True, 0.1, 1e-5)
+                if ri is not None:
+                    y = y + ri.float()
+                y = torch.relu(y) if relu else y
+            y.backward(gy.to(y.dtype))
+            outs.append((y.detach().float(), rm, rv, xi.grad.float(), None if ri is None else ri.grad.float(), wi.grad, bi.grad))
+        h, t = outs
+        assert h[0].is_contiguous(memory_format=torch.channels_last)
+        assert_close(h[0].cpu(), t[0].cpu(), rtol=tol, atol_scale=tol, what="output")
+        assert_close(h[1].cpu(), t[1].cpu(), rtol=1e-5, atol_scale=1e-6, what="running mean")
+        assert_close(h[2].cpu(), t[2].cpu(), rtol=1e-4, atol_scale=1e-5, what="running var")
+        # (16-bit: the mask y > 0 is taken on the rounded output, and gradients are rounded to the activation type)
+        assert_close(h[3].cpu(), t[3].cpu(), rtol=tol, atol_scale=4 * tol, what="d input")
+        if with_residual:
+            assert_close(h[4].cpu(), t[4].cpu(), rtol=tol, atol_scale=4 * tol, what="d residual")
+        assert_close(h[5].cpu(), t[5].cpu(), rtol=max(tol, 1e-4), atol_scale=4 * tol, what="d weight")
+        assert_close(h[6].cpu(), t[6].cpu(), rtol=max(tol, 1e-4), atol_scale=4 * tol, what="d bias")
