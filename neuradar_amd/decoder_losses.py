@@ -109,7 +109,7 @@ class DecoderLossHead:
         if os.environ.get("NR_FUSED_BN", "1") != "0" and hasattr(model, "rgb_decoder"):
             for blk in model.rgb_decoder.modules():
                 if hasattr(blk, "fused_bn"):
-                    blk.fused_bn = True
+                    blk.fused_bn, blk.fused_bn_counts = True, False
                     self._bn_counters += [b.num_batches_tracked for b in blk.modules()
                                           if isinstance(b, torch.nn.BatchNorm2d) and b.num_batches_tracked is not None]
         self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"

@@ -127,6 +127,7 @@ class BasicBlock(nn.Module):
         self.final_activation = nn.ReLU(inplace=True)
 
     fused_bn = False  # set by the training step (DecoderLossHead): batch norm + ReLU (+ residual) as nr_bn_act_fwd/bwd
+    fused_bn_counts = True  # BatchNorm2d.forward's `num_batches_tracked += 1` here (DecoderLossHead: one launch for all blocks)
 
     def forward(self, x: Tensor) -> Tensor:
         if (self.fused_bn and self.training and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
@@ -136,6 +137,10 @@ class BasicBlock(nn.Module):
             from . import ops
 
             conv1, bn1, _, conv2, bn2 = self.main_branch
+            if self.fused_bn_counts:
+                for bn in (bn1, bn2):
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
             h = conv1(x)
             if not h.is_contiguous(memory_format=torch.channels_last):
                 h = h.contiguous(memory_format=torch.channels_last)
