@@ -861,6 +861,8 @@ def main():
                     "default: BASELINE.json configs[1]")
     ap.add_argument("--full-model", default="mixed16384_neuradar_full,mixed8192_vod_nll,mixed16384_neuradar_full_fp16",
                     help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
+    ap.add_argument("--full-model-trained-steps", type=int, default=300, help="report every full-model workload again after this many "
+                    "training steps (block `after_training`: the radar predictions have left the one-cluster state of a fresh model); 0 = skip")
     ap.add_argument("--no-render", action="store_true", help="skip the rendering-entry block of the full-model workloads")
     ap.add_argument("--regime", default="fresh", choices=["fresh", "trained"], help="trained: the MAIN measurement itself runs in the "
                     "trained regime (--trained-steps steps on scene-consistent targets first; no separate `trained` block) -- for "
@@ -926,9 +928,19 @@ def main():
                                "radar_loss": fr["wl"].get("radar_loss"), "radar_grid": fr["wl"].get("radar", "zod"),
                                "mlp_operands": fr["mlp_dtype"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
-                               "loss_after_run": fr["loss"], "render": fr["render"],
+                               "loss_after_run": fr["loss"], "render": fr["render"], "after_training": None,
                                "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
                                            "the linear sum assignment on the device"})
+            if args.full_model_trained_steps > 0:
+                # the same workload once the radar predictions have spread (the assignment's fast regime): same timing rules
+                # (plain training steps on the workload's own supervision: `--warmup` of that length, not the headline's scene targets)
+                a2 = argparse.Namespace(**vars(args))
+                a2.warmup = -(-args.full_model_trained_steps // 2) * 2
+                a2.no_render = True
+                ft = measure(a2, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
+                full_model[-1]["after_training"] = {"steps_trained": a2.warmup, "value": round(ft["value"], 1),
+                                                    "unit": "rays/s", "ms_per_step": round(ft["ms_per_step"], 4),
+                                                    "ms_per_step_min": round(ft["ms_min"], 4), "ms_per_step_max": round(ft["ms_max"], 4)}
     trained = None
     if args.trained_steps > 0 and not args.autograd and args.regime != "trained":
         # the headline workload in the TRAINED regime: scene-consistent targets, args.trained_steps training steps, then the same

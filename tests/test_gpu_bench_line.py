@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--min-seconds", "0.05",
-                          "--cpu-sample-rays", "64", "--secondary", "", "--trained-steps", "40", "--full-model", "mixed8192_vod_nll"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          "--cpu-sample-rays", "64", "--secondary", "", "--trained-steps", "40", "--full-model", "mixed8192_vod_nll", "--full-model-trained-steps", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -40,6 +40,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert len(fm) == 1 and fm[0]["workload"] == "mixed8192_vod_nll" and fm[0]["value"] > 0 and fm[0]["decoders_us_in_step"] > 0
     assert fm[0]["rays"] == {"camera": 2048, "lidar": 1599, "radar": 4545} and fm[0]["radar_loss"] == "nll"
     # the rendering entry with the model the step trained: one camera image at a third of the resolution, one radar scan
+    assert fm[0]["after_training"]["steps_trained"] == 40 and fm[0]["after_training"]["value"] > 0
     rd = fm[0]["render"]
     assert rd["camera_image"]["rays"] == 640 * 360 and rd["camera_image"]["outputs"]["rgb"] == [1080, 1920, 3] and rd["camera_image"]["ms"] > 0
     assert rd["radar_scan"]["rays"] == 4545 and rd["radar_scan"]["outputs"]["radar_output"] == [1, 4545, 7]
