@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 18
+#define NR_ABI_VERSION 19
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -192,6 +192,24 @@ int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* d
 int nr_radar_points_fwd(const float* depth, const float* dirs_spher, int64_t n, const float* dim_t, const int* code, int C,
                         float* xyz, float* dirs, float* pos, nr_stream_t stream);
 int nr_radar_points_bwd(const float* g_xyz, const float* dirs, int64_t n, float* g_depth, nr_stream_t stream);
+
+/* The radar decoder's three heads and the assembly of radar_output in one launch each way (models/neuradar.py:252-278,480-491):
+ * head h = MLP in_dim -> 16 -> 16 -> {3, 1, 3} with ReLU hidden layers (h = 0 offset, 1 existence probability, 2 uncertainty;
+ * weight[h][l] is layer l's [out, in] matrix, bias[h][l] its bias), x [n, in_dim] the transformer's output, xyz [n, 3] the rendered points:
+ *   out [n, 7] = [sigmoid(e), xyz + 1.5 tanh(o), softplus(u)]      (torch.nn.Softplus: identity above 20); in_dim <= 64.
+ * nr_radar_heads_bwd: grad_x [n, in_dim] and grad_xyz [n, 3] (overwritten), parameter gradients "+=". */
+typedef struct nr_radar_heads {
+  const float* weight[3][3];
+  const float* bias[3][3];
+} nr_radar_heads_t;
+typedef struct nr_radar_heads_grads {
+  float* weight[3][3];
+  float* bias[3][3];
+} nr_radar_heads_grads_t;
+int nr_radar_heads_fwd(const nr_radar_heads_t* heads, const float* x, int in_dim, const float* xyz, int64_t n, float* out,
+                       nr_stream_t stream);
+int nr_radar_heads_bwd(const nr_radar_heads_t* heads, const float* x, int in_dim, const float* grad_out, int64_t n, float* grad_x,
+                       float* grad_xyz, const nr_radar_heads_grads_t* grads, nr_stream_t stream);
 
 /* Training-mode batch normalisation of a channels-last activation x [M, C] (M = batch * height * width pixels, C = 8, 16, 32
  * or 64; x 16-byte aligned) with the residual add and the ReLU behind it, as the RGB decoder's BasicBlock chains them

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 18
+NR_ABI_VERSION = 19
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 
 
@@ -25,6 +25,10 @@ class NrMlp(Structure):
 
 class NrMlpGrads(Structure):
     _fields_ = [("weight", c_void_p * NR_MAX_LAYERS), ("bias", c_void_p * NR_MAX_LAYERS)]
+
+
+class NrRadarHeads(Structure):  # nr_radar_heads_t / nr_radar_heads_grads_t: [head][layer]
+    _fields_ = [("weight", (c_void_p * 3) * 3), ("bias", (c_void_p * 3) * 3)]
 
 
 class NrField(Structure):
@@ -71,6 +75,8 @@ PROTOTYPES = {
     "nr_radar_loss": [P, I, L, P, I, P, P, I, F, P, P, P],
     "nr_radar_points_fwd": [P, P, L, P, P, I, P, P, P, P],
     "nr_radar_points_bwd": [P, P, L, P, P],
+    "nr_radar_heads_fwd": [P, P, I, P, L, P, P],
+    "nr_radar_heads_bwd": [P, P, I, P, L, P, P, P, P],
     "nr_bn_act_workspace_floats": [L, I],
     "nr_bn_act_fwd": [P, P, L, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "nr_bn_act_bwd": [P, P, P, L, I, I, P, P, P, I, P, P, P, P, P, P],

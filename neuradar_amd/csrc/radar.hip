@@ -580,6 +580,226 @@ radar_points_bwd_kernel(const float* __restrict__ g_xyz, const float* __restrict
   g_depth[r] = g_xyz[r * 3] * dirs[r * 3] + g_xyz[r * 3 + 1] * dirs[r * 3 + 1] + g_xyz[r * 3 + 2] * dirs[r * 3 + 2];
 }
 
+
+// ---- the three radar heads + the assembly of radar_output in one launch each way (models/neuradar.py:252-278,480-491) --------
+// offset / existence / uncertainty head: MLP in -> 16 -> 16 -> {3, 1, 3}, ReLU hidden (field_components/mlp.py), then
+//   radar_output = [sigmoid(e), xyz + 1.5 tanh(o), softplus(u)]                                   (7 floats per ray).
+// torch: three MLP launches + tanh, scale, sigmoid, softplus, add, cat forward; three MLP backward launches (a fixed ~40 us
+// each at a few thousand rays) + the activations' backwards and the slicing of the 7-wide gradient.  Block = 64 rays x 3 heads
+// (wave h = head h, lane = ray; a fourth wave helps with the parameter gradients); parameters in LDS.
+constexpr int kRhHid = 16, kRhRays = 64, kRhThreads = 256, kRhMaxIn = 64;
+__device__ __constant__ const int kRhOut[3] = {3, 1, 3};
+struct RhLayout {  // float offsets of one head's parameters inside the block's LDS image
+  int w1, b1, w2, b2, w3, b3, size;
+};
+__host__ __device__ inline RhLayout rh_layout(int C, int out) {
+  RhLayout l;
+  l.w1 = 0;
+  l.b1 = l.w1 + kRhHid * C;
+  l.w2 = l.b1 + kRhHid;
+  l.b2 = l.w2 + kRhHid * kRhHid;
+  l.w3 = l.b2 + kRhHid;
+  l.b3 = l.w3 + out * kRhHid;
+  l.size = l.b3 + out;
+  return l;
+}
+__device__ __forceinline__ int rh_head_base(int C, int h) {
+  int base = 0;
+  for (int k = 0; k < h; ++k) base += rh_layout(C, kRhOut[k]).size;
+  return base;
+}
+__device__ __forceinline__ void rh_load_params(const nr_radar_heads_t& hd, int C, float* __restrict__ lw) {
+  for (int h = 0; h < 3; ++h) {
+    const RhLayout l = rh_layout(C, kRhOut[h]);
+    float* dst = lw + rh_head_base(C, h);
+    for (int k = threadIdx.x; k < kRhHid * C; k += blockDim.x) dst[l.w1 + k] = hd.weight[h][0][k];
+    for (int k = threadIdx.x; k < kRhHid * kRhHid; k += blockDim.x) dst[l.w2 + k] = hd.weight[h][1][k];
+    for (int k = threadIdx.x; k < kRhOut[h] * kRhHid; k += blockDim.x) dst[l.w3 + k] = hd.weight[h][2][k];
+    for (int k = threadIdx.x; k < kRhHid; k += blockDim.x) {
+      dst[l.b1 + k] = hd.bias[h][0][k];
+      dst[l.b2 + k] = hd.bias[h][1][k];
+    }
+    for (int k = threadIdx.x; k < kRhOut[h]; k += blockDim.x) dst[l.b3 + k] = hd.bias[h][2][k];
+  }
+}
+// one head of one ray: hidden activations h1, h2 and the raw outputs y (x: the ray's C inputs, read from LDS row xs)
+__device__ __forceinline__ void rh_head_fwd(const float* __restrict__ lw, const RhLayout& l, int C, int out, const float* __restrict__ xs,
+                                            float (&h1)[kRhHid], float (&h2)[kRhHid], float (&y)[3]) {
+#pragma unroll
+  for (int j = 0; j < kRhHid; ++j) h1[j] = lw[l.b1 + j];
+  for (int k = 0; k < C; ++k) {
+    const float xv = xs[k];
+#pragma unroll
+    for (int j = 0; j < kRhHid; ++j) h1[j] += lw[l.w1 + j * C + k] * xv;
+  }
+#pragma unroll
+  for (int j = 0; j < kRhHid; ++j) h1[j] = fmaxf(h1[j], 0.0f);
+#pragma unroll
+  for (int j = 0; j < kRhHid; ++j) {
+    float a = lw[l.b2 + j];
+#pragma unroll
+    for (int k = 0; k < kRhHid; ++k) a += lw[l.w2 + j * kRhHid + k] * h1[k];
+    h2[j] = fmaxf(a, 0.0f);
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    float a = 0.0f;
+    if (o < out) {
+      a = lw[l.b3 + o];
+#pragma unroll
+      for (int k = 0; k < kRhHid; ++k) a += lw[l.w3 + o * kRhHid + k] * h2[k];
+    }
+    y[o] = a;
+  }
+}
+__device__ __forceinline__ float rh_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float rh_softplus(float v) { return v > 20.0f ? v : log1pf(expf(v)); }  // torch.nn.Softplus(beta=1, threshold=20)
+
+__global__ void __launch_bounds__(kRhThreads)
+radar_heads_fwd_kernel(nr_radar_heads_t hd, const float* __restrict__ x, int C, const float* __restrict__ xyz, int64_t n,
+                       float* __restrict__ out) {
+  extern __shared__ float rh_lds[];
+  float* lw = rh_lds;                                                         // the three heads' parameters
+  float* xs = lw + rh_head_base(C, 3);                                        // [64 rays][C + 1]
+  rh_load_params(hd, C, lw);
+  const int64_t r0 = (int64_t)blockIdx.x * kRhRays;
+  for (int k = threadIdx.x; k < kRhRays * C; k += blockDim.x) {
+    const int t = k / C, c = k - t * C;
+    xs[t * (C + 1) + c] = (r0 + t) < n ? x[(r0 + t) * C + c] : 0.0f;
+  }
+  __syncthreads();
+  const int h = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const int64_t r = r0 + t;
+  if (h >= 3 || r >= n) return;
+  const RhLayout l = rh_layout(C, kRhOut[h]);
+  float h1[kRhHid], h2[kRhHid], y[3];
+  rh_head_fwd(lw + rh_head_base(C, h), l, C, kRhOut[h], xs + t * (C + 1), h1, h2, y);
+  float* o = out + r * 7;
+  if (h == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[1 + a] = xyz[r * 3 + a] + 1.5f * tanhf(y[a]);
+  } else if (h == 1) {
+    o[0] = rh_sigmoid(y[0]);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[4 + a] = rh_softplus(y[a]);
+  }
+}
+
+// Backward: wave h recomputes its head for its ray, backpropagates, leaves (d y, d h2, d h1) and (h2, h1) in LDS; then all four
+// waves sum the outer products over the block's 64 rays -- every thread owns parameter entries -- and add them to the gradients.
+__global__ void __launch_bounds__(kRhThreads)
+radar_heads_bwd_kernel(nr_radar_heads_t hd, const float* __restrict__ x, int C, const float* __restrict__ g_out, int64_t n,
+                       float* __restrict__ g_x, float* __restrict__ g_xyz, nr_radar_heads_grads_t gr) {
+  extern __shared__ float rh_lds[];
+  float* lw = rh_lds;
+  float* xs = lw + rh_head_base(C, 3);                  // [64][C + 1]
+  float* act = xs + kRhRays * (C + 1);                  // [3 heads][64 rays][h1 16 | h2 16 | dh1 16 | dh2 16 | dy 3 | pad 1] = 68 floats
+  float* gxs = act + 3 * kRhRays * 68;                  // [3 heads][64 rays][C + 1]: every head's d x
+  rh_load_params(hd, C, lw);
+  const int64_t r0 = (int64_t)blockIdx.x * kRhRays;
+  for (int k = threadIdx.x; k < kRhRays * C; k += blockDim.x) {
+    const int t = k / C, c = k - t * C;
+    xs[t * (C + 1) + c] = (r0 + t) < n ? x[(r0 + t) * C + c] : 0.0f;
+  }
+  __syncthreads();
+  const int h = threadIdx.x >> 6, t = threadIdx.x & 63;
+  const int64_t r = r0 + t;
+  if (h < 3) {
+    const int out = kRhOut[h];
+    const RhLayout l = rh_layout(C, out);
+    const float* w = lw + rh_head_base(C, h);
+    float* a = act + (h * kRhRays + t) * 68;
+    float* gx = gxs + (h * kRhRays + t) * (C + 1);
+    float h1[kRhHid], h2[kRhHid], y[3], dy[3] = {0.0f, 0.0f, 0.0f}, d2[kRhHid], d1[kRhHid];
+    const bool live = r < n;
+    if (live) {
+      rh_head_fwd(w, l, C, out, xs + t * (C + 1), h1, h2, y);
+      const float* g = g_out + r * 7;
+      if (h == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float th = tanhf(y[q]);
+          dy[q] = 1.5f * (1.0f - th * th) * g[1 + q];
+          g_xyz[r * 3 + q] = g[1 + q];
+        }
+      } else if (h == 1) {
+        const float e = rh_sigmoid(y[0]);
+        dy[0] = e * (1.0f - e) * g[0];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dy[q] = (y[q] > 20.0f ? 1.0f : rh_sigmoid(y[q])) * g[4 + q];
+      }
+#pragma unroll
+      for (int k = 0; k < kRhHid; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+          if (o < out) s += w[l.w3 + o * kRhHid + k] * dy[o];
+        d2[k] = h2[k] > 0.0f ? s : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < kRhHid; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kRhHid; ++j) s += w[l.w2 + j * kRhHid + k] * d2[j];
+        d1[k] = h1[k] > 0.0f ? s : 0.0f;
+      }
+      for (int c = 0; c < C; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kRhHid; ++j) s += w[l.w1 + j * C + c] * d1[j];
+        gx[c] = s;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kRhHid; ++k) h1[k] = h2[k] = d1[k] = d2[k] = 0.0f;
+      for (int c = 0; c < C; ++c) gx[c] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kRhHid; ++k) {
+      a[k] = h1[k];
+      a[16 + k] = h2[k];
+      a[32 + k] = d1[k];
+      a[48 + k] = d2[k];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[64 + q] = dy[q];
+  }
+  __syncthreads();
+  // d x = sum over the heads
+  for (int k = threadIdx.x; k < kRhRays * C; k += blockDim.x) {
+    const int tt = k / C, c = k - tt * C;
+    if (r0 + tt < n)
+      g_x[(r0 + tt) * C + c] = gxs[(0 * kRhRays + tt) * (C + 1) + c] + gxs[(1 * kRhRays + tt) * (C + 1) + c] + gxs[(2 * kRhRays + tt) * (C + 1) + c];
+  }
+  // parameter gradients: entry e of a head's image = sum over the 64 rays of (left factor) * (right factor)
+  for (int hh = 0; hh < 3; ++hh) {
+    const int out = kRhOut[hh];
+    const RhLayout l = rh_layout(C, out);
+    const float* a0 = act + hh * kRhRays * 68;
+    for (int e = threadIdx.x; e < l.size; e += blockDim.x) {
+      int lo, ro;      // offsets of the left (gradient) and right (activation) factor inside a ray's 68 floats; ro < 0: bias;
+      bool from_x = false;  // right factor = the ray's input x
+      int xc = 0;
+      float* dst;
+      if (e < l.b1) { const int j = e / C; xc = e - j * C; lo = 32 + j; ro = 0; from_x = true; dst = gr.weight[hh][0] + e; }
+      else if (e < l.w2) { lo = 32 + (e - l.b1); ro = -1; dst = gr.bias[hh][0] + (e - l.b1); }
+      else if (e < l.b2) { const int q = e - l.w2, j = q / kRhHid, k2 = q - j * kRhHid; lo = 48 + j; ro = k2; dst = gr.weight[hh][1] + q; }
+      else if (e < l.w3) { lo = 48 + (e - l.b2); ro = -1; dst = gr.bias[hh][1] + (e - l.b2); }
+      else if (e < l.b3) { const int q = e - l.w3, o = q / kRhHid, k2 = q - o * kRhHid; lo = 64 + o; ro = 16 + k2; dst = gr.weight[hh][2] + q; }
+      else { lo = 64 + (e - l.b3); ro = -1; dst = gr.bias[hh][2] + (e - l.b3); }
+      float s = 0.0f;
+      for (int tt = 0; tt < kRhRays; ++tt) {
+        const float left = a0[tt * 68 + lo];
+        const float right = from_x ? xs[tt * (C + 1) + xc] : (ro < 0 ? 1.0f : a0[tt * 68 + ro]);
+        s += left * right;
+      }
+      if (s != 0.0f) unsafeAtomicAdd(dst, s);
+    }
+  }
+}
+
 }  // namespace
 
 static int lsa_q(int64_t small) {  // slots per lane: 1, 2, 4, 8, 16
@@ -678,6 +898,48 @@ extern "C" int nr_radar_points_bwd(const float* g_xyz, const float* dirs, int64_
   if (n == 0) return 0;
   if (!g_xyz || !dirs || !g_depth || n < 0) return NR_EINVAL;
   hipLaunchKernelGGL(radar_points_bwd_kernel, dim3((unsigned)nr_cdiv(n, 256)), dim3(256), 0, nr_s(stream), g_xyz, dirs, n, g_depth);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+static size_t rh_lds_bytes(int C, bool bwd) {
+  size_t f = 0;
+  const int outs[3] = {3, 1, 3};
+  for (int h = 0; h < 3; ++h) f += (size_t)rh_layout(C, outs[h]).size;
+  f += (size_t)kRhRays * (C + 1);
+  if (bwd) f += (size_t)3 * kRhRays * 68 + (size_t)3 * kRhRays * (C + 1);
+  return f * sizeof(float);
+}
+
+extern "C" int nr_radar_heads_fwd(const nr_radar_heads_t* heads, const float* x, int in_dim, const float* xyz, int64_t n, float* out,
+                                  nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!heads || !x || !xyz || !out || n < 0 || in_dim < 1 || in_dim > kRhMaxIn) return NR_EINVAL;
+  for (int h = 0; h < 3; ++h)
+    for (int l = 0; l < 3; ++l)
+      if (!heads->weight[h][l] || !heads->bias[h][l]) return NR_EINVAL;
+  hipLaunchKernelGGL(radar_heads_fwd_kernel, dim3((unsigned)nr_cdiv(n, kRhRays)), dim3(kRhThreads), rh_lds_bytes(in_dim, false), nr_s(stream),
+                     *heads, x, in_dim, xyz, n, out);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_radar_heads_bwd(const nr_radar_heads_t* heads, const float* x, int in_dim, const float* grad_out, int64_t n,
+                                  float* grad_x, float* grad_xyz, const nr_radar_heads_grads_t* grads, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!heads || !x || !grad_out || !grad_x || !grad_xyz || !grads || n < 0 || in_dim < 1 || in_dim > kRhMaxIn) return NR_EINVAL;
+  for (int h = 0; h < 3; ++h)
+    for (int l = 0; l < 3; ++l)
+      if (!heads->weight[h][l] || !heads->bias[h][l] || !grads->weight[h][l] || !grads->bias[h][l]) return NR_EINVAL;
+  static bool raised = false;  // (64 rays x 3 heads of activations: more than the default 64 KB of dynamic LDS at 64 inputs)
+  const size_t lds = rh_lds_bytes(in_dim, true);
+  if (!raised && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radar_heads_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(radar_heads_bwd_kernel, dim3((unsigned)nr_cdiv(n, kRhRays)), dim3(kRhThreads), lds, nr_s(stream), *heads, x, in_dim,
+                     grad_out, n, grad_x, grad_xyz, *grads);
   NR_LAUNCH_CHECK();
   return 0;
 }

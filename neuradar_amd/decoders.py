@@ -186,10 +186,27 @@ class Decoders(nn.Module):
         xyz, pos = ops.radar_points(depth, directions_spher, C)
         xyz, pos = xyz.view(num_radar_scans, -1, 3), pos.view(num_radar_scans, -1, C)
         out = self.radar_decoder(radar_features.reshape(num_radar_scans, -1, C), pos, seed_epoch)
+        if self._heads_fusable(C):
+            # the three heads (MLP C -> 16 -> 16 -> 3 | 1 | 3), tanh / sigmoid / softplus and the concatenation: one launch each way
+            return ops.radar_heads(out.reshape(-1, C), xyz.reshape(-1, 3), self.offset_head, self.existence_probability_head,
+                                   self.radar_uncertainty_head).view(num_radar_scans, -1, 7)
         offset = 1.5 * self.offset_head(out)
         ep = self.existence_probability_head(out)
         unc = self.radar_uncertainty_head(out)
         return torch.cat((ep, xyz + offset, unc), dim=-1).float()
+
+    def _heads_fusable(self, C: int) -> bool:
+        import os
+
+        if os.environ.get("NR_FUSED_RADAR_HEADS", "1") == "0" or C > 64:
+            return False
+        for head, act, k in ((self.offset_head, nn.Tanh, 3), (self.existence_probability_head, nn.Sigmoid, 1),
+                             (self.radar_uncertainty_head, nn.Softplus, 3)):
+            if not (isinstance(head, MLP) and head.num_layers == 3 and head.layer_width == 16 and head.out_dim == k
+                    and head.in_dim == C and isinstance(head.out_activation, act)):
+                return False
+        sp = self.radar_uncertainty_head.out_activation
+        return sp.beta == 1 and sp.threshold == 20
 
     def forward(self, features: Tensor, patch_size: Tuple[int, int], depth: Tensor, directions_spher: Tensor,
                 is_lidar: Optional[Tensor] = None, is_radar: Optional[Tensor] = None, num_radar_scans: Optional[int] = None):

@@ -690,6 +690,58 @@ def bn_act(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Optional[Tenso
     return _BnAct.apply(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
 
 
+def _radar_heads_struct(tensors) -> "_lib.NrRadarHeads":
+    st = _lib.NrRadarHeads()
+    for h in range(3):
+        for l in range(3):
+            st.weight[h][l] = tensors[(h * 3 + l) * 2].data_ptr()
+            st.bias[h][l] = tensors[(h * 3 + l) * 2 + 1].data_ptr()
+    return st
+
+
+class _RadarHeads(torch.autograd.Function):
+    """nr_radar_heads_fwd/bwd: (transformer output [n, C], rendered points [n, 3], 18 parameter tensors: head (offset, existence,
+    uncertainty) x layer x (weight, bias)) -> radar_output [n, 7]."""
+
+    @staticmethod
+    def forward(ctx, x, xyz, *params):
+        x, xyz = _f32(x, "x"), _f32(xyz, "xyz")
+        ps = [_f32(p, "head parameter") for p in params]
+        n, C = x.shape
+        assert len(ps) == 18 and xyz.shape == (n, 3)
+        for h, k_out in enumerate((3, 1, 3)):
+            assert ps[h * 6].shape == (16, C) and ps[h * 6 + 2].shape == (16, 16) and ps[h * 6 + 4].shape == (k_out, 16), "heads are C -> 16 -> 16 -> 3 | 1 | 3"
+        out = torch.empty(n, 7, device=x.device, dtype=torch.float32)
+        check(_lib.lib().nr_radar_heads_fwd(byref(_radar_heads_struct(ps)), _p(x), C, _p(xyz), n, _p(out), _stream()), "nr_radar_heads_fwd")
+        ctx.save_for_backward(x, *ps)
+        ctx.param_refs = params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *ps = ctx.saved_tensors
+        n, C = x.shape
+        g = _f32(g, "g")
+        refs = ctx.param_refs
+        direct = _DIRECT_PARAM_GRADS and all(p.is_leaf and p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+                                             and p.grad.is_contiguous() and p.dtype == torch.float32 and p.is_contiguous() for p in refs)
+        grads = [p.grad for p in refs] if direct else [torch.zeros_like(p) for p in ps]
+        gx, gxyz = torch.empty_like(x), torch.empty(n, 3, device=x.device, dtype=torch.float32)
+        check(_lib.lib().nr_radar_heads_bwd(byref(_radar_heads_struct(ps)), _p(x), C, _p(g), n, _p(gx), _p(gxyz),
+                                            byref(_radar_heads_struct(grads)), _stream()), "nr_radar_heads_bwd")
+        return (gx, gxyz, *([None] * 18 if direct else grads))
+
+
+def radar_heads(x: Tensor, xyz: Tensor, offset_head, existence_head, uncertainty_head) -> Tensor:
+    """radar_output [n, 7] = [sigmoid(existence(x)), xyz + 1.5 tanh(offset(x)), softplus(uncertainty(x))] -- the three MLP heads of
+    the radar decoder (in -> 16 -> 16 -> 3 | 1 | 3) and the assembly of neuradar.py:480-491 in one launch each way."""
+    params = []
+    for head in (offset_head, existence_head, uncertainty_head):
+        for layer in head.layers:
+            params += [layer.weight, layer.bias]
+    return _RadarHeads.apply(x, xyz, *params)
+
+
 _POSEMB_TABLES: dict = {}
 
 

@@ -287,3 +287,38 @@ def test_bn_act_kernels_vs_torch_batch_norm(dtype, tol, with_residual, relu):
             assert_close(h[4].cpu(), t[4].cpu(), rtol=tol, atol_scale=4 * tol, what="d residual")
         assert_close(h[5].cpu(), t[5].cpu(), rtol=max(tol, 1e-4), atol_scale=4 * tol, what="d weight")
         assert_close(h[6].cpu(), t[6].cpu(), rtol=max(tol, 1e-4), atol_scale=4 * tol, what="d bias")
+
+
+@pytest.mark.parametrize("C,n", [(48, 3531), (64, 130), (48, 1)])
+def test_radar_heads_kernels_vs_the_three_mlp_heads(C, n, monkeypatch):
+    """nr_radar_heads_fwd/bwd against the expression it replaces (three MLP heads on nr_mlp_fwd/bwd + tanh / sigmoid / softplus +
+    concatenation, neuradar.py:480-491): radar_output and the gradients w.r.t. the transformer output, the points and all 18
+    parameter tensors; ray counts that are not multiples of the block's 64."""
+    from neuradar_amd.decoders import Decoders
+
+    torch.manual_seed(C + n)
+    dec = Decoders(C).to(DEV).train()
+    with torch.no_grad():  # away from the small default initialisation: saturating activations included
+        for head in (dec.offset_head, dec.existence_probability_head, dec.radar_uncertainty_head):
+            for p in head.parameters():
+                p.mul_(4.0)
+    x0 = torch.randn(n, C, device=DEV)
+    xyz0 = torch.randn(n, 3, device=DEV) * 30.0
+    gy = torch.randn(n, 7, device=DEV)
+    heads = (dec.offset_head, dec.existence_probability_head, dec.radar_uncertainty_head)
+    params = [p for h in heads for p in h.parameters()]
+    res = []
+    for fused in (True, False):
+        x, xyz = x0.clone().requires_grad_(True), xyz0.clone().requires_grad_(True)
+        if fused:
+            from neuradar_amd import ops
+
+            y = ops.radar_heads(x, xyz, *heads)
+        else:
+            y = torch.cat((dec.existence_probability_head(x), xyz + 1.5 * dec.offset_head(x), dec.radar_uncertainty_head(x)), dim=-1)
+        grads = torch.autograd.grad((y * gy).sum(), [x, xyz] + params)
+        res.append((y.detach(), grads))
+    (ya, ga), (yb, gb) = res
+    assert_close(ya.cpu(), yb.cpu(), rtol=1e-5, atol_scale=1e-6, what="radar_output")
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert_close(a.cpu(), b.cpu(), rtol=1e-4, atol_scale=1e-5, what=f"gradient {i}")
