@@ -259,8 +259,8 @@ def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_cnn_16_bit_working_copies_equal_autocast(dtype, monkeypatch):
     """DecoderLossHead runs the RGB CNN on 16-bit working copies of its convolution parameters (one copy before the forward,
-    one mixed-precision add of the gradients after the backward) instead of torch.autocast's per-parameter casts: bit-identical
-    output, loss and batch-norm statistics; gradients as close to the fp32 CNN's as autocast's are (the backward runs the same
+    one mixed-precision add of the gradients after the backward) instead of torch.autocast's per-parameter casts: the same
+    output, loss and batch-norm statistics (to the operand type's rounding); gradients as close to the fp32 CNN's as autocast's are (the backward runs the same
     operations on the same 16-bit operands, but MIOpen's benchmark mode picks the algorithms of every head independently and
     the gradients sit at 1e-4 ... 1e-8 -- fp16's subnormal range -- so two 16-bit runs differ by ~2 % in relative L2)."""
     from neuradar_amd.decoder_losses import DecoderLossHead
@@ -289,9 +289,12 @@ def test_cnn_16_bit_working_copies_equal_autocast(dtype, monkeypatch):
                      {k: v.grad.clone() for k, v in dec.rgb_decoder.named_parameters()},
                      {k: v.clone() for k, v in dec.rgb_decoder.named_buffers()})
     a, b, f = res["copies"], res["autocast"], res["fp32"]
-    assert torch.equal(a[0], b[0]) and a[1] == b[1], "rgb / loss"
+    # (usually bit-identical; MIOpen's benchmark mode may pick another forward algorithm for the second head: 1 run in ~8)
+    tol = 4e-3 if dtype == torch.float16 else 3e-2
+    assert_close(a[0].cpu(), b[0].cpu(), rtol=tol, atol_scale=tol, what="rgb")
+    assert abs(a[1] - b[1]) <= tol * abs(b[1]), ("loss", a[1], b[1])
     for k in a[4]:
-        assert torch.equal(a[4][k], b[4][k]), "batch-norm statistics " + k
+        assert_close(a[4][k].float().cpu(), b[4][k].float().cpu(), rtol=tol, atol_scale=tol, what="batch-norm statistics " + k)
     rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
     rows = {"d loss / d features": (a[2], b[2], f[2])}
     rows.update({k: (a[3][k], b[3][k], f[3][k]) for k in a[3] if not k.endswith(("main_branch.0.bias", "main_branch.3.bias"))})
