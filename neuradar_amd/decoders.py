@@ -74,7 +74,9 @@ class _EncoderLayer(nn.Module):
         x2 = self.norm1(x)
         qk = x2 + pos
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
-        q, k, v = F.linear(qk, w[:C], b[:C]), F.linear(qk, w[C:2 * C], b[C:2 * C]), F.linear(x2, w[2 * C:], b[2 * C:])
+        # q and k read the same input: one projection for both (two launches less forward, five less backward; same dot products)
+        q, k = F.linear(qk, w[:2 * C], b[:2 * C]).split(C, dim=-1)
+        q, k, v = q.contiguous(), k.contiguous(), F.linear(x2, w[2 * C:], b[2 * C:])
         p_att = self.p_drop if self.training else 0.0
         if self.attention == "hip" and C in self.HIP_WIDTHS:
             # nr_attention_fwd/bwd: exact fp32 on the matrix cores, the hash of (seed, query, key) decides the drops (a new seed
