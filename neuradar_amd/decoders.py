@@ -75,8 +75,12 @@ class _EncoderLayer(nn.Module):
         qk = x2 + pos
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         # q and k read the same input: one projection for both (two launches less forward, five less backward; same dot products)
-        q, k = F.linear(qk, w[:2 * C], b[:2 * C]).split(C, dim=-1)
-        q, k, v = q.contiguous(), k.contiguous(), F.linear(x2, w[2 * C:], b[2 * C:])
+        # projections: library GEMMs with the three-launch backward of ops.linear_direct ("torch" layers: plain F.linear)
+        lin = ops.linear_direct if self.attention == "hip" else (
+            lambda t, w_, b_, rows=None: F.linear(t, w_, b_) if rows is None else
+            F.linear(t, w_[rows[0]:rows[0] + rows[1]], b_[rows[0]:rows[0] + rows[1]]))
+        q, k = lin(qk, w, b, (0, 2 * C)).split(C, dim=-1)
+        q, k, v = q.contiguous(), k.contiguous(), lin(x2, w, b, (2 * C, C))
         p_att = self.p_drop if self.training else 0.0
         if self.attention == "hip" and C in self.HIP_WIDTHS:
             # nr_attention_fwd/bwd: exact fp32 on the matrix cores, the hash of (seed, query, key) decides the drops (a new seed
@@ -85,10 +89,11 @@ class _EncoderLayer(nn.Module):
             att = ops.attention(q, k, v, p_att, seed=self._dropout_seed(), seed_epoch=seed_epoch if p_att > 0 else None)
         else:
             att = F.scaled_dot_product_attention(q, k, v, dropout_p=p_att)
-        x = x + F.dropout(self.self_attn.out_proj(att), self.p_drop, self.training)
+        x = x + F.dropout(lin(att, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias), self.p_drop, self.training)
         x2 = self.norm2(x)
-        if self.training and self.p_drop > 0:  # dropout sits between the two linears: plain torch ops
-            ff = self.linear2(F.dropout(torch.relu(self.linear1(x2)), self.p_drop, True))
+        if self.training and self.p_drop > 0:  # dropout sits between the two linears: library GEMMs + torch's dropout
+            ff = lin(F.dropout(torch.relu(lin(x2, self.linear1.weight, self.linear1.bias)), self.p_drop, True),
+                     self.linear2.weight, self.linear2.bias)
         else:  # 48 -> 64 -> 48 on the MFMA MLP kernels
             ff = ops.mlp(x2.reshape(-1, C), [self.linear1.weight, self.linear2.weight], [self.linear1.bias, self.linear2.bias]).view_as(x)
         return x + F.dropout(ff, self.p_drop, self.training)

@@ -629,6 +629,64 @@ def appearance_concat(features: Tensor, table: Tensor, times: Tensor, sensor_idx
     return _AppearanceConcat.apply(features, table, times, sensor_idx, duration, embeds_per_sensor)
 
 
+_ONES: dict = {}
+
+
+def _ones(n: int, device) -> Tensor:
+    key = (n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ONES[key]
+
+
+class _LinearDirect(torch.autograd.Function):
+    """y = x W^T + b on the library GEMM (torch.addmm) for [rows, in] inputs; W / b may be row slices of larger parameters (the
+    attention's in_proj_weight).  Inside `direct_param_grads` the backward is three launches -- d x = g W; W.grad += g^T x and
+    b.grad += g^T 1 written straight into the gradient buffers (slices of them for sliced parameters) -- instead of autograd's
+    two GEMMs + bias reduction + AccumulateGrad adds + the zero-fill and copy of every parameter slice's backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner_w, owner_b, row0, rows):
+        w = weight if owner_w is None else owner_w[row0:row0 + rows]
+        b = bias if owner_b is None else owner_b[row0:row0 + rows]
+        y = torch.addmm(b, x, w.t())
+        ctx.save_for_backward(x, w)
+        ctx.refs = (weight if owner_w is None else owner_w, bias if owner_b is None else owner_b, row0, rows, owner_w is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        pw, pb, row0, rows, sliced = ctx.refs
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        direct = _DIRECT_PARAM_GRADS and all(p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_contiguous() for p in (pw, pb))
+        if direct:
+            gw = pw.grad[row0:row0 + rows] if sliced else pw.grad
+            gb = pb.grad[row0:row0 + rows] if sliced else pb.grad
+            gw.addmm_(g.t(), x)
+            gb.addmv_(g.t(), _ones(g.shape[0], g.device))
+            return gx, None, None, None, None, None, None
+        gw, gb = g.t() @ x, g.sum(0)
+        if sliced:  # gradients of the owners: zero outside the slice
+            fw, fb = torch.zeros_like(pw), torch.zeros_like(pb)
+            fw[row0:row0 + rows], fb[row0:row0 + rows] = gw, gb
+            return gx, None, None, fw, fb, None, None
+        return gx, gw, gb, None, None, None, None
+
+
+def linear_direct(x: Tensor, weight: Tensor, bias: Tensor, rows: Optional[Tuple[int, int]] = None) -> Tensor:
+    """F.linear(x, weight, bias) -- or, with rows = (first, count), F.linear(x, weight[first:first + count], bias[...]) -- for
+    [..., in] float32 inputs, with the three-launch backward of _LinearDirect."""
+    lead = x.shape[:-1]
+    x2 = _f32(x, "x").reshape(-1, x.shape[-1])
+    if rows is None:
+        y = _LinearDirect.apply(x2, weight, bias, None, None, 0, weight.shape[0])
+    else:
+        y = _LinearDirect.apply(x2, None, None, weight, bias, int(rows[0]), int(rows[1]))
+    return y.view(*lead, y.shape[-1])
+
+
 _BN_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _BN_WS: dict = {}
 
