@@ -929,8 +929,8 @@ def main():
                                "mlp_operands": fr["mlp_dtype"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
                                "loss_after_run": fr["loss"], "render": fr["render"], "after_training": None,
-                               "decoders": "RGB CNN (MIOpen convolutions under autocast) + lidar MLP + radar transformer/heads; losses incl. "
-                                           "the linear sum assignment on the device"})
+                               "decoders": "RGB CNN (MIOpen NHWC convolutions on 16-bit working copies, hand-written batch norm + ReLU + residual) + lidar MLP + "
+                                           "radar transformer / heads; losses incl. the linear sum assignment on the device"})
             if args.full_model_trained_steps > 0:
                 # the same workload once the radar predictions have spread (the assignment's fast regime): same timing rules
                 # (plain training steps on the workload's own supervision: `--warmup` of that length, not the headline's scene targets)
