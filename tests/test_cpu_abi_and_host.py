@@ -152,3 +152,48 @@ def test_flat_adam_steps_back_to_back_tables_as_one_buffer():
     views[1].grad = torch.zeros(n // 2, 2)
     assert [b.numel() for b, _ in FlatAdam._coalesce([views[0], views[1]])] == [n, n]
     assert [b.numel() for b, _ in FlatAdam._coalesce(views[:1])] == [n]
+
+
+def test_flatten_parameters_keeps_values_and_lays_convolutions_out_channels_last():
+    """fused_step.flatten_parameters: parameters and gradients become views of one flat buffer each; 4-D (convolution) weights
+    sit channels-last in it (what lets MIOpen run NHWC kernels on the patch rows), values and shapes unchanged."""
+    from neuradar_amd.decoders import make_rgb_decoder
+    from neuradar_amd.fused_step import flatten_parameters
+
+    torch.manual_seed(0)
+    net = make_rgb_decoder(12, hidden_dim=8)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    flat = flatten_parameters(list(net.parameters()))
+    n = sum(v.numel() for v in before.values())
+    assert flat["param"].numel() >= n and flat["grad"].numel() == flat["param"].numel()
+    lo, hi = flat["param"].data_ptr(), flat["param"].data_ptr() + flat["param"].numel() * 4
+    for k, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[k]) and p.shape == before[k].shape, k
+        assert lo <= p.data_ptr() < hi and p.grad is not None and p.grad.shape == p.shape and p.grad.stride() == p.stride(), k
+        if p.dim() == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1:
+            assert p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous(), k
+    with torch.no_grad():  # the optimizer's view: an elementwise update of the flat buffer moves every parameter
+        flat["param"].add_(1.0)
+    for k, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[k] + 1.0), k
+    x = torch.randn(2, 12, 5, 5)
+    net(x).sum().backward()  # gradients land in the flat gradient buffer
+    assert float(flat["grad"].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("C", [48, 52, 32, 64])
+def test_position_embedding_tables_reproduce_the_reference_expression(C):
+    """ops._posemb_tables (what nr_radar_points_fwd indexes: per channel the axis, sin | cos and the divisor) against
+    decoders.sine_position_embedding, the port of position_encoding_3d.py:56-103, evaluated with the same torch ops."""
+    import math
+
+    from neuradar_amd import ops
+    from neuradar_amd.decoders import sine_position_embedding
+
+    dim_t, code = ops._posemb_tables(C, 10000.0, "cpu")
+    assert dim_t.shape == (C,) and code.shape == (C,) and code.dtype == torch.int32
+    xyz = torch.randn(3, 7, 3) * 40.0
+    ref = sine_position_embedding(xyz, C)
+    arg = xyz[..., (code // 2).long()] * (2 * math.pi) / dim_t
+    got = torch.where((code % 2).bool(), arg.cos(), arg.sin())
+    assert torch.equal(got, ref)
