@@ -539,10 +539,11 @@ class FusedTrainStep:
                 check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 
-        # The main table's `seen` bytes set by its scatter (single GPU, fused optimizer, every row through the merging kernel, no
-        # actors writing into other tables of the same buffer): NR_ADAM_MARKED=0 disables
+        # The main table's `seen` bytes set by its scatter (single GPU, fused optimizer, every row through the merging kernel; the
+        # optimizer's buffer must be exactly the static table -- the actors' tables live in a buffer of their own):
+        # NR_ADAM_MARKED=0 disables
         mark_seen = None
-        if (optimizers is not None and reducer is None and not self.n_actors and self.binned_ws[2] is None
+        if (optimizers is not None and reducer is None and self.binned_ws[2] is None
                 and os.environ.get("NR_ADAM_MARKED", "1") != "0"):
             t_opt = optimizers[0]
             i_m = t_opt.buffer_of(mg.hash_table)
