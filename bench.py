@@ -100,6 +100,31 @@ def build_model(wl, device, mlp_dtype="float32", grad_scale=1.0):
     return NeuRadarHotPath(cfg, actors=actors).to(device).train()
 
 
+def build_optimizers(model):
+    """The reference's optimizers for the parameter groups of the model (configs/method_configs.py:384-409), as FlatAdam
+    instances in the order the fused step expects: [hashgrids, fields, (trajectory_opt), (cnn, transformer)]."""
+    from neuradar_amd.step import FlatAdam
+
+    groups = model.get_param_groups()
+    # hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
+    unused = list(model.proposal_fields[0].parameters())  # never evaluated (reference quirk) -> never stepped
+    lr_scale = float(os.environ.get("NR_BENCH_LR_SCALE", "1"))  # 1e-12 ~ frozen parameters (drift experiments)
+    opts = [FlatAdam(groups["hashgrids"], lr=1e-2 * lr_scale, eps=1e-15, lr_final=1e-3 * lr_scale, max_steps=20001, warmup_steps=500,
+                     skip=unused),
+            FlatAdam(groups["fields"], lr=1e-2 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3 * lr_scale,
+                     max_steps=20001, warmup_steps=500, skip=unused)]
+    if "trajectory_opt" in groups:  # Adam lr 1e-3 -> 1e-4, 2 500 warm-up steps (method_configs.py:401-405)
+        opts.append(FlatAdam(groups["trajectory_opt"], lr=1e-3 * lr_scale, eps=1e-15, lr_final=1e-4 * lr_scale, max_steps=20001,
+                             warmup_steps=2500))
+    if "cnn" in groups:  # cnn AdamW 1e-3 -> 1e-4 (wd 1e-6, 2 500 warm-up), transformer AdamW 1e-3 -> 1e-7
+        # (wd 1e-7, 10 001 steps, 5 000 warm-up); radar_angle_head is built but never evaluated (grad None: skipped like torch.optim)
+        opts.append(FlatAdam(groups["cnn"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-6, adamw=True, lr_final=1e-4 * lr_scale,
+                             max_steps=20001, warmup_steps=2500))
+        opts.append(FlatAdam(groups["transformer"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-7 * lr_scale,
+                             max_steps=10001, warmup_steps=5000, skip=list(model.radar_angle_head.parameters())))
+    return opts
+
+
 class SyntheticScene:
     """Seeded synthetic sensor rig: ego drives 0->100 m in 20 s, 10 Hz forward camera,
     1920x1080 pinhole with fx=fy=2000, rolling shutter; 32x32 patches at stride 3."""
@@ -261,6 +286,13 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                 radar=torch.zeros(max(n_scans, 1) * m_det, scene.radar_points.shape[-1], device=dev),
                                 radar_seg=(torch.arange(n_scans + 1, device=dev, dtype=torch.int32) * m_det)) for k_ in range(2)]
             stepper.set_decoders(head, dec_batches, sensor)
+        if fuse_optimizer and model.field.config.mlp_dtype == "float16" and os.environ.get("NR_AMP", "1") != "0":
+            # fp16 operands: the reference trains them under torch's GradScaler (engine/trainer.py:200,572-594) -- here its
+            # device-resident counterpart: dynamic scale (starting at the configured static one), found-inf -> the flagged
+            # optimizers skip the step and the scale backs off, no host read (step.GradScalerState)
+            from neuradar_amd.step import GradScalerState
+
+            stepper.set_grad_scaler(GradScalerState(dev, init_scale=float(model.field.config.mlp_grad_scale)).attach(opts))
 
         # ONE uniform draw per step: PowerSampler's per-edge jitter [B,S0+1] (ray_samplers.py:111), PDFSampler's
         # per-ray jitter for the two rounds (:326) and the random numbers of the batch assembly.
@@ -573,23 +605,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     grad_scale = args.mlp_grad_scale if args.mlp_grad_scale is not None else (8192.0 if mlp_dtype == "float16" else 1.0)
     model = build_model(wl, device, mlp_dtype, grad_scale)
     broadcast_parameters(model)
-    groups = model.get_param_groups()
-    # configs/method_configs.py:384-409: hashgrids Adam 1e-2 -> 1e-3, fields AdamW 1e-2 -> 1e-3 (wd 1e-7)
-    unused = list(model.proposal_fields[0].parameters())  # never evaluated (reference quirk) -> never stepped
-    lr_scale = float(os.environ.get("NR_BENCH_LR_SCALE", "1"))  # 1e-12 ~ frozen parameters (drift experiments)
-    opts = [FlatAdam(groups["hashgrids"], lr=1e-2 * lr_scale, eps=1e-15, lr_final=1e-3 * lr_scale, max_steps=20001, warmup_steps=500,
-                     skip=unused),
-            FlatAdam(groups["fields"], lr=1e-2 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3 * lr_scale,
-                     max_steps=20001, warmup_steps=500, skip=unused)]
-    if "trajectory_opt" in groups:  # Adam lr 1e-3 -> 1e-4, 2 500 warm-up steps (method_configs.py:401-405)
-        opts.append(FlatAdam(groups["trajectory_opt"], lr=1e-3 * lr_scale, eps=1e-15, lr_final=1e-4 * lr_scale, max_steps=20001,
-                             warmup_steps=2500))
-    if "cnn" in groups:  # method_configs.py:384-409: cnn AdamW 1e-3 -> 1e-4 (wd 1e-6, 2 500 warm-up), transformer AdamW 1e-3 -> 1e-7
-        # (wd 1e-7, 10 001 steps, 5 000 warm-up); radar_angle_head is built but never evaluated (grad None: skipped like torch.optim)
-        opts.append(FlatAdam(groups["cnn"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-6, adamw=True, lr_final=1e-4 * lr_scale,
-                             max_steps=20001, warmup_steps=2500))
-        opts.append(FlatAdam(groups["transformer"], lr=1e-3 * lr_scale, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-7 * lr_scale,
-                             max_steps=10001, warmup_steps=5000, skip=list(model.radar_angle_head.parameters())))
+    opts = build_optimizers(model)
     # the main table's gradient exchange: row lists where a step touches ~1 % of the rows (camera-only
     # batches), reduce-scatter -> Adam on 1/world of the rows -> all-gather where the union over the ranks is most of the table
     # (mixed batches: 9-22 % of the rows per rank)

@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 19
+#define NR_ABI_VERSION 20
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -84,6 +84,19 @@ int nr_hash_encode_bwd_marked(const float* x, const float* std, const float* sca
                               int num_levels, int features_per_level, int log2_hashmap_size,
                               const float* grad_out, int64_t out_stride_n, int64_t out_stride_l,
                               float* grad_table, int64_t n, int sample_major, int wave_cells, unsigned char* seen_grad,
+                              nr_stream_t stream);
+
+/* The same scatter-add through a BLOCK-SHARED, vertex-keyed LDS table on 32-bit integer atomics (grid_shared.hip): a block of
+ * 256 threads takes 256 rows as stored and, level by level, merges their 8 corners each in one table (insert-or-add on the
+ * entry index; 32-bit fixed-point sums scaled by the tile's largest gradient entry on that level), then adds every occupied
+ * record to grad_table with ONE 16-byte atomic request.  For tables too large for the slice-owner kernels below (NeuRadar's
+ * main grid) in steps whose MLPs already run on 16-bit operands: an addend is rounded to 2^-22 ... 2^-21 of the largest
+ * gradient entry of its 256-row tile on that level (smaller ones vanish); otherwise equal to nr_hash_encode_bwd up to
+ * summation order.  features_per_level = 4, num_levels <= 8, grad_out level-major with out_stride_n = 4 (one float4 per row
+ * and level); NR_EINVAL otherwise.  seen_grad: NULL, or the optimizer's bytes as for nr_hash_encode_bwd_marked. */
+int nr_hash_encode_bwd_shared(const float* x01, const float* std01, const float* scalings, int num_levels,
+                              int features_per_level, int log2_hashmap_size, const float* grad_out, int64_t out_stride_n,
+                              int64_t out_stride_l, float* grad_table, int64_t n, unsigned char* seen_grad,
                               nr_stream_t stream);
 
 /* The same scatter-add by TABLE SLICE OWNERSHIP, for tables a step hits densely (the proposal grids) and for incoherent rows
@@ -391,6 +404,10 @@ typedef struct nr_field {
   float grad_scale;    /* reduced precision only: gradients are multiplied by this factor where they enter the 16-bit
                           domain and divided back where they leave it (a static GradScaler, trainer.py:200,585-595);
                           <= 0 means 1.  bf16 needs none; fp16 gradients underflow without it. */
+  float* amp;          /* NULL, or the device-resident state of a DYNAMIC loss scale (nr_amp_*, below): the 16-bit backward then
+                          takes its scale from amp[NR_AMP_SCALE] instead of grad_scale and stores 1.0f to amp[NR_AMP_FOUND + g] for
+                          every optimizer group g of amp_groups when a gradient it writes is inf / NaN (GradScaler's found_inf) */
+  unsigned amp_groups; /* bit g set: group g's optimizer consumes gradients that pass through this backward */
 } nr_field_t;
 
 typedef struct nr_field_grads {
@@ -727,7 +744,10 @@ int nr_lidar_head_loss(const float* y, const float* target_intensity, const uint
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
                  int step, float grad_scale, int zero_grad, const float* dev_hyper, uint8_t* seen_grad,
-                 nr_stream_t stream);
+                 const float* skip, nr_stream_t stream);
+/* skip: NULL, or a device float (an nr_amp found-inf flag): when it is non-zero the update is SKIPPED -- parameters and moments
+ * stay as they are, the gradient is still cleared when zero_grad (GradScaler.step: "optimizer.step() is skipped if the
+ * gradients contain infs or NaNs", engine/optimizers.py:154-166). */
 /* seen_grad: NULL, or n/4 bytes owned by the caller, zeroed when exp_avg / exp_avg_sq are zeroed.  Byte i is set
  * the first time parameters 4i..4i+3 receive a non-zero gradient; while it is 0 their moments are known to be
  * zero, and (weight_decay == 0) a zero gradient leaves them untouched without reading the moments.  Exact. */
@@ -737,14 +757,52 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, i
  * reads its gradient to notice a first arrival: 4 B per parameter of the whole table per step); n % 4 == 0.  Exact. */
 int nr_adam_step_marked(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                         float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
-                        const unsigned char* seen_grad, nr_stream_t stream);
+                        const unsigned char* seen_grad, const float* skip, nr_stream_t stream);
 
 /* Advance the optimizer step counter step_t[0] (device float, 0-based scheduler step) and refresh
  * dev_hyper = {lr(step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))} with the reference's
  * ExponentialDecayScheduler (engine/schedulers.py:112-143: cosine ramp from 1e-8 over `warmup` steps,
  * then log-linear decay lr -> lr_final until max_steps).  One launch, graph-replayable. */
 int nr_adam_hyper(float* step_t, float* dev_hyper, float lr, float lr_final, int warmup, int max_steps,
-                  float beta1, float beta2, nr_stream_t stream);
+                  float beta1, float beta2, const float* amp, int amp_group, nr_stream_t stream);
+/* step_t: TWO device floats -- [0] the scheduler's step count, [1] the optimizer's own step count (bias corrections); without
+ * `amp` they advance together.  With amp (nr_amp state) and amp_group (this optimizer's group): a step that the previous
+ * nr_amp_update recorded as skipped is not counted -- the scheduler's when ANY group was skipped (the reference steps its
+ * schedulers only if the scale did not decrease, engine/trainer.py:590-594), the optimizer's own when ITS step was skipped
+ * (torch.optim.Adam's `step` counts performed updates). */
+
+/* ------------------------------------------------------------------------------------------------
+ * Dynamic loss scale with found-inf guard: torch.cuda.amp.GradScaler (engine/trainer.py:200,572-594;
+ * engine/optimizers.py:154-166) as device-resident state -- no host read anywhere, graph-replayable.
+ *   amp [NR_AMP_FLOATS] floats:
+ *     [NR_AMP_SCALE] the loss scale S        [NR_AMP_GROWTH_TRACKER] steps without inf / NaN since the last change
+ *     [NR_AMP_INV_SCALE] 1 / S               [NR_AMP_SKIPPED_PREV] 1 if the last finished step skipped any optimizer
+ *     [NR_AMP_SKIPPED_TOTAL] skipped steps so far
+ *     [NR_AMP_FOUND + g] found_inf of optimizer group g in the CURRENT step: producers (the 16-bit field backward,
+ *        nr_nonfinite_check, nr_unscale_add_16) store 1.0f; the group's Adam launches take it as `skip`
+ *     [NR_AMP_FOUND_PREV + g] the same flags of the previous step (nr_adam_hyper reads them)
+ *   nr_amp_update (once per step, after every optimizer launch): found anywhere -> S *= backoff, tracker = 0; else tracker += 1 and
+ *   S *= growth when it reaches growth_interval (GradScaler.update); copies the flags to FOUND_PREV and clears them.
+ * ---------------------------------------------------------------------------------------------- */
+#define NR_AMP_MAX_GROUPS 8
+#define NR_AMP_SCALE 0
+#define NR_AMP_GROWTH_TRACKER 1
+#define NR_AMP_INV_SCALE 2
+#define NR_AMP_SKIPPED_PREV 3
+#define NR_AMP_SKIPPED_TOTAL 4
+#define NR_AMP_FOUND 8
+#define NR_AMP_FOUND_PREV (NR_AMP_FOUND + NR_AMP_MAX_GROUPS)
+#define NR_AMP_FLOATS (NR_AMP_FOUND + 2 * NR_AMP_MAX_GROUPS)
+int nr_amp_init(float* amp, float init_scale, nr_stream_t stream);
+int nr_amp_update(float* amp, int n_groups, float growth_factor, float backoff_factor, int growth_interval, nr_stream_t stream);
+/* flag[0] = 1.0f if any of x[0..n) is inf / NaN (left alone otherwise): found_inf of a gradient buffer that no flagging
+ * producer covers (torch's _amp_foreach_non_finite_check_and_unscale_ without the unscale). */
+int nr_nonfinite_check(const float* x, int64_t n, float* flag, nr_stream_t stream);
+/* Gradients of 16-bit working copies folded into the fp32 gradient buffer they mirror, unscaled:
+ *   dst[i] = (dst[i] + float(src[i])) * inv_scale[0];  src[i] = 0;  flag[0] = 1.0f if a result is inf / NaN.
+ * src: n 16-bit floats (src_dtype NR_DTYPE_BF16 / NR_DTYPE_F16); inv_scale: device float or NULL (= 1); flag nullable.
+ * dst must hold only this step's (scaled) contributions (the fused optimizers clear gradients every step). */
+int nr_unscale_add_16(float* dst, void* src, int64_t n, int src_dtype, const float* inv_scale, float* flag, nr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse exchange of a hash table's gradient between data-parallel ranks (replaces the dense DDP

@@ -14,8 +14,11 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 19
+NR_ABI_VERSION = 20
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
+# nr_amp state layout (include/neuradar_hip.h)
+NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
+NR_AMP_FOUND, NR_AMP_FOUND_PREV, NR_AMP_FLOATS = 8, 16, 24
 
 
 class NrMlp(Structure):
@@ -33,7 +36,7 @@ class NrRadarHeads(Structure):  # nr_radar_heads_t / nr_radar_heads_grads_t: [he
 
 class NrField(Structure):
     _fields_ = [("geo", NrMlp), ("feat", NrMlp), ("beta", c_void_p), ("packed", c_void_p), ("stash", c_void_p),
-                ("dtype", c_int), ("sample_dirs", c_void_p), ("grad_scale", c_float)]
+                ("dtype", c_int), ("sample_dirs", c_void_p), ("grad_scale", c_float), ("amp", c_void_p), ("amp_groups", c_uint32)]
 
 
 class NrLidarSup(Structure):
@@ -61,6 +64,7 @@ PROTOTYPES = {
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
     "nr_hash_encode_bwd_tuned": [P, P, P, I, I, I, P, L, L, P, L, I, I, P],
     "nr_hash_encode_bwd_marked": [P, P, P, I, I, I, P, L, L, P, L, I, I, P, P],
+    "nr_hash_encode_bwd_shared": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
@@ -132,13 +136,17 @@ PROTOTYPES = {
     "nr_sample_radar_scans": [P, I, L, P, P],
     "nr_permutation_from_uniform": [P, I, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
-    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P],
-    "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P],
+    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P, P],
+    "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P, P],
+    "nr_amp_init": [P, F, P],
+    "nr_amp_update": [P, I, F, F, I, P],
+    "nr_nonfinite_check": [P, L, P, P],
+    "nr_unscale_add_16": [P, P, L, I, P, P, P],
     "nr_supervision_loss": [P, I, P, I, P, P, L, F, F, P, P, P, P],
     "nr_distortion_loss": [P, I, P, I, I, L, F, P, P, P],
     "nr_interlevel_loss": [P, I, P, I, I, P, P, I, L, F, F, P, P, P],
     "nr_interlevel_loss_to_density": [P, I, P, I, I, P, P, P, P, I, L, F, F, P, P, POINTER(NrLidarSup), P],
-    "nr_adam_hyper": [P, P, F, F, I, I, F, F, P],
+    "nr_adam_hyper": [P, P, F, F, I, I, F, F, P, I, P],
     "nr_grad_compact": [P, L, I, L, P, P, P, P],
     "nr_grad_apply": [P, P, P, L, I, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -449,7 +449,8 @@ field_bwd_feat_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_
   unsigned char* scr = lds + oScr + wave * kScrPerWave;
   const float beta_raw = fld.beta[0];
   const float beta = fabsf(beta_raw) + kBetaMin;
-  const float gs = fld.grad_scale > 0.0f ? fld.grad_scale : 1.0f, inv_gs = 1.0f / gs;
+  // loss scale of the 16-bit domain: the caller's dynamic scale (nr_amp state) when it is given, the static one otherwise
+  const float gs = fld.amp != nullptr ? fld.amp[NR_AMP_SCALE] : (fld.grad_scale > 0.0f ? fld.grad_scale : 1.0f), inv_gs = 1.0f / gs;
   f32x16 aF1[HT][2], aF2[HT][HT], aF3[1][HT];
   float bF1[HT], bF2[HT], bF3[1], d_beta = 0.0f;
 #pragma unroll
@@ -572,7 +573,8 @@ field_bwd_geo_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t
   const unsigned char* wG1t = lds + oB, *wG2t = wG1t + I::szG1t;
   const int lane = nr_lane(), i = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
   unsigned char* scr = lds + oScr + wave * kScrPerWave;
-  const float gs = fld.grad_scale > 0.0f ? fld.grad_scale : 1.0f, inv_gs = 1.0f / gs;
+  // loss scale of the 16-bit domain: the caller's dynamic scale (nr_amp state) when it is given, the static one otherwise
+  const float gs = fld.amp != nullptr ? fld.amp[NR_AMP_SCALE] : (fld.grad_scale > 0.0f ? fld.grad_scale : 1.0f), inv_gs = 1.0f / gs;
   f32x16 aG1[HT][1], aG2[1][HT], aSdf[HT];
   float bG1[HT], bG2[1], bSdf = 0.0f;
 #pragma unroll
@@ -583,6 +585,7 @@ field_bwd_geo_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t
   const FeatOff<FW> foff{sl, F};
   f32x16 xn[1], wn;  // the next tile's features and its d_e / d_sdf rows from the feature half, one tile ahead
   float wn_sdf = 0.0f;
+  bool bad = false;
   auto request = [&](int64_t t) {
     const int64_t s_ = t * 32 + i;
     const bool v = t < tiles && s_ < n;
@@ -636,9 +639,18 @@ field_bwd_geo_lp_kernel(nr_field_t fld, const float* __restrict__ feats, int64_t
     if (valid) {
       float* gf = g_feats + smp * sn;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gf[foff(rowmap(r, 0) + 4 * h)] = d_x0[0][r] * inv_gs;
+      for (int r = 0; r < 16; ++r) {
+        const float v = d_x0[0][r] * inv_gs;
+        bad |= !isfinite(v);
+        gf[foff(rowmap(r, 0) + 4 * h)] = v;
+      }
     }
   }
+  // found-inf (GradScaler): an overflowed 16-bit operand anywhere upstream of this row shows here as inf / NaN -- the flag makes
+  // the optimizers of fld.amp_groups skip the step (every writer stores the same value: no atomic)
+  if (fld.amp != nullptr && __any(bad) && lane == 0)
+    for (int g = 0; g < NR_AMP_MAX_GROUPS; ++g)
+      if ((fld.amp_groups >> g) & 1u) fld.amp[NR_AMP_FOUND + g] = 1.0f;
   scale_acc(aG1, bG1, inv_gs);
   scale_acc(aG2, bG2, inv_gs);
 #pragma unroll

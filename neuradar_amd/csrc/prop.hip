@@ -89,7 +89,22 @@ sh4_kernel(const float* __restrict__ dirs, int64_t n, float* __restrict__ out) {
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
             int64_t n, float lr, float beta1, float beta2, float eps, float wd, int adamw, float bc1, float bc2_sqrt,
-            float grad_scale, int zero_grad, const float* __restrict__ dev_hyper, uint8_t* __restrict__ seen_grad) {
+            float grad_scale, int zero_grad, const float* __restrict__ dev_hyper, uint8_t* __restrict__ seen_grad,
+            const float* __restrict__ skip) {
+  if (skip != nullptr && skip[0] != 0.0f) {  // found-inf (GradScaler.step): no update; the gradient is still cleared
+    if (zero_grad) {
+      const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float4* g4z = reinterpret_cast<float4*>(grad);
+      const int64_t n4z = n / 4;
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4z; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 g = g4z[i];
+        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) g4z[i] = z;  // (NaN != 0: cleared as well)
+      }
+      if (blockIdx.x == 0)
+        for (int64_t i = n4z * 4 + threadIdx.x; i < n; i += blockDim.x) grad[i] = 0.0f;
+    }
+    return;
+  }
   if (dev_hyper != nullptr) {  // graph-replay friendly: {lr, 1-beta1^t, sqrt(1-beta2^t)} live on the device
     lr = dev_hyper[0];
     bc1 = dev_hyper[1];
@@ -181,7 +196,7 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
 __global__ void __launch_bounds__(256)
 adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float grad_scale, int zero_grad,
-                   const float* __restrict__ dev_hyper, const uint8_t* __restrict__ seen_grad) {
+                   const float* __restrict__ dev_hyper, const uint8_t* __restrict__ seen_grad, const float* __restrict__ skip) {
   if (dev_hyper != nullptr) {
     lr = dev_hyper[0];
     bc1 = dev_hyper[1];
@@ -192,6 +207,17 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
   float4* g4 = reinterpret_cast<float4*>(grad);
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* v4 = reinterpret_cast<float4*>(v);
+  if (skip != nullptr && skip[0] != 0.0f) {  // found-inf: no update; marked groups' gradients are cleared (their moments stay
+    if (zero_grad) {                         // zero: the next step finds them at the fixed point or with a fresh gradient)
+      const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (seen_grad[i] == 0) continue;
+        const float4 g = g4[i];
+        if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) g4[i] = z;
+      }
+    }
+    return;
+  }
   const float step_size = lr / bc1;
   auto upd = [&](float& p, float& g, float& mm, float& vv) {
     const float gr = g * grad_scale;
@@ -247,9 +273,16 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
 // One-thread kernel: advances the optimizer step counter and refreshes {lr, 1-beta1^t, sqrt(1-beta2^t)}
 // (ExponentialDecayScheduler, engine/schedulers.py:112-143; LambdaLR applies func(k-1) to step k).
 __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict__ hyper, float lr, float lr_final,
-                                  int warmup, int max_steps, float beta1, float beta2) {
+                                  int warmup, int max_steps, float beta1, float beta2, const float* __restrict__ amp,
+                                  int amp_group) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double step = (double)step_t[0];
+  // step_t[0]: scheduler steps so far, step_t[1]: optimizer updates so far.  A step the loss scaler skipped is not counted:
+  // the counters were advanced at the top of that step, before its gradients were known, so they are taken back here.
+  double step = (double)step_t[0], upd = (double)step_t[1];
+  if (amp != nullptr) {
+    if (amp[NR_AMP_SKIPPED_PREV] != 0.0f && step > 0.0) step -= 1.0;
+    if (amp[NR_AMP_FOUND_PREV + amp_group] != 0.0f && upd > 0.0) upd -= 1.0;
+  }
   double cur;
   if (step < (double)warmup) {
     const double pre = 1e-8;
@@ -262,11 +295,87 @@ __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict_
     t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
     cur = exp(log((double)lr) * (1.0 - t) + log((double)lr_final) * t);
   }
-  const double k = step + 1.0;
-  step_t[0] = (float)k;
+  const double k = upd + 1.0;
+  step_t[0] = (float)(step + 1.0);
+  step_t[1] = (float)k;
   hyper[0] = (float)cur;
   hyper[1] = (float)(1.0 - pow((double)beta1, k));
   hyper[2] = (float)sqrt(1.0 - pow((double)beta2, k));
+}
+
+// ---- dynamic loss scale (GradScaler) --------------------------------------------------------------------------------
+__global__ void amp_init_kernel(float* __restrict__ amp, float init_scale) {
+  const int i = threadIdx.x;
+  if (i < NR_AMP_FLOATS) amp[i] = i == NR_AMP_SCALE ? init_scale : (i == NR_AMP_INV_SCALE ? 1.0f / init_scale : 0.0f);
+}
+
+__global__ void amp_update_kernel(float* __restrict__ amp, int n_groups, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool any = false;
+  for (int g = 0; g < NR_AMP_MAX_GROUPS; ++g) {
+    const float f = g < n_groups ? amp[NR_AMP_FOUND + g] : 0.0f;
+    any |= f != 0.0f;
+    amp[NR_AMP_FOUND_PREV + g] = f != 0.0f ? 1.0f : 0.0f;
+    amp[NR_AMP_FOUND + g] = 0.0f;
+  }
+  float scale = amp[NR_AMP_SCALE], tracker = amp[NR_AMP_GROWTH_TRACKER];
+  if (any) {  // torch.cuda.amp.GradScaler.update (_amp_update_scale_)
+    scale *= backoff;
+    tracker = 0.0f;
+    amp[NR_AMP_SKIPPED_TOTAL] += 1.0f;
+  } else {
+    tracker += 1.0f;
+    if (tracker >= (float)interval) {
+      const float grown = scale * growth;
+      if (grown < 3.0e38f) scale = grown;  // (torch keeps the old scale when the grown one is not finite)
+      tracker = 0.0f;
+    }
+  }
+  amp[NR_AMP_SCALE] = scale;
+  amp[NR_AMP_INV_SCALE] = 1.0f / scale;
+  amp[NR_AMP_GROWTH_TRACKER] = tracker;
+  amp[NR_AMP_SKIPPED_PREV] = any ? 1.0f : 0.0f;
+}
+
+__global__ void __launch_bounds__(256)
+nonfinite_check_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ flag) {
+  bool bad = false;
+  const int64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) bad |= !isfinite(x[i]);
+  if (__any(bad) && nr_lane() == 0) flag[0] = 1.0f;  // (every writer stores the same value: no atomic needed)
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256)
+unscale_add_16_kernel(float* __restrict__ dst, E* __restrict__ src, int64_t n, const float* __restrict__ inv_scale,
+                      float* __restrict__ flag) {
+  const float inv = inv_scale != nullptr ? inv_scale[0] : 1.0f;
+  bool bad = false;
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 d = reinterpret_cast<float4*>(dst)[i];
+    const uint2 raw = reinterpret_cast<const uint2*>(src)[i];
+    E e[4];
+    __builtin_memcpy(e, &raw, 8);
+    d.x = (d.x + (float)e[0]) * inv; d.y = (d.y + (float)e[1]) * inv; d.z = (d.z + (float)e[2]) * inv; d.w = (d.w + (float)e[3]) * inv;
+    bad |= !(isfinite(d.x) && isfinite(d.y) && isfinite(d.z) && isfinite(d.w));
+    reinterpret_cast<float4*>(dst)[i] = d;
+    reinterpret_cast<uint2*>(src)[i] = make_uint2(0u, 0u);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float d = (dst[i] + (float)src[i]) * inv;
+      bad |= !isfinite(d);
+      dst[i] = d;
+      src[i] = (E)0.0f;
+    }
+  if (flag != nullptr && __any(bad) && nr_lane() == 0) flag[0] = 1.0f;
 }
 
 // ---- sparse exchange of a hash table's gradient between data-parallel ranks ----------------------
@@ -380,10 +489,56 @@ extern "C" int nr_grad_apply(const int* idx, const float* val, const int* count,
 }
 
 extern "C" int nr_adam_hyper(float* step_t, float* hyper, float lr, float lr_final, int warmup, int max_steps,
-                             float beta1, float beta2, nr_stream_t stream) {
+                             float beta1, float beta2, const float* amp, int amp_group, nr_stream_t stream) {
   if (!step_t || !hyper || !(lr > 0.0f) || !(lr_final > 0.0f) || warmup < 0 || max_steps < 1) return NR_EINVAL;
+  if (amp != nullptr && (amp_group < 0 || amp_group >= NR_AMP_MAX_GROUPS)) return NR_EINVAL;
   hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, nr_s(stream), step_t, hyper, lr, lr_final, warmup, max_steps,
-                     beta1, beta2);
+                     beta1, beta2, amp, amp_group);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_amp_init(float* amp, float init_scale, nr_stream_t stream) {
+  if (!amp || !(init_scale > 0.0f)) return NR_EINVAL;
+  hipLaunchKernelGGL(amp_init_kernel, dim3(1), dim3(64), 0, nr_s(stream), amp, init_scale);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_amp_update(float* amp, int n_groups, float growth_factor, float backoff_factor, int growth_interval,
+                             nr_stream_t stream) {
+  if (!amp || n_groups < 1 || n_groups > NR_AMP_MAX_GROUPS || !(growth_factor >= 1.0f) || !(backoff_factor > 0.0f) ||
+      !(backoff_factor <= 1.0f) || growth_interval < 1)
+    return NR_EINVAL;
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, nr_s(stream), amp, n_groups, growth_factor, backoff_factor,
+                     growth_interval);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_nonfinite_check(const float* x, int64_t n, float* flag, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !flag || n < 0 || ((uintptr_t)x & 15u) != 0) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  hipLaunchKernelGGL(nonfinite_check_kernel, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, nr_s(stream), x, n, flag);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_unscale_add_16(float* dst, void* src, int64_t n, int src_dtype, const float* inv_scale, float* flag,
+                                 nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!dst || !src || n < 0 || ((uintptr_t)dst & 15u) != 0 || ((uintptr_t)src & 7u) != 0) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+  if (src_dtype == NR_DTYPE_F16)
+    hipLaunchKernelGGL(unscale_add_16_kernel<_Float16>, dim3(blocks), dim3(256), 0, nr_s(stream), dst, static_cast<_Float16*>(src), n,
+                       inv_scale, flag);
+  else if (src_dtype == NR_DTYPE_BF16)
+    hipLaunchKernelGGL(unscale_add_16_kernel<__bf16>, dim3(blocks), dim3(256), 0, nr_s(stream), dst, static_cast<__bf16*>(src), n,
+                       inv_scale, flag);
+  else
+    return NR_EINVAL;
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -430,7 +585,7 @@ extern "C" int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t 
 
 extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float wd, int adamw, int step, float grad_scale, int zero_grad,
-                            const float* dev_hyper, uint8_t* seen_grad, nr_stream_t stream) {
+                            const float* dev_hyper, uint8_t* seen_grad, const float* skip, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!param || !grad || !m || !v || n < 0 || step < 1) return NR_EINVAL;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
@@ -441,14 +596,14 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
-                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad);
+                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip);
   NR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                    float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
-                                   const uint8_t* seen_grad, nr_stream_t stream) {
+                                   const uint8_t* seen_grad, const float* skip, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!param || !grad || !m || !v || !seen_grad || n < 0 || step < 1 || (n & 3) != 0) return NR_EINVAL;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
@@ -459,7 +614,7 @@ extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v
   if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_marked_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps, bc1,
-                     bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad);
+                     bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -83,6 +83,21 @@ def lidar_losses(depth: Tensor, y: Tensor, did_return: Tensor, lidar_range: Tens
     return _LidarLosses.apply(depth, y, cfg, (did_return, lidar_range, target_intensity))
 
 
+class _ScaleGrad(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by a device scalar: the loss scale where the gradient enters the RGB
+    CNN's 16-bit backward, its inverse where it leaves (no host value involved: the scale may change between graph replays)."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        ctx.save_for_backward(factor)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (factor,) = ctx.saved_tensors
+        return g * factor, None
+
+
 class DecoderLossHead:
     """Decoders + their losses for ONE batch layout (segments of camera / lidar / radar rays at fixed offsets).
 
@@ -95,6 +110,14 @@ class DecoderLossHead:
         self.model, self.layout, self.patch, self.n_scans, self.max_det = model, layout, patch, n_scans, max_detections
         self.c = settings or DecoderLossSettings()
         self.cnn_autocast = cnn_autocast
+        # fp16 CNN: its backward runs on fp16 activations and gradients, and d loss / d rgb ~ 1e-5 sits below fp16's smallest
+        # normal (6e-5) -- the reference trains under GradScaler.  `amp` (step.GradScalerState, set by
+        # FusedTrainStep.set_grad_scaler): the camera chain's gradient is multiplied by the dynamic scale where it enters the
+        # CNN's backward and divided back where it leaves it (input gradient, parameter gradients), with found-inf detection;
+        # without one a static scale of `cnn_loss_scale` is used.  bf16 / fp32 need none.
+        self.amp = None
+        self.cnn_loss_scale = 8192.0
+        self._static_scale = None
         # MIOpen's immediate mode picked its naive (non-tuned) kernels for one 7x7 layer in about every second step of the bench
         # (17 ms instead of 0.3): let it search once per shape and cache the choice
         torch.backends.cudnn.benchmark = True
@@ -150,6 +173,17 @@ class DecoderLossHead:
         self._shadow = dict(flat32=flat32, gflat32=gflat32, flat16=flat16, gflat16=gflat16, params=params)
         return self._shadow
 
+    def _cnn_scale(self):
+        """(scale, 1 / scale) device scalars of the camera chain's 16-bit backward, or None (fp32 / bf16 CNN)."""
+        if self.cnn_autocast != torch.float16:
+            return None
+        if self.amp is not None:
+            return self.amp.scale, self.amp.inv_scale
+        if self._static_scale is None:
+            dev = next(self.model.rgb_decoder.parameters()).device
+            self._static_scale = (torch.full((1,), self.cnn_loss_scale, device=dev), torch.full((1,), 1.0 / self.cnn_loss_scale, device=dev))
+        return self._static_scale
+
     def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
                seed_epoch: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """features [B,C] rendered features, depth [B]; times [B], sensor_idx [B] int64 (appearance embedding); batch:
@@ -203,7 +237,12 @@ class DecoderLossHead:
                 if sh:
                     with torch.no_grad():
                         sh["flat16"].copy_(sh["flat32"])
+                    scale = self._cnn_scale()
+                    if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
+                        patches = _ScaleGrad.apply(patches, scale[1])
                     rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
+                    if scale is not None:  # d loss / d rgb enters it multiplied by the loss scale
+                        rgb = _ScaleGrad.apply(rgb, scale[0])
                     self._shadow_used = True
                 elif self.cnn_autocast is not None:
                     with torch.autocast("cuda", dtype=self.cnn_autocast):
@@ -241,9 +280,18 @@ class DecoderLossHead:
             total = sum(terms.values())
         with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
             total.backward()
-        if self._shadow and getattr(self, "_shadow_used", False):  # the CNN's 16-bit gradients into the fp32 gradient buffer
-            self._shadow["gflat32"].add_(self._shadow["gflat16"])
-            self._shadow["gflat16"].zero_()
+        if self._shadow and getattr(self, "_shadow_used", False):
+            # the CNN's 16-bit gradients into the fp32 gradient buffer (which holds the batch-norm parameters' gradients of this
+            # step -- the optimizers clear gradients every step), unscaled, the 16-bit buffer cleared, found-inf flagged: one launch
+            sh, scale = self._shadow, self._cnn_scale()
+            flag = None
+            if self.amp is not None:
+                g_ = self.amp.group_of(next(iter(self.model.rgb_decoder.parameters())))
+                flag = self.amp.found(g_) if g_ is not None else None
+            check(_lib.lib().nr_unscale_add_16(ops._p(sh["gflat32"]), ops._p(sh["gflat16"]), sh["gflat16"].numel(),
+                                               _lib.NR_DTYPES[str(self.cnn_autocast).split(".")[-1]],
+                                               ops._p(scale[1]) if scale is not None else None, ops._p(flag), ops._stream()),
+                  "nr_unscale_add_16")
             self._shadow_used = False
         loss_slots[-1:].add_(total.detach().reshape(1))  # (the LAST entry: FusedTrainStep keeps it free of the kernels' atomics)
         self.last["terms"] = {k: v.detach() for k, v in terms.items()}

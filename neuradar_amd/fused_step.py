@@ -117,6 +117,7 @@ class FusedTrainStep:
         # and the lidar decoder in the model, the decoder and its two losses run inside the step on the lidar rows
         self.lidar = None
         self.dec = None  # set_decoders
+        self.amp = None  # set_grad_scaler
         self.g_features_extra = None
         for p in model.parameters():
             if p.requires_grad and p.grad is None:
@@ -241,6 +242,20 @@ class FusedTrainStep:
         then needs the rays' `times`."""
         assert self.C == self.cfg.field.nff_out_dim
         self.dec = dict(head=head, batches=list(batches), sensor_idx=sensor_idx)
+        if self.amp is not None:
+            head.amp = self.amp
+
+    def set_grad_scaler(self, amp, field_groups=(0, 1)) -> None:
+        """Dynamic loss scale with found-inf guard (step.GradScalerState = the reference's GradScaler, engine/trainer.py:200,
+        572-594) for a step whose MLPs run on fp16 operands: the 16-bit field backward takes its scale from the state and flags
+        the optimizers `field_groups` (indices into the `optimizers` the state is attached to: the tables' and the fields') when
+        it writes an inf / NaN; the small gradient buffers are checked before their Adam; every flagged optimizer skips its
+        update; the scale is updated at the end of the step.  All on the device: the step stays graph-capturable."""
+        self.amp, self._amp_field_groups = amp, tuple(field_groups)
+        self.field_struct.amp = amp.buf.data_ptr()
+        self.field_struct.amp_groups = sum(1 << g for g in field_groups)
+        if self.dec is not None:
+            self.dec["head"].amp = amp
 
     def _timed(self, name: str, launch):
         """Run `launch()` (one library call on the current stream); with self.timers set, bracket it with
@@ -289,6 +304,8 @@ class FusedTrainStep:
         if beta.grad is None:  # learnable_beta=False: the kernels still write d_beta somewhere
             self._beta_grad_sink = torch.zeros_like(beta)
         self.field_grads.beta = (beta.grad if beta.grad is not None else self._beta_grad_sink).data_ptr()
+        if self.amp is not None:
+            self.set_grad_scaler(self.amp, self._amp_field_groups)
 
     # -------------------------------------------------------------------------------------------
     def prepare(self, slot: int, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Optional[Tensor],
@@ -658,6 +675,15 @@ class FusedTrainStep:
         check(self._timed("field_bwd", lambda: lib.nr_field_bwd(
             byref(self.field_struct), p(self.feats[2]), F, n * F, F, d, Sm, self.sm, n, p(self.g_feature), p(self.g_alpha), None,
             p(self.g_feats[2]), None if split_reduce else byref(self.field_grads), p(self.field_ws), st)), "field_bwd")
+        amp_ev = None
+        if self.amp is not None and optimizers is not None:
+            # the found-inf flags of the tables' optimizer are final once the field backward has run: the proposal table's Adam
+            # (a side stream that may have started before nr_field_bwd) waits for this point, the main table's follows it anyway
+            if reducer is not None:  # every rank must take the same decision: SUM of the ranks' flags (non-zero = found)
+                reducer.start(self.amp.buf[self.amp._F:self.amp._F + 8])
+                reducer.wait_all()
+            amp_ev = torch.cuda.Event()
+            amp_ev.record(main)
         for i_, (lvl, stream) in enumerate(chains):
             late = i_ not in before
             if not (late or (split_reduce and i_ == 0)):
@@ -719,6 +745,8 @@ class FusedTrainStep:
                 if reducer is not None:
                     reducer.start(table_opt.buffers[i_prop][1])
                     reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
+                if amp_ev is not None and side[0] is not main:
+                    side[0].wait_event(amp_ev)
                 table_opt.step_buffer(i_prop, scale)
         for s_ in side:
             if s_ is not main:
@@ -729,6 +757,7 @@ class FusedTrainStep:
                     reducer.start(g_)
                 reducer.wait_all()
             for i in range(len(field_opt.buffers)):
+                field_opt.check_buffer(i)  # (loss scaler attached: found-inf of the small parameters' gradients)
                 field_opt.step_buffer(i, scale)
             # whatever else the table optimizer holds (per-actor grids) and the trajectory optimizer
             # ... except the tables of proposal_fields[:-1]: never evaluated (the reference's late-binding lambda,
@@ -742,7 +771,11 @@ class FusedTrainStep:
                     reducer.start(o_.buffers[i][1])
                 reducer.wait_all()
             for o_, i in others:
+                if o_ is not table_opt:
+                    o_.check_buffer(i)
                 o_.step_buffer(i, scale)
+            if self.amp is not None:
+                self.amp.update()
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:

@@ -859,20 +859,21 @@ def radar_points(depth: Tensor, dirs_spher: Tensor, num_channels: int, temperatu
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
               betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,
               grad_scale: float = 1.0, zero_grad: bool = True, dev_hyper: Optional[Tensor] = None,
-              seen_grad: Optional[Tensor] = None, marked: bool = False) -> None:
+              seen_grad: Optional[Tensor] = None, marked: bool = False, skip: Optional[Tensor] = None) -> None:
     """seen_grad: optional uint8 [numel/4], zero while exp_avg / exp_avg_sq are zero (see include/neuradar_hip.h).
-    marked: the scatter sets the bytes (nr_hash_encode_bwd_marked) -- never-marked groups are skipped without reading their gradient."""
+    marked: the scatter sets the bytes (nr_hash_encode_bwd_marked) -- never-marked groups are skipped without reading their gradient.
+    skip: optional device float (a loss scaler's found-inf flag): non-zero = no update, the gradient is still cleared."""
     if seen_grad is not None:
         assert seen_grad.dtype == torch.uint8 and seen_grad.numel() >= param.numel() // 4
     if marked:
         assert seen_grad is not None and weight_decay == 0.0 and param.numel() % 4 == 0
         check(_lib.lib().nr_adam_step_marked(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
-                                             eps, step, grad_scale, int(zero_grad), _p(dev_hyper), _p(seen_grad), _stream()),
+                                             eps, step, grad_scale, int(zero_grad), _p(dev_hyper), _p(seen_grad), _p(skip), _stream()),
               "nr_adam_step_marked")
         return
     check(_lib.lib().nr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0],
                                   betas[1], eps, weight_decay, int(adamw), step, grad_scale, int(zero_grad),
-                                  _p(dev_hyper), _p(seen_grad), _stream()), "nr_adam_step")
+                                  _p(dev_hyper), _p(seen_grad), _p(skip), _stream()), "nr_adam_step")
 
 
 # ------------------------------------------------------------------------------------------------ loss tail

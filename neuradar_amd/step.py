@@ -334,6 +334,84 @@ class NeuRadarHotPath(nn.Module):
         return loss
 
 
+class GradScalerState:
+    """torch.cuda.amp.GradScaler (engine/trainer.py:200,572-594; engine/optimizers.py:154-166) as device-resident state
+    (nr_amp, include/neuradar_hip.h): the loss scale, its growth tracker and one found-inf flag per optimizer.  Nothing is
+    read on the host, so a step that uses it is captured into a hipGraph like any other:
+      * the 16-bit field backward takes its scale from the state and raises the flags of the optimizers it feeds when a
+        gradient it writes is inf / NaN (FusedTrainStep.set_grad_scaler);
+      * FlatAdam.check_buffer flags a small gradient buffer directly, the RGB CNN's 16-bit gradients are flagged while they
+        are unscaled into the fp32 buffer (DecoderLossHead);
+      * every Adam launch of a flagged optimizer leaves parameters and moments alone and clears the gradient
+        (GradScaler.step); `update()` -- once per step, after the optimizers -- backs the scale off or grows it
+        (GradScaler.update: x0.5 on inf / NaN, x2 after 2 000 clean steps) and the next step's schedule kernel does not
+        count a skipped step (trainer.py:590-594).
+    attach(optimizers): optimizer i becomes group i."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000) -> None:
+        from . import _lib
+
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.buf = torch.zeros(_lib.NR_AMP_FLOATS, device=device, dtype=torch.float32)
+        ops.check(_lib.lib().nr_amp_init(ops._p(self.buf), float(init_scale), ops._stream()), "nr_amp_init")
+        self.n_groups = 0
+        self._F = _lib.NR_AMP_FOUND
+
+    def attach(self, optimizers) -> "GradScalerState":
+        from . import _lib
+
+        assert len(optimizers) <= _lib.NR_AMP_MAX_GROUPS
+        for g, o in enumerate(optimizers):
+            o.amp, o.amp_group = self, g
+        self.n_groups = len(optimizers)
+        self.optimizers = list(optimizers)
+        return self
+
+    def group_of(self, param: nn.Parameter) -> Optional[int]:
+        """The group (attached optimizer) that steps `param`; None if no attached optimizer manages it."""
+        for g, o in enumerate(getattr(self, "optimizers", [])):
+            try:
+                o.buffer_of(param)
+                return g
+            except KeyError:
+                continue
+        return None
+
+    def found(self, group: int) -> Tensor:
+        """The found-inf flag of optimizer `group` (a one-element view of the state)."""
+        return self.buf[self._F + group:self._F + group + 1]
+
+    @property
+    def scale(self) -> Tensor:
+        return self.buf[0:1]
+
+    @property
+    def inv_scale(self) -> Tensor:
+        return self.buf[2:3]
+
+    def update(self) -> None:
+        from . import _lib
+
+        ops.check(_lib.lib().nr_amp_update(ops._p(self.buf), max(self.n_groups, 1), self.growth_factor, self.backoff_factor,
+                                           self.growth_interval, ops._stream()), "nr_amp_update")
+
+    def get_scale(self) -> float:
+        """Host read (diagnostics / checkpoints only -- never inside a step)."""
+        return float(self.buf[0])
+
+    def skipped_steps(self) -> int:
+        return int(self.buf[4])
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"amp": self.buf.clone(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        self.buf.copy_(sd["amp"])
+        self.growth_factor, self.backoff_factor, self.growth_interval = sd["growth_factor"], sd["backoff_factor"], sd["growth_interval"]
+
+
 class FlatAdam:
     """Adam/AdamW with the fused HIP kernel.  Small parameters are re-homed into ONE flat buffer
     (views keep names/shapes), so a step is one launch for all of them plus one per hash table.
@@ -369,8 +447,9 @@ class FlatAdam:
         # the kernel leave never-touched rows alone after reading 4 instead of 12 bytes per parameter (no weight decay)
         self.seen = [torch.zeros(b.numel() // 4, device=dev, dtype=torch.uint8) if (b.numel() > self.BIG and weight_decay == 0.0)
                      else None for b, _ in self.buffers]
-        self.step_t = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.step_t = torch.zeros(2, device=dev, dtype=torch.float32)  # [scheduler steps, optimizer updates]: nr_adam_hyper
         self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
+        self.amp, self.amp_group = None, 0  # GradScalerState.attach
 
     @staticmethod
     def _coalesce(big: List[nn.Parameter]):
@@ -447,7 +526,9 @@ class FlatAdam:
         """One tiny kernel: lr(step) [LambdaLR: step k uses func(k-1)], bias corrections, step += 1."""
         ops.check(ops._lib.lib().nr_adam_hyper(ops._p(self.step_t), ops._p(self.hyper), self.lr,
                                                self.lr if self.lr_final is None else self.lr_final, self.warmup,
-                                               self.max_steps, self.betas[0], self.betas[1], ops._stream()), "nr_adam_hyper")
+                                               self.max_steps, self.betas[0], self.betas[1],
+                                               ops._p(self.amp.buf) if self.amp is not None else None, self.amp_group,
+                                               ops._stream()), "nr_adam_hyper")
 
     @torch.no_grad()
     def step_buffer(self, i: int, grad_scale: float = 1.0) -> None:
@@ -461,19 +542,71 @@ class FlatAdam:
         # a gradient are skipped on their byte alone
         marked = bool(getattr(self, "marked", {}).get(i)) and lo_hi is None and self.seen[i] is not None
         ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
-                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked)
+                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked,
+                      skip=self.amp.found(self.amp_group) if self.amp is not None else None)
+
+    @torch.no_grad()
+    def check_buffer(self, i: int) -> None:
+        """With a loss scaler attached: raise this optimizer's found-inf flag if gradient buffer i holds an inf / NaN (one
+        small launch; meant for the flat buffer of the small parameters -- the tables' gradients are flagged by their
+        producer, the 16-bit field backward)."""
+        if self.amp is None:
+            return
+        g = self.buffers[i][1]
+        ops.check(ops._lib.lib().nr_nonfinite_check(ops._p(g), g.numel(), ops._p(self.amp.found(self.amp_group)), ops._stream()),
+                  "nr_nonfinite_check")
 
     def state_dict(self) -> Dict[str, object]:
-        """Moments, the device-side step counter / schedule triple and the `seen` flags (what the reference's
-        trainer checkpoints as optimizer + scheduler state, engine/trainer.py:514-548)."""
+        """Moments, the device-side step counters / schedule triple (what the reference's trainer checkpoints as optimizer +
+        scheduler state, engine/trainer.py:514-548).  A buffer sharded by `shard_buffer` holds the moments of this rank's
+        elements [lo, hi) only: `shards` records (lo, hi, numel) per such buffer, so a checkpoint written by one rank is not
+        mistaken for the whole table -- `gather_state_dict()` assembles the full moments on every rank for a checkpoint that
+        any world size can load."""
+        sh = getattr(self, "shards", {})
         return {"exp_avg": [m.clone() for m, _ in self.state], "exp_avg_sq": [v.clone() for _, v in self.state],
-                "step_t": self.step_t.clone(), "hyper": self.hyper.clone()}
+                "step_t": self.step_t.clone(), "hyper": self.hyper.clone(),
+                "shards": {i: (lo, hi, self.buffers[i][0].numel()) for i, (lo, hi) in sh.items()}}
+
+    def gather_state_dict(self, group=None) -> Dict[str, object]:
+        """state_dict() with every sharded buffer's moments all-gathered into the full table (collective: every rank calls it;
+        equal shard sizes by construction of shard_buffer).  The result carries no `shards` and loads into any world size."""
+        import torch.distributed as dist
+
+        sd = self.state_dict()
+        for i, (lo, hi, n) in sd["shards"].items():
+            for key in ("exp_avg", "exp_avg_sq"):
+                mine = sd[key][i].contiguous()
+                world = n // (hi - lo)
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine, group=group)
+                sd[key][i] = torch.cat(parts)
+        sd["shards"] = {}
+        return sd
 
     def load_state_dict(self, sd: Dict[str, object]) -> None:
-        for (m, v), m_, v_ in zip(self.state, sd["exp_avg"], sd["exp_avg_sq"]):
-            m.copy_(m_)
-            v.copy_(v_)
-        self.step_t.copy_(sd["step_t"])
+        mine = getattr(self, "shards", {})
+        theirs = {int(k): tuple(v) for k, v in (sd.get("shards") or {}).items()}
+        for i, ((m, v), m_, v_) in enumerate(zip(self.state, sd["exp_avg"], sd["exp_avg_sq"])):
+            n = self.buffers[i][0].numel()
+            if i in theirs:  # the checkpoint holds ONE rank's shard of this buffer
+                lo, hi, n_ = theirs[i]
+                if i not in mine or mine[i] != (lo, hi) or n_ != n:
+                    raise RuntimeError(
+                        f"FlatAdam.load_state_dict: buffer {i} of the checkpoint holds the moments of elements [{lo}, {hi}) of {n_} "
+                        f"only (a per-rank shard), this optimizer " + (f"owns [{mine[i][0]}, {mine[i][1]})" if i in mine else "is not sharded")
+                        + "; save with gather_state_dict() or load each rank's own file")
+                m_, v_ = m_.reshape(-1), v_.reshape(-1)
+            elif i in mine:  # a full-table checkpoint into a sharded optimizer: this rank's slice
+                if m_.numel() != n:
+                    raise RuntimeError(f"FlatAdam.load_state_dict: buffer {i} has {n} elements, the checkpoint {m_.numel()}")
+                lo, hi = mine[i]
+                m_, v_ = m_.reshape(-1)[lo:hi], v_.reshape(-1)[lo:hi]
+            if m_.numel() != m.numel():
+                raise RuntimeError(f"FlatAdam.load_state_dict: buffer {i}: {m_.numel()} checkpointed moments for {m.numel()} elements")
+            m.copy_(m_.reshape(m.shape))
+            v.copy_(v_.reshape(v.shape))
+        st = sd["step_t"].reshape(-1)
+        self.step_t.copy_(st if st.numel() == 2 else st[:1].expand(2))  # (checkpoints of ABI < 20 hold one counter)
         self.hyper.copy_(sd["hyper"])
         for s, (m, v) in zip(self.seen, self.state):  # "has had a gradient" = any moment non-zero, per group of four
             if s is not None:

@@ -20,27 +20,31 @@ WARM, STEPS = 3, 4
 def _setup(workload, mlp_dtype):
     import bench
     from neuradar_amd.parallel import GradAllReducer
-    from neuradar_amd.step import FlatAdam
 
     wl = bench.WORKLOADS[workload]
     n_rays = wl["rays"]
-    model = bench.build_model(wl, DEV, mlp_dtype, 1.0)
-    groups = model.get_param_groups()
-    unused = list(model.proposal_fields[0].parameters())
-    opts = [FlatAdam(groups["hashgrids"], lr=1e-2, eps=1e-15, lr_final=1e-3, max_steps=20001, warmup_steps=500, skip=unused),
-            FlatAdam(groups["fields"], lr=1e-2, eps=1e-15, weight_decay=1e-7, adamw=True, lr_final=1e-3, max_steps=20001,
-                     warmup_steps=500, skip=unused)]
+    mlp_dtype = wl.get("mlp_dtype", mlp_dtype)
+    model = bench.build_model(wl, DEV, mlp_dtype, 8192.0 if mlp_dtype == "float16" else 1.0)
+    opts = bench.build_optimizers(model)  # incl. the cnn / transformer optimizers of the decoder workloads
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()])
-    scene = bench.SyntheticScene(DEV, seed=1000)
+    scene = bench.SyntheticScene(DEV, seed=1000, radar=wl.get("radar", "zod"))
     torch.manual_seed(1234)
     targets = (0.1 * torch.randn(n_rays, 32, device=DEV), 5.0 + 50.0 * torch.rand(n_rays, 1, device=DEV))
+    if wl.get("decoders"):
+        # the dropout masks of an eager step and of a replayed one are DIFFERENT draws by construction (host-side call counter
+        # vs the device-side step counter folded into the attention kernels' seed; torch's generator advances per replay), so
+        # the equality below is checked without dropout; that replays do draw fresh masks: test_replays_draw_fresh_dropout_masks
+        model.radar_decoder.encoder.layers[0].p_drop = 0.0
     fwd_bwd, _, stepper = bench.make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=True,
                                           mixed=wl if "cam_rays" in wl else None)
     return model, fwd_bwd, stepper
 
 
 def _params(model):
-    return {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    """Parameters and the floating-point buffers (the RGB CNN's batch-norm running statistics)."""
+    out = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    out.update({"buffer." + n: b.detach().clone() for n, b in model.named_buffers() if b.is_floating_point() and b.numel() > 1})
+    return out
 
 
 def _run(workload, mlp_dtype, graph):
@@ -68,7 +72,10 @@ def _run(workload, mlp_dtype, graph):
     return start, end, float(stepper.loss.sum())  # the LAST step's loss: depends on every update before it
 
 
-@pytest.mark.parametrize("workload,mlp_dtype", [("cam4096_l16f2_w64", "float32"), ("mixed16384_neuradar", "bfloat16")])
+# the two decoder workloads: the captured step then holds the decoder segment too -- three more streams, ~330 launches, an
+# autograd-replayed backward, dropout seeds folded with the device-side step counter (`seed_epoch`), MIOpen convolutions
+@pytest.mark.parametrize("workload,mlp_dtype", [("cam4096_l16f2_w64", "float32"), ("mixed16384_neuradar", "bfloat16"),
+                                                ("mixed16384_neuradar_full", "bfloat16"), ("mixed16384_neuradar_full_fp16", "float16")])
 def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
     start, eager, loss_e = _run(workload, mlp_dtype, graph=False)
     start2, replay, loss_r = _run(workload, mlp_dtype, graph=True)
@@ -76,6 +83,7 @@ def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
     print(f"last-step loss: eager {loss_e:.8f} / {loss_e2:.8f}, replay {loss_r:.8f}")
     assert abs(loss_r - loss_e) <= max(5.0 * abs(loss_e2 - loss_e), 1e-4 * abs(loss_e)), (loss_e, loss_e2, loss_r)
     checked = 0
+    rows = {}
     for name in eager:
         assert torch.equal(start[name], start2[name]), f"{name}: the two runs did not start from the same parameters"
         moved = (eager[name] - start[name]).double()
@@ -83,12 +91,48 @@ def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
         if norm == 0.0:  # never receives a gradient (proposal_fields[0]: the reference's quirk)
             assert torch.equal(replay[name], start[name]), name
             continue
-        err = float((replay[name] - eager[name]).double().norm()) / norm
-        spread = float((eager2[name] - eager[name]).double().norm()) / norm
+        rows[name] = (float((replay[name] - eager[name]).double().norm()) / norm, float((eager2[name] - eager[name]).double().norm()) / norm)
+    # the run-to-run spread of one parameter is a noisy estimate (MIOpen's benchmark mode may pick another algorithm for a
+    # convolution in one run of eight: a whole module then moves together) -- the module's median spread is the second yardstick
+    groups = {}
+    for name, (_, spread) in rows.items():
+        groups.setdefault(name.split(".")[0], []).append(spread)
+    med = {k: sorted(v)[len(v) // 2] for k, v in groups.items()}
+    for name, (err, spread) in rows.items():
         # Adam turns a sign flip of a cancelling gradient into a full-size update of that entry, so single entries may differ
         # by 2 lr after a step: the NORM of the difference is what can be bounded -- by a small multiple of the eager
         # path's own run-to-run spread, and absolutely
         print(f"{name:60s} replay vs eager {err:.2e}   eager vs eager {spread:.2e}")
-        assert err <= max(3.0 * spread, 2e-3), f"{name}: replay differs from eager by {err:.2e} of the update (eager spread {spread:.2e})"
+        bound = max(3.0 * spread, 3.0 * med[name.split(".")[0]], 2e-3)
+        assert err <= bound, f"{name}: replay differs from eager by {err:.2e} of the update (eager spread {spread:.2e}, bound {bound:.2e})"
         checked += 1
     assert checked >= 4
+
+
+def test_replays_draw_fresh_dropout_masks():
+    """The attention kernels fold a device-resident step counter (`seed_epoch`) into their dropout seed, so that a captured
+    step draws new masks at every replay: same counter -> the same output bit for bit, another counter -> another mask."""
+    from neuradar_amd import ops
+
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 300, 48, device=DEV) for _ in range(3))
+    epoch = torch.zeros(2, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.attention(q, k, v, 0.1, seed=5, seed_epoch=epoch)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = ops.attention(q, k, v, 0.1, seed=5, seed_epoch=epoch)
+        outs = []
+        for e in (1.0, 2.0, 1.0):
+            epoch.fill_(e)
+            g.replay()
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(outs[0], outs[2]), "the same step counter must reproduce the mask"
+    assert not torch.equal(outs[0], outs[1]), "a replay with an advanced step counter drew the same dropout mask"
+    nodrop = ops.attention(q, k, v, 0.0, seed=5)
+    assert float((outs[0] - nodrop).abs().max()) > 1e-3

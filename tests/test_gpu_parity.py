@@ -1227,14 +1227,14 @@ def test_patch_ray_assembly_matches_index_path_and_adam_hyper_schedule():
     torch.testing.assert_close(b.pixel_area, ref.pixel_area * 9.0, rtol=1e-6, atol=0)
     assert torch.equal(b.times, ref.times)
 
-    step_t, hyper = torch.zeros(1, device=DEV), torch.zeros(3, device=DEV)
+    step_t, hyper = torch.zeros(2, device=DEV), torch.zeros(3, device=DEV)  # (scheduler steps, optimizer updates)
     for k in range(1, 4):
-        ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, ops._stream()), "hyper")
+        ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, None, 0, ops._stream()), "hyper")
         lr = 1e-8 + (1e-2 - 1e-8) * np.sin(0.5 * np.pi * (k - 1) / 500)
         want = torch.tensor([lr, 1 - 0.9**k, math.sqrt(1 - 0.999**k)])
         torch.testing.assert_close(cpu(hyper), want.float(), rtol=1e-5, atol=1e-12)
     step_t.fill_(10000.0)
-    ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, ops._stream()), "hyper")
+    ops.check(ops._lib.lib().nr_adam_hyper(ops._p(step_t), ops._p(hyper), 1e-2, 1e-3, 500, 20001, 0.9, 0.999, None, 0, ops._stream()), "hyper")
     t = (10000 - 500) / (20001 - 500)
     assert abs(float(hyper[0]) - math.exp(math.log(1e-2) * (1 - t) + math.log(1e-3) * t)) < 1e-8
 
