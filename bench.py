@@ -353,6 +353,10 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                     sl_ = asm.seg("lidar")
                     asm.slots[slot]["directions_norm"][sl_] = depth[sl_]
                     asm.slots[slot]["did_return"][sl_] = (depth[sl_] < 150.0).to(torch.uint8)
+                if decoders and n_cam:  # the cameras see the same surfaces: a colour per hit point, one ray = one 3 x 3 pixel block
+                    sl_ = asm.seg("camera")
+                    col = 0.5 + 0.5 * torch.sin((o_[sl_] + depth[sl_, None] * d_[sl_]) @ Wf[:, :3] * 2.0)
+                    dec_batches[slot]["image"].copy_(col.view(n_p, scene.PATCH, scene.PATCH, 3).repeat_interleave(3, 1).repeat_interleave(3, 2))
 
         def head(slot):
             rays[slot] = assemble(slot)
@@ -385,6 +389,30 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                                             times=times_of[k] if (has_actors or decoders) else None,
                                             flips=list(flip_buf[k]) if has_actors else None)
 
+        def quality():
+            """Convergence figures of the LAST step against its own scene-consistent targets (one host read each; call after
+            the timed region): PSNR of the rendered features (peak-to-peak 1) / of the decoded image, mean |depth - surface|."""
+            if not scene_targets:
+                return None
+            k = (1 - state["k"]) if pipelined else 0  # the slot the last step rendered
+            tf_k, td_k = tgt_slots[k]
+            out_ = stepper.outputs()
+            q = {"depth_l1_m": round(float((out_["depth"][:, 0] - td_k).abs().mean()), 4),
+                 "depth_l1_m_median": round(float((out_["depth"][:, 0] - td_k).abs().median()), 4)}
+            if n_lidar:
+                sl_ = asm.seg("lidar")
+                q["depth_l1_m_lidar_rays"] = round(float((out_["depth"][sl_, 0] - td_k[sl_]).abs().mean()), 4)
+            if decoders:
+                rgb = stepper.dec["head"].last.get("rgb")
+                if rgb is not None:
+                    mse = float(((rgb.float() - dec_batches[k]["image"]) ** 2).mean())
+                    q["image_psnr_db"] = round(-10.0 * math.log10(max(mse, 1e-12)), 3)
+            else:
+                mse = float(((out_["features"] - tf_k) ** 2).mean())
+                q["feature_psnr_db"] = round(-10.0 * math.log10(max(mse, 1e-12)), 3)
+            return q
+
+        fwd_bwd.quality = quality
         fwd_bwd.state = state if pipelined else None
         fwd_bwd.last_rays = lambda: next(x for x in rays if x is not None)[:3]  # (origins, directions, pixel_area) of a slot
     else:
@@ -614,6 +642,12 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         mode = "dense" if (args.dense_allreduce or args.autograd) else ("shard" if "cam_rays" in wl else "sparse")
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None, table_mode=mode)
+    # sharded table step: bf16 on both halves of the exchange and the all-gather deferred into the next step by default
+    # (--table-delta fp32 / --no-defer-gather: the round-3 behaviour)
+    reducer.table_delta = torch.bfloat16 if args.table_delta == "bf16" else None
+    reducer.defer_gather = not args.no_defer_gather
+    if mode == "shard" and args.table_transport == "bf16":
+        reducer.table_dtype = torch.bfloat16
     if mode == "shard" and world > 1:
         if opts[0].shard_buffer(opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table), rank, world) is None:
             reducer.table_mode, reducer.sparse_tables = "dense", False
@@ -742,6 +776,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     per_block = sorted(b[0] for b in blocks)
     elapsed = statistics.median(per_block)
     host_elapsed = statistics.median(b[1] for b in blocks)
+    reducer.flush()  # (a deferred all-gather of the last step)
     if args.check_replicas and world > 1:
         for name, prm in model.named_parameters():
             ref = prm.detach().clone()
@@ -767,7 +802,12 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         exchange = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                     "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.get_backend() == "nccl" else None,
                     "main_table_mode": reducer.table_mode, "ms_per_step_without_exchange": round(ms_off, 4),
-                    "exposed_ms_per_step": round(ms_per_step - ms_off, 4)}
+                    "exposed_ms_per_step": round(ms_per_step - ms_off, 4),
+                    # per GPU and step, from the collectives' sizes: each half of the main table's exchange, the proposal
+                    # table's dense all-reduce (2 (w-1)/w of its bytes), the small-parameter bucket
+                    "main_table": {k_: v_ for k_, v_ in (reducer.last_sparse or {}).items() if k_ != "rows"},
+                    "proposal_table_allreduce_bytes_per_gpu": int(2 * (world - 1) / world * model.proposal_fields[1].hashgrid.static_grid.hash_table.numel()
+                                                                  * (2 if reducer.table_dtype is not None else 4))}
 
     roof, cpu = None, None
     mlp_times = {}
@@ -836,6 +876,10 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             roof["serialised_us"] = round(ser * 1e6, 2)
             roof["frac_serialised"] = round(dom["bytes"] / ser / 1e9 / HBM_PEAK_GBS, 4)
             roof["all_hash_kernels_serialised_us"] = {k: round(v * 1e6, 2) for k, v in times_serial.items() if k.startswith("hash_encode")}
+        # `bound` is the contract's field (hbm | mfma); what actually limits the dominant launch site is neither: the traffic
+        # (FETCH + WRITE) is 0.6 x the algorithmic bytes, MFMA plays no role
+        roof["limiter"] = ("LDS capacity and LDS-atomic issue of the on-chip merge (bin pass 48 KB per block, apply pass 132 KB), plus the "
+                           "memory side's float-atomic path it shares with the two other scatters running beside it -- not HBM bandwidth")
         roof["mfma_busy_frac"] = pmc_mfma_busy(workload)
         bwd = [r for r in rows if "bwd" in r["kernel"]]
         if stepper is not None and len(bwd) in (2, 3):
@@ -852,7 +896,14 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     render = None
     if rank == 0 and world == 1 and wl.get("decoders") and not args.no_render and not has_actors_wl(wl):
         render = measure_render(model, scene, device)
+    quality = fwd_bwd.quality() if (rank == 0 and getattr(fwd_bwd, "quality", None) is not None and stepper is not None) else None
+    amp_info = None
+    if stepper is not None and stepper.amp is not None:
+        amp_info = {"loss_scale": stepper.amp.get_scale(), "skipped_steps": stepper.amp.skipped_steps(),
+                    "what": "device-resident GradScaler: dynamic scale, found-inf -> optimizer step skipped, no host read"}
     result = {"workload": workload, "wl": wl, "value": value, "ms_per_step": ms_per_step, "n_rays": n_rays, "use_graph": bool(use_graph),
+              "quality": quality, "amp": amp_info, "sum_bits": (stepper.bin_sum_bits if stepper is not None else None),
+              "main_scatter": ("shared LDS table" if (stepper is not None and stepper.main_shared) else "merging") if stepper is not None else None,
               "render": render,
               "unroll": (unroll if use_graph else 1), "host_ms": host_elapsed / args.steps * 1e3, "roof": roof, "cpu": cpu,
               "blocks": n_blocks, "ms_min": per_block[0] / args.steps * 1e3, "ms_max": per_block[-1] / args.steps * 1e3,
@@ -901,6 +952,12 @@ def main():
     ap.add_argument("--table-exchange", default="auto", choices=["auto", "sparse", "dense", "shard"],
                     help="main table's gradient exchange for world > 1: row lists | dense all-reduce | reduce-scatter + sharded Adam + "
                     "all-gather (auto: shard for mixed batches, sparse for camera-only ones)")
+    ap.add_argument("--table-transport", default="bf16", choices=["fp32", "bf16"], help="shard mode: type the main table's gradient "
+                    "travels in through the reduce-scatter")
+    ap.add_argument("--table-delta", default="bf16", choices=["fp32", "bf16"], help="shard mode: all-gather the updated rows as fp32 "
+                    "parameters, or as bf16 update deltas that owner and receivers apply alike (replicas stay bit-identical)")
+    ap.add_argument("--no-defer-gather", action="store_true", help="shard mode: finish the all-gather inside the step instead of "
+                    "deferring it to the next step's first read of the table")
     ap.add_argument("--dense-allreduce", action="store_true",
                     help="all-reduce the main table's gradient densely instead of exchanging its non-zero rows")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' + "
@@ -942,7 +999,7 @@ def main():
                                "rays": {"camera": fr["wl"]["cam_rays"], "lidar": fr["wl"]["lidar_rays"],
                                         "radar": fr["n_rays"] - fr["wl"]["cam_rays"] - fr["wl"]["lidar_rays"]},
                                "radar_loss": fr["wl"].get("radar_loss"), "radar_grid": fr["wl"].get("radar", "zod"),
-                               "mlp_operands": fr["mlp_dtype"],
+                               "mlp_operands": fr["mlp_dtype"], "loss_scaler": fr["amp"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
                                "loss_after_run": fr["loss"], "render": fr["render"], "after_training": None,
                                "decoders": "RGB CNN (MIOpen NHWC convolutions on 16-bit working copies, hand-written batch norm + ReLU + residual) + lidar MLP + "
@@ -950,13 +1007,17 @@ def main():
             if args.full_model_trained_steps > 0:
                 # the same workload once the radar predictions have spread (the assignment's fast regime): same timing rules
                 # (plain training steps on the workload's own supervision: `--warmup` of that length, not the headline's scene targets)
+                # (scene-consistent supervision: lidar ranges and camera colours of the analytic street canyon, so that the block
+                # can say what the trained model renders -- `quality`; the radar detections stay synthetic points)
                 a2 = argparse.Namespace(**vars(args))
-                a2.warmup = -(-args.full_model_trained_steps // 2) * 2
                 a2.no_render = True
-                ft = measure(a2, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
-                full_model[-1]["after_training"] = {"steps_trained": a2.warmup, "value": round(ft["value"], 1),
+                ft = measure(a2, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5),
+                             trained_steps=args.full_model_trained_steps)
+                full_model[-1]["after_training"] = {"steps_trained": -(-args.full_model_trained_steps // 2) * 2, "value": round(ft["value"], 1),
                                                     "unit": "rays/s", "ms_per_step": round(ft["ms_per_step"], 4),
-                                                    "ms_per_step_min": round(ft["ms_min"], 4), "ms_per_step_max": round(ft["ms_max"], 4)}
+                                                    "ms_per_step_min": round(ft["ms_min"], 4), "ms_per_step_max": round(ft["ms_max"], 4),
+                                                    "targets": "analytic street canyon (lidar ranges, camera colours)",
+                                                    "quality": ft["quality"], "loss_scaler": ft["amp"]}
     trained = None
     if args.trained_steps > 0 and not args.autograd and args.regime != "trained":
         # the headline workload in the TRAINED regime: scene-consistent targets, args.trained_steps training steps, then the same
@@ -966,19 +1027,26 @@ def main():
         trained = {"workload": tr["workload"], "steps_trained": -(-args.trained_steps // 2) * 2, "targets": "analytic street canyon (scene-consistent)",
                    "value": round(tr["value"], 1), "unit": "rays/s", "ms_per_step": round(tr["ms_per_step"], 4),
                    "ms_per_step_min": round(tr["ms_min"], 4), "ms_per_step_max": round(tr["ms_max"], 4), "timed_blocks": tr["blocks"],
-                   "roofline": tr["roof"]}
+                   "quality": tr["quality"], "roofline": tr["roof"]}
     if rank == 0:
         r, wl = main_res, main_res["wl"]
         line = {
             "metric": "training rays/sec", "value": round(r["value"], 1), "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[args.mlp_dtype], "data": "synthetic",
+            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[r["mlp_dtype"]], "data": "synthetic",
             "config": {"workload": args.workload, "rays_per_gpu_per_step": r["n_rays"], "samples_per_ray": "128/64/32",
                        "rays": ({"camera": wl["cam_rays"], "lidar": wl["lidar_rays"], "radar": r["n_rays"] - wl["cam_rays"] - wl["lidar_rays"]}
                                 if "cam_rays" in wl else {"camera": r["n_rays"]}),
                        "main_grid": wl["grid"], "mlp_width": wl["hidden"], "proposal_grid": "L6/F1/T2^20",
-                       "mlp_operands": args.mlp_dtype, "tables_and_accumulation": "float32",
+                       "mlp_operands": r["mlp_dtype"],
+                       "tables_and_accumulation": "float32 tables, gradients, optimizer state and MFMA accumulation; the scatters' on-chip tile sums are "
+                       + ("32-bit fixed point (an addend is rounded to 2^-22..2^-21 of the largest contribution of its 256/512-row tile; bound under "
+                          "test: tests/test_gpu_binned.py, test_gpu_shared_scatter.py)" if r["sum_bits"] == 32 else "64-bit fixed point (exact to fp32's resolution)"),
+                       "main_grid_scatter": r["main_scatter"], "loss_scaler": r["amp"],
+                       # the step supervised through the decoders, per workload: ms per step fresh / after training (details: full_model)
+                       "full_model_ms_per_step": {f_["workload"]: {"fresh": f_["ms_per_step"],
+                                                                    "trained": (f_["after_training"] or {}).get("ms_per_step")} for f_ in full_model},
                        "graph": r["use_graph"], "steps_per_graph_replay": r["unroll"], "host_ms_per_step": round(r["host_ms"], 4),
                        "timed_blocks": r["blocks"], "ms_per_step_min": round(r["ms_min"], 4), "ms_per_step_max": round(r["ms_max"], 4),
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",

@@ -190,6 +190,15 @@ int nr_attention_bwd(const float* q, const float* k, const float* v, const float
  * unmatched prediction and -log r_k + |xyz_k - det| (loss_type 0, :156-164) or -log r_k - Laplace log-likelihood of det
  * (loss_type 1, :132-154) for a matched one; grad_pred [n_scans, n_pred, 7] = its gradient (overwritten). */
 int64_t nr_radar_assign_workspace_bytes(int n_scans, int64_t n_pred, int max_detections);
+/* nr_radar_assign leaves one int32 STATUS word per scan in the workspace, at this byte offset (-1: bad arguments):
+ *   0  assigned;
+ *   1  the search gave up (its iteration cap: not observed on finite costs) -- assoc holds the partial matching found so far;
+ *   2  the scan has more detections than max_detections, or exceeds the static limits above: NOTHING was assigned -- assoc is -1
+ *      for the whole scan, and nr_radar_loss then treats every prediction of it as unmatched (all existence probabilities are
+ *      pushed towards 0).  scipy's linear_sum_assignment, which the reference calls, has no such limit: size max_detections
+ *      from the data (the largest scan of the dataset) and check the words outside the captured step -- e.g. when a batch's
+ *      segments are built, or with a periodic host read (ops.radar_status / DecoderLossHead.check_radar_status). */
+int64_t nr_radar_assign_status_offset(int n_scans, int64_t n_pred, int max_detections);
 int nr_radar_assign(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
                     int max_detections, int cost_type, int* assoc, void* workspace, nr_stream_t stream);
 int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
@@ -744,10 +753,20 @@ int nr_lidar_head_loss(const float* y, const float* target_intensity, const uint
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
                  int step, float grad_scale, int zero_grad, const float* dev_hyper, uint8_t* seen_grad,
-                 const float* skip, nr_stream_t stream);
+                 const float* skip, void* delta16, nr_stream_t stream);
 /* skip: NULL, or a device float (an nr_amp found-inf flag): when it is non-zero the update is SKIPPED -- parameters and moments
  * stay as they are, the gradient is still cleared when zero_grad (GradScaler.step: "optimizer.step() is skipped if the
- * gradients contain infs or NaNs", engine/optimizers.py:154-166). */
+ * gradients contain infs or NaNs", engine/optimizers.py:154-166); the value 2.0f skips WITHOUT clearing the gradient (the caller
+ * carries it into the next step: an overflowed row-list exchange, GradAllReducer.reduce_sparse).
+ * delta16: NULL, or n bf16 values (8-byte aligned): the sharded data-parallel table step -- the update of every element is
+ * rounded to bf16, applied as param = param_old + float(delta) and stored (0 where nothing moved); the other replicas apply the
+ * same deltas with nr_apply_delta16 and end up bit-identical to the owner (pipelines/base_pipeline.py:305-307's DDP keeps
+ * replicas identical by all-reducing gradients; here the table's optimizer runs on 1/world of the rows per rank instead). */
+/* param[i] += float(delta16[i]) for i outside [lo, hi) (this rank's own shard: whole 16-byte groups). */
+int nr_apply_delta16(float* param, const void* delta16, int64_t n, int64_t lo, int64_t hi, nr_stream_t stream);
+/* low16[i] = bf16(grad[i]); grad[i] = 0 -- the reduce-scatter's bf16 send buffer and the clearing of the spent local gradient
+ * in one pass. */
+int nr_grad_to16_clear(float* grad, void* low16, int64_t n, nr_stream_t stream);
 /* seen_grad: NULL, or n/4 bytes owned by the caller, zeroed when exp_avg / exp_avg_sq are zeroed.  Byte i is set
  * the first time parameters 4i..4i+3 receive a non-zero gradient; while it is 0 their moments are known to be
  * zero, and (weight_decay == 0) a zero gradient leaves them untouched without reading the moments.  Exact. */
@@ -816,6 +835,13 @@ int nr_grad_compact(float* grad, int64_t rows, int row_width, int64_t cap, int* 
                     nr_stream_t stream);
 int nr_grad_apply(const int* idx, const float* val, const int* count, int64_t cap, int row_width, float* grad,
                   nr_stream_t stream);
+/* nr_grad_apply of the list of rank `list_rank`, guarded by the TRUE row counts of all `world` ranks (device, as gathered;
+ * counts[r] > m means rank r's list of capacity m overflowed): if any list overflowed, only the OWN list is applied (the local
+ * gradient is whole again) and flag[0] = 2.0f -- the value that makes nr_adam_step skip the step and keep the gradient for the
+ * next one; otherwise the list is applied and flag[0] = 0.  Launch once per rank, in rank order.  No host read: every rank sees
+ * the same counts and takes the same branch. */
+int nr_grad_apply_guarded(const int* idx, const float* val, const int* counts, int world, int list_rank, int own_rank, int64_t m,
+                          int row_width, float* grad, float* flag, nr_stream_t stream);
 
 /* On-device batch assembly for camera patches (the reference samples patches
  * in data/pixel_samplers.py and generates rays on CPU workers): u [n_patches,3] uniform [0,1) ->

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "nr_attention_fwd": [P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P],
     "nr_attention_bwd": [P, P, P, P, P, P, L, L, I, F, c_uint32, P, P, P, P, P, P, P],
     "nr_radar_assign_workspace_bytes": [I, L, I],
+    "nr_radar_assign_status_offset": [I, L, I],
     "nr_radar_assign": [P, I, L, P, I, P, I, I, P, P, P],
     "nr_radar_loss": [P, I, L, P, I, P, P, I, F, P, P, P],
     "nr_radar_points_fwd": [P, P, L, P, P, I, P, P, P, P],
@@ -136,7 +137,9 @@ PROTOTYPES = {
     "nr_sample_radar_scans": [P, I, L, P, P],
     "nr_permutation_from_uniform": [P, I, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
-    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P, P],
+    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P, P, P],
+    "nr_apply_delta16": [P, P, L, L, L, P],
+    "nr_grad_to16_clear": [P, P, L, P],
     "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P, P],
     "nr_amp_init": [P, F, P],
     "nr_amp_update": [P, I, F, F, I, P],
@@ -149,13 +152,15 @@ PROTOTYPES = {
     "nr_adam_hyper": [P, P, F, F, I, I, F, F, P, I, P],
     "nr_grad_compact": [P, L, I, L, P, P, P, P],
     "nr_grad_apply": [P, P, P, L, I, P, P],
+    "nr_grad_apply_guarded": [P, P, P, I, I, I, L, I, P, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
 _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
-             "nr_radar_assign_workspace_bytes": c_int64, "nr_bn_act_workspace_floats": c_int64}
+             "nr_radar_assign_workspace_bytes": c_int64, "nr_radar_assign_status_offset": c_int64,
+             "nr_bn_act_workspace_floats": c_int64}
 
 _lib = None
 

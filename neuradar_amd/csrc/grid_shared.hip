@@ -26,6 +26,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "grid_dev.h"
 #include "nr_common.h"
 
@@ -38,12 +40,25 @@ constexpr int kMaxOcc = kRows * 8;  // distinct vertices of a tile on one level
 constexpr int kFixBits = 21;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kMaxLevels = 8;
+constexpr int kPlane = kSlots + 16;  // floats of one feature's plane of sums: slot s of feature f at f * kPlane + s -- an insert's 64
+                                     // lanes (one feature, random slots) spread over all LDS banks, and so do a flush's lanes
+                                     // (4 features of one slot: banks s, s + 16, s + 32, s + 48); [slot][feature] rows put the
+                                     // 64 lanes of every insert on a quarter of the banks (PMC: 4x the bank-conflict cycles)
 
 __device__ __forceinline__ void lds_barrier() {  // orders LDS traffic only (no vmcnt(0): the next tile's loads stay in flight)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+// -DNR_SHARED_CLOCKS: wave-cycles per phase, summed over all waves (tools/probe_main_shared.py reads them through
+// nr_debug_shared_clocks, which only that build exports)
+#ifdef NR_SHARED_CLOCKS
+__device__ unsigned long long g_shared_clocks[8];
+#define NR_CLK(i) { const long long t_ = clock64(); clk[i] += t_ - tlast; tlast = t_; }
+#else
+#define NR_CLK(i)
+#endif
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t key) { return __umulhi(key * 2654435761u, (uint32_t)kSlots); }
 
@@ -54,19 +69,24 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
                       int64_t n_tiles, unsigned char* __restrict__ seen) {
   constexpr int F = 4;
   __shared__ __attribute__((aligned(16))) uint32_t keys[kSlots];
-  __shared__ __attribute__((aligned(16))) uint32_t vals[kSlots * F];
+  __shared__ __attribute__((aligned(16))) uint32_t vals[kPlane * F];
   __shared__ uint16_t occ[kMaxOcc];
   __shared__ uint32_t count[2];
   __shared__ float wmax[kWaves];
   const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1), wave = tid >> 6;
   const uint32_t mask = (1u << log2T) - 1u;
   for (int i = tid; i < kSlots; i += kRows) keys[i] = kEmpty;
-  for (int i = tid; i < kSlots * F; i += kRows) vals[i] = 0u;
+  for (int i = tid; i < kPlane * F; i += kRows) vals[i] = 0u;
   if (tid < 2) count[tid] = 0u;
   __syncthreads();
 
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
+  // Everything a tile needs from memory -- position, std, the gradient rows of all its levels -- is requested one TILE ahead
+  // and waited for once per tile: gfx9 has one counter for loads and atomics, and behind a flush loop of unknown length the
+  // compiler can only wait for "everything", i.e. for every float atomic of the flush to come back from the memory side.
+  // (A wait per (tile, level) made every unit cost the same 15 us whatever its level held.)  The level loop is unrolled so
+  // that the register array of gradients is indexed statically (a dynamic index moves it to scratch memory).
   float px[3] = {0.0f, 0.0f, 0.0f}, pstd = 0.0f;
   float4 pg[kMaxLevels];
   auto fetch = [&](int64_t t) {
@@ -81,6 +101,9 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
   };
   fetch(tile);
   uint32_t unit = 0;
+#ifdef NR_SHARED_CLOCKS
+  long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
 #pragma unroll 1
   for (; tile < n_tiles; tile += gridDim.x) {
     float cx[3], cstd;
@@ -91,12 +114,11 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
 #pragma unroll
     for (int l = 0; l < kMaxLevels; ++l) cg[l] = pg[l];
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
-#pragma unroll 1
-    for (int level = 0; level < L; ++level, ++unit) {
-      float4 g4 = cg[0];
+    NR_CLK(0)
 #pragma unroll
-      for (int l = 1; l < kMaxLevels; ++l) g4 = level == l ? cg[l] : g4;  // (level is uniform: selects, no indexing)
-      float g[F] = {g4.x, g4.y, g4.z, g4.w};
+    for (int level = 0; level < kMaxLevels; ++level) {
+      if (level >= L) break;
+      float g[F] = {cg[level].x, cg[level].y, cg[level].z, cg[level].w};
       const float scale = scalings[level];
       float* base = gtable + (((int64_t)level << log2T) * F);
       const bool live = g[0] != 0.0f || g[1] != 0.0f || g[2] != 0.0f || g[3] != 0.0f;  // (true for NaN)
@@ -110,32 +132,35 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
         finite = finite && fabsf(g[f]) <= 3.0e38f;  // (false for NaN)
         mag = fmaxf(mag, fabsf(g[f]));
       }
-      // ---- the row's 8 corners: entry index and trilinear weight (the reference's ceil / floor corners, weight `offset` on
-      // the ceil side, encodings.py:434,454-464)
+      // ---- the row's 8 corners: entry index and trilinear weight.  The reference takes the ceil / floor corners with weight
+      // `offset` on the ceil side (encodings.py:434,454-464); floor + 1 is the same vertex wherever its weight is not zero
+      // (an integer coordinate has ceil = floor and offset 0: nothing is added on that side either way), and makes the 8
+      // entries a function of the CELL alone -- what the merge across lanes below relies on
       uint32_t idx[8];
       float w[8];
+      int lo[3];
       {
-        int lo[3], hi[3];
         float o[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           const float p = cx[a] * scale;
           const float fl = floorf(p);
           lo[a] = (int)fl;
-          hi[a] = (int)ceilf(p);
           o[a] = p - fl;
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const bool hx = c & 1, hy = c & 2, hz = c & 4;
-          idx[c] = nr_hash3(hx ? hi[0] : lo[0], hy ? hi[1] : lo[1], hz ? hi[2] : lo[2], mask);
+          idx[c] = nr_hash3(lo[0] + (hx ? 1 : 0), lo[1] + (hy ? 1 : 0), lo[2] + (hz ? 1 : 0), mask);
           w[c] = (hx ? o[0] : 1.0f - o[0]) * (hy ? o[1] : 1.0f - o[1]) * (hz ? o[2] : 1.0f - o[2]);
         }
       }
       // ---- block maximum -> fixed-point scale of (tile, level)
       float vmax = nr_wave_max_to_lane63(live && finite ? mag : 0.0f);
       if (lane == NR_WAVE - 1) wmax[wave] = vmax;
+      NR_CLK(1)
       lds_barrier();  // A: the wave maxima are visible; the previous unit's flush is complete
+      NR_CLK(2)
       float bmax = wmax[0];
 #pragma unroll
       for (int k = 1; k < kWaves; ++k) bmax = fmaxf(bmax, wmax[k]);
@@ -155,69 +180,167 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
 #pragma unroll
           for (int c = 0; c < 8; ++c) seen[((int64_t)level << log2T) + idx[c]] = 1;
       }
-      // ---- insert-or-add.  The first probe of all 8 corners is issued before any is looked at (independent LDS round trips)
-      const bool ins = live && finite;
+      // ---- the row's 32 addends in fixed point, then merged across the wave's lanes: neighbouring lanes in ONE cell (camera
+      // pixels at a coarse level -- or at every level while a fresh model's samples sit within a metre of the camera; samples
+      // of one lidar ray in a coarse cell) are summed by a segmented scan on DPP operands, and only the last lane of a run goes
+      // to the table.  Integer sums: the result is the same whatever is merged where; without the scan 64 lanes of a wave
+      // queue on one LDS address (PMC: 4x the bank-conflict cycles of the bin pass, the insert phase 68 % of the kernel).
+      const bool ins_row = live && finite;
+      int q[8][F];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int f = 0; f < F; ++f) q[c][f] = ins_row ? (int)rintf(g[f] * w[c] * fix) : 0;
+      int cell[3] = {ins_row ? lo[0] : INT_MIN + lane, ins_row ? lo[1] : INT_MIN + lane, ins_row ? lo[2] : INT_MIN + lane};
+      const bool head = lane == 0 || !(nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, cell[0]) == cell[0] &&
+                                       nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, cell[1]) == cell[1] &&
+                                       nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, cell[2]) == cell[2]);
+      const unsigned long long heads = __ballot(head);
+      if (heads != ~0ull) {  // (uniform) some run is longer than one lane
+        int flag = head ? 1 : 0;
+        auto scan_step = [&](auto ctrl, auto rowmask) {
+          constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
+          const int take = flag ? 0 : -1;
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int f = 0; f < F; ++f) q[c][f] += nr_dpp_i<C, R>(0, q[c][f]) & take;
+          flag |= nr_dpp_i<C, R>(0, flag);
+        };
+        // (the scan stops once every lane has reached its run's head: the remaining steps would add nothing)
+        do {
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 1>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 2>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 4>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_SHR + 8>{}, std::integral_constant<int, 0xF>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x2>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x4>{});
+          if (__ballot(flag == 0) == 0ull) break;
+          scan_step(std::integral_constant<int, NR_DPP_ROW_BCAST15>{}, std::integral_constant<int, 0x8>{});
+        } while (false);
+      }
+      const bool tail = lane == NR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull);
+      // ---- insert-or-add of the run sums.  The first probe of all 8 corners is issued before any is looked at (independent
+      // LDS round trips); the adds return nothing; the slots a lane has claimed join the block's list of occupied slots with
+      // ONE returning atomic per wave for all 8 corners
+      uint32_t nz = 0u;  // bit c: corner c has something to add
+#pragma unroll
+      for (int c = 0; c < 8; ++c) nz |= ((q[c][0] | q[c][1] | q[c][2] | q[c][3]) != 0 ? 1u : 0u) << c;
+      const bool ins = ins_row && tail;
       uint32_t s[8], old[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         s[c] = slot_of(idx[c]);
-        old[c] = ins ? atomicCAS(&keys[s[c]], kEmpty, idx[c]) : idx[c];  // ds_cmpst_rtn_b32
+        old[c] = (ins && ((nz >> c) & 1u)) ? atomicCAS(&keys[s[c]], kEmpty, idx[c]) : idx[c];  // ds_cmpst_rtn_b32
       }
+      uint32_t claimed = 0u;  // bit c: this lane created the slot of corner c
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        bool claimed = ins && old[c] == kEmpty;
-        if (ins && old[c] != kEmpty && old[c] != idx[c]) {  // taken by another vertex: linear probing
+        const bool act = ins && ((nz >> c) & 1u);
+        if (act && old[c] == kEmpty) claimed |= 1u << c;
+        if (act && old[c] != kEmpty && old[c] != idx[c]) {  // taken by another vertex: linear probing
           uint32_t sc = s[c];
           int probes = 0;
           while (true) {
             sc = sc + 1u == (uint32_t)kSlots ? 0u : sc + 1u;
             const uint32_t o2 = atomicCAS(&keys[sc], kEmpty, idx[c]);
-            if (o2 == kEmpty) { claimed = true; break; }
+            if (o2 == kEmpty) { claimed |= 1u << c; break; }
             if (o2 == idx[c]) break;
             if (++probes >= kSlots) { sc = kEmpty; break; }  // (cannot happen: at most 2 048 keys for 3 840 slots)
           }
           s[c] = sc;
         }
-        // a claimed slot joins the list of occupied slots: one returning atomic per wave instruction
-        const unsigned long long cm = __ballot(claimed);
-        if (cm != 0ull) {
-          uint32_t at = 0;
-          if (lane == (int)__builtin_ctzll(cm)) at = atomicAdd(cnt, (uint32_t)__popcll(cm));  // ds_add_rtn_u32
-          at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)__builtin_ctzll(cm));
-          if (claimed) occ[at + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = (uint16_t)s[c];
-        }
-        if (ins && s[c] != kEmpty) {
+        if (act && s[c] != kEmpty) {
 #pragma unroll
-          for (int f = 0; f < F; ++f) {
-            const int q = (int)rintf(g[f] * w[c] * fix);
-            if (q != 0) atomicAdd(&vals[s[c] * F + f], (uint32_t)q);  // ds_add_u32
-          }
-        } else if (ins) {  // (no slot: see above)
+          for (int f = 0; f < F; ++f)
+            if (q[c][f] != 0) atomicAdd(&vals[f * kPlane + s[c]], (uint32_t)q[c][f]);  // ds_add_u32
+        } else if (act) {  // (no slot: see above)
 #pragma unroll
-          for (int f = 0; f < F; ++f) unsafeAtomicAdd(base + (int64_t)idx[c] * F + f, g[f] * w[c]);
+          for (int f = 0; f < F; ++f) unsafeAtomicAdd(base + (int64_t)idx[c] * F + f, (float)q[c][f] * inv_fix);
           if (MARK) seen[((int64_t)level << log2T) + idx[c]] = 1;
         }
       }
-      lds_barrier();  // B: every insert is done
-      // ---- flush: lane = (occupied slot, feature); the slot is empty again afterwards
-      const uint32_t n_occ = *cnt;
-      if (tid == 0) count[(unit + 1u) & 1u] = 0u;  // (the other counter: last read in the previous unit's flush)
-      for (uint32_t item = (uint32_t)tid; item < n_occ * F; item += kRows) {
-        const uint32_t sc = occ[item >> 2], f = item & 3u;
-        const uint32_t key = keys[sc];
-        const int q = (int)vals[sc * F + f];
-        vals[sc * F + f] = 0u;
-        if (f == 0u) keys[sc] = kEmpty;  // (the 4 lanes of a slot sit in one wave instruction: all have read the key)
-        if (q != 0) {
-          unsafeAtomicAdd(base + (int64_t)key * F + f, (float)q * inv_fix);
-          if (MARK) seen[((int64_t)level << log2T) + key] = 1;
+      {
+        const uint32_t mine = (uint32_t)__popc(claimed);
+        // exclusive prefix of `mine` over the wave (DPP adds), the wave's total in lane 63
+        int incl = (int)mine;
+        incl += nr_dpp_i<NR_DPP_ROW_SHR + 1, 0xF>(0, incl);
+        incl += nr_dpp_i<NR_DPP_ROW_SHR + 2, 0xF>(0, incl);
+        incl += nr_dpp_i<NR_DPP_ROW_SHR + 4, 0xF>(0, incl);
+        incl += nr_dpp_i<NR_DPP_ROW_SHR + 8, 0xF>(0, incl);
+        incl += nr_dpp_i<NR_DPP_ROW_BCAST15, 0xA>(0, incl);
+        incl += nr_dpp_i<NR_DPP_ROW_BCAST31, 0xC>(0, incl);
+        const int total = __builtin_amdgcn_readlane(incl, NR_WAVE - 1);
+        if (total > 0) {  // (uniform)
+          uint32_t at = 0;
+          if (lane == NR_WAVE - 1) at = atomicAdd(cnt, (uint32_t)total);  // ds_add_rtn_u32
+          at = (uint32_t)__builtin_amdgcn_readlane((int)at, NR_WAVE - 1) + (uint32_t)incl - mine;
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if ((claimed >> c) & 1u) occ[at++] = (uint16_t)s[c];
         }
       }
+      NR_CLK(3)
+      lds_barrier();  // B: every insert is done
+      NR_CLK(4)
+      // ---- flush: lane = (occupied slot, feature); the slot is empty again afterwards.  Four slots per lane and trip, their LDS
+      // reads issued together
+      const uint32_t n_items = *cnt * F;
+      if (tid == 0) count[(unit + 1u) & 1u] = 0u;  // (the other counter: last read in the previous unit's flush)
+      for (uint32_t item0 = (uint32_t)tid; item0 < n_items; item0 += kRows * 4) {
+        uint32_t sc[4], key[4];
+        int q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t item = item0 + (uint32_t)k * kRows;
+          sc[k] = item < n_items ? occ[item >> 2] : kEmpty;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t f = (item0 + (uint32_t)k * kRows) & 3u;
+          key[k] = sc[k] != kEmpty ? keys[sc[k]] : 0u;
+          q[k] = sc[k] != kEmpty ? (int)vals[f * kPlane + sc[k]] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t f = (item0 + (uint32_t)k * kRows) & 3u;
+          if (sc[k] == kEmpty) continue;
+          vals[f * kPlane + sc[k]] = 0u;
+          if (f == 0u) keys[sc[k]] = kEmpty;  // (the 4 lanes of a slot sit in one wave instruction: all have read the key)
+          if (q[k] != 0) {
+            unsafeAtomicAdd(base + (int64_t)key[k] * F + f, (float)q[k] * inv_fix);
+            if (MARK) seen[((int64_t)level << log2T) + key[k]] = 1;
+          }
+        }
+      }
+      NR_CLK(5)
+      ++unit;
     }
   }
+#ifdef NR_SHARED_CLOCKS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_shared_clocks[i], (unsigned long long)clk[i]);
+#endif
 }
 
 }  // namespace
+
+#ifdef NR_SHARED_CLOCKS
+extern "C" int nr_debug_shared_clocks(unsigned long long* out8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_shared_clocks), 64);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_shared_clocks), z, 64);
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
                                          const float* grad_out, int64_t sn, int64_t sl, float* grad_table, int64_t n,
@@ -227,7 +350,9 @@ extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const
   // built for 4-float entries read as one float4 per row and level (the level-major [L, n, 4] gradient of the fused step)
   if (F != 4 || sn != 4 || (sl & 3) != 0 || (((uintptr_t)grad_out | (uintptr_t)grad_table) & 15u) != 0) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, kRows);
-  int cap = 512;  // two blocks per CU (81 KB of LDS each)
+  // ONE block per CU (81 KB of its 160 KB of LDS): beside the step's other scatters -- whose bin blocks take 48 KB each -- that
+  // beats two per CU by 4.5 % per step, same call (2.27 -> 2.17 ms fresh; 384 / 192 / 128 blocks: 2.24 / 2.20 / 2.45 ms)
+  int cap = 256;
   if (const char* e = getenv("NR_SHARED_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
   if (seen_grad != nullptr)

@@ -90,8 +90,11 @@ __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
             int64_t n, float lr, float beta1, float beta2, float eps, float wd, int adamw, float bc1, float bc2_sqrt,
             float grad_scale, int zero_grad, const float* __restrict__ dev_hyper, uint8_t* __restrict__ seen_grad,
-            const float* __restrict__ skip) {
+            const float* __restrict__ skip, __bf16* __restrict__ delta16) {
   if (skip != nullptr && skip[0] != 0.0f) {  // found-inf (GradScaler.step): no update; the gradient is still cleared
+    if (delta16 != nullptr)  // (nothing moved: zero deltas for the replicas)
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) delta16[i] = (__bf16)0.0f;
+    if (skip[0] == 2.0f) return;  // 2: the caller keeps the gradient for the next step (an overflowed row-list exchange)
     if (zero_grad) {
       const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       float4* g4z = reinterpret_cast<float4*>(grad);
@@ -162,6 +165,7 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
     for (int k = 0; k < kU; ++k) {
       const int64_t i = i0 + k * stride;
       had[k] = g[k].x != 0.0f || g[k].y != 0.0f || g[k].z != 0.0f || g[k].w != 0.0f;
+      if (delta16 != nullptr && live[k]) reinterpret_cast<uint2*>(delta16)[i] = make_uint2(0u, 0u);  // (rewritten below if the group moves)
       // never had a gradient: m = v = 0 without reading them, the update is the identity (4 B/param)
       if (can_skip && !had[k] && seen[k] == 0) live[k] = false;
       if (live[k]) {
@@ -178,14 +182,74 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
           vv[k].y == 0.0f && vv[k].z == 0.0f && vv[k].w == 0.0f)
         continue;  // fixed point (weights restored from a checkpoint without moments): no stores
       if (seen_grad != nullptr && seen[k] == 0) seen_grad[i] = 1;
+      const float4 p_old = pp[k];
       upd(pp[k].x, g[k].x, mm[k].x, vv[k].x); upd(pp[k].y, g[k].y, mm[k].y, vv[k].y);
       upd(pp[k].z, g[k].z, mm[k].z, vv[k].z); upd(pp[k].w, g[k].w, mm[k].w, vv[k].w);
+      if (delta16 != nullptr) {
+        // sharded data-parallel step: the replicas receive the update as a bf16 DELTA, and the owner applies the same rounded
+        // delta to its own copy -- every replica computes p_old + float(delta) from identical inputs: bit-identical tables
+        __bf16 d[4] = {(__bf16)(pp[k].x - p_old.x), (__bf16)(pp[k].y - p_old.y), (__bf16)(pp[k].z - p_old.z), (__bf16)(pp[k].w - p_old.w)};
+        pp[k] = make_float4(p_old.x + (float)d[0], p_old.y + (float)d[1], p_old.z + (float)d[2], p_old.w + (float)d[3]);
+        uint2 raw;
+        __builtin_memcpy(&raw, d, 8);
+        reinterpret_cast<uint2*>(delta16)[i] = raw;
+      }
       stv(p4 + i, pp[k]); stv(m4 + i, mm[k]); stv(v4 + i, vv[k]);
       if (zero_grad && had[k]) stv(g4 + i, g[k]);  // a gradient that is already zero is not zeroed again (28 B/param)
     }
   }
   if (blockIdx.x == 0)
-    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) upd(param[i], grad[i], m[i], v[i]);
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float p_old = param[i];
+      upd(param[i], grad[i], m[i], v[i]);
+      if (delta16 != nullptr) {
+        delta16[i] = (__bf16)(param[i] - p_old);
+        param[i] = p_old + (float)delta16[i];
+      }
+    }
+}
+
+// Sharded data-parallel table step, receiving side: p[i] += float(delta[i]) for the elements OUTSIDE this rank's own shard
+// [lo, hi) (the owner's Adam launch has applied its deltas already); zero groups -- most of a table in any one step -- cost
+// their 8 bytes of delta only.
+__global__ void __launch_bounds__(256)
+apply_delta16_kernel(float* __restrict__ p, const __bf16* __restrict__ delta, int64_t n, int64_t lo, int64_t hi) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i * 4 >= lo && i * 4 < hi) continue;  // (shards are whole 16-byte groups)
+    const uint2 raw = reinterpret_cast<const uint2*>(delta)[i];
+    if ((raw.x | raw.y) == 0u) continue;
+    __bf16 d[4];
+    __builtin_memcpy(d, &raw, 8);
+    float4 v = reinterpret_cast<float4*>(p)[i];
+    v.x += (float)d[0]; v.y += (float)d[1]; v.z += (float)d[2]; v.w += (float)d[3];
+    reinterpret_cast<float4*>(p)[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x)
+      if (i < lo || i >= hi) p[i] += (float)delta[i];
+}
+
+// ... sending side of the reduce-scatter: low[i] = bf16(g[i]) and g[i] = 0 in one pass (the reduced shard comes back from the
+// collective; everything else of the local gradient is spent) -- instead of a conversion pass plus a 537-MB memset
+__global__ void __launch_bounds__(256)
+grad_to16_clear_kernel(float* __restrict__ g, __bf16* __restrict__ low, int64_t n) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    uint2 raw = make_uint2(0u, 0u);
+    if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
+      __bf16 d[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      __builtin_memcpy(&raw, d, 8);
+      reinterpret_cast<float4*>(g)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    reinterpret_cast<uint2*>(low)[i] = raw;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+      low[i] = (__bf16)g[i];
+      g[i] = 0.0f;
+    }
 }
 
 // The same update where the SCATTER marks `seen_grad` (nr_hash_encode_bwd_marked: a byte is set wherever a gradient sum is
@@ -451,7 +515,48 @@ grad_apply_kernel(const int* __restrict__ idx, const float* __restrict__ val, co
   }
 }
 
+// The same for the list of rank `list_rank` out of `world` gathered lists of capacity m, GUARDED by the ranks' true row counts
+// (counts[r] may exceed m: rank r then could not move all its rows into its list): if ANY list overflowed, only the rank's OWN
+// list is applied -- its rows go back where they came from, the local gradient is whole again -- and flag[0] = 2 tells the
+// table's optimizer launch to skip this step and KEEP the gradient (nr_adam_step's skip = 2); otherwise every list is applied
+// (the caller launches this once per rank, in rank order: bit-identical sums on every rank) and flag[0] = 0.  Every rank sees
+// the same counts, so every rank takes the same branch: no host read, replicas stay identical.
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_apply_guarded_kernel(const int* __restrict__ idx, const float* __restrict__ val, const int* __restrict__ counts, int world,
+                          int list_rank, int own_rank, int64_t m, float* __restrict__ grad, float* __restrict__ flag) {
+  bool ovf = false;
+  for (int r = 0; r < world; ++r) ovf = ovf || (int64_t)counts[r] > m;
+  if (flag != nullptr && list_rank == 0 && blockIdx.x == 0 && threadIdx.x == 0) flag[0] = ovf ? 2.0f : 0.0f;
+  if (ovf && list_rank != own_rank) return;
+  const int64_t n = (int64_t)counts[list_rank] < m ? (int64_t)counts[list_rank] : m;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) grad[r * F + f] += val[i * F + f];
+  }
+}
+
 }  // namespace
+
+extern "C" int nr_grad_apply_guarded(const int* idx, const float* val, const int* counts, int world, int list_rank, int own_rank,
+                                     int64_t m, int F, float* grad, float* flag, nr_stream_t stream) {
+  if (!idx || !val || !counts || !grad || m < 1 || world < 1 || list_rank < 0 || list_rank >= world || own_rank < 0 || own_rank >= world)
+    return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(m, 256) < 1024 ? nr_cdiv(m, 256) : 1024);
+#define CALL(FF) hipLaunchKernelGGL(grad_apply_guarded_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), idx, val, counts, world, \
+                                    list_rank, own_rank, m, grad, flag)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int nr_grad_compact(float* grad, int64_t rows, int F, int64_t cap, int* idx, float* val, int* count,
                                nr_stream_t stream) {
@@ -585,10 +690,10 @@ extern "C" int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t 
 
 extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float wd, int adamw, int step, float grad_scale, int zero_grad,
-                            const float* dev_hyper, uint8_t* seen_grad, const float* skip, nr_stream_t stream) {
+                            const float* dev_hyper, uint8_t* seen_grad, const float* skip, void* delta16, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!param || !grad || !m || !v || n < 0 || step < 1) return NR_EINVAL;
-  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0 || ((uintptr_t)delta16 & 7u) != 0) return NR_EINVAL;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int64_t want = nr_cdiv(n / 4 + 1, 256);
@@ -596,7 +701,29 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
-                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip);
+                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, static_cast<__bf16*>(delta16));
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_apply_delta16(float* param, const void* delta16, int64_t n, int64_t lo, int64_t hi, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!param || !delta16 || n < 0 || lo < 0 || hi < lo || hi > n || (lo & 3) != 0 || ((hi & 3) != 0 && hi != n) ||
+      ((uintptr_t)param & 15u) != 0 || ((uintptr_t)delta16 & 7u) != 0)
+    return NR_EINVAL;
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  hipLaunchKernelGGL(apply_delta16_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, nr_s(stream), param,
+                     static_cast<const __bf16*>(delta16), n, lo, hi);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_grad_to16_clear(float* grad, void* low16, int64_t n, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!grad || !low16 || n < 0 || ((uintptr_t)grad & 15u) != 0 || ((uintptr_t)low16 & 7u) != 0) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  hipLaunchKernelGGL(grad_to16_clear_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, nr_s(stream), grad,
+                     static_cast<__bf16*>(low16), n);
   NR_LAUNCH_CHECK();
   return 0;
 }

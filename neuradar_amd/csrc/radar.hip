@@ -821,6 +821,12 @@ extern "C" int64_t nr_radar_assign_workspace_bytes(int n_scans, int64_t n_pred, 
   return (int64_t)n_scans * small * small * 8 + (int64_t)n_scans * small * (large + lsa_q(small) * NR_WAVE) * 4 + (int64_t)n_scans * 4 + 64;
 }
 
+extern "C" int64_t nr_radar_assign_status_offset(int n_scans, int64_t n_pred, int max_detections) {
+  if (n_scans < 0 || n_pred < 0 || max_detections < 0) return -1;
+  const int64_t small = max_detections < n_pred ? max_detections : n_pred, large = max_detections < n_pred ? n_pred : max_detections;
+  return (int64_t)n_scans * small * small * 8 + (int64_t)n_scans * small * (large + lsa_q(small) * NR_WAVE) * 4;
+}
+
 template <int Q, bool LDS_CM>
 static int lsa_launch(const float* cost, const unsigned long long* sorted, float* cm, const int* seg, int small, int large, int n_pred,
                       int* assoc, int* status, int n_scans, nr_stream_t stream) {

@@ -173,6 +173,16 @@ class DecoderLossHead:
         self._shadow = dict(flat32=flat32, gflat32=gflat32, flat16=flat16, gflat16=gflat16, params=params)
         return self._shadow
 
+    def check_radar_status(self) -> None:
+        """Host read of the last step's assignment status words (call it OUTSIDE the captured step: after a block of steps, at
+        a checkpoint): raises if a scan was left unassigned (more detections than max_detections: its existence probabilities
+        would silently be trained towards 0) or the search gave up.  ops.validate_radar_segments does the same check on a
+        batch's segments before the step."""
+        st = self.last.get("radar_status")
+        if st is not None and bool((st != 0).any()):
+            raise RuntimeError(f"nr_radar_assign status {st.cpu().tolist()} (2: scan beyond max_detections = {self.max_det} or the "
+                               "kernel's limits -- nothing assigned; 1: the search gave up)")
+
     def _cnn_scale(self):
         """(scale, 1 / scale) device scalars of the camera chain's 16-bit backward, or None (fp32 / bf16 CNN)."""
         if self.cnn_autocast != torch.float16:
@@ -222,7 +232,7 @@ class DecoderLossHead:
                                         seed_epoch=seed_epoch)
                     out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, c.radar_loss_type,
                                                               mult=c.radar_mult, training=True, workspace=self.radar_ws)
-                    self.last.update(radar_output=ro, assoc=assoc)
+                    self.last.update(radar_output=ro, assoc=assoc, radar_status=assoc.status)
 
         def camera_chain():
             r0, n = self.layout["camera"]

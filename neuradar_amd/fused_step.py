@@ -178,6 +178,12 @@ class FusedTrainStep:
                 self.merged_ws = torch.empty(need, device=dev, dtype=torch.uint8)
                 self.binned_ws[0] = self.binned_ws[1] = self.merged_ws  # (the per-round workspaces are not needed)
         self.field_ws = torch.empty(self.lib.nr_field_bwd_workspace_floats(byref(self.field_struct), B * Sm), **f32)
+        # the main grid's scatter: the block-shared LDS table (nr_hash_encode_bwd_shared) where it applies -- 4-float entries, at
+        # most 8 levels, a table too large for the slice-owner kernels, no actor rows, and 32-bit tile sums allowed (16-bit MLP
+        # operands: self.bin_sum_bits).  NR_MAIN_SHARED=0 / 1 overrides the last condition (A/B runs).
+        mg_ = self.mgrid
+        self.main_shared = (mg_.features_per_level == 4 and mg_.num_levels <= 8 and self.binned_ws[2] is None and not self.n_actors
+                            and os.environ.get("NR_MAIN_SHARED", "1" if self.bin_sum_bits == 32 else "0") == "1")
 
     def set_lidar(self, is_lidar: Tensor, did_return: Tensor, lidar_range: Tensor, row0: int, n_lidar: int,
                   target_intensity: Optional[Tensor] = None, sensor_idx: Optional[Tensor] = None, slot: Optional[int] = None,
@@ -329,7 +335,7 @@ class FusedTrainStep:
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
                          jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None, slot: int = 0,
-                         prepared: bool = False, times: Optional[Tensor] = None, flips=None) -> Tensor:
+                         prepared: bool = False, times: Optional[Tensor] = None, flips=None, grads_accumulated: bool = False) -> Tensor:
         """Inputs: origins/directions [B,3], pixel_area [B] (already x9 for camera rays), fars [B],
         targets [B,C] / [B], jitters.  Accumulates into every parameter's .grad; returns the loss as
         NR_LOSS_SLOTS partial sums (call .sum() when the value is needed).
@@ -349,6 +355,13 @@ class FusedTrainStep:
         times [B] / flips: with dynamic actors, the rays' times and the per-ray random x-flips (+-1 [B] each) of the three
         field evaluations (proposal round 0, round 1, main field; neurad_encoding.py:218-225), None = no flip.  optimizers may
         then carry a third entry, the trajectory optimizer.
+
+        grads_accumulated: the parameters' .grad buffers already hold gradients that this step's optimizer must apply too
+        (gradient accumulation, a modular backward before this call).  PRECONDITION otherwise, with fused `optimizers`: the main
+        table's .grad is all zero on entry (the fused optimizers clear gradients every step, so steps chained through
+        forward_backward(optimizers=...) satisfy it) -- the main table's Adam then trusts the `seen` bytes that THIS step's
+        scatter marks and never reads the gradient of an unmarked group: a gradient left there by another writer would neither be
+        applied nor cleared until its group is marked by a later step.  True falls back to the Adam launch that reads every gradient.
 
         reducer (parallel.GradAllReducer, world > 1; needs `optimizers`): data-parallel step.  The main table's
         gradient is exchanged as (row, value) lists right after its scatter (reduce_sparse), the proposal table's
@@ -460,6 +473,8 @@ class FusedTrainStep:
         # 32-wide stack on 16-bit operands, no actor rows to patch in between.  NR_FUSE_MAIN_GATHER=0: two launches.
         fuse_gather = (mg.num_levels == 8 and F == 4 and self.field_struct.dtype != 0 and self.model.field.config.geo_hidden_dim == 32
                        and not self.n_actors and os.environ.get("NR_FUSE_MAIN_GATHER", "1") != "0")
+        if reducer is not None:
+            reducer.wait_table_sync()  # a deferred all-gather of the previous step's sharded table update lands here: first read
         if not fuse_gather:
             check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
                 p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
@@ -529,7 +544,8 @@ class FusedTrainStep:
             # weights, spacings and densities) exist once the forward has composited -- the inter-level loss does not see the
             # decoders -- and the segment is ~560 small dependent launches that leave the chip idle: the two bin + apply pairs
             # (0.73 ms of kernel time) run beside it instead of beside the main table's scatter and Adam afterwards.
-            if self.dec is not None and reducer is None and os.environ.get("NR_PROP_BESIDE_DECODERS", "1") != "0":
+            # (data parallel as well: the proposal table's all-reduce then also starts before the decoder segment)
+            if self.dec is not None and os.environ.get("NR_PROP_BESIDE_DECODERS", "1") != "0":
                 early = 5
         split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
         # Order of the three table scatters.  "concurrent" (single process): all at once -- 2.5 % faster than either serial
@@ -560,7 +576,7 @@ class FusedTrainStep:
         # optimizer's buffer must be exactly the static table -- the actors' tables live in a buffer of their own):
         # NR_ADAM_MARKED=0 disables
         mark_seen = None
-        if (optimizers is not None and reducer is None and self.binned_ws[2] is None
+        if (optimizers is not None and reducer is None and self.binned_ws[2] is None and not grads_accumulated
                 and os.environ.get("NR_ADAM_MARKED", "1") != "0"):
             t_opt = optimizers[0]
             i_m = t_opt.buffer_of(mg.hash_table)
@@ -592,6 +608,13 @@ class FusedTrainStep:
                 # batches with incoherent rows: the wide per-wave table of the F = 4 merging kernel (fewer atomics per sample,
                 # more of the chip left to the two binned scatters and Adam beside it: step -3 % fresh, -6 % after 1 500 steps)
                 cells = 256 if self.sm < B and os.environ.get("NR_WIDE_MERGE", "1") != "0" else 0
+                if lvl == 2 and self.main_shared:
+                    # NeuRadar's main grid in a step on 16-bit MLP operands: the block-shared vertex-keyed LDS table on 32-bit
+                    # integer atomics (grid_shared.hip) for every row -- two waves per SIMD and a third of the merging kernel's
+                    # instructions; marks the optimizer's `seen` bytes itself when the marked Adam follows
+                    return lib.nr_hash_encode_bwd_shared(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                         grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
+                                                         p(grid.hash_table.grad), nl, p(mark_seen), sp_)
                 if mark_seen is not None and lvl == 2:
                     # the main table's scatter sets the optimizer's `seen` bytes itself: Adam then skips never-touched groups
                     # on the byte alone instead of reading 4 B of gradient per parameter of the whole table (FlatAdam.marked)
@@ -728,15 +751,19 @@ class FusedTrainStep:
             if not shared:
                 if reducer is not None and reducer.table_mode == "shard" and i_main in getattr(table_opt, "shards", {}):
                     # reduce-scatter -> Adam on this rank's 1/world of the rows -> all-gather (parallel.shard_step)
-                    reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype)
+                    # (reducer.table_delta / defer_gather: the update deltas in bf16, the all-gather deferred into the next step)
+                    reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype,
+                                       delta_dtype=getattr(reducer, "table_delta", None), defer=getattr(reducer, "defer_gather", False))
                 else:
+                    keep = None
                     if reducer is not None:
                         if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
-                            reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level)
+                            # (flag = 2 where a rank's list overflowed: the table's Adam then skips this step and keeps the gradient)
+                            keep = reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level).get("flag")
                         else:
                             reducer.start(table_opt.buffers[i_main][1])
                             reducer.wait_all()
-                    table_opt.step_buffer(i_main, scale)
+                    table_opt.step_buffer(i_main, scale, skip_extra=keep)
             if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
                 side[0].wait_stream(side[1])
                 if shared:

@@ -559,7 +559,25 @@ def radar_assign(pred: Tensor, detections: Tensor, seg: Tensor, max_detections: 
     assoc = torch.empty((N, n), device=pred.device, dtype=torch.int32)
     check(_lib.lib().nr_radar_assign(_p(pred), N, n, _p(detections), detections.shape[1], _p(seg), max_detections,
                                      {"euclidean": 0, "nll": 1}[cost_type], _p(assoc), _p(workspace), _stream()), "nr_radar_assign")
+    assoc.status = radar_status(workspace, N, n, max_detections)  # [scans] int32 view of the workspace: see radar_status
     return assoc
+
+
+def radar_status(workspace: Tensor, n_scans: int, n_pred: int, max_detections: int) -> Tensor:
+    """The per-scan status words nr_radar_assign leaves in its workspace (a device view; reading it is a host sync -- do that
+    outside the step): 0 assigned, 1 the search gave up, 2 the scan exceeds max_detections / the kernel's static limits and
+    NOTHING was assigned (assoc = -1: nr_radar_loss then trains every existence probability of the scan towards 0)."""
+    off = _lib.lib().nr_radar_assign_status_offset(n_scans, n_pred, max_detections)
+    return workspace[off:off + 4 * n_scans].view(torch.int32)
+
+
+def validate_radar_segments(seg: Tensor, max_detections: int) -> None:
+    """Data-load-time check (host): every scan of `seg` [scans + 1] holds at most max_detections detections and at most the
+    kernel's 8 192 -- what nr_radar_assign would otherwise answer with status 2 in the middle of a captured step."""
+    counts = (seg[1:] - seg[:-1]).cpu()
+    if counts.numel() and (int(counts.max()) > max_detections or int(counts.max()) > 8192 or int(counts.min()) < 0):
+        raise ValueError(f"radar scans with {counts.tolist()} detections: max_detections = {max_detections} (static limit 8192); "
+                         "nr_radar_assign would leave such a scan unassigned (status 2)")
 
 
 class _RadarLoss(torch.autograd.Function):
@@ -859,10 +877,14 @@ def radar_points(depth: Tensor, dirs_spher: Tensor, num_channels: int, temperatu
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
               betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,
               grad_scale: float = 1.0, zero_grad: bool = True, dev_hyper: Optional[Tensor] = None,
-              seen_grad: Optional[Tensor] = None, marked: bool = False, skip: Optional[Tensor] = None) -> None:
+              seen_grad: Optional[Tensor] = None, marked: bool = False, skip: Optional[Tensor] = None,
+              delta16: Optional[Tensor] = None) -> None:
     """seen_grad: optional uint8 [numel/4], zero while exp_avg / exp_avg_sq are zero (see include/neuradar_hip.h).
     marked: the scatter sets the bytes (nr_hash_encode_bwd_marked) -- never-marked groups are skipped without reading their gradient.
-    skip: optional device float (a loss scaler's found-inf flag): non-zero = no update, the gradient is still cleared."""
+    skip: optional device float (a loss scaler's found-inf flag): non-zero = no update, the gradient is still cleared (2.0: kept).
+    delta16: optional bf16 [numel]: the update leaves as a rounded delta that is also what the owner applies (sharded DP step)."""
+    if delta16 is not None:
+        assert delta16.dtype == torch.bfloat16 and delta16.numel() == param.numel() and delta16.is_contiguous() and not marked
     if seen_grad is not None:
         assert seen_grad.dtype == torch.uint8 and seen_grad.numel() >= param.numel() // 4
     if marked:
@@ -873,7 +895,19 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
         return
     check(_lib.lib().nr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0],
                                   betas[1], eps, weight_decay, int(adamw), step, grad_scale, int(zero_grad),
-                                  _p(dev_hyper), _p(seen_grad), _p(skip), _stream()), "nr_adam_step")
+                                  _p(dev_hyper), _p(seen_grad), _p(skip), _p(delta16), _stream()), "nr_adam_step")
+
+
+def apply_delta16(param: Tensor, delta16: Tensor, lo: int, hi: int) -> None:
+    """param[i] += float(delta16[i]) outside [lo, hi): the receiving side of the sharded table step (nr_apply_delta16)."""
+    assert delta16.dtype == torch.bfloat16 and delta16.numel() == param.numel() and param.is_contiguous() and delta16.is_contiguous()
+    check(_lib.lib().nr_apply_delta16(_p(param), _p(delta16), param.numel(), int(lo), int(hi), _stream()), "nr_apply_delta16")
+
+
+def grad_to16_clear(grad: Tensor, low16: Tensor) -> None:
+    """low16 = bf16(grad); grad = 0 (nr_grad_to16_clear)."""
+    assert low16.dtype == torch.bfloat16 and low16.numel() == grad.numel() and grad.is_contiguous() and low16.is_contiguous()
+    check(_lib.lib().nr_grad_to16_clear(_p(grad), _p(low16), grad.numel(), _stream()), "nr_grad_to16_clear")
 
 
 # ------------------------------------------------------------------------------------------------ loss tail
@@ -928,6 +962,14 @@ def grad_apply(idx: Tensor, val: Tensor, count: Tensor, row_width: int, grad: Te
     if idx.numel() == 0:
         return
     check(_lib.lib().nr_grad_apply(_p(idx), _p(val), _p(count), idx.numel(), row_width, _p(g), _stream()), "nr_grad_apply")
+
+
+def grad_apply_guarded(idx: Tensor, val: Tensor, counts: Tensor, list_rank: int, own_rank: int, m: int, row_width: int, grad: Tensor,
+                       flag: Tensor) -> None:
+    """nr_grad_apply_guarded: the list of `list_rank` (capacity m) into grad unless some rank's count exceeds m -- then only the
+    own list, and flag = 2 (the optimizer keeps the gradient for the next step)."""
+    check(_lib.lib().nr_grad_apply_guarded(_p(idx), _p(val), _p(counts), counts.numel(), int(list_rank), int(own_rank), int(m), row_width,
+                                           _p(grad), _p(flag), _stream()), "nr_grad_apply_guarded")
 
 
 def uniform_fill(out: Tensor, seed: int, epoch: Optional[Tensor] = None) -> Tensor:

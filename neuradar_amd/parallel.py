@@ -17,6 +17,14 @@ from torch import nn
 SMALL_PARAM_NUMEL = 1 << 16
 
 
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,41 +110,58 @@ class GradAllReducer:
         self._pending = []
 
     # ---- sharded table step: reduce-scatter -> Adam on the owned rows -> all-gather ------------------
-    def shard_step(self, opt, i: int, grad_scale: float, transport: Optional[torch.dtype] = None, chunks: int = 1) -> dict:
+    def shard_step(self, opt, i: int, grad_scale: float, transport: Optional[torch.dtype] = None,
+                   delta_dtype: Optional[torch.dtype] = None, defer: bool = False, kernels=None) -> dict:
         """The data-parallel step of ONE big table whose gradient is dense across the ranks (the mixed batch touches 9-22 % of
         the main table's rows per rank: the union over 8 ranks is most of the table, so row lists no longer pay).  Instead of
         all-reduce + a replicated Adam over the whole table on every GPU:
-          1. reduce-scatter (SUM) of the gradient: rank r receives the reduced rows [lo, hi) = its 1/world of the table
-             (`transport`: optionally carried in bf16 -- half the bytes of the step's largest exchange);
+          1. reduce-scatter (SUM) of the gradient: rank r receives the reduced rows [lo, hi) = its 1/world of the table.
+             `transport` = torch.bfloat16 carries it in bf16 (half the bytes); the send buffer is written and the spent local
+             gradient cleared in ONE pass (nr_grad_to16_clear) -- no 537-MB memset of the rows outside the shard;
           2. Adam on those rows only (opt.shard_buffer: moments exist for the shard only; the dense 4.3 GB stream of the
              replicated step becomes 1/world of it on every GPU);
-          3. all-gather of the updated rows into every replica (fp32, in place: replicas stay bit-identical by construction --
-             everybody receives the owner's result);
-          4. the gradient outside the shard is cleared (the owner's Adam kernel clears its own rows).
-        The same bytes on the wire as a ring all-reduce of the table (reduce-scatter + all-gather IS that all-reduce), but the
-        optimizer sits between the halves.  `chunks`: the shard is exchanged in that many pieces so that Adam of piece k runs
-        while piece k+1 is still being reduced (collectives execute in issue order on the communicator).
-        No host read, no allocation after the first call.  opt: step.FlatAdam with shard_buffer(i) applied."""
+          3. the updated rows reach every replica by all-gather, either as fp32 parameters in place (delta_dtype None) or --
+             delta_dtype = torch.bfloat16 -- as the UPDATE rounded to bf16: the owner applies p_old + float(delta) itself
+             (nr_adam_step's delta16) and the receivers do the same (nr_apply_delta16), so every replica computes the same sum
+             from identical inputs -- bit-identical tables at half the bytes; what is lost is 2^-9 of each update, not of the
+             parameter;
+          4. defer=True: step 3 runs on a communication stream of its own and is only waited for where the table is read next
+             (wait_table_sync: the next step's main-grid gather, ~0.4 ms into that step; flush() before anything else reads the
+             parameters) -- the all-gather hides behind the next step's sampling rounds instead of ending this one.
+        The same bytes on the wire as a ring all-reduce of the table in the transport types (reduce-scatter + all-gather IS that
+        all-reduce), but the optimizer sits between the halves.  The owner's Adam is 1/world of the replicated one (~70 us of
+        550 at 8 ranks), so nothing is gained by pipelining it against a chunked exchange: what matters is where the wire time
+        of the two halves hides (the reduce-scatter behind the proposal scatters, the all-gather in the next step).
+        No host read, no allocation after the first call.  opt: step.FlatAdam with shard_buffer(i) applied.
+        kernels: (to16_clear, apply_delta16) callables; default = the HIP kernels (CPU tests pass torch stand-ins)."""
         p, g = opt.buffers[i]
         if self.world == 1 and not self.force_collectives:
             opt.step_buffer(i, grad_scale)
             return {"mode": "single"}
+        if kernels is None:
+            from . import ops as hip_ops
+            kernels = (hip_ops.grad_to16_clear, hip_ops.apply_delta16)
+        to16_clear, apply_delta = kernels
         lo, hi = opt.shards[i]
         n, per = p.numel(), hi - lo
         nccl = dist.get_backend(self.group) == "nccl"
-        key = ("shard", g.data_ptr(), transport)
+        key = ("shard", g.data_ptr(), transport, delta_dtype)
         st = self.__dict__.setdefault("_shard_state", {}).get(key)
         if st is None:
             st = {}
             if transport is not None:
+                assert transport == torch.bfloat16, "the 16-bit transport of the reduce-scatter is bf16"
                 st["low"] = torch.empty(n, device=g.device, dtype=transport)
                 st["low_out"] = torch.empty(per, device=g.device, dtype=transport)
+            if delta_dtype is not None:
+                assert delta_dtype == torch.bfloat16, "the update delta travels in bf16"
+                st["delta"] = torch.zeros(n, device=g.device, dtype=delta_dtype)
             if not nccl:  # gloo (CPU / one-GPU tests) has neither reduce_scatter nor in-place all_gather
-                st["mine"] = torch.empty(per, device=g.device, dtype=torch.float32)
+                st["mine"] = torch.empty(per, device=g.device, dtype=delta_dtype or torch.float32)
             self._shard_state[key] = st
         # 1. reduce-scatter
         if transport is not None:
-            st["low"].copy_(g)
+            to16_clear(g, st["low"])  # low = bf16(g); g = 0
             if nccl:
                 dist.reduce_scatter_tensor(st["low_out"], st["low"], op=dist.ReduceOp.SUM, group=self.group)
             else:
@@ -147,77 +172,152 @@ class GradAllReducer:
             dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM, group=self.group)  # in place: output = input's own slice
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)  # (test backends: same result on the shard)
-        # 2. the owner's Adam (zeroes g[lo:hi])
-        opt.step_buffer(i, grad_scale)
-        # 3. all-gather of the updated rows
-        if nccl:
-            dist.all_gather_into_tensor(p, p[lo:hi], group=self.group)  # in place: input = output's own slice
+        # 2. the owner's Adam (zeroes g[lo:hi]).  With a delta buffer it must not be overwritten while a deferred all-gather of
+        #    the previous step still reads it (and the receivers' apply of that step must be done before this step's arrives)
+        self.wait_table_sync()
+        if delta_dtype is not None:
+            opt.step_buffer(i, grad_scale, delta16=st["delta"][lo:hi])
         else:
-            st["mine"].copy_(p[lo:hi])
-            dist.all_gather([p[r * per:(r + 1) * per] for r in range(self.world)], st["mine"], group=self.group)
-        # 4. the rest of the local gradient
-        if lo > 0:
-            g[:lo].zero_()
-        if hi < n:
-            g[hi:].zero_()
-        esz = 4 if transport is None else torch.empty((), dtype=transport).element_size()
-        self.last_sparse = {"mode": "shard", "rows": [per] * self.world,
-                            "bytes": int((self.world - 1) / self.world * n * (esz + 4))}
+            opt.step_buffer(i, grad_scale)
+        # 3. all-gather of the updated rows (parameters, or their bf16 update deltas), 4. optionally on its own stream
+        cur = torch.cuda.current_stream() if g.is_cuda else None
+        comm = None
+        if defer and cur is not None:
+            if getattr(self, "_comm_stream", None) is None:
+                self._comm_stream = torch.cuda.Stream(device=g.device)
+            comm = self._comm_stream
+            comm.wait_stream(cur)
+        with (torch.cuda.stream(comm) if comm is not None else _nullcontext()):
+            buf = st["delta"] if delta_dtype is not None else p
+            if nccl:
+                dist.all_gather_into_tensor(buf, buf[lo:hi], group=self.group)  # in place: input = output's own slice
+            else:
+                st["mine"].copy_(buf[lo:hi])
+                dist.all_gather([buf[r * per:(r + 1) * per] for r in range(self.world)], st["mine"], group=self.group)
+            if delta_dtype is not None:
+                apply_delta(p, st["delta"], lo, hi)  # p[outside the shard] += float(delta)
+            if comm is not None:
+                self._table_sync = torch.cuda.Event()
+                self._table_sync.record(comm)
+        if transport is None:  # (the bf16 send pass has cleared the local gradient already)
+            if lo > 0:
+                g[:lo].zero_()
+            if hi < n:
+                g[hi:].zero_()
+        e_rs = 4 if transport is None else 2
+        e_ag = 4 if delta_dtype is None else 2
+        f = (self.world - 1) / self.world
+        self.last_sparse = {"mode": "shard", "rows": [per] * self.world, "bytes": int(f * n * (e_rs + e_ag)),
+                            "reduce_scatter_bytes_per_gpu": int(f * n * e_rs), "all_gather_bytes_per_gpu": int(f * n * e_ag),
+                            "reduce_scatter_dtype": "float32" if transport is None else "bfloat16",
+                            "all_gather": "float32 parameters" if delta_dtype is None else "bfloat16 update deltas", "deferred": bool(comm is not None)}
         return self.last_sparse
+
+    def wait_table_sync(self) -> None:
+        """Make the current stream wait for a deferred all-gather (+ delta apply) of the previous sharded step: call it in
+        front of whatever reads the table next.  No-op when nothing is pending."""
+        ev = getattr(self, "_table_sync", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def flush(self) -> None:
+        """Host-side: block until a deferred all-gather has landed (before checkpoints, evaluation, replica checks)."""
+        ev = getattr(self, "_table_sync", None)
+        if ev is not None:
+            ev.synchronize()
+            self._table_sync = None
 
     # ---- sparse table exchange ---------------------------------------------------------------------
     def reduce_sparse(self, grad: torch.Tensor, row_width: int, cap_rows: Optional[int] = None, ops=None) -> dict:
         """SUM of `grad` (flat view of a [rows, row_width] table gradient) over the ranks by exchanging the
-        non-zero rows only; result bit-identical on every rank (lists are added in rank order).  Falls back
-        to the dense all-reduce when some rank's list exceeds `cap_rows`.  Default: the list length at which the
-        all-gather of the lists ((world-1) * m * (1+w) floats into every rank) costs half of what the ring all-reduce of the
-        table moves (2 (world-1)/world * rows * w floats): rows * w / ((1+w) * world) -- rows/10 for the NeuRadar main grid
-        (w = 4) on 8 GPUs, 0.4 rows on 2; the mixed 16 384-ray batch touches 9 % of that table's rows freshly initialised,
-        22 % after 600 steps.  Synchronous
-        with respect to the current stream; one small host read (the ranks' row counts) per call.
-        `ops`: (compact, apply) callables; default = the HIP kernels (neuradar_amd.ops)."""
+        non-zero rows only; result bit-identical on every rank (lists are added in rank order).  `cap_rows`: the list length
+        beyond which the dense all-reduce is cheaper.  Default: the length at which the all-gather of the lists ((world-1) * m *
+        (1+w) floats into every rank) costs half of what the ring all-reduce of the table moves (2 (world-1)/world * rows * w
+        floats): rows * w / ((1+w) * world) -- rows/10 for the NeuRadar main grid (w = 4) on 8 GPUs, 0.4 rows on 2.
+
+        NO HOST READ after the first call.  The lists travel with a fixed length m chosen from the PREVIOUS step's row counts
+        (all-gathered on the device, copied to pinned host memory asynchronously: by the next step the copy has long landed) with
+        2x headroom; the same counts decide -- one step late, identically on every rank -- to go dense when the lists no longer
+        pay.  A step whose count jumps past m is handled on the device: every rank sees the gathered counts, so every rank takes
+        the same branch of the guarded apply (nr_grad_apply_guarded) -- nobody applies foreign rows, every rank puts its own rows
+        back, the returned `flag` (= 2) makes the table's optimizer launch skip the step and KEEP the gradient, which the next
+        step's scatter adds onto and the next exchange (sized from the counts that are known by then) carries.  The update of that
+        table is postponed by one step and sums two batches -- replicas stay bit-identical, nothing is lost.  The very first call
+        has no history: it reads the counts once (before any graph capture / timed region).
+        Returns {"mode": "sparse" | "dense" | "single", "flag": device float or None, ...}; pass `flag` as the optimizer's skip.
+        `ops`: (compact, apply_guarded) callables; default = the HIP kernels (neuradar_amd.ops)."""
         if self.world == 1 and not self.force_collectives:
-            return {"mode": "single"}
+            return {"mode": "single", "flag": None}
         if ops is None:
             from . import ops as hip_ops
-            ops = (hip_ops.grad_compact, hip_ops.grad_apply)
-        compact, apply = ops
+            ops = (hip_ops.grad_compact, hip_ops.grad_apply_guarded)
+        compact, apply_guarded = ops
         rows = grad.numel() // row_width
         cap = int(cap_rows) if cap_rows is not None else max(rows * row_width // ((1 + row_width) * self.world), 1)
         key = (grad.data_ptr(), cap, row_width)
         st = getattr(self, "_sparse_state", {}).get(key)
+        world = self.world
+        rank = dist.get_rank(self.sparse_group) if dist.is_initialized() else 0
         if st is None:
             dev = grad.device
-            st = dict(send=torch.zeros(cap * (1 + row_width) + 1, device=dev, dtype=torch.float32),
-                      counts=torch.zeros(self.world, device=dev, dtype=torch.int32))
+            st = dict(idx=torch.zeros(cap, device=dev, dtype=torch.int32), val=torch.zeros(cap * row_width, device=dev, dtype=torch.float32),
+                      count=torch.zeros(1, device=dev, dtype=torch.int32), counts=torch.zeros(world, device=dev, dtype=torch.int32),
+                      out_idx=torch.zeros(world * cap, device=dev, dtype=torch.int32),
+                      out_val=torch.zeros(world * cap * row_width, device=dev, dtype=torch.float32),
+                      flag=torch.zeros(1, device=dev, dtype=torch.float32),
+                      host=torch.zeros(world, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(world, dtype=torch.int32),
+                      event=None, prev_max=None)
             self.__dict__.setdefault("_sparse_state", {})[key] = st
-        send = st["send"]  # [count | idx (int32 bits) x cap | val x cap*row_width]
-        count = send[:1].view(torch.int32)
-        idx = send[1:1 + cap].view(torch.int32)
-        val = send[1 + cap:]
-        count.zero_()
-        compact(grad, row_width, idx, val, count)
-        self._all_gather(st["counts"], count)
-        n_rows = st["counts"].cpu()  # the step's one host read: sizes the list exchange (all ranks read the same numbers)
-        max_rows = int(n_rows.max())
-        if max_rows == 0:  # nobody touched the table: nothing to exchange, nothing to apply
-            self.last_sparse = {"mode": "sparse", "rows": n_rows.tolist(), "bytes": 0}
-            return self.last_sparse
-        if max_rows > cap:  # a rank's list does not fit: put the local rows back, reduce densely
-            apply(idx, val, count, row_width, grad)
+        # ---- what the previous step's counts say about this one (host values, no wait in practice)
+        prev = st["prev_max"]
+        if st["event"] is not None:
+            st["event"].synchronize()  # (recorded a whole step ago)
+            prev = int(st["host"].max())
+            st["event"] = None
+        count, idx, val = st["count"], st["idx"], st["val"]
+        first = prev is None
+        dense = (not first) and prev > cap  # lists no longer pay (decided from the last known counts, alike on every rank)
+        m = cap if first else min(cap, max(256, (2 * prev + 255) // 256 * 256))
+        if dense:
+            # (a gradient kept from an overflowed step is part of `grad` and travels with it)
+            # (and from here on it stays dense: the touched-row count of a training run only grows, DESIGN.md section 5)
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.sparse_group)
-            self.last_sparse = {"mode": "dense", "rows": n_rows.tolist(), "bytes": grad.numel() * 4}
+            st["prev_max"] = prev
+            st["flag"].zero_()
+            self.last_sparse = {"mode": "dense", "rows": None, "bytes": grad.numel() * 4, "flag": st["flag"]}
             return self.last_sparse
-        m = min(cap, (max_rows + 255) // 256 * 256)
-        # one collective: [count, idx[:m], val[:m*row_width]] of every rank
-        piece = 1 + m + m * row_width
-        out = torch.empty(self.world * piece, device=grad.device, dtype=torch.float32)
-        mine = torch.cat([send[:1 + m], val[:m * row_width]])
-        self._all_gather(out, mine)
-        for r in range(self.world):
-            seg = out[r * piece:(r + 1) * piece]
-            apply(seg[1:1 + m].view(torch.int32), seg[1 + m:], seg[:1].view(torch.int32), row_width, grad)
-        self.last_sparse = {"mode": "sparse", "rows": n_rows.tolist(), "bytes": self.world * piece * 4}
+        count.zero_()
+        compact(grad, row_width, idx[:m], val[:m * row_width], count)  # rows beyond m stay in grad; count = ALL non-zero rows
+        self._all_gather(st["counts"], count)
+        if first:
+            n_rows = st["counts"].cpu()  # the one synchronous read: sizes the very first exchange
+            if int(n_rows.max()) > cap:  # a rank's list does not fit: put the local rows back, reduce densely
+                apply_guarded(idx[:m], val[:m * row_width], st["counts"], rank, rank, m, row_width, grad, None)  # (own list: always applied)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.sparse_group)
+                st["prev_max"] = int(n_rows.max())
+                st["flag"].zero_()
+                self.last_sparse = {"mode": "dense", "rows": n_rows.tolist(), "bytes": grad.numel() * 4, "flag": st["flag"]}
+                return self.last_sparse
+            st["prev_max"] = int(n_rows.max())
+            m_x = min(m, max(256, (int(n_rows.max()) + 255) // 256 * 256))  # (known exactly this once)
+        else:
+            if grad.is_cuda:
+                st["host"].copy_(st["counts"], non_blocking=True)
+                st["event"] = torch.cuda.Event()
+                st["event"].record()
+            else:
+                st["host"].copy_(st["counts"])
+                st["prev_max"] = int(st["host"].max())
+            m_x = m
+        # two collectives over preallocated buffers: the index parts and the value parts of every rank's list
+        oi, ov = st["out_idx"][:world * m_x], st["out_val"][:world * m_x * row_width]
+        self._all_gather(oi, idx[:m_x])
+        self._all_gather(ov, val[:m_x * row_width])
+        for r in range(world):  # rank order, plain adds: every rank computes the same sums
+            apply_guarded(oi[r * m_x:(r + 1) * m_x], ov[r * m_x * row_width:(r + 1) * m_x * row_width], st["counts"], r, rank, m_x,
+                          row_width, grad, st["flag"])
+        self.last_sparse = {"mode": "sparse", "rows": None if not first else n_rows.tolist(), "list_rows": m_x,
+                            "bytes": world * m_x * (1 + row_width) * 4, "flag": st["flag"]}
         return self.last_sparse
 
     def _all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:

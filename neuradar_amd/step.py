@@ -531,9 +531,12 @@ class FlatAdam:
                                                ops._stream()), "nr_adam_hyper")
 
     @torch.no_grad()
-    def step_buffer(self, i: int, grad_scale: float = 1.0) -> None:
+    def step_buffer(self, i: int, grad_scale: float = 1.0, delta16: Optional[Tensor] = None, skip_extra: Optional[Tensor] = None) -> None:
         """Adam on buffer i (after `advance()`), on the current stream.  grad_scale = 1/world turns the
-        SUM all-reduce of the data-parallel ranks into DDP's mean without a separate pass."""
+        SUM all-reduce of the data-parallel ranks into DDP's mean without a separate pass.  delta16 (bf16, one per element of
+        this rank's shard): the update also leaves as a rounded delta for the other replicas (GradAllReducer.shard_step).
+        skip_extra: a second skip flag (device float; GradAllReducer.reduce_sparse's overflow flag, value 2 = skip and keep the
+        gradient): the loss scaler's found-inf flag, when one is attached and raised, takes precedence."""
         (p, g), (m, v) = self.buffers[i], self.state[i]
         lo_hi = getattr(self, "shards", {}).get(i)
         if lo_hi is not None:  # this rank's rows only (the rest of the gradient buffer is cleared by the exchange)
@@ -541,9 +544,11 @@ class FlatAdam:
         # marked[i]: this step's scatter set the buffer's `seen` bytes itself (FusedTrainStep, single GPU): groups that never had
         # a gradient are skipped on their byte alone
         marked = bool(getattr(self, "marked", {}).get(i)) and lo_hi is None and self.seen[i] is not None
+        skip = self.amp.found(self.amp_group) if self.amp is not None else None
+        if skip_extra is not None:
+            skip = skip_extra if skip is None else torch.where(skip != 0, skip, skip_extra)
         ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
-                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked,
-                      skip=self.amp.found(self.amp_group) if self.amp is not None else None)
+                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked, skip=skip, delta16=delta16)
 
     @torch.no_grad()
     def check_buffer(self, i: int) -> None:

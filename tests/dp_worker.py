@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--shard", action="store_true", help="main table: reduce-scatter -> Adam on this rank's rows -> all-gather")
+    ap.add_argument("--bf16", action="store_true", help="shard: bf16 reduce-scatter, bf16 update-delta all-gather, deferred into the next step")
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--force-collectives", action="store_true", help="world 1: issue the collectives anyway (one-rank RCCL group)")
     args = ap.parse_args()
@@ -53,6 +54,8 @@ def main():
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_mode="shard" if args.shard else ("dense" if args.dense else "sparse"))
     reducer.force_collectives = args.force_collectives
+    if args.bf16:
+        reducer.table_dtype, reducer.table_delta, reducer.defer_gather = torch.bfloat16, torch.bfloat16, True
     shard = None
     if args.shard and (world > 1 or args.force_collectives):
         i_main = opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)
@@ -83,6 +86,8 @@ def main():
         tr, j1, j2 = draws[k]
         step.forward_backward(sl(o), sl(d), sl(area), fars, sl(tf), sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts),
                               reducer=reducer if (world > 1 or args.force_collectives) else None)
+        if k == args.steps - 1:
+            reducer.flush()  # (a deferred all-gather of the last step; earlier ones are waited for by the next step's gather)
         torch.cuda.synchronize()
         info.append(dict(reducer.last_sparse))
     out = {"rank": rank, "world": world, "exchange": info,

@@ -46,3 +46,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rd["radar_scan"]["rays"] == 4545 and rd["radar_scan"]["outputs"]["radar_output"] == [1, 4545, 7]
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "rays/s" and cpu["sample"]
+    # round 4: what limits the dominant site in words, the effective operand type, the scatters' arithmetic, the convergence
+    # figures beside the speed (BASELINE's metric is "rays/sec + PSNR"), the decoder workloads' step times in `config`
+    assert "limiter" in roof and "LDS" in roof["limiter"]
+    assert r["config"]["mlp_operands"] == "bfloat16" and "32-bit fixed point" in r["config"]["tables_and_accumulation"]
+    assert r["config"]["full_model_ms_per_step"]["mixed8192_vod_nll"]["fresh"] == fm[0]["ms_per_step"]
+    assert r["config"]["full_model_ms_per_step"]["mixed8192_vod_nll"]["trained"] == fm[0]["after_training"]["ms_per_step"]
+    q = tr["quality"]
+    assert q["feature_psnr_db"] > 0 and q["depth_l1_m"] >= 0 and q["depth_l1_m_lidar_rays"] >= 0
+    qf = fm[0]["after_training"]["quality"]
+    assert qf["image_psnr_db"] > 0 and qf["depth_l1_m_lidar_rays"] >= 0

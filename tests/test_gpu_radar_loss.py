@@ -65,3 +65,24 @@ def test_assignment_is_scipys_optimum(n, counts, cost_type):
         c_want = float(cost[want >= 0, want[want >= 0]].sum())
         assert c_got <= c_want * (1 + 1e-6) + 1e-6, (c_got, c_want)  # optimal (the kernel's float32 cost entries differ in the last bits)
         assert float((got != want).float().mean()) <= 2e-3, "assignment differs from scipy's beyond near-ties"
+
+
+def test_assignment_status_words_report_an_unassigned_scan():
+    """The per-scan status words nr_radar_assign leaves in its workspace (include/neuradar_hip.h): 0 for assigned scans, 2 for a
+    scan with more detections than max_detections -- it is left unassigned (assoc = -1), which the callers must be able to see
+    (scipy has no such limit); ops.validate_radar_segments rejects such a batch before the step."""
+    from neuradar_amd import ops
+
+    gen = torch.Generator().manual_seed(11)
+    n, counts = 300, [40, 90, 7]
+    pred = torch.cat([torch.rand(3, n, 1, generator=gen), torch.randn(3, n, 3, generator=gen) * 20.0, torch.rand(3, n, 3, generator=gen) + 1e-4], dim=-1)
+    det = torch.randn(sum(counts), 5, generator=gen) * 20.0
+    assoc = ops.radar_assign(pred.to(DEV), det.to(DEV), _seg(counts), 90, "euclidean")
+    assert assoc.status.cpu().tolist() == [0, 0, 0] and int((assoc.cpu() >= 0).sum()) == sum(counts)
+    assoc = ops.radar_assign(pred.to(DEV), det.to(DEV), _seg(counts), 64, "euclidean")  # scan 1 has 90 > 64 detections
+    assert assoc.status.cpu().tolist() == [0, 2, 0]
+    a = assoc.cpu()
+    assert bool((a[1] == -1).all()) and int((a[0] >= 0).sum()) == 40 and int((a[2] >= 0).sum()) == 7
+    ops.validate_radar_segments(_seg(counts), 90)
+    with pytest.raises(ValueError):
+        ops.validate_radar_segments(_seg(counts), 64)
