@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 20
+#define NR_ABI_VERSION 21
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -753,7 +753,7 @@ int nr_lidar_head_loss(const float* y, const float* target_intensity, const uint
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, int adamw,
                  int step, float grad_scale, int zero_grad, const float* dev_hyper, uint8_t* seen_grad,
-                 const float* skip, void* delta16, nr_stream_t stream);
+                 const float* skip, void* delta16, int state_stride, nr_stream_t stream);
 /* skip: NULL, or a device float (an nr_amp found-inf flag): when it is non-zero the update is SKIPPED -- parameters and moments
  * stay as they are, the gradient is still cleared when zero_grad (GradScaler.step: "optimizer.step() is skipped if the
  * gradients contain infs or NaNs", engine/optimizers.py:154-166); the value 2.0f skips WITHOUT clearing the gradient (the caller
@@ -776,7 +776,10 @@ int nr_grad_to16_clear(float* grad, void* low16, int64_t n, nr_stream_t stream);
  * reads its gradient to notice a first arrival: 4 B per parameter of the whole table per step); n % 4 == 0.  Exact. */
 int nr_adam_step_marked(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                         float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
-                        const unsigned char* seen_grad, const float* skip, nr_stream_t stream);
+                        const unsigned char* seen_grad, const float* skip, int state_stride, nr_stream_t stream);
+/* state_stride (both entry points): 1 -- exp_avg and exp_avg_sq are two arrays of n floats; 2 -- they are the two halves of ONE
+ * array of n/4 records [exp_avg x 4 | exp_avg_sq x 4] (exp_avg_sq == exp_avg + 4, n % 4 == 0): the hash tables' layout, where the
+ * live 16-byte groups are scattered and every array touched costs a cache line per live group. */
 
 /* Advance the optimizer step counter step_t[0] (device float, 0-based scheduler step) and refresh
  * dev_hyper = {lr(step), 1-beta1^(step+1), sqrt(1-beta2^(step+1))} with the reference's

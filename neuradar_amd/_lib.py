@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 20
+NR_ABI_VERSION = 21
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -137,10 +137,10 @@ PROTOTYPES = {
     "nr_sample_radar_scans": [P, I, L, P, P],
     "nr_permutation_from_uniform": [P, I, P, P],
     "nr_gen_rays_radar": [P, L, P, P, F, F, I, F, F, I, P, P, P, P, P, P],
-    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P, P, P],
+    "nr_adam_step": [P, P, P, P, L, F, F, F, F, F, I, I, F, I, P, P, P, P, I, P],
     "nr_apply_delta16": [P, P, L, L, L, P],
     "nr_grad_to16_clear": [P, P, L, P],
-    "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P, P],
+    "nr_adam_step_marked": [P, P, P, P, L, F, F, F, F, I, F, I, P, P, P, I, P],
     "nr_amp_init": [P, F, P],
     "nr_amp_update": [P, I, F, F, I, P],
     "nr_nonfinite_check": [P, L, P, P],

@@ -266,23 +266,27 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
         }
       }
       {
-        const uint32_t mine = (uint32_t)__popc(claimed);
-        // exclusive prefix of `mine` over the wave (DPP adds), the wave's total in lane 63
-        int incl = (int)mine;
-        incl += nr_dpp_i<NR_DPP_ROW_SHR + 1, 0xF>(0, incl);
-        incl += nr_dpp_i<NR_DPP_ROW_SHR + 2, 0xF>(0, incl);
-        incl += nr_dpp_i<NR_DPP_ROW_SHR + 4, 0xF>(0, incl);
-        incl += nr_dpp_i<NR_DPP_ROW_SHR + 8, 0xF>(0, incl);
-        incl += nr_dpp_i<NR_DPP_ROW_BCAST15, 0xA>(0, incl);
-        incl += nr_dpp_i<NR_DPP_ROW_BCAST31, 0xC>(0, incl);
-        const int total = __builtin_amdgcn_readlane(incl, NR_WAVE - 1);
+        // The list is filled CORNER-major, lanes in order inside a corner: neighbouring lanes are neighbouring rays, whose
+        // same-numbered corners are neighbouring vertices -- along x these share a 64-byte line of the table (4 entries), and
+        // the flush below puts 4 consecutive list entries on 16 adjacent lanes of one atomic instruction, which the memory
+        // side takes as ONE request.  One returning atomic per wave reserves the span for all 8 corners.
+        unsigned long long cm[8];
+        int total = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          cm[c] = __ballot((claimed >> c) & 1u);
+          total += (int)__popcll(cm[c]);
+        }
         if (total > 0) {  // (uniform)
           uint32_t at = 0;
-          if (lane == NR_WAVE - 1) at = atomicAdd(cnt, (uint32_t)total);  // ds_add_rtn_u32
-          at = (uint32_t)__builtin_amdgcn_readlane((int)at, NR_WAVE - 1) + (uint32_t)incl - mine;
+          if (lane == 0) at = atomicAdd(cnt, (uint32_t)total);  // ds_add_rtn_u32
+          at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+          const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-          for (int c = 0; c < 8; ++c)
-            if ((claimed >> c) & 1u) occ[at++] = (uint16_t)s[c];
+          for (int c = 0; c < 8; ++c) {
+            if ((claimed >> c) & 1u) occ[at + (uint32_t)__popcll(cm[c] & below)] = (uint16_t)s[c];
+            at += (uint32_t)__popcll(cm[c]);
+          }
         }
       }
       NR_CLK(3)

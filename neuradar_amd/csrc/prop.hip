@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
             int64_t n, float lr, float beta1, float beta2, float eps, float wd, int adamw, float bc1, float bc2_sqrt,
             float grad_scale, int zero_grad, const float* __restrict__ dev_hyper, uint8_t* __restrict__ seen_grad,
-            const float* __restrict__ skip, __bf16* __restrict__ delta16) {
+            const float* __restrict__ skip, __bf16* __restrict__ delta16, int ss) {
+  // ss: stride of the moments in 16-byte groups -- 1: two arrays; 2: ONE array of [exp_avg x4 | exp_avg_sq x4] records (v = m + 4
+  // floats): a live group between never-touched neighbours then costs three cache lines (parameter, gradient, moments) instead of four
   if (skip != nullptr && skip[0] != 0.0f) {  // found-inf (GradScaler.step): no update; the gradient is still cleared
     if (delta16 != nullptr)  // (nothing moved: zero deltas for the replicas)
       for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) delta16[i] = (__bf16)0.0f;
@@ -169,8 +171,8 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
       // never had a gradient: m = v = 0 without reading them, the update is the identity (4 B/param)
       if (can_skip && !had[k] && seen[k] == 0) live[k] = false;
       if (live[k]) {
-        mm[k] = ld(m4 + i);
-        vv[k] = ld(v4 + i);
+        mm[k] = ld(m4 + i * ss);
+        vv[k] = ld(v4 + i * ss);
         pp[k] = ld(p4 + i);
       }
     }
@@ -194,11 +196,11 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
         __builtin_memcpy(&raw, d, 8);
         reinterpret_cast<uint2*>(delta16)[i] = raw;
       }
-      stv(p4 + i, pp[k]); stv(m4 + i, mm[k]); stv(v4 + i, vv[k]);
+      stv(p4 + i, pp[k]); stv(m4 + i * ss, mm[k]); stv(v4 + i * ss, vv[k]);
       if (zero_grad && had[k]) stv(g4 + i, g[k]);  // a gradient that is already zero is not zeroed again (28 B/param)
     }
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0)  // (n % 4 tail: separate arrays only, checked by the entry point)
     for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
       const float p_old = param[i];
       upd(param[i], grad[i], m[i], v[i]);
@@ -260,7 +262,7 @@ grad_to16_clear_kernel(float* __restrict__ g, __bf16* __restrict__ low, int64_t 
 __global__ void __launch_bounds__(256)
 adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, int64_t n,
                    float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float grad_scale, int zero_grad,
-                   const float* __restrict__ dev_hyper, const uint8_t* __restrict__ seen_grad, const float* __restrict__ skip) {
+                   const float* __restrict__ dev_hyper, const uint8_t* __restrict__ seen_grad, const float* __restrict__ skip, int ss) {
   if (dev_hyper != nullptr) {
     lr = dev_hyper[0];
     bc1 = dev_hyper[1];
@@ -313,8 +315,8 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
       mark[k] = nx < n4 ? seen_grad[nx] : (uint8_t)0;
       if (cur[k] != 0) {
         g[k] = ld(g4 + i);
-        mm[k] = ld(m4 + i);
-        vv[k] = ld(v4 + i);
+        mm[k] = ld(m4 + i * ss);
+        vv[k] = ld(v4 + i * ss);
         pp[k] = ld(p4 + i);
       }
     }
@@ -328,7 +330,7 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
         continue;  // fixed point: no stores
       upd(pp[k].x, g[k].x, mm[k].x, vv[k].x); upd(pp[k].y, g[k].y, mm[k].y, vv[k].y);
       upd(pp[k].z, g[k].z, mm[k].z, vv[k].z); upd(pp[k].w, g[k].w, mm[k].w, vv[k].w);
-      stv(p4 + i, pp[k]); stv(m4 + i, mm[k]); stv(v4 + i, vv[k]);
+      stv(p4 + i, pp[k]); stv(m4 + i * ss, mm[k]); stv(v4 + i * ss, vv[k]);
       if (zero_grad && had) stv(g4 + i, g[k]);
     }
   }
@@ -690,9 +692,11 @@ extern "C" int nr_sh4_fwd(const float* dirs, int64_t n, float* out, nr_stream_t 
 
 extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float wd, int adamw, int step, float grad_scale, int zero_grad,
-                            const float* dev_hyper, uint8_t* seen_grad, const float* skip, void* delta16, nr_stream_t stream) {
+                            const float* dev_hyper, uint8_t* seen_grad, const float* skip, void* delta16, int state_stride,
+                            nr_stream_t stream) {
   if (n == 0) return 0;
   if (!param || !grad || !m || !v || n < 0 || step < 1) return NR_EINVAL;
+  if (state_stride != 1 && !(state_stride == 2 && (n & 3) == 0 && v == m + 4)) return NR_EINVAL;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0 || ((uintptr_t)delta16 & 7u) != 0) return NR_EINVAL;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -701,7 +705,7 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
-                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, static_cast<__bf16*>(delta16));
+                     wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, static_cast<__bf16*>(delta16), state_stride);
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -730,9 +734,10 @@ extern "C" int nr_grad_to16_clear(float* grad, void* low16, int64_t n, nr_stream
 
 extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                    float eps, int step, float grad_scale, int zero_grad, const float* dev_hyper,
-                                   const uint8_t* seen_grad, const float* skip, nr_stream_t stream) {
+                                   const uint8_t* seen_grad, const float* skip, int state_stride, nr_stream_t stream) {
   if (n == 0) return 0;
   if (!param || !grad || !m || !v || !seen_grad || n < 0 || step < 1 || (n & 3) != 0) return NR_EINVAL;
+  if (state_stride != 1 && !(state_stride == 2 && v == m + 4)) return NR_EINVAL;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
@@ -741,7 +746,7 @@ extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v
   if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_marked_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps, bc1,
-                     bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip);
+                     bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, state_stride);
   NR_LAUNCH_CHECK();
   return 0;
 }

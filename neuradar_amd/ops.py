@@ -887,15 +887,21 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
         assert delta16.dtype == torch.bfloat16 and delta16.numel() == param.numel() and delta16.is_contiguous() and not marked
     if seen_grad is not None:
         assert seen_grad.dtype == torch.uint8 and seen_grad.numel() >= param.numel() // 4
+    # moments: two contiguous arrays, or the two halves of one array of [exp_avg x 4 | exp_avg_sq x 4] records (FlatAdam's tables)
+    stride = 1
+    if not exp_avg.is_contiguous():
+        assert exp_avg.dim() == 2 and exp_avg.stride() == (8, 1) and exp_avg_sq.stride() == (8, 1) and \
+            exp_avg_sq.data_ptr() == exp_avg.data_ptr() + 16, "moments must be contiguous or the halves of one interleaved array"
+        stride = 2
     if marked:
         assert seen_grad is not None and weight_decay == 0.0 and param.numel() % 4 == 0
         check(_lib.lib().nr_adam_step_marked(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
-                                             eps, step, grad_scale, int(zero_grad), _p(dev_hyper), _p(seen_grad), _p(skip), _stream()),
+                                             eps, step, grad_scale, int(zero_grad), _p(dev_hyper), _p(seen_grad), _p(skip), stride, _stream()),
               "nr_adam_step_marked")
         return
     check(_lib.lib().nr_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0],
                                   betas[1], eps, weight_decay, int(adamw), step, grad_scale, int(zero_grad),
-                                  _p(dev_hyper), _p(seen_grad), _p(skip), _p(delta16), _stream()), "nr_adam_step")
+                                  _p(dev_hyper), _p(seen_grad), _p(skip), _p(delta16), stride, _stream()), "nr_adam_step")
 
 
 def apply_delta16(param: Tensor, delta16: Tensor, lo: int, hi: int) -> None:

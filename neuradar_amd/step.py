@@ -8,6 +8,7 @@ radar loss): direct supervision of the path's own outputs with the reference's l
 plus the reference's two regularisers -- see DESIGN.md.
 """
 import math
+import os
 import dataclasses
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -442,7 +443,11 @@ class FlatAdam:
 
             flat = flatten_parameters(small)
             self.buffers.append((flat["param"], flat["grad"]))
-        self.state = [(torch.zeros_like(b), torch.zeros_like(b)) for b, _ in self.buffers]
+        # Adam's moments.  A hash table's live 16-byte groups are scattered (15 % of them in a fresh step, a cache line each in
+        # every array touched), so its two moments live in ONE array of [exp_avg x 4 | exp_avg_sq x 4] records: a live group costs
+        # three lines (parameter, gradient, moments) instead of four.  `state` exposes the halves as strided views.
+        self.state = [self._new_state(b.numel(), b.device, b.numel() > self.BIG and b.numel() % 4 == 0
+                                      and os.environ.get("NR_ADAM_INTERLEAVED", "1") != "0") for b, _ in self.buffers]
         # one byte per four parameters of the hash tables: "has had a gradient" (zero together with the moments), lets
         # the kernel leave never-touched rows alone after reading 4 instead of 12 bytes per parameter (no weight decay)
         self.seen = [torch.zeros(b.numel() // 4, device=dev, dtype=torch.uint8) if (b.numel() > self.BIG and weight_decay == 0.0)
@@ -450,6 +455,13 @@ class FlatAdam:
         self.step_t = torch.zeros(2, device=dev, dtype=torch.float32)  # [scheduler steps, optimizer updates]: nr_adam_hyper
         self.hyper = torch.zeros(3, device=dev, dtype=torch.float32)
         self.amp, self.amp_group = None, 0  # GradScalerState.attach
+
+    @staticmethod
+    def _new_state(n: int, device, interleaved: bool):
+        if not interleaved:
+            return torch.zeros(n, device=device), torch.zeros(n, device=device)
+        mv = torch.zeros(n // 4, 2, 4, device=device)
+        return mv[:, 0, :], mv[:, 1, :]
 
     @staticmethod
     def _coalesce(big: List[nn.Parameter]):
@@ -487,7 +499,7 @@ class FlatAdam:
     def grad_buffers(self) -> List[Tensor]:
         return [g for _, g in self.buffers]
 
-    def shard_buffer(self, i: int, rank: int, world: int) -> Optional[Tuple[int, int]]:
+    def shard_buffer(self, i: int, rank: int, world: int, force: bool = False) -> Optional[Tuple[int, int]]:
         """Data-parallel optimizer-state sharding of buffer i (a hash table): this rank keeps Adam's moments for -- and
         steps -- only elements [lo, hi) = its 1/world of the buffer (parallel.GradAllReducer.shard_step reduce-scatters the
         gradient onto the owners and all-gathers the updated rows).  Moments and `seen` flags shrink to the shard (2 x 537 MB
@@ -495,7 +507,7 @@ class FlatAdam:
         divide into world pieces of whole 16-byte groups (it then stays replicated)."""
         p, g = self.buffers[i]
         n = p.numel()
-        if world <= 1 or n % (world * 4) != 0:
+        if (world <= 1 and not force) or n % (world * 4) != 0:  # (force: a one-rank group that runs the collectives anyway -- tests)
             return None
         self.buffers[i] = (p.view(-1), g.view(-1))  # (a table's buffer is its [L*T, F] parameter: shards are element ranges)
         per = n // world
@@ -504,7 +516,10 @@ class FlatAdam:
             self.shards = {}
         self.shards[i] = (lo, hi)
         m, v = self.state[i]
-        self.state[i] = (m.view(-1)[lo:hi].clone(), v.view(-1)[lo:hi].clone())
+        ms, vs = self._new_state(hi - lo, m.device, not m.is_contiguous())
+        ms.reshape(-1).copy_(m.reshape(-1)[lo:hi]) if ms.is_contiguous() else ms.copy_(m[lo // 4:hi // 4])
+        vs.reshape(-1).copy_(v.reshape(-1)[lo:hi]) if vs.is_contiguous() else vs.copy_(v[lo // 4:hi // 4])
+        self.state[i] = (ms, vs)
         if self.seen[i] is not None:
             self.seen[i] = self.seen[i][lo // 4:hi // 4].clone()
         return lo, hi
@@ -568,7 +583,7 @@ class FlatAdam:
         mistaken for the whole table -- `gather_state_dict()` assembles the full moments on every rank for a checkpoint that
         any world size can load."""
         sh = getattr(self, "shards", {})
-        return {"exp_avg": [m.clone() for m, _ in self.state], "exp_avg_sq": [v.clone() for _, v in self.state],
+        return {"exp_avg": [m.reshape(-1).clone() for m, _ in self.state], "exp_avg_sq": [v.reshape(-1).clone() for _, v in self.state],
                 "step_t": self.step_t.clone(), "hyper": self.hyper.clone(),
                 "shards": {i: (lo, hi, self.buffers[i][0].numel()) for i, (lo, hi) in sh.items()}}
 
@@ -615,7 +630,7 @@ class FlatAdam:
         self.hyper.copy_(sd["hyper"])
         for s, (m, v) in zip(self.seen, self.state):  # "has had a gradient" = any moment non-zero, per group of four
             if s is not None:
-                nz = ((m != 0) | (v != 0)).view(-1)[: s.numel() * 4].view(-1, 4).any(dim=1)
+                nz = ((m != 0) | (v != 0)).reshape(-1)[: s.numel() * 4].view(-1, 4).any(dim=1)
                 s.copy_(nz.to(torch.uint8))
 
     def check_views(self) -> None:

@@ -61,12 +61,7 @@ def main():
         i_main = opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)
         if args.force_collectives and world == 1:
             reducer.world = 1
-            pb, gb = opts[0].buffers[i_main]
-            opts[0].buffers[i_main] = (pb.view(-1), gb.view(-1))
-            mb, vb = opts[0].state[i_main]
-            opts[0].state[i_main] = (mb.view(-1), vb.view(-1))
-            opts[0].shards = {i_main: (0, pb.numel())}  # one rank owns everything
-            shard = opts[0].shards[i_main]
+            shard = opts[0].shard_buffer(i_main, 0, 1, force=True)  # one rank owns everything
         else:
             shard = opts[0].shard_buffer(i_main, rank, world)
             assert shard is not None

@@ -78,7 +78,8 @@ def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
             assert err < tol, f"{path}: Adam first moment of the main table: relative L2 error {err:.3e} against the single-process run"
             continue
         err = float((a - b).norm() / b.norm().clamp_min(1e-30))
-        assert err < 1e-4, f"{path}: Adam first moment of buffer {i}: relative L2 error {err:.3e} against the single-process run"
+        tol = 2.0 ** -8 if (path == "shard_bf16" and a.numel() > (1 << 16)) else 1e-4  # (tables all-reduced in bf16 there)
+        assert err < tol, f"{path}: Adam first moment of buffer {i}: relative L2 error {err:.3e} against the single-process run"
         assert torch.equal(a, first[1]["exp_avg"][i])
 
 

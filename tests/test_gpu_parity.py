@@ -590,6 +590,10 @@ def test_adam_sparse_gradients_are_exact():
             # kernel of the fused step): never-marked groups are skipped without reading their gradient
             dict(p=p0.clone(), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV),
                  seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV), marked=True)]
+    # the tables' layout in FlatAdam: the two moments as the halves of ONE array of [exp_avg x 4 | exp_avg_sq x 4] records
+    for marked in (False, True):
+        mv = torch.zeros(n // 4, 2, 4, device=DEV)
+        runs.append(dict(p=p0.clone(), m=mv[:, 0, :], v=mv[:, 1, :], seen=torch.zeros(n // 4, dtype=torch.uint8, device=DEV), marked=marked))
     ever = torch.zeros(n, dtype=torch.bool, device=DEV)
     for step in range(1, 7):
         g = torch.zeros(n, device=DEV)
@@ -605,7 +609,9 @@ def test_adam_sparse_gradients_are_exact():
                 r["seen"] |= (g != 0).view(-1, 4).any(1).to(torch.uint8)
             ops.adam_step(r["p"], gbuf, r["m"], r["v"], 1e-2, step, eps=1e-15, seen_grad=r["seen"], marked=bool(r.get("marked")))
             assert float(gbuf.abs().max()) == 0.0
-    a_, b_, c_ = runs
+    a_, b_, c_ = runs[:3]
+    for r in runs[3:]:  # interleaved moments: bit-identical to the two-array launches
+        assert torch.equal(a_["p"], r["p"]) and torch.equal(a_["m"], r["m"].reshape(-1)) and torch.equal(a_["v"], r["v"].reshape(-1))
     assert torch.equal(a_["p"], b_["p"]) and torch.equal(a_["m"], b_["m"]) and torch.equal(a_["v"], b_["v"])
     assert torch.equal(a_["p"], c_["p"]) and torch.equal(a_["m"], c_["m"]) and torch.equal(a_["v"], c_["v"])
     assert torch.equal(b_["seen"], c_["seen"])
