@@ -447,7 +447,7 @@ class FlatAdam:
         # every array touched), so its two moments live in ONE array of [exp_avg x 4 | exp_avg_sq x 4] records: a live group costs
         # three lines (parameter, gradient, moments) instead of four.  `state` exposes the halves as strided views.
         self.state = [self._new_state(b.numel(), b.device, b.numel() > self.BIG and b.numel() % 4 == 0
-                                      and os.environ.get("NR_ADAM_INTERLEAVED", "1") != "0") for b, _ in self.buffers]
+                                      and os.environ.get("NR_ADAM_INTERLEAVED", "0") == "1") for b, _ in self.buffers]
         # one byte per four parameters of the hash tables: "has had a gradient" (zero together with the moments), lets
         # the kernel leave never-touched rows alone after reading 4 instead of 12 bytes per parameter (no weight decay)
         self.seen = [torch.zeros(b.numel() // 4, device=dev, dtype=torch.uint8) if (b.numel() > self.BIG and weight_decay == 0.0)

@@ -87,7 +87,7 @@ def main():
         info.append(dict(reducer.last_sparse))
     out = {"rank": rank, "world": world, "exchange": info,
            "params": {n: p.detach().cpu() for n, p in model.named_parameters()},
-           "exp_avg": [m.cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
+           "exp_avg": [m.reshape(-1).cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
            "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)}
     torch.save(out, f"{args.out}.rank{rank}")
     if world > 1 or args.force_collectives:
