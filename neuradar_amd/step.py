@@ -68,6 +68,10 @@ class HotPathConfig:
     eval_num_rays_per_chunk: int = 1 << 15
     rgb_upsample_factor: int = 3
     compensate_upsampling_when_rendering: bool = True
+    # rendering: run the RGB CNN on the operand type the model trains with (torch.autocast) when the field's MLPs are 16-bit.
+    # The reference renders its torch CNN in fp32 (autocast wraps train_iteration only, engine/trainer.py:564) -- 17 ms for the
+    # 1080p image here, 6 ms in bf16; a CNN trained on 16-bit operands is evaluated consistently on them.  False: fp32.
+    render_decoders_in_training_dtype: bool = True
 
 
 class NeuRadarHotPath(nn.Module):
@@ -265,17 +269,32 @@ class NeuRadarHotPath(nn.Module):
         radar = image_shape is None and "is_radar" in bundle.metadata
         chunk = n if radar else self.config.eval_num_rays_per_chunk
         keep = ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1")
-        lists: Dict[str, List[Tensor]] = {k: [] for k in keep}
-        for lo in range(0, n, chunk):
-            sl = slice(lo, min(lo + chunk, n))
-            cut = (lambda t: None if t is None else t[sl])  # noqa: E731
-            part = RayBundle(rays.origins[sl], rays.directions[sl], rays.pixel_area[sl], cut(rays.camera_indices), cut(rays.nears),
-                             cut(rays.fars), {k: v[sl] for k, v in rays.metadata.items()}, cut(rays.times))
-            out = self.get_nff_outputs(part)
-            for k in keep:
-                if k in out:
-                    lists[k].append(out[k])
-        outputs = {k: torch.cat(v).view(*output_size, -1) for k, v in lists.items() if v}
+        fused = self._fused_renderer(min(chunk, n)) if (rays.origins.is_cuda and rays.nears is None and n > 0) else None
+        if fused is not None:
+            # forward-only launch chain over preallocated buffers (fused_render.FusedRenderer: ten launches per chunk, straight
+            # into the output arrays) instead of the modular modules' ~60 launches and their temporaries per chunk
+            dev = rays.origins.device
+            C = self.config.field.nff_out_dim
+            flat = {"features": torch.empty(n, C, device=dev), **{k: torch.empty(n, 1, device=dev) for k in keep[1:]}}
+            for lo in range(0, n, chunk):
+                hi = min(lo + chunk, n)
+                fused.render(rays.origins[lo:hi], rays.directions[lo:hi], rays.pixel_area[lo:hi],
+                             None if rays.fars is None else rays.fars[lo:hi], flat, lo)
+            if self.config.appearance_dim > 0:  # neuradar.py:510-512
+                flat["features"] = torch.cat([flat["features"], self._get_appearance_embedding(rays)], dim=-1)
+            outputs = {k: v.view(*output_size, -1) for k, v in flat.items()}
+        else:
+            lists: Dict[str, List[Tensor]] = {k: [] for k in keep}
+            for lo in range(0, n, chunk):
+                sl = slice(lo, min(lo + chunk, n))
+                cut = (lambda t: None if t is None else t[sl])  # noqa: E731
+                part = RayBundle(rays.origins[sl], rays.directions[sl], rays.pixel_area[sl], cut(rays.camera_indices), cut(rays.nears),
+                                 cut(rays.fars), {k: v[sl] for k, v in rays.metadata.items()}, cut(rays.times))
+                out = self.get_nff_outputs(part)
+                for k in keep:
+                    if k in out:
+                        lists[k].append(out[k])
+            outputs = {k: torch.cat(v).view(*output_size, -1) for k, v in lists.items() if v}
         if getattr(self, "_decoders", None) is None:
             return outputs
         features = outputs["features"].view(-1, outputs["features"].shape[-1])
@@ -289,11 +308,32 @@ class NeuRadarHotPath(nn.Module):
             patch = features.view(1, *patch_size, features.shape[-1]).permute(0, 3, 1, 2)
             if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in dec.rgb_decoder.parameters()):
                 patch = patch.contiguous()
-            outputs["rgb"] = dec.rgb_decoder(patch).permute(0, 2, 3, 1).squeeze(0)
+            low = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(self.field.config.mlp_dtype)
+            if low is not None and self.config.render_decoders_in_training_dtype and patch.is_cuda:
+                with torch.autocast("cuda", dtype=low):
+                    rgb = dec.rgb_decoder(patch).float()
+            else:
+                rgb = dec.rgb_decoder(patch)
+            outputs["rgb"] = rgb.permute(0, 2, 3, 1).squeeze(0)
         elif radar:
             outputs["radar_output"] = dec.decode_radar(features, outputs["depth"].reshape(-1, 1), rays.metadata["directions_spher"],
                                                         num_radar_scans)
         return outputs
+
+    def _fused_renderer(self, max_rays: int):
+        """The forward-only launch chain of the rendering entry (fused_render.FusedRenderer), built once per chunk size; None
+        where it does not apply (dynamic actors, density branch, tcnn-layout tables, NR_FUSED_RENDER=0): the modular path."""
+        if os.environ.get("NR_FUSED_RENDER", "1") == "0":
+            return None
+        cache = self.__dict__.setdefault("_fused_render_cache", {})
+        if max_rays not in cache:
+            from .fused_render import FusedRenderer
+
+            try:
+                cache[max_rays] = FusedRenderer(self, max_rays)
+            except NotImplementedError:
+                cache[max_rays] = None
+        return cache[max_rays]
 
     def decode_lidar(self, features: Tensor, is_lidar: Tensor):
         """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--shard", action="store_true", help="main table: reduce-scatter -> Adam on this rank's rows -> all-gather")
     ap.add_argument("--bf16", action="store_true", help="shard: bf16 reduce-scatter, bf16 update-delta all-gather, deferred into the next step")
+    ap.add_argument("--fp16-amp", action="store_true", help="fp16 MFMA operands under the device-side loss scaler; rank 1's batch of "
+                    "step 1 is poisoned (an overflowing target): BOTH ranks must skip that step")
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--force-collectives", action="store_true", help="world 1: issue the collectives anyway (one-rank RCCL group)")
     args = ap.parse_args()
@@ -74,18 +76,30 @@ def main():
     draws = [(torch.rand(B, 129, generator=g), torch.rand(B, generator=g), torch.rand(B, generator=g)) for _ in range(args.steps)]
     lo, hi = rank * (B // world), (rank + 1) * (B // world)
     sl = lambda t: t[lo:hi].contiguous().to(dev)  # noqa: E731
+    amp = None
+    if args.fp16_amp:
+        from neuradar_amd.step import GradScalerState
+
+        model.field.config.mlp_dtype, model.field.config.mlp_grad_scale = "float16", 1024.0
     step = FusedTrainStep(model, hi - lo)
+    if args.fp16_amp:
+        amp = GradScalerState(dev, init_scale=1024.0).attach(opts)
+        step.set_grad_scaler(amp)
     fars = torch.full((hi - lo,), 1e6, device=dev)
     info = []
     for k in range(args.steps):
         tr, j1, j2 = draws[k]
-        step.forward_backward(sl(o), sl(d), sl(area), fars, sl(tf), sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts),
+        tf_k = sl(tf)
+        if args.fp16_amp and k == 1 and rank == 1:
+            tf_k = torch.full_like(tf_k, 1e30)  # only THIS rank's gradients overflow
+        step.forward_backward(sl(o), sl(d), sl(area), fars, tf_k, sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts),
                               reducer=reducer if (world > 1 or args.force_collectives) else None)
         if k == args.steps - 1:
             reducer.flush()  # (a deferred all-gather of the last step; earlier ones are waited for by the next step's gather)
         torch.cuda.synchronize()
         info.append(dict(reducer.last_sparse))
-    out = {"rank": rank, "world": world, "exchange": info,
+    out = {"rank": rank, "world": world, "exchange": [{k_: v_ for k_, v_ in e.items() if k_ != "flag"} for e in info],
+           "amp": None if amp is None else {"scale": amp.get_scale(), "skipped": amp.skipped_steps()},
            "params": {n: p.detach().cpu() for n, p in model.named_parameters()},
            "exp_avg": [m.reshape(-1).cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
            "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)}

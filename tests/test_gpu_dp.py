@@ -122,3 +122,18 @@ def test_two_rank_decoder_workload_replicas_stay_identical(tmp_path, workload):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     ex = line["config"]["gradient_exchange"]
     assert ex["main_table_mode"] == "shard" and ex["main_table"]["reduce_scatter_dtype"] == "bfloat16" and ex["main_table"]["deferred"]
+
+
+def test_two_rank_loss_scaler_skips_on_every_rank(tmp_path):
+    """fp16 operands under the device-side loss scaler, two ranks: rank 1's batch of step 1 overflows, rank 0's does not -- the
+    found-inf flags are summed over the ranks before the first Adam launch, so BOTH ranks skip that step (and halve the scale):
+    replicas bit-identical, nothing non-finite in any parameter or moment, one skipped step counted on both."""
+    dp = _run(str(tmp_path), "amp", 2, ["--log2t", "16", "--rays", "512", "--shard", "--fp16-amp"])
+    for r in dp:
+        assert r["amp"] == {"scale": 512.0, "skipped": 1}, r["amp"]
+        for n, p in r["params"].items():
+            assert bool(torch.isfinite(p).all()), n
+        for m in r["exp_avg"]:
+            assert bool(torch.isfinite(m).all())
+    for n, p in dp[0]["params"].items():
+        assert torch.equal(p, dp[1]["params"][n]), f"parameter {n} differs between the ranks"

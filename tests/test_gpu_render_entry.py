@@ -103,3 +103,32 @@ def test_lidar_and_radar_readings():
     assert float((ro["radar_output"][..., 1:4] - xyz).abs().max()) <= 1.5 + 1e-4
     with pytest.raises(AssertionError):
         model.train().get_outputs_for_camera_ray_bundle(lidar)
+
+
+@pytest.mark.parametrize("mlp_dtype", ["float32", "bfloat16"])
+def test_fused_render_chain_equals_the_modular_eval_path(mlp_dtype, monkeypatch):
+    """The forward-only launch chain of the rendering entry (fused_render.FusedRenderer: fused per-ray launches over
+    preallocated buffers, sample-major rows, the main gather inside the field forward on 16-bit operands) against the
+    modular modules' eval path (NR_FUSED_RENDER=0) on the same rays: the fused launches equal the chains they replace to
+    2e-5 (tests/test_gpu_parity.py), so the rendered values agree to 1e-4 of their scale -- with ragged chunks, and for a
+    lidar reading (rays without the camera's constant far plane)."""
+    from neuradar_amd.rays import RayBundle
+
+    gen = torch.Generator().manual_seed(7)
+    H, W = 23, 40
+    model = _model(chunk=101)
+    model.field.config.mlp_dtype = mlp_dtype
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NR_FUSED_RENDER", mode)
+        cam = model.get_outputs_for_camera_ray_bundle(_camera_rays(H, W, torch.Generator().manual_seed(7)), image_shape=(H, W))
+        base = _camera_rays(150, 1, torch.Generator().manual_seed(8))
+        lid = model.get_outputs_for_camera_ray_bundle(RayBundle(base.origins, base.directions, base.pixel_area, fars=base.fars.clone(),
+                                                                metadata={"is_lidar": torch.ones(150, 1, dtype=torch.bool, device=DEV)}))
+        outs[mode] = (cam, lid)
+        assert (model._fused_renderer(101) is not None) == (mode == "1")
+    for a, b, what in ((outs["1"][0], outs["0"][0], "camera"), (outs["1"][1], outs["0"][1], "lidar")):
+        for k in ("features", "depth", "accumulation", "prop_depth_0", "prop_depth_1", "intensity"):
+            _check(a[k].reshape(-1, a[k].shape[-1]).cpu(), b[k].reshape(-1, b[k].shape[-1]).cpu(), f"{what} {k} ({mlp_dtype})", rtol=1e-4, floor=1e-5,
+                   few=5e-3)
+    _check(outs["1"][0]["rgb"].reshape(-1, 3).cpu(), outs["0"][0]["rgb"].reshape(-1, 3).cpu(), "rgb", rtol=1e-3, floor=1e-4, few=5e-3)
