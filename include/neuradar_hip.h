@@ -173,6 +173,29 @@ int nr_attention_bwd(const float* q, const float* k, const float* v, const float
                      int64_t n_scans, int64_t n, int d, float dropout_p, uint32_t seed, const float* seed_epoch,
                      const float* keep_mask, float* grad_q, float* grad_k, float* grad_v, float* workspace, nr_stream_t stream);
 
+/* 7 x 7 convolution, 32 -> 32 channels, stride 1, padding 3, channels-last 16-bit activations: the convolutions of the RGB
+ * decoder's BasicBlocks (model_components/cnns.py:21-47 as built by models/neuradar.py:225-240) on the matrix cores (conv7.hip).
+ *   nr_conv7_pack: weights of up to NR_CONV7_MAX convolutions -- each [32][7][7][32] 16-bit, CONTIGUOUS in that order (the
+ *     channels-last memory of a torch [O, I, 7, 7] parameter), at element offsets list->offset[k] from weights16, biases [32]
+ *     16-bit at list->bias_offset[k] (-1: none) -- into the kernels' LDS images: images[k][0] for the convolution itself
+ *     (weights in MFMA fragment order + the bias in fp32), images[k][1] (flipped taps, in / out swapped, no bias) for its data
+ *     gradient; nr_conv7_image_bytes() bytes per convolution (both orientations, each half of it), 16-byte aligned.  Once per
+ *     optimizer step.
+ *   nr_conv7_fwd: y[p, r, c, :] = act( bias + sum_taps W[:, ky, kx, :] x[p, r + ky - 3, c + kx - 3, :] (+ residual[p, r, c, :]) )
+ *     (zero padding; act = ReLU when `relu`, residual nullable) for x, y, residual [n_images, height, width, 32] of dtype
+ *     NR_DTYPE_BF16 | NR_DTYPE_F16, fp32 accumulation; `image` = one orientation of one convolution's images.  With the
+ *     data-gradient image and grad_y as x it returns grad_x. */
+#define NR_CONV7_MAX 16
+typedef struct nr_conv7_list {
+  int n;
+  int64_t offset[NR_CONV7_MAX];
+  int64_t bias_offset[NR_CONV7_MAX];
+} nr_conv7_list_t;
+int64_t nr_conv7_image_bytes(void);
+int nr_conv7_pack(const void* weights16, const nr_conv7_list_t* list, int dtype, void* images, nr_stream_t stream);
+int nr_conv7_fwd(const void* x16, const void* image, const void* residual16, int relu, void* y16, int n_images, int height,
+                 int width, int dtype, nr_stream_t stream);
+
 /* Radar point-set loss on the device (model_components/radar_utils.py:54-168, called from
  * models/neuradar.py:652-662): the reference copies a cost matrix to the host and runs scipy's linear_sum_assignment per scan
  * in the middle of every training step.

@@ -39,6 +39,10 @@ class NrField(Structure):
                 ("dtype", c_int), ("sample_dirs", c_void_p), ("grad_scale", c_float), ("amp", c_void_p), ("amp_groups", c_uint32)]
 
 
+class NrConv7List(Structure):
+    _fields_ = [("n", c_int), ("offset", c_int64 * 16), ("bias_offset", c_int64 * 16)]
+
+
 class NrLidarSup(Structure):
     _fields_ = [("is_lidar", c_void_p), ("did_return", c_void_p), ("range", c_void_p), ("carving_epsilon", c_float),
                 ("non_return_distance", c_float), ("weight", c_float), ("depth_weight", c_float), ("non_return_loss_mult", c_float)]
@@ -82,6 +86,9 @@ PROTOTYPES = {
     "nr_radar_points_bwd": [P, P, L, P, P],
     "nr_radar_heads_fwd": [P, P, I, P, L, P, P],
     "nr_radar_heads_bwd": [P, P, I, P, L, P, P, P, P],
+    "nr_conv7_image_bytes": [],
+    "nr_conv7_pack": [P, POINTER(NrConv7List), I, P, P],
+    "nr_conv7_fwd": [P, P, P, I, P, I, I, I, I, P],
     "nr_bn_act_workspace_floats": [L, I],
     "nr_bn_act_fwd": [P, P, L, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "nr_bn_act_bwd": [P, P, P, L, I, I, P, P, P, I, P, P, P, P, P, P],
@@ -160,7 +167,7 @@ _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int6
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
              "nr_radar_assign_workspace_bytes": c_int64, "nr_radar_assign_status_offset": c_int64,
-             "nr_bn_act_workspace_floats": c_int64}
+             "nr_bn_act_workspace_floats": c_int64, "nr_conv7_image_bytes": c_int64}
 
 _lib = None
 

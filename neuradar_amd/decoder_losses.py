@@ -171,6 +171,30 @@ class DecoderLossHead:
             sp.grad = gflat16.as_strided(p_.size(), p_.stride(), p_.storage_offset())
             params[n] = sp
         self._shadow = dict(flat32=flat32, gflat32=gflat32, flat16=flat16, gflat16=gflat16, params=params)
+        # the BasicBlocks' 7 x 7 convolutions (32 -> 32) on nr_conv7_fwd: their weights sit channels-last ([O, kh, kw, I]
+        # contiguous) inside flat16, so ONE pack launch per step writes every convolution's two LDS images (NR_CONV7=0: MIOpen)
+        self._shadow["conv7"] = None
+        if os.environ.get("NR_CONV7", "1") != "0":
+            from .decoders import BasicBlock
+
+            blocks = [(k, m_) for k, m_ in mod.named_modules() if isinstance(m_, BasicBlock)]
+            w_off, b_off = [], []
+            for k, blk in blocks:
+                for ci in (0, 3):
+                    w_, b_ = params.get(f"{k}.main_branch.{ci}.weight"), params.get(f"{k}.main_branch.{ci}.bias")
+                    ok7 = (w_ is not None and tuple(w_.shape) == (32, 32, 7, 7) and w_.stride() == (32 * 49, 1, 7 * 32, 32))
+                    if not ok7:
+                        w_off = None
+                        break
+                    w_off.append(w_.storage_offset())
+                    b_off.append(b_.storage_offset() if b_ is not None else -1)
+                if w_off is None:
+                    break
+            if w_off:
+                images = ops.conv7_pack(flat16, w_off, b_off)
+                self._shadow["conv7"] = (images, w_off, b_off)
+                for i, (_, blk) in enumerate(blocks):
+                    blk.conv7_images = (images[2 * i], images[2 * i + 1])
         return self._shadow
 
     def check_radar_status(self) -> None:
@@ -247,6 +271,8 @@ class DecoderLossHead:
                 if sh:
                     with torch.no_grad():
                         sh["flat16"].copy_(sh["flat32"])
+                        if sh.get("conv7") is not None:  # this step's weights into the convolution kernels' LDS images: one launch
+                            ops.conv7_pack(sh["flat16"], sh["conv7"][1], sh["conv7"][2], sh["conv7"][0])
                     scale = self._cnn_scale()
                     if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
                         patches = _ScaleGrad.apply(patches, scale[1])

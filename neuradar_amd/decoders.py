@@ -135,8 +135,21 @@ class BasicBlock(nn.Module):
 
     fused_bn = False  # set by the training step (DecoderLossHead): batch norm + ReLU (+ residual) as nr_bn_act_fwd/bwd
     fused_bn_counts = True  # BatchNorm2d.forward's `num_batches_tracked += 1` here (DecoderLossHead: one launch for all blocks)
+    # the block's two 7 x 7 convolutions on nr_conv7_fwd (ops.conv7: forward + data gradient on the matrix cores).
+    # conv7_images: (images of conv 1 [2, bytes], of conv 2) packed from THIS step's 16-bit weights -- set by the training step;
+    # conv7_eval: (image of conv 1 with its batch norm's running statistics folded in, of conv 2, dtype) -- set by
+    # Decoders.prepare_conv7_eval for rendering: the block is then two launches (conv + ReLU, conv + residual + ReLU).
+    conv7_images = None
+    conv7_eval = None
 
     def forward(self, x: Tensor) -> Tensor:
+        if not self.training and self.conv7_eval is not None and x.is_cuda and x.dtype == self.conv7_eval[2] and x.shape[1] == 32:
+            from . import ops
+
+            if not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            h = ops.conv7_forward(x, self.conv7_eval[0], None, relu=True)
+            return ops.conv7_forward(h, self.conv7_eval[1], x, relu=True)
         if (self.fused_bn and self.training and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
                 and x.shape[1] in (8, 16, 32, 64)):
             # conv -> [BN + ReLU] -> conv -> [BN + residual + ReLU]: two launches per bracket each way instead of torch's
@@ -148,11 +161,13 @@ class BasicBlock(nn.Module):
                 for bn in (bn1, bn2):
                     if bn.num_batches_tracked is not None:
                         bn.num_batches_tracked.add_(1)
-            h = conv1(x)
+            c7 = self.conv7_images if (self.conv7_images is not None and x.shape[1] == 32 and x.dtype in (torch.bfloat16, torch.float16)
+                                       and conv1.weight.dtype == x.dtype) else None
+            h = conv1(x) if c7 is None else ops.conv7(x, conv1.weight, conv1.bias, c7[0])
             if not h.is_contiguous(memory_format=torch.channels_last):
                 h = h.contiguous(memory_format=torch.channels_last)
             h = ops.bn_act(h, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, None, bn1.momentum, bn1.eps, True)
-            h = conv2(h)
+            h = conv2(h) if c7 is None else ops.conv7(h, conv2.weight, conv2.bias, c7[1])
             if not h.is_contiguous(memory_format=torch.channels_last):
                 h = h.contiguous(memory_format=torch.channels_last)
             return ops.bn_act(h, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, x, bn2.momentum, bn2.eps, True)
@@ -180,6 +195,42 @@ class Decoders(nn.Module):
         self.radar_angle_head = mk(2, nn.Tanh())  # built and checkpointed by the reference, never evaluated
         self.radar_uncertainty_head = mk(3, nn.Softplus())
         self.existence_probability_head = mk(1, nn.Sigmoid())
+
+    def prepare_conv7_eval(self, dtype: Optional[torch.dtype]) -> None:
+        """Rendering: the BasicBlocks' 7 x 7 convolutions on nr_conv7_fwd with their (eval-mode) batch norms FOLDED into weights
+        and biases -- BN(conv(x)) = conv'(x) with W' = W gamma / sigma, b' = (b - mean) gamma / sigma + beta -- so that a block is
+        two launches: conv + ReLU, conv + residual + ReLU (model_components/cnns.py:21-47 in eval mode).  dtype: the 16-bit
+        operand type (None switches it off).  Re-packed when a parameter or running statistic has changed."""
+        from . import ops
+
+        blocks = [m for m in self.rgb_decoder.modules() if isinstance(m, BasicBlock)]
+        if dtype is None or not blocks or next(self.parameters()).device.type != "cuda":
+            for b in blocks:
+                b.conv7_eval = None
+            return
+        tensors = [t for b in blocks for t in (*b.main_branch.parameters(), *b.main_branch.buffers())]
+        version = (dtype, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        if getattr(self, "_conv7_eval_version", None) == version:
+            return
+        with torch.no_grad():
+            pieces, w_off, b_off, off = [], [], [], 0
+            for b in blocks:
+                conv1, bn1, _, conv2, bn2 = b.main_branch
+                for conv, bn in ((conv1, bn1), (conv2, bn2)):
+                    if conv.kernel_size != (7, 7) or conv.in_channels != 32 or conv.out_channels != 32:
+                        raise NotImplementedError("prepare_conv7_eval: 7 x 7 convolutions 32 -> 32")
+                    k = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                    w = (conv.weight.float() * k[:, None, None, None]).permute(0, 2, 3, 1).contiguous()  # [O, kh, kw, I]
+                    bias = ((conv.bias.float() if conv.bias is not None else 0.0) - bn.running_mean.float()) * k + bn.bias.float()
+                    pieces += [w.reshape(-1), bias.reshape(-1)]
+                    w_off.append(off)
+                    b_off.append(off + w.numel())
+                    off += w.numel() + 32
+            flat16 = torch.cat(pieces).to(dtype)
+            images = ops.conv7_pack(flat16, w_off, b_off)
+        for i, b in enumerate(blocks):
+            b.conv7_eval = (images[2 * i, 0], images[2 * i + 1, 0], dtype)
+        self._conv7_eval_version = version
 
     def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int,
                      seed_epoch: Optional[Tensor] = None) -> Tensor:

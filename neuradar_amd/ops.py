@@ -873,6 +873,65 @@ def radar_points(depth: Tensor, dirs_spher: Tensor, num_channels: int, temperatu
     return _RadarPoints.apply(depth, dirs_spher, int(num_channels), float(temperature))
 
 
+# ------------------------------------------------------------------------------------------------ 7 x 7 convolutions of the RGB decoder
+_DT16 = {torch.bfloat16: 1, torch.float16: 2}
+
+
+def conv7_pack(flat16: Tensor, weight_offsets, bias_offsets, images: Optional[Tensor] = None) -> Tensor:
+    """nr_conv7_pack: the 7 x 7 convolutions whose [32, 7, 7, 32] (channels-last) 16-bit weights sit at element offsets
+    `weight_offsets` of the flat 16-bit buffer `flat16` (biases [32] at `bias_offsets`, -1 = none) -> images uint8
+    [n, 2, nr_conv7_image_bytes() / 2]: [k, 0] the convolution's LDS image, [k, 1] its data gradient's."""
+    n = len(weight_offsets)
+    half = _lib.lib().nr_conv7_image_bytes() // 2
+    if images is None:
+        images = torch.empty(n, 2, half, device=flat16.device, dtype=torch.uint8)
+    lst = _lib.NrConv7List()
+    lst.n = n
+    for k in range(n):
+        lst.offset[k], lst.bias_offset[k] = int(weight_offsets[k]), int(bias_offsets[k])
+    check(_lib.lib().nr_conv7_pack(_p(flat16), byref(lst), _DT16[flat16.dtype], _p(images), _stream()), "nr_conv7_pack")
+    return images
+
+
+def conv7_forward(x: Tensor, image: Tensor, residual: Optional[Tensor] = None, relu: bool = False) -> Tensor:
+    """nr_conv7_fwd on a channels-last 16-bit activation x [P, 32, H, W] (memory [P, H, W, 32]) -> the same shape and format."""
+    P, C, H, W = x.shape
+    assert C == 32 and x.dtype in _DT16 and x.is_contiguous(memory_format=torch.channels_last) and x.is_cuda
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    check(_lib.lib().nr_conv7_fwd(_p(x), _p(image), _p(residual), int(relu), _p(y), P, H, W, _DT16[x.dtype], _stream()), "nr_conv7_fwd")
+    return y
+
+
+class _Conv7(torch.autograd.Function):
+    """Conv2d(32, 32, 7, padding=3) on channels-last 16-bit activations: forward and DATA gradient on nr_conv7_fwd (the two
+    orientations of the packed weights); the weight / bias gradients are the library's (aten.convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, images):
+        ctx.save_for_backward(x, weight)
+        ctx.images, ctx.has_bias = images, bias is not None
+        return conv7_forward(x, images[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous(memory_format=torch.channels_last)
+        gx = conv7_forward(g, ctx.images[1]) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            _, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, [32] if ctx.has_bias else None, [1, 1], [3, 3], [1, 1], False,
+                                                            [0, 0], 1, [False, True, ctx.has_bias])
+        return gx, gw, gb, None
+
+
+def conv7(x: Tensor, weight: Tensor, bias: Optional[Tensor], images: Tensor) -> Tensor:
+    """x [P, 32, H, W] channels-last 16-bit; weight / bias: the convolution's (16-bit) parameters, for the library's weight
+    gradient; images [2, bytes]: their nr_conv7_pack images of THIS optimizer step."""
+    return _Conv7.apply(x, weight, bias, images)
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
               betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,

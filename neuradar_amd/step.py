@@ -310,9 +310,12 @@ class NeuRadarHotPath(nn.Module):
                 patch = patch.contiguous()
             low = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(self.field.config.mlp_dtype)
             if low is not None and self.config.render_decoders_in_training_dtype and patch.is_cuda:
+                # (the BasicBlocks' 7 x 7 convolutions on the matrix-core kernel with their batch norms folded in: conv7.hip)
+                dec.prepare_conv7_eval(low if os.environ.get("NR_CONV7", "1") != "0" else None)
                 with torch.autocast("cuda", dtype=low):
                     rgb = dec.rgb_decoder(patch).float()
             else:
+                dec.prepare_conv7_eval(None)
                 rgb = dec.rgb_decoder(patch)
             outputs["rgb"] = rgb.permute(0, 2, 3, 1).squeeze(0)
         elif radar:
