@@ -195,6 +195,14 @@ int64_t nr_conv7_image_bytes(void);
 int nr_conv7_pack(const void* weights16, const nr_conv7_list_t* list, int dtype, void* images, nr_stream_t stream);
 int nr_conv7_fwd(const void* x16, const void* image, const void* residual16, int relu, void* y16, int n_images, int height,
                  int width, int dtype, nr_stream_t stream);
+/* Weight and bias gradient of the same convolution: grad_w [32][7][7][32] (the parameter's channels-last memory, 16-bit;
+ * overwritten, or "+=" when `accumulate`) = sum over pixels of grad_y[pixel][o] x[pixel + tap - 3][i], grad_b [32] (nullable) =
+ * sum over pixels of grad_y;
+ * fp32 accumulation on the matrix cores (operands read column-wise from LDS with ds_read_b64_tr_b16), per-block partials in
+ * `workspace` (nr_conv7_wgrad_workspace_bytes() bytes, 16-byte aligned, caller-owned) summed by a second launch. */
+int64_t nr_conv7_wgrad_workspace_bytes(void);
+int nr_conv7_wgrad(const void* x16, const void* grad_y16, void* grad_w16, void* grad_b16, int accumulate, void* workspace,
+                   int n_images, int height, int width, int dtype, nr_stream_t stream);
 
 /* Radar point-set loss on the device (model_components/radar_utils.py:54-168, called from
  * models/neuradar.py:652-662): the reference copies a cost matrix to the host and runs scipy's linear_sum_assignment per scan

@@ -89,6 +89,8 @@ PROTOTYPES = {
     "nr_conv7_image_bytes": [],
     "nr_conv7_pack": [P, POINTER(NrConv7List), I, P, P],
     "nr_conv7_fwd": [P, P, P, I, P, I, I, I, I, P],
+    "nr_conv7_wgrad_workspace_bytes": [],
+    "nr_conv7_wgrad": [P, P, P, P, I, P, I, I, I, I, P],
     "nr_bn_act_workspace_floats": [L, I],
     "nr_bn_act_fwd": [P, P, L, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "nr_bn_act_bwd": [P, P, P, L, I, I, P, P, P, I, P, P, P, P, P, P],
@@ -167,7 +169,8 @@ _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int6
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
              "nr_radar_assign_workspace_bytes": c_int64, "nr_radar_assign_status_offset": c_int64,
-             "nr_bn_act_workspace_floats": c_int64, "nr_conv7_image_bytes": c_int64}
+             "nr_bn_act_workspace_floats": c_int64, "nr_conv7_image_bytes": c_int64,
+             "nr_conv7_wgrad_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -162,7 +162,157 @@ conv7_kernel(const typename T::elem* __restrict__ x, const unsigned char* __rest
   }
 }
 
+// ---- weight gradient ------------------------------------------------------------------------------------------------
+//   dW[o][t][i] = sum over pixels  dY[pixel][o] * X[pixel + t - 3][i],   db[o] = sum over pixels dY[pixel][o]
+// Per tap a 32 x 32 product that contracts over PIXELS: A[row o][k = pixel], B[k = pixel][col i] -- both operands are columns of
+// the channels-last tiles, read from LDS with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered
+// column-major: the lane's channel for 4 consecutive pixels; two reads per operand).  Pixel rows of 64 bytes: the 4 pixels of a
+// read are 256 contiguous bytes = all 64 banks once, whatever the tap's shift.  A block stages a tile of dY (8 x 32 pixels) and
+// the 14 x 38 halo of X; its 8 waves split the 49 taps (wave w: taps w, w + 8, ...: 7 accumulators of 16 registers), the tile's
+// 16 A fragments stay in registers for all of a wave's taps.  Persistent blocks keep their accumulators across tiles and leave
+// ONE partial [49][32][32] (+ bias row) each; conv7_wgrad_reduce_kernel sums the partials.
+constexpr int kWPix = 64;                       // bytes per staged pixel (no padding: transposed reads)
+constexpr int kWHalo = kHH * kHW * kWPix;       // 34 048
+constexpr int kWTile = kTH * kTW * kWPix;       // 16 384
+constexpr int kWPart = kTaps * kC * kC + kC;    // floats of one block's partial: dW [t][o][i], then db [o]
+constexpr int kWMaxBlocks = 64;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// 8 consecutive pixels (8h + j) of the lane's channel (lane & 31), starting at pixel `pix0` of an image with 64-byte pixel rows
+__device__ __forceinline__ u32x4 tr_pixels(const unsigned char* img, int pix0, int lane) {
+  const int h = lane >> 5, q = (lane & 15) >> 2, p = lane & 3, u = 4 * ((lane >> 4) & 1) + p;
+  u32x4 f;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const unsigned char* a = img + (pix0 + 8 * h + 4 * jj + q) * kWPix + 8 * u;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a));
+    const u32x2 w = __builtin_bit_cast(u32x2, v);
+    f[2 * jj] = w[0];
+    f[2 * jj + 1] = w[1];
+  }
+  return f;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+conv7_wgrad_kernel(const typename T::elem* __restrict__ x, const typename T::elem* __restrict__ gy, float* __restrict__ partial,
+                   int P, int H, int W, int tiles_y, int tiles_x, int64_t n_tiles) {
+  using E = typename T::elem;
+  __shared__ __attribute__((aligned(16))) unsigned char xs[kWHalo];
+  __shared__ __attribute__((aligned(16))) unsigned char gs[kWTile];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  constexpr int kMine = (kTaps + kTH - 1) / kTH;  // taps per wave (7)
+  f32x16 acc[kMine];
+#pragma unroll
+  for (int m = 0; m < kMine; ++m)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[m][q] = 0.0f;
+  float bsum = 0.0f;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int p = (int)(tile / ((int64_t)tiles_y * tiles_x)), rem = (int)(tile % ((int64_t)tiles_y * tiles_x));
+    const int ty0 = (rem / tiles_x) * kTH, tx0 = (rem % tiles_x) * kTW;
+    __syncthreads();  // the previous tile's reads are done
+    for (int c = tid; c < kChunks; c += kThreads) {  // X halo: 14 x 38 pixels x 4 pieces of 16 bytes
+      const int pix = c >> 2, q = c & 3, ry = pix / kHW, rx = pix - ry * kHW, gy_ = ty0 - 3 + ry, gx_ = tx0 - 3 + rx;
+      const bool in = gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+      *reinterpret_cast<uint4*>(xs + pix * kWPix + q * 16) =
+          in ? *reinterpret_cast<const uint4*>(x + (((int64_t)p * H + gy_) * W + gx_) * kC + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    for (int c = tid; c < kTH * kTW * 4; c += kThreads) {  // dY tile
+      const int pix = c >> 2, q = c & 3, ry = pix / kTW, rx = pix - ry * kTW, gy_ = ty0 + ry, gx_ = tx0 + rx;
+      const bool in = gy_ < H && gx_ < W;
+      *reinterpret_cast<uint4*>(gs + pix * kWPix + q * 16) =
+          in ? *reinterpret_cast<const uint4*>(gy + (((int64_t)p * H + gy_) * W + gx_) * kC + q * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int kb = 0; kb < 16; ++kb) {  // k-block = (tile row, half of the row): 16 pixels
+      const u32x4 a = tr_pixels(gs, (kb >> 1) * kTW + (kb & 1) * 16, lane);  // dY, shared by the wave's taps
+      if (wave == 0) {  // db: every lane sums its channel over its 8 pixels of the k-block
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t word = a[q];
+          E e2[2];
+          __builtin_memcpy(e2, &word, 4);
+          bsum += (float)e2[0] + (float)e2[1];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < kMine; ++m) {
+        const int t = wave + m * kTH;
+        if (t < kTaps) {  // (uniform per wave)
+          const int ky = t / 7, kx = t - ky * 7;
+          const u32x4 b = tr_pixels(xs, ((kb >> 1) + ky) * kHW + (kb & 1) * 16 + kx, lane);
+          acc[m] = T::mfma(a, b, acc[m]);
+        }
+      }
+    }
+  }
+  // D[row o][col i]: column on the lane, rows (reg & 3) + 8 (reg >> 2) + 4 h
+  float* out = partial + (int64_t)blockIdx.x * kWPart;
+  const int i = lane & 31;
+#pragma unroll
+  for (int m = 0; m < kMine; ++m) {
+    const int t = wave + m * kTH;
+    if (t < kTaps) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) out[(t * kC + (q & 3) + 8 * (q >> 2) + 4 * h) * kC + i] = acc[m][q];
+    }
+  }
+  if (wave == 0) {
+    bsum += nr_xor32_f(bsum);  // the two pixel halves of the lane's channel
+    if (lane < kC) out[kTaps * kC * kC + lane] = bsum;
+  }
+}
+
+// dW [o][t][i] (the parameter's channels-last memory) and db [o] = sum of the blocks' partials [t][o][i] | [o]
+template <typename E>
+__global__ void __launch_bounds__(256)
+conv7_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, E* __restrict__ gw, E* __restrict__ gb, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kWPart) return;
+  float s = 0.0f;
+  for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * kWPart + e];
+  if (e < kTaps * kC * kC) {
+    const int i = e % kC, o = (e / kC) % kC, t = e / (kC * kC);
+    E* dst = gw + (o * kTaps + t) * kC + i;
+    *dst = (E)(accumulate ? (float)*dst + s : s);
+  } else if (gb != nullptr) {
+    E* dst = gb + (e - kTaps * kC * kC);
+    *dst = (E)(accumulate ? (float)*dst + s : s);
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t nr_conv7_wgrad_workspace_bytes(void) { return (int64_t)kWMaxBlocks * kWPart * 4; }
+
+extern "C" int nr_conv7_wgrad(const void* x16, const void* grad_y16, void* grad_w16, void* grad_b16, int accumulate, void* workspace,
+                              int n_images, int height, int width, int dtype, nr_stream_t stream) {
+  if (!x16 || !grad_y16 || !grad_w16 || !workspace || n_images < 0 || height < 0 || width < 0 ||
+      (dtype != NR_DTYPE_BF16 && dtype != NR_DTYPE_F16) || (((uintptr_t)x16 | (uintptr_t)grad_y16 | (uintptr_t)workspace) & 15u) != 0)
+    return NR_EINVAL;
+  const int ty = (height + kTH - 1) / kTH, tx = (width + kTW - 1) / kTW;
+  const int64_t tiles = (int64_t)n_images * ty * tx;
+  const unsigned blocks = (unsigned)(tiles < kWMaxBlocks ? (tiles > 0 ? tiles : 1) : kWMaxBlocks);
+  float* part = static_cast<float*>(workspace);
+  const unsigned rblocks = (kWPart + 255) / 256;
+  if (dtype == NR_DTYPE_BF16) {
+    hipLaunchKernelGGL(conv7_wgrad_kernel<CBf16>, dim3(blocks), dim3(kThreads), 0, nr_s(stream), static_cast<const __bf16*>(x16),
+                       static_cast<const __bf16*>(grad_y16), part, n_images, height, width, ty, tx, tiles);
+    hipLaunchKernelGGL(conv7_wgrad_reduce_kernel<__bf16>, dim3(rblocks), dim3(256), 0, nr_s(stream), part, (int)blocks,
+                       static_cast<__bf16*>(grad_w16), static_cast<__bf16*>(grad_b16), accumulate);
+  } else {
+    hipLaunchKernelGGL(conv7_wgrad_kernel<CFp16>, dim3(blocks), dim3(kThreads), 0, nr_s(stream), static_cast<const _Float16*>(x16),
+                       static_cast<const _Float16*>(grad_y16), part, n_images, height, width, ty, tx, tiles);
+    hipLaunchKernelGGL(conv7_wgrad_reduce_kernel<_Float16>, dim3(rblocks), dim3(256), 0, nr_s(stream), part, (int)blocks,
+                       static_cast<_Float16*>(grad_w16), static_cast<_Float16*>(grad_b16), accumulate);
+  }
+  NR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int64_t nr_conv7_image_bytes(void) { return 2 * (int64_t)kImgAll; }
 

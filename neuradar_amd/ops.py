@@ -3,6 +3,7 @@
 Every function here launches hand-written gfx950 kernels on torch's current stream; tensors must live
 on a ROCm device.  torch is plumbing only (memory, streams, autograd bookkeeping).
 """
+import os
 from ctypes import byref, c_void_p
 from typing import List, Optional, Sequence, Tuple
 
@@ -904,14 +905,38 @@ def conv7_forward(x: Tensor, image: Tensor, residual: Optional[Tensor] = None, r
     return y
 
 
+_conv7_ws = {}
+
+
+def conv7_wgrad(x: Tensor, grad_y: Tensor, want_bias: bool = True, into: Optional[Tuple[Tensor, Optional[Tensor]]] = None):
+    """nr_conv7_wgrad: x, grad_y [P, 32, H, W] channels-last 16-bit -> (grad_weight, logically [32, 32, 7, 7] in the parameter's
+    channels-last memory [O, kh, kw, I]; grad_bias [32] or None), 16-bit, fp32 accumulation.  into = (weight.grad, bias.grad):
+    ADDED into those buffers instead (weight.grad in the same channels-last memory), returns (None, None)."""
+    P, C, H, W = x.shape
+    assert C == 32 and x.dtype in _DT16 and grad_y.dtype == x.dtype and grad_y.shape == x.shape
+    assert x.is_contiguous(memory_format=torch.channels_last) and grad_y.is_contiguous(memory_format=torch.channels_last)
+    ws = _conv7_ws.get(x.device)
+    if ws is None:
+        ws = _conv7_ws[x.device] = torch.empty(_lib.lib().nr_conv7_wgrad_workspace_bytes(), device=x.device, dtype=torch.uint8)
+    if into is not None:
+        check(_lib.lib().nr_conv7_wgrad(_p(x), _p(grad_y), _p(into[0]), _p(into[1]), 1, _p(ws), P, H, W, _DT16[x.dtype], _stream()),
+              "nr_conv7_wgrad")
+        return None, None
+    gw = torch.empty(32 * 49 * 32, device=x.device, dtype=x.dtype)
+    gb = torch.empty(32, device=x.device, dtype=x.dtype) if want_bias else None
+    check(_lib.lib().nr_conv7_wgrad(_p(x), _p(grad_y), _p(gw), _p(gb), 0, _p(ws), P, H, W, _DT16[x.dtype], _stream()), "nr_conv7_wgrad")
+    return gw.view(32, 7, 7, 32).permute(0, 3, 1, 2), gb
+
+
 class _Conv7(torch.autograd.Function):
     """Conv2d(32, 32, 7, padding=3) on channels-last 16-bit activations: forward and DATA gradient on nr_conv7_fwd (the two
-    orientations of the packed weights); the weight / bias gradients are the library's (aten.convolution_backward)."""
+    orientations of the packed weights), weight / bias gradient on nr_conv7_wgrad (NR_CONV7_WGRAD=0: aten.convolution_backward)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, images):
         ctx.save_for_backward(x, weight)
         ctx.images, ctx.has_bias = images, bias is not None
+        ctx.param_refs = (weight, bias)  # the caller's tensors (their .grad, for direct_param_grads)
         return conv7_forward(x, images[0])
 
     @staticmethod
@@ -920,7 +945,14 @@ class _Conv7(torch.autograd.Function):
         g = g.contiguous(memory_format=torch.channels_last)
         gx = conv7_forward(g, ctx.images[1]) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and os.environ.get("NR_CONV7_WGRAD", "1") != "0":
+            w_, b_ = ctx.param_refs
+            chl = (32 * 49, 1, 7 * 32, 32)  # the channels-last memory [O, kh, kw, I] of a [32, 32, 7, 7] tensor
+            direct = (_DIRECT_PARAM_GRADS and w_.is_leaf and w_.grad is not None and w_.grad.dtype == x.dtype and w_.grad.stride() == chl
+                      and (b_ is None or (b_.is_leaf and b_.grad is not None and b_.grad.dtype == x.dtype and b_.grad.is_contiguous())))
+            # (direct: added straight into the parameters' .grad buffers -- no temporaries, no AccumulateGrad adds)
+            gw, gb = conv7_wgrad(x, g, ctx.has_bias, into=(w_.grad, None if b_ is None else b_.grad) if direct else None)
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             _, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, [32] if ctx.has_bias else None, [1, 1], [3, 3], [1, 1], False,
                                                             [0, 0], 1, [False, True, ctx.has_bias])
         return gx, gw, gb, None

@@ -103,7 +103,11 @@ def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
         # by 2 lr after a step: the NORM of the difference is what can be bounded -- by a small multiple of the eager
         # path's own run-to-run spread, and absolutely
         print(f"{name:60s} replay vs eager {err:.2e}   eager vs eager {spread:.2e}")
-        bound = max(3.0 * spread, 3.0 * med[name.split(".")[0]], 2e-3)
+        # absolute floor: 2e-3, or four unit roundoffs of the operand type for the 16-bit workloads -- the library convolutions
+        # that remain in the decoder chain (1 x 1, transposed) cannot search for their algorithm inside a capture and may run
+        # another valid one than the eager step's: a different summation order = a different 16-bit rounding of their outputs
+        u = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}.get(mlp_dtype, 0.0)
+        bound = max(3.0 * spread, 3.0 * med[name.split(".")[0]], 2e-3, 4.0 * u)
         assert err <= bound, f"{name}: replay differs from eager by {err:.2e} of the update (eager spread {spread:.2e}, bound {bound:.2e})"
         checked += 1
     assert checked >= 4
