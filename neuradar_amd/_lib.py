@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 21
+NR_ABI_VERSION = 22
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
