@@ -878,8 +878,12 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             roof["all_hash_kernels_serialised_us"] = {k: round(v * 1e6, 2) for k, v in times_serial.items() if k.startswith("hash_encode")}
         # `bound` is the contract's field (hbm | mfma); what actually limits the dominant launch site is neither: the traffic
         # (FETCH + WRITE) is 0.6 x the algorithmic bytes, MFMA plays no role
-        roof["limiter"] = ("LDS capacity and LDS-atomic issue of the on-chip merge (bin pass 48 KB per block, apply pass 132 KB), plus the "
-                           "memory side's float-atomic path it shares with the two other scatters running beside it -- not HBM bandwidth")
+        if "main_s32" in dom["kernel"] and stepper is not None and stepper.main_shared:
+            roof["limiter"] = ("LDS-atomic issue of the block-shared table (one block per CU, 80 KB of LDS: CAS insert + 4 ds_add per merged run) and "
+                               "the 16-byte float atomics of its flush, on the memory-side atomic path shared with the proposal scatters -- not HBM bandwidth")
+        else:
+            roof["limiter"] = ("LDS capacity and LDS-atomic issue of the on-chip merge (bin pass 48 KB per block, apply pass 132 KB), plus the "
+                               "memory side's float-atomic path it shares with the two other scatters running beside it -- not HBM bandwidth")
         roof["mfma_busy_frac"] = pmc_mfma_busy(workload)
         bwd = [r for r in rows if "bwd" in r["kernel"]]
         if stepper is not None and len(bwd) in (2, 3):
@@ -1002,7 +1006,7 @@ def main():
                                "mlp_operands": fr["mlp_dtype"], "loss_scaler": fr["amp"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
                                "loss_after_run": fr["loss"], "render": fr["render"], "after_training": None,
-                               "decoders": "RGB CNN (MIOpen NHWC convolutions on 16-bit working copies, hand-written batch norm + ReLU + residual) + lidar MLP + "
+                               "decoders": "RGB CNN (7 x 7 convolutions: nr_conv7_fwd / nr_conv7_wgrad MFMA implicit GEMMs on 16-bit working copies; hand-written batch norm + ReLU + residual; 1 x 1 and transposed convolutions: library) + lidar MLP + "
                                            "radar transformer / heads; losses incl. the linear sum assignment on the device"})
             if args.full_model_trained_steps > 0:
                 # the same workload once the radar predictions have spread (the assignment's fast regime): same timing rules

@@ -16,7 +16,7 @@ import sys
 prefix, out_path = sys.argv[1], sys.argv[2]
 workload = sys.argv[3] if len(sys.argv) > 3 else "cam4096_l16f2_w64"
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-WANT = ("hash_encode", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel", "adam_kernel", "adam_marked_kernel")
+WANT = ("hash_encode", "scatter_shared_kernel", "field_", "prop_field_fwd", "bin_kernel", "apply_kernel", "adam_kernel", "adam_marked_kernel")
 
 
 def short(name):
@@ -76,7 +76,12 @@ for f in sorted(glob.glob(prefix + "*/out_counter_collection.csv")):
             # the main table's Adam is launched right behind the main grid's scatter, the proposal table's behind the apply
             # passes, the small parameters' (and any other buffer's) after those
             t = {"hash_encode_bwd": "main_table", "apply_kernel": "proposal_table"}.get(last_kind, "small_parameters")
+            if k.startswith("adam_marked_kernel"):  # only the main table's optimizer runs the marked kernel (dispatch order across
+                t = "main_table"                    # the step's streams differs from pass to pass)
             last_kind = "adam"
+        elif k.startswith("scatter_shared_kernel"):  # the main grid's block-shared scatter (grid_shared.hip): one launch site
+            last_kind = "hash_encode_bwd"
+            t = "main_s32"
         elif k.startswith("hash_encode_bwd"):
             last_kind = "hash_encode_bwd"
             t = bwd_tag(k, g, rows_full) or bwd_tag(k, g, rows_coh) or ("main_s32" if "kernel<4," in k or "kernel<2," in k else last_bwd)
