@@ -777,6 +777,18 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     elapsed = statistics.median(per_block)
     host_elapsed = statistics.median(b[1] for b in blocks)
     reducer.flush()  # (a deferred all-gather of the last step)
+    if args.gate_ms > 0 and world == 1:
+        # for a kernel trace: under rocprofv3 the host needs longer to submit a replay than the GPU to run it, and the trace
+        # shows the submission order instead of the step.  Hold the stream with a spinning kernel, submit a few replays behind it,
+        # release: their kernels then start as early as their dependencies allow (tools/timeline.py --overlapped reads the last one)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
+        per_ms = 10_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        torch.cuda._sleep(int(args.gate_ms * per_ms))
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
     if args.check_replicas and world > 1:
         for name, prm in model.named_parameters():
             ref = prm.detach().clone()
@@ -934,6 +946,8 @@ def main():
                     help="comma-separated decoder workloads (BASELINE configs[2] full / [3] / [4] per-GPU shapes) reported in the same line; '' = none")
     ap.add_argument("--full-model-trained-steps", type=int, default=300, help="report every full-model workload again after this many "
                     "training steps (block `after_training`: the radar predictions have left the one-cluster state of a fresh model); 0 = skip")
+    ap.add_argument("--gate-ms", type=float, default=0.0, help="after the timed blocks: six more steps submitted behind a kernel that "
+                    "spins this long (for rocprofv3 kernel traces: a timeline that is not bound by the traced host's submission rate)")
     ap.add_argument("--no-render", action="store_true", help="skip the rendering-entry block of the full-model workloads")
     ap.add_argument("--regime", default="fresh", choices=["fresh", "trained"], help="trained: the MAIN measurement itself runs in the "
                     "trained regime (--trained-steps steps on scene-consistent targets first; no separate `trained` block) -- for "

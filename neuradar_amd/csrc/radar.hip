@@ -225,6 +225,8 @@ lsa_kernel(const float* __restrict__ cost_all, const unsigned long long* __restr
   int* start_min = start_row + Q * NR_WAVE;
   float* cm_l = reinterpret_cast<float*>(lsa_lds + kLsaMaxCols / 32);  // afterwards (LDS_CM): [small][small]
   const int scan = blockIdx.x, lane = threadIdx.x;
+  // ONE wave per scan on the step's critical chain, sharing its SIMD with whatever else the step has in flight: highest issue priority
+  __builtin_amdgcn_s_setprio(3);
   const int m = seg[scan + 1] - seg[scan];
   int* assoc = assoc_all + (int64_t)scan * n_pred;  // per prediction: detection index or -1
   const bool tr = m > n_pred;

@@ -136,8 +136,10 @@ class DecoderLossHead:
                     self._bn_counters += [b.num_batches_tracked for b in blk.modules()
                                           if isinstance(b, torch.nn.BatchNorm2d) and b.num_batches_tracked is not None]
         self.overlap = os.environ.get("NR_DECODER_STREAMS", "1") != "0"
+        self.chainwise = os.environ.get("NR_DECODER_CHAINWISE", "1") != "0"  # backward chain by chain (see _backward_chainwise)
         self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
+        self._leaf_streams: Dict[str, torch.cuda.Stream] = {}
 
     def _cnn_shadow(self):
         """16-bit working copies of the RGB CNN's convolution weights / biases, instead of torch.autocast's per-parameter casts:
@@ -218,6 +220,80 @@ class DecoderLossHead:
             self._static_scale = (torch.full((1,), self.cnn_loss_scale, device=dev), torch.full((1,), 1.0 / self.cnn_loss_scale, device=dev))
         return self._static_scale
 
+    def _chain_streams(self, device, cur):
+        """(lidar stream, radar stream): a stream each beside the CNN on the step's stream -- three concurrent branches, which
+        is as many as a captured step runs without losing more than the overlap wins (fused_step.py, `early`; with the step's
+        two proposal chains beside the segment the lidar chain is better off on the step's stream: NR_LIDAR_STREAM=main)."""
+        if not self.overlap:
+            return cur, cur
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        s_lidar = self._streams[0] if os.environ.get("NR_LIDAR_STREAM", "own") == "own" else cur
+        return s_lidar, self._streams[1]
+
+    def _leaf_stream(self, kind: str, device):
+        which = os.environ.get("NR_LEAF_STREAMS", "").split(",")
+        if kind not in which:
+            return None
+        if kind not in self._leaf_streams:
+            self._leaf_streams[kind] = torch.cuda.Stream(device=device)
+        return self._leaf_streams[kind]
+
+    def _lidar_chain(self, xs: Tensor, depth: Tensor, batch: Dict[str, Tensor], out: Dict[str, Tensor]) -> None:
+        """Lidar decoder + the quantile-masked lidar losses; xs [n,C]: the lidar rows of the decoders' input, depth [B] (current stream)."""
+        r0, n = self.layout["lidar"]
+        if n and "lidar" not in self._skip:
+            y = self.model.lidar_decoder(xs)
+            out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
+                                                                        batch["target_intensity"], r0, n, self.c)
+            self.last["lidar_y"] = y
+
+    def _radar_chain(self, xs: Tensor, depth_rows: Tensor, batch: Dict[str, Tensor], out: Dict[str, Tensor], seed_epoch: Optional[Tensor]) -> None:
+        """Radar transformer + heads + the matched radar loss; xs [n,C], depth_rows [n]: the radar rows (current stream)."""
+        r0, n = self.layout["radar"]
+        if n and "radar" not in self._skip:
+            ro = self.model.decode_radar(xs, depth_rows[:, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
+                                         seed_epoch=seed_epoch)
+            out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, self.c.radar_loss_type,
+                                                      mult=self.c.radar_mult, training=True, workspace=self.radar_ws)
+            self.last.update(radar_output=ro, assoc=assoc, radar_status=assoc.status)
+
+    def _camera_chain(self, xs: Tensor, batch: Dict[str, Tensor], out: Dict[str, Tensor]) -> None:
+        """RGB CNN + the image loss; xs [n,C]: the camera rows, patch after patch (current stream)."""
+        m, c = self.model, self.c
+        r0, n = self.layout["camera"]
+        if n and "cnn" not in self._skip:
+            # [P, h, w, C] rows ARE the channels-last layout of [P, C, h, w]; the convolution weights sit channels-last in the
+            # optimizer's buffer (fused_step.flatten_parameters), so MIOpen runs NHWC kernels on both without a layout copy.
+            # (NHWC input with NCHW weights made it fall back to its naive kernels: 28 ms per step.)
+            patches = xs.view(-1, self.patch, self.patch, xs.shape[-1]).permute(0, 3, 1, 2)
+            if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in m.rgb_decoder.parameters()):
+                patches = patches.contiguous()  # (a model whose parameters were not flattened: packed NCHW for both)
+            sh = self._cnn_shadow()
+            if sh:
+                with torch.no_grad():
+                    sh["flat16"].copy_(sh["flat32"])
+                    if sh.get("conv7") is not None:  # this step's weights into the convolution kernels' LDS images: one launch
+                        ops.conv7_pack(sh["flat16"], sh["conv7"][1], sh["conv7"][2], sh["conv7"][0])
+                scale = self._cnn_scale()
+                if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
+                    patches = _ScaleGrad.apply(patches, scale[1])
+                rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
+                if scale is not None:  # d loss / d rgb enters it multiplied by the loss scale
+                    rgb = _ScaleGrad.apply(rgb, scale[0])
+                self._shadow_used = True
+            elif self.cnn_autocast is not None:
+                with torch.autocast("cuda", dtype=self.cnn_autocast):
+                    rgb = m.rgb_decoder(patches)
+                rgb = rgb.float()
+            else:
+                rgb = m.rgb_decoder(patches)
+            if self._bn_counters and m.rgb_decoder.training:  # BatchNorm2d.forward's `num_batches_tracked += 1`
+                torch._foreach_add_(self._bn_counters, 1)
+            rgb = rgb.permute(0, 2, 3, 1)
+            out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
+            self.last["rgb"] = rgb
+
     def losses(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
                seed_epoch: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """features [B,C] rendered features, depth [B]; times [B], sensor_idx [B] int64 (appearance embedding); batch:
@@ -235,62 +311,20 @@ class DecoderLossHead:
         # CNN (autograd replays every node's backward on the stream of its forward, so the backward overlaps the same way):
         # the segment's critical path is its longest chain instead of their sum.  NR_DECODER_STREAMS=0: one stream.
         cur = torch.cuda.current_stream()
-        if self._streams is None and self.overlap:
-            self._streams = (torch.cuda.Stream(device=features.device), torch.cuda.Stream(device=features.device))
-        s_lidar, s_radar = self._streams if self.overlap else (cur, cur)
+        s_lidar, s_radar = self._chain_streams(features.device, cur)
         for s_ in (s_lidar, s_radar):
             if s_ is not cur:
                 s_.wait_stream(cur)
+        rows = lambda k: x[self.layout[k][0]:self.layout[k][0] + self.layout[k][1]]  # noqa: E731
+
         def side_chains():
-            r0, n = self.layout["lidar"]
-            if n and "lidar" not in self._skip:
-                with (torch.cuda.stream(s_lidar) if s_lidar is not cur else contextlib.nullcontext()):
-                    y = m.lidar_decoder(x[r0:r0 + n])
-                    out["lidar_losses"], self.last["lidar_stats"] = lidar_losses(depth, y, batch["did_return"], batch["range"],
-                                                                                batch["target_intensity"], r0, n, c)
-                    self.last["lidar_y"] = y
-            r0, n = self.layout["radar"]
-            if n and "radar" not in self._skip:
-                with (torch.cuda.stream(s_radar) if s_radar is not cur else contextlib.nullcontext()):
-                    ro = m.decode_radar(x[r0:r0 + n], depth[r0:r0 + n, None], batch["directions_spher"][r0:r0 + n], self.n_scans,
-                                        seed_epoch=seed_epoch)
-                    out["radar_loss"], assoc = ops.radar_loss(ro, batch["radar"], batch["radar_seg"], self.max_det, c.radar_loss_type,
-                                                              mult=c.radar_mult, training=True, workspace=self.radar_ws)
-                    self.last.update(radar_output=ro, assoc=assoc, radar_status=assoc.status)
+            with (torch.cuda.stream(s_lidar) if s_lidar is not cur else contextlib.nullcontext()):
+                self._lidar_chain(rows("lidar"), depth, batch, out)
+            with (torch.cuda.stream(s_radar) if s_radar is not cur else contextlib.nullcontext()):
+                self._radar_chain(rows("radar"), depth[self.layout["radar"][0]:self.layout["radar"][0] + self.layout["radar"][1]], batch, out, seed_epoch)
 
         def camera_chain():
-            r0, n = self.layout["camera"]
-            if n and "cnn" not in self._skip:
-                # [P, h, w, C] rows ARE the channels-last layout of [P, C, h, w]; the convolution weights sit channels-last in the
-                # optimizer's buffer (fused_step.flatten_parameters), so MIOpen runs NHWC kernels on both without a layout copy.
-                # (NHWC input with NCHW weights made it fall back to its naive kernels: 28 ms per step.)
-                patches = x[r0:r0 + n].view(-1, self.patch, self.patch, x.shape[-1]).permute(0, 3, 1, 2)
-                if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in m.rgb_decoder.parameters()):
-                    patches = patches.contiguous()  # (a model whose parameters were not flattened: packed NCHW for both)
-                sh = self._cnn_shadow()
-                if sh:
-                    with torch.no_grad():
-                        sh["flat16"].copy_(sh["flat32"])
-                        if sh.get("conv7") is not None:  # this step's weights into the convolution kernels' LDS images: one launch
-                            ops.conv7_pack(sh["flat16"], sh["conv7"][1], sh["conv7"][2], sh["conv7"][0])
-                    scale = self._cnn_scale()
-                    if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
-                        patches = _ScaleGrad.apply(patches, scale[1])
-                    rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
-                    if scale is not None:  # d loss / d rgb enters it multiplied by the loss scale
-                        rgb = _ScaleGrad.apply(rgb, scale[0])
-                    self._shadow_used = True
-                elif self.cnn_autocast is not None:
-                    with torch.autocast("cuda", dtype=self.cnn_autocast):
-                        rgb = m.rgb_decoder(patches)
-                    rgb = rgb.float()
-                else:
-                    rgb = m.rgb_decoder(patches)
-                if self._bn_counters and m.rgb_decoder.training:  # BatchNorm2d.forward's `num_batches_tracked += 1`
-                    torch._foreach_add_(self._bn_counters, 1)
-                rgb = rgb.permute(0, 2, 3, 1)
-                out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
-                self.last["rgb"] = rgb
+            self._camera_chain(rows("camera"), batch, out)
 
         if self.overlap:  # the side streams' launches first, the CNN beside them
             side_chains()
@@ -309,13 +343,17 @@ class DecoderLossHead:
                       loss_slots: Tensor, seed_epoch: Optional[Tensor] = None):
         """Run the segment on detached leaves of (features, depth), accumulate the parameter gradients into their .grad
         buffers and the loss value into loss_slots[-1]; returns (d loss / d features [B,C], d loss / d depth [B])."""
-        f = features.detach().requires_grad_(True)
-        d = depth.detach().requires_grad_(True)
-        with torch.enable_grad():
-            terms = self.losses(f, d, times, sensor_idx, batch, seed_epoch)
-            total = sum(terms.values())
-        with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
-            total.backward()
+        if self.overlap and self.chainwise:
+            total, terms, g_f, g_d = self._backward_chainwise(features, depth, times, sensor_idx, batch, seed_epoch)
+        else:
+            f = features.detach().requires_grad_(True)
+            d = depth.detach().requires_grad_(True)
+            with torch.enable_grad():
+                terms = self.losses(f, d, times, sensor_idx, batch, seed_epoch)
+                total = sum(terms.values())
+            with ops.direct_param_grads():  # the MLP kernels add into the parameters' .grad buffers themselves
+                total.backward()
+            g_f, g_d = f.grad, (d.grad if d.grad is not None else torch.zeros_like(depth))
         if self._shadow and getattr(self, "_shadow_used", False):
             # the CNN's 16-bit gradients into the fp32 gradient buffer (which holds the batch-norm parameters' gradients of this
             # step -- the optimizers clear gradients every step), unscaled, the 16-bit buffer cleared, found-inf flagged: one launch
@@ -331,5 +369,78 @@ class DecoderLossHead:
             self._shadow_used = False
         loss_slots[-1:].add_(total.detach().reshape(1))  # (the LAST entry: FusedTrainStep keeps it free of the kernels' atomics)
         self.last["terms"] = {k: v.detach() for k, v in terms.items()}
-        g_d = d.grad if d.grad is not None else torch.zeros_like(depth)
-        return f.grad, g_d
+        return g_f, g_d
+
+    def _backward_chainwise(self, features: Tensor, depth: Tensor, times: Tensor, sensor_idx: Tensor, batch: Dict[str, Tensor],
+                            seed_epoch: Optional[Tensor]):
+        """The segment as three independent forward + backward chains, each entirely on its own stream, cut at the decoders'
+        common input x = [features | appearance embedding]: every chain differentiates its loss down to ITS rows of x (a
+        detached leaf), the three row blocks are written into one [B, C] buffer and x's own backward (the appearance concat)
+        runs once, after the join.  Same numbers as one `backward()` over the sum of the terms (the row blocks are disjoint).
+        Why not leave it to autograd: its engine runs the three chains' backward nodes one chain after the other and orders
+        each stream switch behind everything launched so far on the producing stream -- measured (rocprofv3 timeline of the
+        captured step): CNN backward -> radar backward -> lidar backward strictly in sequence, the
+        segment's length their SUM (4.36 ms per step; with the lidar chain alone removed 3.72)."""
+        m = self.model
+        f = features.detach().requires_grad_(True)
+        with torch.enable_grad():
+            if m.config.appearance_dim > 0:
+                x = ops.appearance_concat(f, m.appearance_embedding.weight, times, sensor_idx, m.config.duration, m._num_embeds_per_sensor)
+            else:
+                x = f.view_as(f)
+        xd, dd = x.detach(), depth.detach()
+        B = xd.shape[0]
+        segs = {k: self.layout[k] for k in ("camera", "lidar", "radar")}
+        live = {k: (r0, n) for k, (r0, n) in segs.items() if n and {"camera": "cnn"}.get(k, k) not in self._skip}
+        covered = sum(n for _, n in live.values()) == B
+        g_x = torch.empty_like(xd) if covered else torch.zeros_like(xd)
+        g_depth = [None, None]
+        cur = torch.cuda.current_stream()
+        s_lidar, s_radar = self._chain_streams(features.device, cur)
+        terms: Dict[str, Tensor] = {}
+
+        def run(kind, stream):
+            if kind not in live:
+                return
+            r0, n = live[kind]
+            if stream is not cur:
+                stream.wait_stream(cur)
+            with (torch.cuda.stream(stream) if stream is not cur else contextlib.nullcontext()):
+                xl = xd[r0:r0 + n].requires_grad_(True)  # the chain's rows of x: a leaf of its own
+                out: Dict[str, Tensor] = {}
+                with torch.enable_grad():
+                    if kind == "lidar":
+                        dl = depth.detach().requires_grad_(True)
+                        self._lidar_chain(xl, dl, batch, out)
+                    elif kind == "radar":
+                        dr = dd[r0:r0 + n].requires_grad_(True)  # (the rendered points xyz = origin + depth * direction carry a gradient)
+                        self._radar_chain(xl, dr, batch, out, seed_epoch)
+                    else:
+                        self._camera_chain(xl, batch, out)
+                    loss = sum(out.values())
+                # the MLP / convolution kernels add into the parameters' .grad buffers themselves; the CNN's and the transformer's
+                # weight-gradient launches (leaves of the backward) on a stream beside the chain's (NR_LEAF_STREAMS=0: on it)
+                with ops.direct_param_grads(), ops.leaf_grad_stream(self._leaf_stream(kind, features.device)):
+                    loss.backward()
+                g_x[r0:r0 + n].copy_(xl.grad)
+                if kind == "lidar" and dl.grad is not None:
+                    g_depth[0] = dl.grad  # [B], zero outside the lidar rows
+                if kind == "radar" and dr.grad is not None:
+                    g_depth[1] = (r0, n, dr.grad)
+                terms.update(out)
+
+        # the side streams' launches first, the CNN beside them on the step's stream
+        run("lidar", s_lidar)
+        run("radar", s_radar)
+        run("camera", cur)
+        for s_ in (s_lidar, s_radar):
+            if s_ is not cur:
+                cur.wait_stream(s_)
+        total = sum(v.detach() for v in terms.values())
+        with ops.direct_param_grads():
+            x.backward(g_x)
+        g_d = g_depth[0] if g_depth[0] is not None else torch.zeros_like(dd)
+        if g_depth[1] is not None:
+            r0, n, g_ = g_depth[1]
+            g_d[r0:r0 + n].copy_(g_)  # (disjoint from the lidar rows)
+        return total, terms, f.grad, g_d

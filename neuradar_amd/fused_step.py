@@ -540,12 +540,14 @@ class FusedTrainStep:
             # data parallel: both proposal chains before field_bwd for camera-only batches (the 25-MB proposal table's
             # all-reduce starts earlier); mixed batches run the main grid's scatter and exchange first instead (`order`)
             early = 1 if reducer is not None and self.sm >= B else 0
-            # with the decoders in the step: both proposal chains BEFORE the decoder segment.  Their inputs (the three levels'
-            # weights, spacings and densities) exist once the forward has composited -- the inter-level loss does not see the
-            # decoders -- and the segment is ~560 small dependent launches that leave the chip idle: the two bin + apply pairs
-            # (0.73 ms of kernel time) run beside it instead of beside the main table's scatter and Adam afterwards.
-            # (data parallel as well: the proposal table's all-reduce then also starts before the decoder segment)
-            if self.dec is not None and os.environ.get("NR_PROP_BESIDE_DECODERS", "1") != "0":
+            # with the decoders in the step, NR_PROP_BESIDE_DECODERS=1: both proposal chains BEFORE the decoder segment.  Their
+            # inputs (the three levels' weights, spacings and densities) exist once the forward has composited -- the inter-level
+            # loss does not see the decoders -- so the two bin + apply pairs (0.73 ms of kernel time) can run beside the segment's
+            # ~300 small dependent launches.  Round 3's default; no longer: a captured step in which MORE THAN THREE branches are
+            # in flight at once loses more than the overlap wins (same call, fp16 full-model workload, trained regime: CNN + lidar
+            # on one stream, radar, two proposal chains = 4 branches 4.02 ms; the lidar chain on a stream of its own = 5 branches
+            # 4.16; the proposal chains behind the segment and CNN | lidar | radar = 3 branches 3.79 -- DESIGN.md section 10)
+            if self.dec is not None and os.environ.get("NR_PROP_BESIDE_DECODERS", "0") != "0":
                 early = 5
         split_reduce = early in (3, 4)  # 3 / 4: schedule 0 / 2 + the reduce on side[0]
         # Order of the three table scatters.  "concurrent" (single process): all at once -- 2.5 % faster than either serial
@@ -657,15 +659,18 @@ class FusedTrainStep:
         if merged and before:
             before = (0, 1)  # (a merged scatter needs both heads: the early-fork schedules start both chains early)
 
+        # (experiment knob: both early chains on ONE side stream, one after the other -- one concurrent branch less beside the decoders)
+        one_stream = early == 5 and os.environ.get("NR_PROP_ONE_STREAM", "0") == "1" and side[1] is not main
+
         def start_chains_before():
             """The proposal chains the schedule starts early: before nr_field_bwd, or (5) before the decoder segment."""
             for i_ in before:
-                if side[i_] is not main:
+                if side[i_] is not main and not (one_stream and i_ == 0):
                     side[i_].wait_stream(main)
             for i_ in before:
                 # (merged: both heads and the scatter on ONE side stream -- a capture in which the two side streams wait for each
                 # other in turn crashed hipStreamEndCapture on this ROCm build; the heads are ~80 us each)
-                with torch.cuda.stream(side[1] if merged else side[i_]):
+                with torch.cuda.stream(side[1] if (merged or one_stream) else side[i_]):
                     chain_head(chains[i_][0])
                     if not merged:
                         chain_scatter(chains[i_][0])

