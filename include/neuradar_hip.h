@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 22
+#define NR_ABI_VERSION 23
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -203,6 +203,54 @@ int nr_conv7_fwd(const void* x16, const void* image, const void* residual16, int
 int64_t nr_conv7_wgrad_workspace_bytes(void);
 int nr_conv7_wgrad(const void* x16, const void* grad_y16, void* grad_w16, void* grad_b16, int accumulate, void* workspace,
                    int n_images, int height, int width, int dtype, nr_stream_t stream);
+
+/* The radar decoder's encoder layer around the attention (detr/models/transformer.py:176-189 `forward_pre` of
+ * TransformerEncoderLayer(d_model = C, nhead = 1, dim_feedforward = FF, dropout = p, normalize_before = True), followed by the
+ * encoder's final LayerNorm, transformer.py:66-68 -- what models/neuradar.py:463-491 runs per radar scan), encoder.hip:
+ *   nr_encoder_pre_fwd   x2 = LN1(x);  [q | k] = (x2 + pos) Wqk^T + bqk;  v = x2 Wv^T + bv        (in_proj rows 0..2C | 2C..3C)
+ *   (nr_attention_fwd:   att = softmax(q k^T / sqrt(C)) v, dropout on the probabilities)
+ *   nr_encoder_post_fwd  x1 = x + drop(att Wo^T + bo);  x3 = x1 + drop(W2 drop(relu(W1 LN2(x1) + b1)) + b2);  out = LNf(x3)
+ *   nr_encoder_post_bwd  grad_out -> grad_att, grad_x1 (the residual path's share of d x) and the gradients of Wo, W1, W2,
+ *                        LN2, LNf; recomputes the forward from (x, att)
+ *   (nr_attention_bwd:   grad_att -> grad_q, grad_k, grad_v)
+ *   nr_encoder_pre_bwd   grad_q / k / v, grad_x1 -> grad_x and the gradients of the in-projection and LN1 (pos: a constant)
+ * All arrays fp32 [n, C] row-major (n = tokens of all scans; the layer is row-wise outside the attention); fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: an fp32 fma chain, like the MLP kernels).  C <= 64 (multiple of 4), FF <= 64.
+ * Dropout (training): keep decisions are a counter-based hash of (seed + *seed_epoch, site, row, feature) that forward and
+ * backward reproduce; p_drop = 0 in eval mode.  Gradients are "+=". */
+typedef struct nr_encoder {
+  const float* in_proj_weight;  /* [3C, C] */
+  const float* in_proj_bias;    /* [3C] */
+  const float* out_proj_weight; /* [C, C] */
+  const float* out_proj_bias;   /* [C] */
+  const float* linear1_weight;  /* [FF, C] */
+  const float* linear1_bias;    /* [FF] */
+  const float* linear2_weight;  /* [C, FF] */
+  const float* linear2_bias;    /* [C] */
+  const float* norm1_weight; const float* norm1_bias;   /* [C] each */
+  const float* norm2_weight; const float* norm2_bias;
+  const float* norm_weight;  const float* norm_bias;    /* the encoder's final LayerNorm */
+  int d_model, dim_feedforward;
+  float eps;                    /* LayerNorm eps (1e-5) */
+  float p_drop;
+  uint32_t seed;
+  const float* seed_epoch;      /* nullable device-resident step counter folded into the seed (captured graphs) */
+} nr_encoder_t;
+
+typedef struct nr_encoder_grads {  /* all "+=", any pointer may be NULL */
+  float* in_proj_weight; float* in_proj_bias; float* out_proj_weight; float* out_proj_bias;
+  float* linear1_weight; float* linear1_bias; float* linear2_weight; float* linear2_bias;
+  float* norm1_weight; float* norm1_bias; float* norm2_weight; float* norm2_bias; float* norm_weight; float* norm_bias;
+} nr_encoder_grads_t;
+
+int nr_encoder_pre_fwd(const nr_encoder_t* enc, const float* x, const float* pos, int64_t n, float* q, float* k, float* v,
+                       nr_stream_t stream);
+int nr_encoder_post_fwd(const nr_encoder_t* enc, const float* x, const float* att, int64_t n, float* out, nr_stream_t stream);
+int nr_encoder_post_bwd(const nr_encoder_t* enc, const float* x, const float* att, const float* grad_out, int64_t n,
+                        float* grad_att, float* grad_x1, const nr_encoder_grads_t* grads, nr_stream_t stream);
+int nr_encoder_pre_bwd(const nr_encoder_t* enc, const float* x, const float* pos, const float* grad_q, const float* grad_k,
+                       const float* grad_v, const float* grad_x1, int64_t n, float* grad_x, const nr_encoder_grads_t* grads,
+                       nr_stream_t stream);
 
 /* Radar point-set loss on the device (model_components/radar_utils.py:54-168, called from
  * models/neuradar.py:652-662): the reference copies a cost matrix to the host and runs scipy's linear_sum_assignment per scan

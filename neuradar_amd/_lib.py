@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 22
+NR_ABI_VERSION = 23
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -41,6 +41,19 @@ class NrField(Structure):
 
 class NrConv7List(Structure):
     _fields_ = [("n", c_int), ("offset", c_int64 * 16), ("bias_offset", c_int64 * 16)]
+
+
+_ENC_PARAMS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "linear1_weight", "linear1_bias",
+               "linear2_weight", "linear2_bias", "norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias", "norm_weight", "norm_bias")
+
+
+class NrEncoder(Structure):
+    _fields_ = [(k, c_void_p) for k in _ENC_PARAMS] + [("d_model", c_int), ("dim_feedforward", c_int), ("eps", c_float),
+                                                       ("p_drop", c_float), ("seed", c_uint32), ("seed_epoch", c_void_p)]
+
+
+class NrEncoderGrads(Structure):
+    _fields_ = [(k, c_void_p) for k in _ENC_PARAMS]
 
 
 class NrLidarSup(Structure):
@@ -91,6 +104,10 @@ PROTOTYPES = {
     "nr_conv7_fwd": [P, P, P, I, P, I, I, I, I, P],
     "nr_conv7_wgrad_workspace_bytes": [],
     "nr_conv7_wgrad": [P, P, P, P, I, P, I, I, I, I, P],
+    "nr_encoder_pre_fwd": [P, P, P, L, P, P, P, P],
+    "nr_encoder_post_fwd": [P, P, P, L, P, P],
+    "nr_encoder_post_bwd": [P, P, P, P, L, P, P, P, P],
+    "nr_encoder_pre_bwd": [P, P, P, P, P, P, P, L, P, P, P],
     "nr_bn_act_workspace_floats": [L, I],
     "nr_bn_act_fwd": [P, P, L, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "nr_bn_act_bwd": [P, P, P, L, I, I, P, P, P, I, P, P, P, P, P, P],

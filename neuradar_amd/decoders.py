@@ -120,7 +120,19 @@ class Transformer(nn.Module):
 
     def forward(self, src: Tensor, pos: Tensor, seed_epoch: Optional[Tensor] = None) -> Tensor:
         """src, pos [N, n, C] -> [N, n, C]."""
-        return self.encoder.norm(self.encoder.layers[0](src, pos, seed_epoch))
+        import os
+
+        from . import ops
+
+        lyr = self.encoder.layers[0]
+        if (lyr.attention == "hip" and src.is_cuda and (src.shape[-1], lyr.linear1.out_features) in ops.ENCODER_WIDTHS
+                and os.environ.get("NR_FUSED_ENCODER", "1") != "0"):
+            # the whole layer + the final norm on nr_encoder_* around nr_attention_* (six launches each way instead of ~67)
+            p = lyr.p_drop if self.training else 0.0
+            if p > 0:
+                lyr.dropout_step += 1
+            return ops.encoder_layer(src, pos, lyr, self.encoder.norm, p, seed=lyr._dropout_seed(), seed_epoch=seed_epoch if p > 0 else None)
+        return self.encoder.norm(lyr(src, pos, seed_epoch))
 
 
 class BasicBlock(nn.Module):

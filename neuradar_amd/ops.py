@@ -272,6 +272,80 @@ def attention(q: Tensor, k: Tensor, v: Tensor, dropout_p: float = 0.0, seed: int
                             None if keep_mask is None else keep_mask.contiguous().float(), seed_epoch)
 
 
+class _EncoderLayer(torch.autograd.Function):
+    """nr_encoder_pre_fwd -> nr_attention_fwd -> nr_encoder_post_fwd and their backwards: the radar decoder's pre-norm encoder
+    layer + the encoder's final LayerNorm (detr/models/transformer.py:176-189, :66-68), six launches each way."""
+
+    @staticmethod
+    def _struct(params, C, FF, eps, p_drop, seed, seed_epoch):
+        enc = _lib.NrEncoder()
+        for name, t in zip(_lib._ENC_PARAMS, params):
+            setattr(enc, name, t.data_ptr())
+        enc.d_model, enc.dim_feedforward, enc.eps, enc.p_drop, enc.seed = C, FF, float(eps), float(p_drop), int(seed) & 0xFFFFFFFF
+        enc.seed_epoch = seed_epoch.data_ptr() if seed_epoch is not None else None
+        return enc
+
+    @staticmethod
+    def forward(ctx, x, pos, cfg, *params):
+        p_drop, seed, seed_epoch, eps = cfg
+        x, pos = _f32(x, "x"), _f32(pos, "pos")
+        N, n, C = x.shape
+        FF = params[4].shape[0]
+        lib = _lib.lib()
+        enc = _EncoderLayer._struct(params, C, FF, eps, p_drop, seed, seed_epoch)
+        q, k, v, att, out = (torch.empty_like(x) for _ in range(5))
+        lse = torch.empty((N, n), device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(int(lib.nr_attention_workspace_floats(N, n, C)), 1), device=x.device, dtype=torch.float32)
+        check(lib.nr_encoder_pre_fwd(byref(enc), _p(x), _p(pos), N * n, _p(q), _p(k), _p(v), _stream()), "nr_encoder_pre_fwd")
+        check(lib.nr_attention_fwd(_p(q), _p(k), _p(v), N, n, C, float(p_drop), int(seed) & 0xFFFFFFFF, _p(seed_epoch), None, _p(att),
+                                   _p(lse), _p(ws), _stream()), "nr_attention_fwd")
+        check(lib.nr_encoder_post_fwd(byref(enc), _p(x), _p(att), N * n, _p(out), _stream()), "nr_encoder_post_fwd")
+        ctx.save_for_backward(x, pos, q, k, v, att, lse, *params)
+        ctx.cfg, ctx.ws, ctx.param_refs = (p_drop, seed, seed_epoch, eps, FF), ws, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, pos, q, k, v, att, lse, *params = ctx.saved_tensors
+        p_drop, seed, seed_epoch, eps, FF = ctx.cfg
+        N, n, C = x.shape
+        lib = _lib.lib()
+        enc = _EncoderLayer._struct(params, C, FF, eps, p_drop, seed, seed_epoch)
+        refs = ctx.param_refs
+        direct = _DIRECT_PARAM_GRADS and all(p.is_leaf and p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32
+                                             and p.grad.is_contiguous() for p in refs)
+        # (direct: added straight into the parameters' .grad buffers; otherwise zero-filled temporaries handed to autograd)
+        gp = [p.grad for p in refs] if direct else [torch.zeros_like(p) for p in params]
+        grads = _lib.NrEncoderGrads()
+        for name, t in zip(_lib._ENC_PARAMS, gp):
+            setattr(grads, name, t.data_ptr())
+        g = _f32(g.contiguous(), "grad_out")
+        g_att, g_x1, g_x = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        gq, gk, gv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        check(lib.nr_encoder_post_bwd(byref(enc), _p(x), _p(att), _p(g), N * n, _p(g_att), _p(g_x1), byref(grads), _stream()),
+              "nr_encoder_post_bwd")
+        check(lib.nr_attention_bwd(_p(q), _p(k), _p(v), _p(att), _p(lse), _p(g_att), N, n, C, float(p_drop), int(seed) & 0xFFFFFFFF,
+                                   _p(seed_epoch), None, _p(gq), _p(gk), _p(gv), _p(ctx.ws), _stream()), "nr_attention_bwd")
+        check(lib.nr_encoder_pre_bwd(byref(enc), _p(x), _p(pos), _p(gq), _p(gk), _p(gv), _p(g_x1), N * n, _p(g_x), byref(grads),
+                                     _stream()), "nr_encoder_pre_bwd")
+        return (g_x, None, None) + tuple(None if direct else t for t in gp)
+
+
+ENCODER_WIDTHS = ((32, 64), (48, 64), (64, 64))  # (d_model, dim_feedforward) the encoder kernels are built for
+
+
+def encoder_layer(x: Tensor, pos: Tensor, layer, final_norm, p_drop: float = 0.0, seed: int = 0, seed_epoch: Optional[Tensor] = None) -> Tensor:
+    """final_norm(forward_pre(layer)(x, pos)) for x, pos [N, n, C] (N scans of n tokens; attention inside a scan): `layer` with the
+    reference's TransformerEncoderLayer parameters (self_attn.in_proj_*, self_attn.out_proj, linear1, linear2, norm1, norm2),
+    nhead = 1.  pos is a constant.  p_drop: the three dropouts and the attention's (0 in eval mode)."""
+    a = layer.self_attn
+    params = (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, layer.linear1.weight, layer.linear1.bias,
+              layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias,
+              final_norm.weight, final_norm.bias)
+    assert (x.shape[-1], layer.linear1.out_features) in ENCODER_WIDTHS and layer.norm1.eps == layer.norm2.eps == final_norm.eps
+    return _EncoderLayer.apply(x.contiguous(), pos.contiguous(), (float(p_drop), int(seed), seed_epoch, float(layer.norm1.eps)), *params)
+
+
 class _Field(torch.autograd.Function):
     """nr_field_fwd/bwd: feats (+ strides) -> feature, sdf, alpha."""
 

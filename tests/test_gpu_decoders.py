@@ -204,8 +204,9 @@ def test_transformer_layer_with_hip_attention(monkeypatch):
         (y * wgt).sum().backward()
         return y.detach().cpu(), x.grad.cpu()
 
-    y_hip, g_hip = run(hip)
+    y_hip, g_hip = run(hip)  # (the fused layer: nr_encoder_* around nr_attention_*)
     y_tor, g_tor = run(tor)
+    monkeypatch.setenv("NR_FUSED_ENCODER", "0")  # the reference: the modular layer (torch ops) with its attention in float64
     monkeypatch.setattr(ops, "attention", lambda q, k, v, p, seed=0, seed_epoch=None: _attention_reference(q, k, v, None, 0.0).float())
     y_ref, g_ref = run(hip)
     assert_close(y_hip, y_ref, rtol=1e-4, atol_scale=1e-5, what="encoder output, hip attention")
