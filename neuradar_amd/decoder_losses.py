@@ -140,6 +140,7 @@ class DecoderLossHead:
         self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
         self._leaf_streams: Dict[str, torch.cuda.Stream] = {}
+        self._one = None
 
     def _cnn_shadow(self):
         """16-bit working copies of the RGB CNN's convolution weights / biases, instead of torch.autocast's per-parameter casts:
@@ -397,6 +398,8 @@ class DecoderLossHead:
         g_depth = [None, None]
         cur = torch.cuda.current_stream()
         s_lidar, s_radar = self._chain_streams(features.device, cur)
+        if self._one is None:
+            self._one = torch.ones((), device=features.device)
         terms: Dict[str, Tensor] = {}
 
         def run(kind, stream):
@@ -417,11 +420,12 @@ class DecoderLossHead:
                         self._radar_chain(xl, dr, batch, out, seed_epoch)
                     else:
                         self._camera_chain(xl, batch, out)
-                    loss = sum(out.values())
-                # the MLP / convolution kernels add into the parameters' .grad buffers themselves; the CNN's and the transformer's
-                # weight-gradient launches (leaves of the backward) on a stream beside the chain's (NR_LEAF_STREAMS=0: on it)
+                    vals = list(out.values())
+                    loss = vals[0] if len(vals) == 1 else sum(vals[1:], vals[0])  # (python's sum starts at 0: one more launch)
+                # the MLP / convolution / encoder kernels add into the parameters' .grad buffers themselves (NR_LEAF_STREAMS: the
+                # CNN's weight-gradient launches on a stream beside the chain's -- an experiment knob, off: a fourth branch)
                 with ops.direct_param_grads(), ops.leaf_grad_stream(self._leaf_stream(kind, features.device)):
-                    loss.backward()
+                    loss.backward(self._one)  # (a cached 1.0: no ones_like launch per chain)
                 g_x[r0:r0 + n].copy_(xl.grad)
                 if kind == "lidar" and dl.grad is not None:
                     g_depth[0] = dl.grad  # [B], zero outside the lidar rows
