@@ -1,3 +1,4 @@
+# (NR_MAIN_LEVEL_GROUPS was an experiment knob of FusedTrainStep, removed after this measurement: DESIGN.md section 10, "tried and dropped")
 # The main grid's scatter in groups of levels with the table's Adam of each group on a stream beside the next group's scatter
 # (NR_MAIN_LEVEL_GROUPS): headline workload, fresh and trained regime, same call.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lvl; mkdir -p $O; rm -f $O/ab.txt; cd $R
