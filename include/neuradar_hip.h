@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 23
+#define NR_ABI_VERSION 24
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -203,6 +203,28 @@ int nr_conv7_fwd(const void* x16, const void* image, const void* residual16, int
 int64_t nr_conv7_wgrad_workspace_bytes(void);
 int nr_conv7_wgrad(const void* x16, const void* grad_y16, void* grad_w16, void* grad_b16, int accumulate, void* workspace,
                    int n_images, int height, int width, int dtype, nr_stream_t stream);
+
+/* The RGB decoder's pointwise convolutions on channels-last activations (pw.hip; models/neuradar.py:225-240: Conv2d(C_in, 32, 1)
+ * + ReLU at its head, ConvTranspose2d(32, 32, 3, stride=3) between the block pairs, Conv2d(32, 3, 1) + Sigmoid at its tail):
+ *   y[p, n] = act(b[n] + sum_k x[p, k] W[n, k]),  act: 0 none, 1 ReLU, 2 sigmoid;  fp32 accumulation.
+ * x [n_pixels, in_channels] fp32 (x_f32 != 0) or 16-bit; y [n_pixels, out_channels] 16-bit or fp32 (y_f32 != 0); w16 / b16 the
+ * parameters in `dtype16` (NR_DTYPE_BF16 / NR_DTYPE_F16): a Conv2d weight [out, in, 1, 1] (= [out][in] in memory).
+ * transposed != 0: the ConvTranspose2d(3, stride 3) weight [in, out, 3, 3] in its CHANNELS-LAST memory [in][ky][kx][out]; x are
+ * n_pixels = images * height * width input pixels, y / grad_y have images * 3 height * 3 width pixels of out_channels, pixel
+ * (y, x) of an image owning output pixels (3y + ky, 3x + kx).  in_channels 32 or 48, out_channels <= 32 (a multiple of 8 when
+ * transposed).  16-byte aligned arrays.
+ *   nr_pw_bwd_data:   grad_x = scale[0] * (grad_y * act'(y)) W  (scale: nullable device float -- the inverse loss scale)
+ *   nr_pw_bwd_weight: grad_w16 / grad_b16 (the parameters' memory; nullable bias) = or += (accumulate) the sums over the pixels,
+ *                     via per-block partials in `workspace` (nr_pw_workspace_bytes() bytes) + a reduce launch. */
+int nr_pw_fwd(const void* x, int x_f32, const void* w16, const void* b16, void* y, int y_f32, int64_t n_pixels, int in_channels,
+              int out_channels, int act, int transposed, int height, int width, int dtype16, nr_stream_t stream);
+int nr_pw_bwd_data(const void* grad_y, const void* y, int y_f32, const void* w16, void* grad_x, int x_f32, int64_t n_pixels,
+                   int in_channels, int out_channels, int act, int transposed, int height, int width, const float* scale, int dtype16,
+                   nr_stream_t stream);
+int64_t nr_pw_workspace_bytes(void);
+int nr_pw_bwd_weight(const void* x, int x_f32, const void* grad_y, const void* y, int y_f32, void* grad_w16, void* grad_b16,
+                     int accumulate, void* workspace, int64_t n_pixels, int in_channels, int out_channels, int act, int transposed,
+                     int height, int width, int dtype16, nr_stream_t stream);
 
 /* The radar decoder's encoder layer around the attention (detr/models/transformer.py:176-189 `forward_pre` of
  * TransformerEncoderLayer(d_model = C, nhead = 1, dim_feedforward = FF, dropout = p, normalize_before = True), followed by the

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 23
+NR_ABI_VERSION = 24
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -104,6 +104,10 @@ PROTOTYPES = {
     "nr_conv7_fwd": [P, P, P, I, P, I, I, I, I, P],
     "nr_conv7_wgrad_workspace_bytes": [],
     "nr_conv7_wgrad": [P, P, P, P, I, P, I, I, I, I, P],
+    "nr_pw_fwd": [P, I, P, P, P, I, L, I, I, I, I, I, I, I, P],
+    "nr_pw_bwd_data": [P, P, I, P, P, I, L, I, I, I, I, I, I, P, I, P],
+    "nr_pw_workspace_bytes": [],
+    "nr_pw_bwd_weight": [P, I, P, P, I, P, P, I, P, L, I, I, I, I, I, I, I, P],
     "nr_encoder_pre_fwd": [P, P, P, L, P, P, P, P],
     "nr_encoder_post_fwd": [P, P, P, L, P, P],
     "nr_encoder_post_bwd": [P, P, P, P, L, P, P, P, P],
@@ -187,7 +191,7 @@ _RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int6
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
              "nr_radar_assign_workspace_bytes": c_int64, "nr_radar_assign_status_offset": c_int64,
              "nr_bn_act_workspace_floats": c_int64, "nr_conv7_image_bytes": c_int64,
-             "nr_conv7_wgrad_workspace_bytes": c_int64}
+             "nr_conv7_wgrad_workspace_bytes": c_int64, "nr_pw_workspace_bytes": c_int64}
 
 _lib = None
 

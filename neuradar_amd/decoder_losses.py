@@ -198,6 +198,25 @@ class DecoderLossHead:
                 self._shadow["conv7"] = (images, w_off, b_off)
                 for i, (_, blk) in enumerate(blocks):
                     blk.conv7_images = (images[2 * i], images[2 * i + 1])
+        # the reference's decoder shape (neuradar.py:225-240): Conv2d 1 x 1 + ReLU | 2 blocks | ConvTranspose2d 3 / 3 | 2 blocks |
+        # Conv2d 1 x 1 + Sigmoid -- its three pointwise layers on nr_pw_* (NR_PW=0: the library's)
+        self._shadow["pointwise"] = None
+        if self._shadow["conv7"] is not None and os.environ.get("NR_PW", "1") != "0" and len(mod) == 9:
+            from .decoders import BasicBlock
+
+            c0, r1, t4, c7, s8 = mod[0], mod[1], mod[4], mod[7], mod[8]
+            shape_ok = (isinstance(c0, torch.nn.Conv2d) and isinstance(r1, torch.nn.ReLU) and isinstance(t4, torch.nn.ConvTranspose2d)
+                        and isinstance(c7, torch.nn.Conv2d) and isinstance(s8, torch.nn.Sigmoid)
+                        and all(isinstance(mod[i_], BasicBlock) for i_ in (2, 3, 5, 6))
+                        and c0.kernel_size == (1, 1) and c7.kernel_size == (1, 1) and c0.in_channels in (32, 48) and c0.out_channels == 32
+                        and t4.kernel_size == (3, 3) and t4.stride == (3, 3) and t4.padding == (0, 0) and t4.in_channels == 32
+                        and t4.out_channels == 32 and c7.in_channels == 32 and c7.out_channels <= 32)
+            lay_ok = shape_ok and (
+                ops.pointwise_ok(torch.empty(1, c0.in_channels, device=flat16.device), params["0.weight"], params.get("0.bias"))
+                and ops.pointwise_ok(torch.empty(1, 32, device=flat16.device, dtype=flat16.dtype), params["4.weight"], params.get("4.bias"), True)
+                and ops.pointwise_ok(torch.empty(1, 32, device=flat16.device, dtype=flat16.dtype), params["7.weight"], params.get("7.bias")))
+            if lay_ok:
+                self._shadow["pointwise"] = {i_: {k[len(f"{i_}."):]: v for k, v in params.items() if k.startswith(f"{i_}.")} for i_ in (2, 3, 5, 6)}
         return self._shadow
 
     def check_radar_status(self) -> None:
@@ -271,15 +290,32 @@ class DecoderLossHead:
             if any(p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last) for p in m.rgb_decoder.parameters()):
                 patches = patches.contiguous()  # (a model whose parameters were not flattened: packed NCHW for both)
             sh = self._cnn_shadow()
+            nhwc = False  # rgb leaves the decoder as [P, 3, h, w] (the library path) or already [P, h, w, 3] (nr_pw_*)
             if sh:
                 with torch.no_grad():
                     sh["flat16"].copy_(sh["flat32"])
                     if sh.get("conv7") is not None:  # this step's weights into the convolution kernels' LDS images: one launch
                         ops.conv7_pack(sh["flat16"], sh["conv7"][1], sh["conv7"][2], sh["conv7"][0])
                 scale = self._cnn_scale()
-                if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
-                    patches = _ScaleGrad.apply(patches, scale[1])
-                rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
+                if sh.get("pointwise") is not None and xs.is_contiguous() and xs.dtype == torch.float32:
+                    # the whole CNN on hand-written kernels: the pointwise convolutions (head 1 x 1 + ReLU straight from the fp32
+                    # rows, transposed 3 x 3, tail 1 x 1 + sigmoid to fp32) on nr_pw_*, the blocks' 7 x 7 on nr_conv7_*
+                    prm, subs = sh["params"], sh["pointwise"]
+                    n_p, ph = xs.shape[0] // (self.patch * self.patch), self.patch
+                    h = ops.pointwise(xs, prm["0.weight"], prm.get("0.bias"), act=1, grad_scale=None if scale is None else scale[1])
+                    h = h.view(n_p, ph, ph, h.shape[1]).permute(0, 3, 1, 2)
+                    for i_ in (2, 3):
+                        h = torch.func.functional_call(m.rgb_decoder[i_], subs[i_], (h,))
+                    h = ops.conv_transpose3(h, prm["4.weight"], prm.get("4.bias"))
+                    for i_ in (5, 6):
+                        h = torch.func.functional_call(m.rgb_decoder[i_], subs[i_], (h,))
+                    rgb = ops.pointwise(h.permute(0, 2, 3, 1).reshape(-1, h.shape[1]), prm["7.weight"], prm.get("7.bias"), act=2, out_f32=True)
+                    rgb = rgb.view(n_p, 3 * ph, 3 * ph, rgb.shape[1])
+                    nhwc = True
+                else:
+                    if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here
+                        patches = _ScaleGrad.apply(patches, scale[1])
+                    rgb = torch.func.functional_call(m.rgb_decoder, sh["params"], (patches.to(self.cnn_autocast),)).float()
                 if scale is not None:  # d loss / d rgb enters it multiplied by the loss scale
                     rgb = _ScaleGrad.apply(rgb, scale[0])
                 self._shadow_used = True
@@ -291,7 +327,8 @@ class DecoderLossHead:
                 rgb = m.rgb_decoder(patches)
             if self._bn_counters and m.rgb_decoder.training:  # BatchNorm2d.forward's `num_batches_tracked += 1`
                 torch._foreach_add_(self._bn_counters, 1)
-            rgb = rgb.permute(0, 2, 3, 1)
+            if not nhwc:
+                rgb = rgb.permute(0, 2, 3, 1)
             out["rgb_loss"] = c.rgb_mult * F.mse_loss(rgb, batch["image"])
             self.last["rgb"] = rgb
 

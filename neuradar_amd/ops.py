@@ -1094,6 +1094,92 @@ def conv7(x: Tensor, weight: Tensor, bias: Optional[Tensor], images: Tensor) -> 
     return _Conv7.apply(x, weight, bias, images)
 
 
+# ------------------------------------------------------------------------------------------------ pointwise convolutions (pw.hip)
+_pw_ws: dict = {}
+
+
+class _Pointwise(torch.autograd.Function):
+    """nr_pw_fwd / nr_pw_bwd_data / nr_pw_bwd_weight: y = act(x W^T + b) per pixel on channels-last activations -- a 1 x 1
+    Conv2d, or (transposed) ConvTranspose2d(3, stride 3).  x2d [pixels, K] fp32 or 16-bit, y [pixels (x 9), O] 16-bit or fp32."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, cfg):
+        act, transposed, H, W, out_f32, scale = cfg
+        P, K = x2d.shape
+        O = weight.shape[1] if transposed else weight.shape[0]
+        dt = _DT16[weight.dtype]
+        y = torch.empty((9 * P if transposed else P, O), device=x2d.device, dtype=torch.float32 if out_f32 else weight.dtype)
+        check(_lib.lib().nr_pw_fwd(_p(x2d), int(x2d.dtype == torch.float32), _p(weight), _p(bias), _p(y), int(out_f32), P, K, O, act,
+                                   int(transposed), H, W, dt, _stream()), "nr_pw_fwd")
+        ctx.save_for_backward(x2d, weight, y)
+        ctx.cfg, ctx.param_refs = cfg, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, weight, y = ctx.saved_tensors
+        act, transposed, H, W, out_f32, scale = ctx.cfg
+        P, K = x2d.shape
+        O = y.shape[1]
+        dt = _DT16[weight.dtype]
+        g = g.contiguous()
+        assert g.dtype == y.dtype
+        lib = _lib.lib()
+        x_f32 = int(x2d.dtype == torch.float32)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x2d)
+            check(lib.nr_pw_bwd_data(_p(g), _p(y), int(out_f32), _p(weight), _p(gx), x_f32, P, K, O, act, int(transposed), H, W, _p(scale),
+                                     dt, _stream()), "nr_pw_bwd_data")
+        w_, b_ = ctx.param_refs
+        ws = _pw_ws.get(x2d.device)
+        if ws is None:
+            ws = _pw_ws[x2d.device] = torch.empty(lib.nr_pw_workspace_bytes(), device=x2d.device, dtype=torch.uint8)
+        direct = (_DIRECT_PARAM_GRADS and w_.is_leaf and w_.grad is not None and w_.grad.dtype == w_.dtype and w_.grad.stride() == w_.stride()
+                  and (b_ is None or (b_.is_leaf and b_.grad is not None and b_.grad.dtype == b_.dtype and b_.grad.is_contiguous())))
+        if direct:  # added straight into the parameters' .grad buffers (same memory layout as the parameters)
+            gw, gb = w_.grad, (None if b_ is None else b_.grad)
+        else:
+            gw = torch.empty_strided(weight.shape, weight.stride(), device=weight.device, dtype=weight.dtype)
+            gb = None if b_ is None else torch.empty_like(b_)
+        check(lib.nr_pw_bwd_weight(_p(x2d), x_f32, _p(g), _p(y), int(out_f32), _p(gw), _p(gb), int(direct), _p(ws), P, K, O, act,
+                                   int(transposed), H, W, dt, _stream()), "nr_pw_bwd_weight")
+        return gx, (None if direct else gw), (None if direct else gb), None
+
+
+def pointwise_ok(x2d: Tensor, weight: Tensor, bias: Optional[Tensor], transposed: bool = False) -> bool:
+    """The layouts nr_pw_* are built for: x2d [pixels, K] contiguous (fp32 or the parameters' 16-bit type), K in {32, 48}; a 1 x 1
+    Conv2d weight [O, K, 1, 1] with O <= 32, or the ConvTranspose2d(3, stride 3) weight [K, O, 3, 3] in channels-last memory."""
+    if not (x2d.is_cuda and x2d.dim() == 2 and x2d.is_contiguous() and weight.dtype in _DT16 and x2d.dtype in (torch.float32, weight.dtype)):
+        return False
+    K = x2d.shape[1]
+    if K not in (32, 48) or (bias is not None and (bias.dtype != weight.dtype or not bias.is_contiguous())):
+        return False
+    if transposed:
+        return (weight.dim() == 4 and weight.shape[0] == K and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] % 8 == 0
+                and weight.shape[1] <= 32 and weight.stride() == (9 * weight.shape[1], 1, 3 * weight.shape[1], weight.shape[1]))
+    return (weight.dim() == 4 and weight.shape[1] == K and tuple(weight.shape[2:]) == (1, 1) and weight.shape[0] <= 32
+            and weight.stride(0) == K and weight.stride(1) == 1)
+
+
+def pointwise(x2d: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = 0, out_f32: bool = False, grad_scale: Optional[Tensor] = None) -> Tensor:
+    """act(Conv2d(K, O, 1)(x)) on the pixels' rows: x2d [pixels, K] (= a channels-last [P, K, H, W] tensor's memory) ->
+    [pixels, O]; act 0 none / 1 ReLU / 2 sigmoid; out_f32: fp32 output (and incoming gradient); grad_scale: device scalar the
+    input gradient is multiplied by (the inverse loss scale where the gradient leaves a loss-scaled 16-bit backward)."""
+    assert pointwise_ok(x2d, weight, bias)
+    return _Pointwise.apply(x2d, weight, bias, (int(act), False, 0, 0, bool(out_f32), grad_scale))
+
+
+def conv_transpose3(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """ConvTranspose2d(K, O, 3, stride=3) on a channels-last 16-bit [P, K, H, W] tensor -> channels-last [P, O, 3H, 3W]."""
+    P, K, H, W = x.shape
+    assert x.is_contiguous(memory_format=torch.channels_last)
+    x2d = x.permute(0, 2, 3, 1).reshape(-1, K)
+    assert pointwise_ok(x2d, weight, bias, transposed=True)
+    y = _Pointwise.apply(x2d, weight, bias, (0, True, H, W, False, None))
+    return y.view(P, 3 * H, 3 * W, weight.shape[1]).permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, step: int,
               betas=(0.9, 0.999), eps: float = 1e-15, weight_decay: float = 0.0, adamw: bool = False,

@@ -106,6 +106,13 @@ def test_graph_replay_matches_eager_steps(workload, mlp_dtype):
     rows = {}
     for name in eager:
         assert torch.equal(start[name], start2[name]), f"{name}: the two runs did not start from the same parameters"
+        if name.endswith("self_attn.in_proj_bias"):
+            # the KEY bias of a softmax attention has no gradient (q . b_k shifts all of a query's scores alike): what Adam
+            # makes of its rounding noise is a full-size random update -- rows [C, 2C) are left out of the comparison
+            C3 = eager[name].numel() // 3
+            for d_ in (start, start2, eager, eager2, replay):
+                d_[name] = d_[name].clone()
+                d_[name][C3:2 * C3] = 0.0
         moved = (eager[name] - start[name]).double()
         norm = float(moved.norm())
         if norm == 0.0:  # never receives a gradient (proposal_fields[0]: the reference's quirk)
