@@ -321,7 +321,7 @@ class _EncoderLayer(torch.autograd.Function):
             setattr(grads, name, t.data_ptr())
         g = _f32(g.contiguous(), "grad_out")
         g_att, g_x1, g_x = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        gq, gk, gv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        gq, gk, gv = torch.zeros((3,) + tuple(q.shape), device=q.device, dtype=q.dtype).unbind(0)  # (one fill: the attention backward adds)
         check(lib.nr_encoder_post_bwd(byref(enc), _p(x), _p(att), _p(g), N * n, _p(g_att), _p(g_x1), byref(grads), _stream()),
               "nr_encoder_post_bwd")
         check(lib.nr_attention_bwd(_p(q), _p(k), _p(v), _p(att), _p(lse), _p(g_att), N, n, C, float(p_drop), int(seed) & 0xFFFFFFFF,

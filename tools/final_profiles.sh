@@ -20,9 +20,8 @@ rocprofv3 --kernel-trace --stats -d $O/stats_full -o out --output-format csv -- 
 cd $R
 python tools/timeline.py $O/stats/out_kernel_trace.csv > $O/step_timeline.txt 2>&1
 python tools/timeline.py $O/stats_trained/out_kernel_trace.csv > $O/step_timeline_trained.txt 2>&1
-python tools/timeline.py $O/stats/out_kernel_trace.csv --overlapped > $O/step_timeline_overlapped.txt 2>&1
-python tools/timeline.py $O/stats_trained/out_kernel_trace.csv --overlapped > $O/step_timeline_trained_overlapped.txt 2>&1
-python tools/timeline.py $O/stats_full/out_kernel_trace.csv --overlapped > $O/step_timeline_full_fp16_overlapped.txt 2>&1
+# (a replayed step's trace shows the traced host's submission order, not the step: profiles/r04_ab_runs.txt item 15 -- the
+# timelines above are the SERIALISED eager steps of the roofline block: what every kernel costs alone on the step's own data)
 python tools/kernel_avgs.py $O/stats/out_kernel_trace.csv > $O/kernel_avgs_by_grid.txt 2>&1
 bash tools/pmc_bench.sh mixed16384_neuradar
 python tools/pmc_bench_summary.py gpurun_out/pmc_bench_ $O/hash_kernels_pmc.json mixed16384_neuradar 16384 > $O/pmc_summary.log 2>&1
