@@ -331,6 +331,100 @@ pw_bwd_weight_small_kernel(const EX* __restrict__ x, const EY* __restrict__ dy, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ transposed convolution on MFMA
+// ConvTranspose2d(32, 32, 3, stride 3) is 9 GEMMs [pixels x 32] x [32 x 32] (one per tap); v_mfma_f32_32x32x16_{bf16,f16}, fp32
+// accumulation.  Operand lane maps (cdna_hip_programming.md): lane (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7; D: col = l & 31, rows (reg & 3) + 8 (reg >> 2) + 4h.
+//   forward        D[pixel][o] = sum_i X[pixel][i] W[i][tap][o]: A = 16 contiguous bytes of the pixel's row; B = 8 scalars of the
+//                  weight memory [i][tap][o] (stride 288 elements; consecutive lanes = consecutive o: coalesced)
+//   data gradient  D[pixel][i] = sum_(tap, o) dY[out pixel(tap)][o] W[i][tap][o]: A = 16 contiguous bytes of the output pixel's
+//                  row, B = 16 contiguous bytes of the weight memory -- no transposition anywhere
+// A wave takes tiles of 32 input pixels; D's rows are pixels, its columns the 32 channels: every store is 64 contiguous bytes.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename E> struct Mma;
+template <> struct Mma<__bf16> {
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<_Float16> {
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+__device__ __forceinline__ int mma_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <typename E>
+__global__ void __launch_bounds__(256)
+convt_fwd_mfma_kernel(const E* __restrict__ x, const E* __restrict__ w, const E* __restrict__ b, E* __restrict__ y, PwShape s) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int n_tiles = (s.P + 31) / 32;
+  const float bias = b ? (float)b[r] : 0.0f;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    const int p = tile * 32 + r;
+    u32x4 a[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) a[c] = p < s.P ? *reinterpret_cast<const u32x4*>(x + p * 32 + 16 * c + 8 * h) : zero;
+    int base[16];  // output offsets of this lane's 16 pixel rows
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pp = tile * 32 + mma_row(q, h);
+      base[q] = pp < s.P ? pix_base(s, pp) : -1;
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = bias;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        typedef E e8 __attribute__((ext_vector_type(8)));
+        e8 bv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = w[(16 * c + 8 * h + j) * 288 + tap * 32 + r];
+        acc = Mma<E>::mfma(a[c], __builtin_bit_cast(u32x4, bv), acc);
+      }
+      const int off = ((tap / 3) * 3 * s.W + tap % 3) * 32 + r;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (base[q] >= 0) y[base[q] + off] = (E)acc[q];
+    }
+  }
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256)
+convt_bwd_data_mfma_kernel(const E* __restrict__ dy, const E* __restrict__ w, E* __restrict__ dx, PwShape s) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int n_tiles = (s.P + 31) / 32;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    const int p = tile * 32 + r;
+    const int pb = p < s.P ? pix_base(s, p) : -1;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int off = ((tap / 3) * 3 * s.W + tap % 3) * 32;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const u32x4 av = pb >= 0 ? *reinterpret_cast<const u32x4*>(dy + pb + off + 16 * c + 8 * h) : zero;
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(w + r * 288 + tap * 32 + 16 * c + 8 * h);
+        acc = Mma<E>::mfma(av, bv, acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pp = tile * 32 + mma_row(q, h);
+      if (pp < s.P) dx[pp * 32 + r] = (E)acc[q];
+    }
+  }
+}
+
 // grads (16-bit, the parameters' memory: [N][K] or the transposed convolution's [K][N]; bias [O]) (+)= sum of the partials
 template <typename EW>
 __global__ void __launch_bounds__(256)
@@ -365,6 +459,12 @@ bool shape_ok(const PwShape& s) {
   return s.P >= 0 && s.K > 0 && s.K <= kMaxK && s.K % 8 == 0 && s.N > 0 && s.N <= 9 * 64 && s.O > 0 &&
          (s.transposed ? (s.N == 9 * s.O && s.O % 8 == 0 && s.H > 0 && s.W > 0 && s.P % (s.H * s.W) == 0) : s.N == s.O) &&
          s.N * s.K + s.O <= 256 * 40;
+}
+// the shape the MFMA kernels are written for (NR_PW_MFMA=0: the generic kernels)
+bool convt_mfma(const PwShape& s, int x_f32, int y_f32, int act) {
+  const char* e = getenv("NR_PW_MFMA");
+  const bool on = !(e && e[0] == '0');
+  return on && s.transposed && s.K == 32 && s.O == 32 && !x_f32 && !y_f32 && act == kActNone;
 }
 unsigned pw_blocks(int64_t items) {
   const int64_t b = nr_cdiv(items, 256);
@@ -410,6 +510,17 @@ extern "C" int nr_pw_fwd(const void* x, int x_f32, const void* w16, const void* 
   const PwShape s = pw_shape(n_pixels, in_channels, out_channels, transposed, height, width);
   if (!x || !w16 || !y || !pw_fits(n_pixels, in_channels, out_channels, transposed) || !shape_ok(s) || act < 0 || act > 2 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w16) & 15u) != 0) return NR_EINVAL;
   const size_t lds = (size_t)(s.N * s.K + s.O) * sizeof(float);
+  if (convt_mfma(s, x_f32, y_f32, act)) {  // the decoder's ConvTranspose2d(32, 32, 3, stride 3): 9 GEMMs on the matrix cores
+    const unsigned blocks = (unsigned)nr_cdiv(nr_cdiv(s.P, 32), 4);
+    if (dtype16 == NR_DTYPE_BF16)
+      hipLaunchKernelGGL(convt_fwd_mfma_kernel<__bf16>, dim3(blocks), dim3(256), 0, nr_s(stream), static_cast<const __bf16*>(x),
+                         static_cast<const __bf16*>(w16), static_cast<const __bf16*>(b16), static_cast<__bf16*>(y), s);
+    else
+      hipLaunchKernelGGL(convt_fwd_mfma_kernel<_Float16>, dim3(blocks), dim3(256), 0, nr_s(stream), static_cast<const _Float16*>(x),
+                         static_cast<const _Float16*>(w16), static_cast<const _Float16*>(b16), static_cast<_Float16*>(y), s);
+    NR_LAUNCH_CHECK();
+    return 0;
+  }
 #define CALL(EX, EY, EW, KK)                                                                                                  \
   hipLaunchKernelGGL((pw_fwd_kernel<EX, EY, EW, KK>), dim3(pw_blocks((int64_t)s.P * ((s.N + 7) / 8))), dim3(256), lds, nr_s(stream), static_cast<const EX*>(x), \
                      static_cast<const EW*>(w16), static_cast<const EW*>(b16), static_cast<EY*>(y), s, act)
@@ -428,6 +539,17 @@ extern "C" int nr_pw_bwd_data(const void* grad_y, const void* y, int y_f32, cons
       (((uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)w16) & 15u) != 0)
     return NR_EINVAL;
   const size_t lds = (size_t)(s.N * s.K + s.O) * sizeof(float);
+  if (convt_mfma(s, x_f32, y_f32, act) && scale == nullptr) {
+    const unsigned blocks = (unsigned)nr_cdiv(nr_cdiv(s.P, 32), 4);
+    if (dtype16 == NR_DTYPE_BF16)
+      hipLaunchKernelGGL(convt_bwd_data_mfma_kernel<__bf16>, dim3(blocks), dim3(256), 0, nr_s(stream), static_cast<const __bf16*>(grad_y),
+                         static_cast<const __bf16*>(w16), static_cast<__bf16*>(grad_x), s);
+    else
+      hipLaunchKernelGGL(convt_bwd_data_mfma_kernel<_Float16>, dim3(blocks), dim3(256), 0, nr_s(stream),
+                         static_cast<const _Float16*>(grad_y), static_cast<const _Float16*>(w16), static_cast<_Float16*>(grad_x), s);
+    NR_LAUNCH_CHECK();
+    return 0;
+  }
 #define CALL(EX, EY, EW, KK)                                                                                                       \
   hipLaunchKernelGGL((pw_bwd_data_kernel<EX, EY, EW, KK>), dim3(pw_blocks((int64_t)s.P * (s.K / 8))), dim3(256), lds, nr_s(stream),                       \
                      static_cast<const EY*>(grad_y), static_cast<const EY*>(y), static_cast<const EW*>(w16), static_cast<EX*>(grad_x), s, \
