@@ -1020,8 +1020,8 @@ def main():
                                "mlp_operands": fr["mlp_dtype"], "loss_scaler": fr["amp"],
                                "decoders_us_in_step": None if fr["decoders_us"] is None else round(fr["decoders_us"], 1),
                                "loss_after_run": fr["loss"], "render": fr["render"], "after_training": None,
-                               "decoders": "RGB CNN (7 x 7 convolutions: nr_conv7_fwd / nr_conv7_wgrad MFMA implicit GEMMs on 16-bit working copies; hand-written batch norm + ReLU + residual; 1 x 1 and transposed convolutions: library) + lidar MLP + "
-                                           "radar transformer / heads; losses incl. the linear sum assignment on the device"})
+                               "decoders": "RGB CNN (hand-written throughout: 7 x 7 convolutions nr_conv7_fwd / nr_conv7_wgrad and the transposed 3 x 3 on MFMA, 1 x 1 convolutions nr_pw_*, batch norm + ReLU + residual nr_bn_act_*, on 16-bit working copies) + lidar MLP + "
+                                           "radar encoder layer as four fp32-MFMA kernels around the attention (nr_encoder_*) / heads; losses incl. the linear sum assignment on the device"})
             if args.full_model_trained_steps > 0:
                 # the same workload once the radar predictions have spread (the assignment's fast regime): same timing rules
                 # (plain training steps on the workload's own supervision: `--warmup` of that length, not the headline's scene targets)

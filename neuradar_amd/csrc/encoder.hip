@@ -198,7 +198,10 @@ __device__ __forceinline__ void add_tiles(f32x16 (&a)[N], const f32x16 (&b)[N]) 
     for (int r = 0; r < 16; ++r) a[n][r] += b[n][r];
 }
 
-constexpr int kWaves = 4;
+#ifndef NR_ENC_WAVES
+#define NR_ENC_WAVES 4
+#endif
+constexpr int kWaves = NR_ENC_WAVES;
 
 // ------------------------------------------------------------------------------------------------ pre: LN1 + in-projection
 template <int C>
