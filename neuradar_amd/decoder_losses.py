@@ -139,7 +139,6 @@ class DecoderLossHead:
         self.chainwise = os.environ.get("NR_DECODER_CHAINWISE", "1") != "0"  # backward chain by chain (see _backward_chainwise)
         self._skip = set(filter(None, os.environ.get("NR_DECODER_SKIP", "").split(",")))  # development: time the step without a chain
         self._streams = None
-        self._leaf_streams: Dict[str, torch.cuda.Stream] = {}
         self._one = None
 
     def _cnn_shadow(self):
@@ -250,14 +249,6 @@ class DecoderLossHead:
             self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         s_lidar = self._streams[0] if os.environ.get("NR_LIDAR_STREAM", "own") == "own" else cur
         return s_lidar, self._streams[1]
-
-    def _leaf_stream(self, kind: str, device):
-        which = os.environ.get("NR_LEAF_STREAMS", "").split(",")
-        if kind not in which:
-            return None
-        if kind not in self._leaf_streams:
-            self._leaf_streams[kind] = torch.cuda.Stream(device=device)
-        return self._leaf_streams[kind]
 
     def _lidar_chain(self, xs: Tensor, depth: Tensor, batch: Dict[str, Tensor], out: Dict[str, Tensor]) -> None:
         """Lidar decoder + the quantile-masked lidar losses; xs [n,C]: the lidar rows of the decoders' input, depth [B] (current stream)."""
@@ -459,9 +450,10 @@ class DecoderLossHead:
                         self._camera_chain(xl, batch, out)
                     vals = list(out.values())
                     loss = vals[0] if len(vals) == 1 else sum(vals[1:], vals[0])  # (python's sum starts at 0: one more launch)
-                # the MLP / convolution / encoder kernels add into the parameters' .grad buffers themselves (NR_LEAF_STREAMS: the
-                # CNN's weight-gradient launches on a stream beside the chain's -- an experiment knob, off: a fourth branch)
-                with ops.direct_param_grads(), ops.leaf_grad_stream(self._leaf_stream(kind, features.device)):
+                # the MLP / convolution / encoder kernels add into the parameters' .grad buffers themselves.  (The CNN's weight-
+                # gradient launches on a stream beside the chain's -- leaves of the backward -- were tried: a fourth concurrent
+                # branch, 3.79 -> 4.32 ms per step; profiles/r04_ab_runs.txt item 9)
+                with ops.direct_param_grads():
                     loss.backward(self._one)  # (a cached 1.0: no ones_like launch per chain)
                 g_x[r0:r0 + n].copy_(xl.grad)
                 if kind == "lidar" and dl.grad is not None:

@@ -149,53 +149,6 @@ class direct_param_grads:
         _DIRECT_PARAM_GRADS = self._prev
 
 
-_LEAF_STREAM = {"stream": None, "used": False}
-
-
-class leaf_grad_stream:
-    """Inside this context (around a `backward()` that runs on ONE stream, under direct_param_grads), the parameter-gradient
-    launches of the convolution / linear layers -- leaves of the backward's dependency graph: nothing but the optimizer reads
-    them -- go to `stream` instead of the chain's: the chain is then as long as its data gradients.  Each launch waits for what
-    it reads (the chain's stream at that point); leaving the context makes the chain's stream wait for `stream`.  stream=None:
-    everything stays on the chain's stream."""
-
-    def __init__(self, stream):
-        self.stream = stream
-
-    def __enter__(self):
-        self._prev = dict(_LEAF_STREAM)
-        _LEAF_STREAM.update(stream=self.stream, used=False)
-
-    def __exit__(self, *exc):
-        if _LEAF_STREAM["used"] and self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
-        _LEAF_STREAM.update(self._prev)
-
-
-class _on_leaf_stream:
-    """with _on_leaf_stream(tensors the launches read): ... -- switches to the leaf stream (if one is set) behind the current one."""
-
-    def __init__(self, *reads):
-        self.reads = reads
-
-    def __enter__(self):
-        self.s = _LEAF_STREAM["stream"] if _DIRECT_PARAM_GRADS else None
-        if self.s is None:
-            return
-        cur = torch.cuda.current_stream()
-        self.s.wait_stream(cur)
-        for t in self.reads:  # (allocated on the chain's stream: the allocator must not hand them out again before `s` is done)
-            if t is not None:
-                t.record_stream(self.s)
-        _LEAF_STREAM["used"] = True
-        self.ctx = torch.cuda.stream(self.s)
-        self.ctx.__enter__()
-
-    def __exit__(self, *exc):
-        if self.s is not None:
-            self.ctx.__exit__(*exc)
-
-
 class _Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_layers, *params):
@@ -804,10 +757,8 @@ class _LinearDirect(torch.autograd.Function):
         if direct:
             gw = pw.grad[row0:row0 + rows] if sliced else pw.grad
             gb = pb.grad[row0:row0 + rows] if sliced else pb.grad
-            ones = _ones(g.shape[0], g.device)
-            with _on_leaf_stream(g, x):
-                gw.addmm_(g.t(), x)
-                gb.addmv_(g.t(), ones)
+            gw.addmm_(g.t(), x)
+            gb.addmv_(g.t(), _ones(g.shape[0], g.device))
             return gx, None, None, None, None, None, None
         gw, gb = g.t() @ x, g.sum(0)
         if sliced:  # gradients of the owners: zero outside the slice
@@ -1072,11 +1023,9 @@ class _Conv7(torch.autograd.Function):
             chl = (32 * 49, 1, 7 * 32, 32)  # the channels-last memory [O, kh, kw, I] of a [32, 32, 7, 7] tensor
             direct = (_DIRECT_PARAM_GRADS and w_.is_leaf and w_.grad is not None and w_.grad.dtype == x.dtype and w_.grad.stride() == chl
                       and (b_ is None or (b_.is_leaf and b_.grad is not None and b_.grad.dtype == x.dtype and b_.grad.is_contiguous())))
-            # (direct: added straight into the parameters' .grad buffers -- no temporaries, no AccumulateGrad adds; on the leaf
-            # stream if the caller set one -- launched BEFORE the data gradient so that it does not wait for it)
+            # (direct: added straight into the parameters' .grad buffers -- no temporaries, no AccumulateGrad adds)
             if direct:
-                with _on_leaf_stream(g, x):
-                    conv7_wgrad(x, g, ctx.has_bias, into=(w_.grad, None if b_ is None else b_.grad))
+                conv7_wgrad(x, g, ctx.has_bias, into=(w_.grad, None if b_ is None else b_.grad))
             else:
                 gw, gb = conv7_wgrad(x, g, ctx.has_bias)
             gx = conv7_forward(g, ctx.images[1]) if ctx.needs_input_grad[0] else None
