@@ -246,7 +246,8 @@ class DecoderLossHead:
         if not self.overlap:
             return cur, cur
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            pr = int(os.environ.get("NR_RADAR_PRIORITY", "0"))  # (experiment knob: -1 = the radar chain's stream at high priority)
+            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device, priority=pr))
         s_lidar = self._streams[0] if os.environ.get("NR_LIDAR_STREAM", "own") == "own" else cur
         return s_lidar, self._streams[1]
 
