@@ -642,8 +642,9 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         mode = "dense" if (args.dense_allreduce or args.autograd) else ("shard" if "cam_rays" in wl else "sparse")
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_dtype=torch.bfloat16 if args.bf16_allreduce else None, table_mode=mode)
-    # sharded table step: bf16 on both halves of the exchange and the all-gather deferred into the next step by default
-    # (--table-delta fp32 / --no-defer-gather: the round-3 behaviour)
+    # sharded table step: fp32 on both halves of the exchange (the reference's DDP all-reduces fp32 gradients and its Adam
+    # writes fp32 parameters; --table-transport bf16 / --table-delta bf16 are opt-in and named in the line), the all-gather
+    # deferred into the next step by default (--no-defer-gather: the round-3 behaviour)
     reducer.table_delta = torch.bfloat16 if args.table_delta == "bf16" else None
     reducer.defer_gather = not args.no_defer_gather
     if mode == "shard" and args.table_transport == "bf16":
@@ -925,7 +926,10 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
               "blocks": n_blocks, "ms_min": per_block[0] / args.steps * 1e3, "ms_max": per_block[-1] / args.steps * 1e3,
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                              if reducer.last_sparse.get("mode") == "sparse" else 0)) if world > 1 else 0,
-              "exchange": (reducer.last_sparse or "dense") if world > 1 else None, "decoders_us": decoders_us, "mlp_dtype": mlp_dtype,
+              "exchange": (reducer.last_sparse or "dense") if world > 1 else None,
+              "exchange_dtypes": ({"gradient_transport": "bfloat16" if reducer.table_dtype == torch.bfloat16 else "float32",
+                                   "update_all_gather": "bfloat16 deltas" if (reducer.table_mode == "shard" and reducer.table_delta is not None) else "float32 parameters"}
+                                  if world > 1 else None), "decoders_us": decoders_us, "mlp_dtype": mlp_dtype,
               "exchange_cost": exchange, "loss": float(stepper.loss.sum()) if stepper is not None else None}
     del graphs, stepper, fwd_bwd, optim, model, opts, reducer, scene
     torch.cuda.empty_cache()
@@ -970,10 +974,12 @@ def main():
     ap.add_argument("--table-exchange", default="auto", choices=["auto", "sparse", "dense", "shard"],
                     help="main table's gradient exchange for world > 1: row lists | dense all-reduce | reduce-scatter + sharded Adam + "
                     "all-gather (auto: shard for mixed batches, sparse for camera-only ones)")
-    ap.add_argument("--table-transport", default="bf16", choices=["fp32", "bf16"], help="shard mode: type the main table's gradient "
-                    "travels in through the reduce-scatter")
-    ap.add_argument("--table-delta", default="bf16", choices=["fp32", "bf16"], help="shard mode: all-gather the updated rows as fp32 "
-                    "parameters, or as bf16 update deltas that owner and receivers apply alike (replicas stay bit-identical)")
+    ap.add_argument("--table-transport", default="fp32", choices=["fp32", "bf16"], help="shard mode: type the main table's gradient "
+                    "travels in through the reduce-scatter (fp32 = what the reference's DDP all-reduces; bf16 halves the bytes but "
+                    "rounds every partial sum of the ring to 8 bits: opt-in, recorded in the line)")
+    ap.add_argument("--table-delta", default="fp32", choices=["fp32", "bf16"], help="shard mode: all-gather the updated rows as fp32 "
+                    "parameters (default: the reference's fp32 optimizer), or as bf16 update deltas that owner and receivers apply "
+                    "alike (replicas stay bit-identical; opt-in, recorded in the line)")
     ap.add_argument("--no-defer-gather", action="store_true", help="shard mode: finish the all-gather inside the step instead of "
                     "deferring it to the next step's first read of the table")
     ap.add_argument("--dense-allreduce", action="store_true",
@@ -1069,7 +1075,7 @@ def main():
                        "timed_blocks": r["blocks"], "ms_per_step_min": round(r["ms_min"], 4), "ms_per_step_max": round(r["ms_max"], 4),
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}", "regime": args.regime,
-                       "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"],
+                       "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"], "main_table_exchange_dtypes": r["exchange_dtypes"],
                        "gradient_exchange": r["exchange_cost"]},
             "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,
         }

@@ -6,7 +6,7 @@
  *
  * Conventions
  *   - Every pointer is a DEVICE pointer owned by the caller (torch); the library allocates nothing
- *     persistent and keeps no global state.  All tensors are contiguous fp32 unless stated.
+ *     persistent and keeps no global state beyond the nr_set_tuning() table (set once at load).  All tensors are contiguous fp32 unless stated.
  *   - `stream` is a hipStream_t passed as void* (torch's current stream); calls are asynchronous.
  *   - Return value: 0 on success, a hipError_t (>0) for a runtime failure, NR_EINVAL (-1) for a bad
  *     argument.  Nothing is thrown across the boundary.
@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 24
+#define NR_ABI_VERSION 25
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -37,6 +37,31 @@ typedef void* nr_stream_t;
 /* Library / ABI version (NR_ABI_VERSION) and the code-object target ("gfx950"). */
 int nr_abi_version(void);
 const char* nr_target_arch(void);
+
+/* ABI v25: explicit one-time setup instead of lazily-initialised state inside the entry points.
+ *   nr_init()        once per DEVICE (the current one: call it after hipSetDevice, before the first launch, from any thread):
+ *                    raises hipFuncAttributeMaxDynamicSharedMemorySize for the kernels that stage more than the default 64 KB of
+ *                    LDS (nr_conv7_fwd, nr_encoder_*, nr_radar_assign, nr_radar_heads_bwd).  Idempotent.  Without it those entry
+ *                    points return hipErrorInvalidValue -- they no longer set the attribute on first use (v24 kept a
+ *                    `static bool` per kernel and set it from whichever thread launched first).
+ *   nr_set_tuning()  launch-shape knobs for A/B measurements (value 0 = the built-in default, < 0 = NR_EINVAL).  No entry point
+ *                    reads the environment any more (v24 called getenv() on every launch); the Python binding forwards its
+ *                    NR_* variables once at load (neuradar_amd/_lib.py).  The table is plain process memory: set it at load
+ *                    time, not while another thread launches.  This is the library's only process-level state. */
+enum {
+  NR_TUNE_CONV7_BLOCKS = 0,      /* persistent blocks of nr_conv7_fwd (default 256) */
+  NR_TUNE_BIN_BLOCKS_PER_CU = 1, /* bin blocks per HALF CU of the binned scatters (default: what the LDS allows) */
+  NR_TUNE_SHARED_BLOCKS = 2,     /* blocks of nr_hash_encode_bwd_shared (default 256) */
+  NR_TUNE_FIELD_FWD_BLOCKS = 3,  /* blocks of nr_field_fwd / nr_field_fwd_gather (default min(tiles / 4, 512)) */
+  NR_TUNE_FIELD_BWD_BLOCKS = 4,  /* blocks (= gradient slabs) of nr_field_bwd* (default 256 fp32 / 512 16-bit) */
+  NR_TUNE_PDBWD_BLOCKS = 5,      /* blocks of nr_prop_density_bwd (default 256) */
+  NR_TUNE_ADAM_BLOCKS = 6,       /* blocks of nr_adam_step* (default 4096) */
+  NR_TUNE_PW_MFMA_OFF = 7,       /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+  NR_TUNE_PROP_SHARED_OFF = 8,   /* 1: proposal-table scatters on the binned kernels instead of the block-shared table */
+  NR_TUNE_PROP_SHARED_BLOCKS = 9 /* blocks of the block-shared proposal scatter */
+};
+int nr_init(void);
+int nr_set_tuning(int knob, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Multiresolution hash grid   -- replaces tcnn.Encoding{HashGrid} fwd/bwd reached from

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 24
+NR_ABI_VERSION = 25
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -77,6 +77,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 PROTOTYPES = {
     "nr_abi_version": [],
     "nr_target_arch": [],
+    "nr_init": [],
+    "nr_set_tuning": [I, I],
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],
     "nr_hash_encode_bwd_tuned": [P, P, P, I, I, I, P, L, L, P, L, I, I, P],
@@ -224,8 +226,37 @@ def lib() -> ctypes.CDLL:
             fn.restype = _RESTYPES.get(name, c_int)
         if handle.nr_abi_version() != NR_ABI_VERSION:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
+        for knob, (env, _) in enumerate(TUNING):  # launch-shape knobs for A/B runs: read ONCE, here (the library never reads the environment)
+            value = os.environ.get(env)
+            if value:
+                if handle.nr_set_tuning(knob, int(value)) != 0:
+                    raise RuntimeError(f"{env}={value}: nr_set_tuning refused it")
         _lib = handle
     return _lib
+
+
+# nr_set_tuning knobs (include/neuradar_hip.h, NR_TUNE_*), in enum order: (environment variable forwarded at load, meaning)
+TUNING = (("NR_CONV7_BLOCKS", "persistent blocks of nr_conv7_fwd"), ("NR_BIN_BLOCKS_PER_CU", "bin blocks per half CU"),
+          ("NR_SHARED_BLOCKS", "blocks of nr_hash_encode_bwd_shared"), ("NR_FIELD_FWD_BLOCKS", "blocks of nr_field_fwd*"),
+          ("NR_FIELD_BWD_BLOCKS", "blocks of nr_field_bwd*"), ("NR_PDBWD_BLOCKS", "blocks of nr_prop_density_bwd"),
+          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"),
+          ("NR_PROP_SHARED_OFF", "1: binned kernels for the proposal scatters"), ("NR_PROP_SHARED_BLOCKS", "blocks of the shared proposal scatter"))
+
+def set_tuning(env_name: str, value: int) -> None:
+    """nr_set_tuning by the knob's environment-variable name (tests / probes switching a knob inside one process)."""
+    knob = [e for e, _ in TUNING].index(env_name)
+    check(lib().nr_set_tuning(knob, int(value)), f"nr_set_tuning({env_name})")
+
+
+_inited_devices: set = set()
+
+
+def ensure_device(index: int) -> None:
+    """nr_init() once per device (dynamic-LDS attributes of the > 64 KB kernels): called by ops._stream() before every launch
+    (a set look-up); the caller's current device must be `index`."""
+    if index not in _inited_devices:
+        check(lib().nr_init(), "nr_init")
+        _inited_devices.add(index)
 
 
 class NeuradarHipError(RuntimeError):

@@ -295,6 +295,11 @@ conv7_wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, E* __
 
 }  // namespace
 
+int nr_init_conv7() {
+  if (int rc = nr_raise_lds(conv7_kernel<CBf16>, (size_t)kImgAll + kHalo)) return rc;
+  return nr_raise_lds(conv7_kernel<CFp16>, (size_t)kImgAll + kHalo);
+}
+
 extern "C" int64_t nr_conv7_wgrad_workspace_bytes(void) { return (int64_t)kWMaxBlocks * kWPart * 4; }
 
 extern "C" int nr_conv7_wgrad(const void* x16, const void* grad_y16, void* grad_w16, void* grad_b16, int accumulate, void* workspace,
@@ -348,19 +353,10 @@ extern "C" int nr_conv7_fwd(const void* x16, const void* image, const void* resi
     return NR_EINVAL;
   const int ty = (height + kTH - 1) / kTH, tx = (width + kTW - 1) / kTW;
   const int64_t tiles = (int64_t)n_images * ty * tx;
-  int cap = 256;  // one block per CU (141 KB of LDS)
-  if (const char* e = getenv("NR_CONV7_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const int cap = nr_tuning().conv7_blocks > 0 ? nr_tuning().conv7_blocks : 256;  // one block per CU (141 KB of LDS)
   const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
-  const size_t lds = (size_t)kImgAll + kHalo;
-  static bool raised[2] = {false, false};  // (more than the default 64 KB of dynamic LDS needs the attribute once per kernel)
-  const int which = dtype == NR_DTYPE_BF16 ? 0 : 1;
-  if (!raised[which]) {
-    const void* fn = which == 0 ? reinterpret_cast<const void*>(conv7_kernel<CBf16>) : reinterpret_cast<const void*>(conv7_kernel<CFp16>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    raised[which] = true;
-  }
-  if (which == 0)
+  const size_t lds = (size_t)kImgAll + kHalo;  // (> 64 KB: the attribute is raised in nr_init)
+  if (dtype == NR_DTYPE_BF16)
     hipLaunchKernelGGL(conv7_kernel<CBf16>, dim3(blocks), dim3(kThreads), lds, nr_s(stream), static_cast<const __bf16*>(x16),
                        static_cast<const unsigned char*>(image), static_cast<const __bf16*>(residual16), relu, static_cast<__bf16*>(y16),
                        n_images, height, width, ty, tx, tiles);

@@ -444,16 +444,6 @@ encoder_post_bwd_kernel(nr_encoder_t e, const float* __restrict__ x, const float
   flush_ln<C>(lg + P::g_lnf, grads.norm_weight, grads.norm_bias);
 }
 
-template <typename Kern>
-int raise_lds(Kern kern, size_t bytes, bool* done) {
-  if (!*done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
-    *done = true;
-  }
-  return 0;
-}
-
 bool enc_ok(const nr_encoder_t* e) {
   return e && e->in_proj_weight && e->in_proj_bias && e->out_proj_weight && e->out_proj_bias && e->linear1_weight && e->linear1_bias &&
          e->linear2_weight && e->linear2_bias && e->norm1_weight && e->norm1_bias && e->norm2_weight && e->norm2_bias &&
@@ -466,6 +456,20 @@ unsigned enc_blocks(int64_t n) {
 constexpr size_t kScrBytes = (size_t)kWaves * (2 * kScrTile + 32) * sizeof(float);
 
 }  // namespace
+
+// the four kernels' dynamic-LDS sizes per instantiated width (nr_init; the backward ones exceed the default 64 KB)
+template <int C, int FF>
+static int enc_init_width() {
+  if (int rc = nr_raise_lds(encoder_pre_fwd_kernel<C>, PreLds<C>::W_TOTAL * sizeof(float))) return rc;
+  if (int rc = nr_raise_lds(encoder_post_fwd_kernel<C, FF>, PostLds<C, FF>::W_TOTAL * sizeof(float))) return rc;
+  if (int rc = nr_raise_lds(encoder_post_bwd_kernel<C, FF>, (PostLds<C, FF>::W_TOTAL + PostLds<C, FF>::G_TOTAL) * sizeof(float) + kScrBytes)) return rc;
+  return nr_raise_lds(encoder_pre_bwd_kernel<C>, (PreLds<C>::W_TOTAL + PreLds<C>::G_TOTAL) * sizeof(float) + kScrBytes);
+}
+int nr_init_encoder() {
+  if (int rc = enc_init_width<48, 64>()) return rc;
+  if (int rc = enc_init_width<32, 64>()) return rc;
+  return enc_init_width<64, 64>();
+}
 
 // widths the kernels are instantiated for: (d_model, dim_feedforward) = (48, 64) -- NeuRadar's radar decoder -- and (32, 64), (64, 64)
 #define NR_ENC_DISPATCH(CALL)                                              \
@@ -480,9 +484,7 @@ extern "C" int nr_encoder_pre_fwd(const nr_encoder_t* enc, const float* x, const
   if (!enc_ok(enc) || !x || !pos || !q || !k || !v || n < 0) return NR_EINVAL;
 #define CALL(C, FF)                                                                                                     \
   {                                                                                                                     \
-    static bool done = false;                                                                                           \
     const size_t lds = PreLds<C>::W_TOTAL * sizeof(float);                                                              \
-    if (int rc = raise_lds(encoder_pre_fwd_kernel<C>, lds, &done)) return rc;                                           \
     hipLaunchKernelGGL(encoder_pre_fwd_kernel<C>, dim3(enc_blocks(n)), dim3(kWaves * 64), lds, nr_s(stream), *enc, x, pos, n, q, k, v); \
   }
   NR_ENC_DISPATCH(CALL)
@@ -496,9 +498,7 @@ extern "C" int nr_encoder_post_fwd(const nr_encoder_t* enc, const float* x, cons
   if (!enc_ok(enc) || !x || !att || !out || n < 0) return NR_EINVAL;
 #define CALL(C, FF)                                                                                                     \
   {                                                                                                                     \
-    static bool done = false;                                                                                           \
     const size_t lds = PostLds<C, FF>::W_TOTAL * sizeof(float);                                                         \
-    if (int rc = raise_lds(encoder_post_fwd_kernel<C, FF>, lds, &done)) return rc;                                      \
     hipLaunchKernelGGL((encoder_post_fwd_kernel<C, FF>), dim3(enc_blocks(n)), dim3(kWaves * 64), lds, nr_s(stream), *enc, x, att, n, out); \
   }
   NR_ENC_DISPATCH(CALL)
@@ -513,9 +513,7 @@ extern "C" int nr_encoder_post_bwd(const nr_encoder_t* enc, const float* x, cons
   if (!enc_ok(enc) || !x || !att || !grad_out || !grad_att || !grad_x1 || !grads || n < 0) return NR_EINVAL;
 #define CALL(C, FF)                                                                                                     \
   {                                                                                                                     \
-    static bool done = false;                                                                                           \
     const size_t lds = (PostLds<C, FF>::W_TOTAL + PostLds<C, FF>::G_TOTAL) * sizeof(float) + kScrBytes;                 \
-    if (int rc = raise_lds(encoder_post_bwd_kernel<C, FF>, lds, &done)) return rc;                                      \
     hipLaunchKernelGGL((encoder_post_bwd_kernel<C, FF>), dim3(enc_blocks(n)), dim3(kWaves * 64), lds, nr_s(stream), *enc, x, att,  \
                        grad_out, n, grad_att, grad_x1, *grads);                                                         \
   }
@@ -532,9 +530,7 @@ extern "C" int nr_encoder_pre_bwd(const nr_encoder_t* enc, const float* x, const
   if (!enc_ok(enc) || !x || !pos || !grad_q || !grad_k || !grad_v || !grad_x1 || !grad_x || !grads || n < 0) return NR_EINVAL;
 #define CALL(C, FF)                                                                                                     \
   {                                                                                                                     \
-    static bool done = false;                                                                                           \
     const size_t lds = (PreLds<C>::W_TOTAL + PreLds<C>::G_TOTAL) * sizeof(float) + kScrBytes;                           \
-    if (int rc = raise_lds(encoder_pre_bwd_kernel<C>, lds, &done)) return rc;                                           \
     hipLaunchKernelGGL(encoder_pre_bwd_kernel<C>, dim3(enc_blocks(n)), dim3(kWaves * 64), lds, nr_s(stream), *enc, x, pos, grad_q, \
                        grad_k, grad_v, grad_x1, n, grad_x, *grads);                                                     \
   }

@@ -95,10 +95,7 @@ constexpr int kMaxBwdBlocks = 512;
 inline unsigned field_bwd_blocks(int64_t n, const nr_field_t* field, int hid) {
   const int64_t tiles = nr_cdiv(n, 32);
   int cap = field->dtype != NR_DTYPE_F32 && hid == 32 ? kMaxBwdBlocks : 256;
-  if (const char* e = getenv("NR_FIELD_BWD_BLOCKS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v > 0 && v <= kMaxBwdBlocks) cap = v;
-  }
+  if (const int v = nr_tuning().field_bwd_blocks; v > 0 && v <= kMaxBwdBlocks) cap = v;
   return (unsigned)(nr_cdiv(tiles, 4) < cap ? nr_cdiv(tiles, 4) : cap);
 }
 

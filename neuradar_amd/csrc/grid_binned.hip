@@ -590,14 +590,9 @@ apply_kernel(const uint32_t* __restrict__ rkey, const SumT* __restrict__ rsum, c
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 inline int nr_num_cus() {
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cus[dev] == 0) {
-    int v = 0;
-    cus[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
-  }
-  return cus[dev];
+  int dev = 0, v = 0;  // (two runtime look-ups, ~0.1 us: no cache to keep)
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  return hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
 }
 
 struct Workspace {
@@ -664,7 +659,7 @@ static int launch_binned(const float* x, const float* std, const float* scalings
   if (per_cu * rows_blk > 2048) per_cu = 2048 / rows_blk;
   if (per_cu < 1) per_cu = 1;
   int64_t persistent = per_cu * (int64_t)nr_num_cus();
-  if (const char* e = getenv("NR_BIN_BLOCKS_PER_CU")) persistent = (int64_t)atoi(e) * nr_num_cus() / 2 > 0 ? (int64_t)atoi(e) * nr_num_cus() / 2 : persistent;  // (halves of a CU: tuning knob)
+  if (nr_tuning().bin_blocks_per_cu > 0) persistent = (int64_t)nr_tuning().bin_blocks_per_cu * nr_num_cus() / 2 > 0 ? (int64_t)nr_tuning().bin_blocks_per_cu * nr_num_cus() / 2 : persistent;  // (halves of a CU)
   if (persistent > kMaxBinBlocks) persistent = kMaxBinBlocks;
   const unsigned blocks = (unsigned)(g.nb < persistent ? g.nb : persistent);
   dim3 grid1(blocks), grid2((unsigned)g.ns, (unsigned)L, g.nb >= 64 ? 2u : 1u);

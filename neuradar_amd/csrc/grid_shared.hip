@@ -355,8 +355,7 @@ extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const
   const int64_t tiles = nr_cdiv(n, kRows);
   // ONE block per CU (81 KB of its 160 KB of LDS): beside the step's other scatters -- whose bin blocks take 48 KB each -- that
   // beats two per CU by 4.5 % per step, same call (2.27 -> 2.17 ms fresh; 384 / 192 / 128 blocks: 2.24 / 2.20 / 2.45 ms)
-  int cap = 256;
-  if (const char* e = getenv("NR_SHARED_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const int cap = nr_tuning().shared_blocks > 0 ? nr_tuning().shared_blocks : 256;
   const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
   if (seen_grad != nullptr)
     hipLaunchKernelGGL(scatter_shared_kernel<true>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,

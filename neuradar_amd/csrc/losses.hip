@@ -495,7 +495,7 @@ lidar_losses_kernel(const float* __restrict__ depth, const float* __restrict__ y
 
 }  // namespace
 
-static bool lidar_cfg_ok(const nr_lidar_losses_t* c) {
+inline bool lidar_cfg_ok(const nr_lidar_losses_t* c) {
   return c && c->did_return && c->range && c->target_intensity && c->row0 >= 0 && c->n >= 0 && c->quantile >= 0.0f && c->quantile <= 1.0f;
 }
 

@@ -588,10 +588,7 @@ extern "C" int nr_field_fwd(const nr_field_t* field, const float* feats, int64_t
   if (rows_sample_major < 0 || (rows_sample_major && (S < 1 || n % S != 0 || rows_sample_major > n / S))) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
-  if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
-  }
+  if (const int v = nr_tuning().field_fwd_blocks; v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   if (field->dtype != NR_DTYPE_F32)  // bf16 / fp16 operands (mlp_lp.hip)
     return field_fwd_lp(field, hid, feats, sn, sl, F, dirs, S, rows_sample_major, n, feature, sdf, alpha, blocks, nr_s(stream));
 #define LAUNCH_FWD2(HIDC, FWC, ST)                                                                                    \
@@ -628,10 +625,7 @@ extern "C" int nr_field_fwd_gather(const nr_field_t* field, const float* x01, co
   if (feats_out != nullptr && (((uintptr_t)feats_out & 15u) != 0 || (sl & 3) != 0)) return NR_EINVAL;
   const int64_t tiles = nr_cdiv(n, 32);
   unsigned blocks = (unsigned)(nr_cdiv(tiles, 4) < 512 ? nr_cdiv(tiles, 4) : 512);
-  if (const char* e = getenv("NR_FIELD_FWD_BLOCKS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
-  }
+  if (const int v = nr_tuning().field_fwd_blocks; v > 0 && (int64_t)v < nr_cdiv(tiles, 4)) blocks = (unsigned)v;
   return field_fwd_gather_lp(field, hid, x01, std01, table, scalings, log2T, feats_out, sl, dirs, S, rows_sample_major, n, feature,
                              sdf, alpha, blocks, nr_s(stream));
 }

@@ -15,6 +15,33 @@
 
 static inline hipStream_t nr_s(nr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- launch tuning + one-time kernel attributes (capi.hip) --------------------------------------------
+// No entry point reads the environment or keeps lazily-initialised state: the knobs below are set explicitly through
+// nr_set_tuning() (the Python binding forwards its NR_* variables ONCE, when it loads the library), and the kernels that need
+// more than the default 64 KB of dynamic LDS get their attribute in nr_init() (once per device, before the first launch;
+// a launch without it fails with hipErrorInvalidValue -- loudly).  0 = the built-in default.
+struct NrTuning {
+  int conv7_blocks;        // NR_TUNE_CONV7_BLOCKS: persistent blocks of nr_conv7_fwd
+  int bin_blocks_per_cu;   // NR_TUNE_BIN_BLOCKS_PER_CU: bin blocks per HALF CU of the binned scatters
+  int shared_blocks;       // NR_TUNE_SHARED_BLOCKS: blocks of nr_hash_encode_bwd_shared
+  int field_fwd_blocks;    // NR_TUNE_FIELD_FWD_BLOCKS
+  int field_bwd_blocks;    // NR_TUNE_FIELD_BWD_BLOCKS
+  int pdbwd_blocks;        // NR_TUNE_PDBWD_BLOCKS: blocks of nr_prop_density_bwd
+  int adam_blocks;         // NR_TUNE_ADAM_BLOCKS
+  int pw_mfma_off;         // NR_TUNE_PW_MFMA_OFF: 1 = the transposed convolution on the generic pointwise kernels
+  int prop_shared_off;     // NR_TUNE_PROP_SHARED_OFF: 1 = the proposal scatters on the binned kernels (A/B)
+  int prop_shared_blocks;  // NR_TUNE_PROP_SHARED_BLOCKS
+};
+const NrTuning& nr_tuning();
+// per-file attribute setup, called by nr_init()
+int nr_init_conv7();
+int nr_init_encoder();
+int nr_init_radar();
+template <typename Kern>
+inline int nr_raise_lds(Kern kern, size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 static inline int64_t nr_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __device__ __forceinline__ int64_t nr_cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

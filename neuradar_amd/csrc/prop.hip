@@ -670,8 +670,7 @@ extern "C" int nr_prop_density_bwd(const float* feats, int64_t sn, int64_t sl, i
   if (!feats || !w || !g_density || !g_feats || !g_w || in_dim < 1 || in_dim > 64 || F < 1 || n < 0) return NR_EINVAL;
   if (rows_sample_major < 0 || (rows_sample_major && (n_samples < 1 || n % n_samples != 0 || rows_sample_major > n / n_samples))) return NR_EINVAL;
   // every block ends with ONE atomic request onto the same line (grad_w): keep the queue short
-  int cap_blocks = 256;
-  if (const char* e = getenv("NR_PDBWD_BLOCKS")) cap_blocks = atoi(e) > 0 ? atoi(e) : cap_blocks;  // tuning knob
+  const int cap_blocks = nr_tuning().pdbwd_blocks > 0 ? nr_tuning().pdbwd_blocks : 256;
   const unsigned blocks = (unsigned)(nr_cdiv(n, 256) < cap_blocks ? nr_cdiv(n, 256) : cap_blocks);
 #define CALL(IN)                                                                                                       \
   hipLaunchKernelGGL(prop_density_bwd_kernel<IN>, dim3(blocks), dim3(256), 0, nr_s(stream), feats, sn, sl, F, w, in_dim, n, \
@@ -701,8 +700,7 @@ extern "C" int nr_adam_step(float* param, float* grad, float* m, float* v, int64
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int64_t want = nr_cdiv(n / 4 + 1, 256);
-  int64_t cap = 4096;
-  if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const int64_t cap = nr_tuning().adam_blocks > 0 ? nr_tuning().adam_blocks : 4096;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps,
                      wd, adamw, bc1, bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, static_cast<__bf16*>(delta16), state_stride);
@@ -742,8 +740,7 @@ extern "C" int nr_adam_step_marked(float* param, float* grad, float* m, float* v
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int64_t want = nr_cdiv(n / 4 + 1, 256);
-  int64_t cap = 4096;
-  if (const char* e = getenv("NR_ADAM_BLOCKS")) cap = atoi(e) > 0 ? atoi(e) : cap;  // tuning knob
+  const int64_t cap = nr_tuning().adam_blocks > 0 ? nr_tuning().adam_blocks : 4096;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL(adam_marked_kernel, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, lr, beta1, beta2, eps, bc1,
                      bc2_sqrt, grad_scale, zero_grad, dev_hyper, seen_grad, skip, state_stride);

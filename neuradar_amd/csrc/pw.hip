@@ -460,11 +460,9 @@ bool shape_ok(const PwShape& s) {
          (s.transposed ? (s.N == 9 * s.O && s.O % 8 == 0 && s.H > 0 && s.W > 0 && s.P % (s.H * s.W) == 0) : s.N == s.O) &&
          s.N * s.K + s.O <= 256 * 40;
 }
-// the shape the MFMA kernels are written for (NR_PW_MFMA=0: the generic kernels)
+// the shape the MFMA kernels are written for (NR_TUNE_PW_MFMA_OFF: the generic kernels)
 bool convt_mfma(const PwShape& s, int x_f32, int y_f32, int act) {
-  const char* e = getenv("NR_PW_MFMA");
-  const bool on = !(e && e[0] == '0');
-  return on && s.transposed && s.K == 32 && s.O == 32 && !x_f32 && !y_f32 && act == kActNone;
+  return !nr_tuning().pw_mfma_off && s.transposed && s.K == 32 && s.O == 32 && !x_f32 && !y_f32 && act == kActNone;
 }
 unsigned pw_blocks(int64_t items) {
   const int64_t b = nr_cdiv(items, 256);
@@ -493,7 +491,7 @@ unsigned pw_blocks(int64_t items) {
     else return NR_EINVAL;                                                                                      \
   } else return NR_EINVAL;
 
-static bool pw_fits(int64_t n_pixels, int in_channels, int out_channels, int transposed) {
+inline bool pw_fits(int64_t n_pixels, int in_channels, int out_channels, int transposed) {
   const int64_t n = transposed ? 9 * (int64_t)out_channels : out_channels;
   return n_pixels >= 0 && n_pixels * (n > in_channels ? n : in_channels) < (int64_t)1 << 30;
 }

@@ -810,7 +810,7 @@ static int lsa_q(int64_t small) {  // slots per lane: 1, 2, 4, 8, 16
   return q;
 }
 constexpr int64_t kLsaLdsBytes = 160 * 1024, kLsaLdsFixed = kLsaMaxCols / 8;  // the CU's LDS; the assigned-columns bitmap
-static bool lsa_cm_in_lds(int64_t small) { return kLsaLdsFixed + small * small * 4 <= kLsaLdsBytes; }
+inline bool lsa_cm_in_lds(int64_t small) { return kLsaLdsFixed + small * small * 4 <= kLsaLdsBytes; }
 static int64_t lsa_lds_bytes(int64_t small, int Q) {
   const int64_t start = (int64_t)kLsaMaxCols * 4 + 3 * Q * NR_WAVE * 4, cm = lsa_cm_in_lds(small) ? small * small * 4 : 0;
   return kLsaLdsFixed + (start > cm ? start : cm);
@@ -833,13 +833,6 @@ template <int Q, bool LDS_CM>
 static int lsa_launch(const float* cost, const unsigned long long* sorted, float* cm, const int* seg, int small, int large, int n_pred,
                       int* assoc, int* status, int n_scans, nr_stream_t stream) {
   const int64_t lds = lsa_lds_bytes(small, Q);
-  static bool raised = false;  // (more than the default 64 KB of dynamic LDS needs the attribute once per kernel)
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lsa_kernel<Q, LDS_CM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kLsaLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
   hipLaunchKernelGGL((lsa_kernel<Q, LDS_CM>), dim3((unsigned)n_scans), dim3(NR_WAVE), (size_t)lds, nr_s(stream), cost, sorted, cm, seg,
                      small, large, n_pred, assoc, status);
   NR_LAUNCH_CHECK();
@@ -878,6 +871,16 @@ extern "C" int nr_radar_assign(const float* pred, int n_scans, int64_t n_pred, c
     default: NR_LSA_LAUNCH(16, false);
   }
 #undef NR_LSA_LAUNCH
+}
+
+int nr_init_radar() {  // the six lsa_kernel variants stage up to the CU's whole LDS; the heads' backward 160 KB at 64 inputs
+  if (int rc = nr_raise_lds(lsa_kernel<1, true>, kLsaLdsBytes)) return rc;
+  if (int rc = nr_raise_lds(lsa_kernel<2, true>, kLsaLdsBytes)) return rc;
+  if (int rc = nr_raise_lds(lsa_kernel<4, true>, kLsaLdsBytes)) return rc;
+  if (int rc = nr_raise_lds(lsa_kernel<4, false>, kLsaLdsBytes)) return rc;
+  if (int rc = nr_raise_lds(lsa_kernel<8, false>, kLsaLdsBytes)) return rc;
+  if (int rc = nr_raise_lds(lsa_kernel<16, false>, kLsaLdsBytes)) return rc;
+  return nr_raise_lds(radar_heads_bwd_kernel, 160 * 1024);
 }
 
 extern "C" int nr_radar_loss(const float* pred, int n_scans, int64_t n_pred, const float* detections, int det_stride, const int* seg,
@@ -939,13 +942,7 @@ extern "C" int nr_radar_heads_bwd(const nr_radar_heads_t* heads, const float* x,
   for (int h = 0; h < 3; ++h)
     for (int l = 0; l < 3; ++l)
       if (!heads->weight[h][l] || !heads->bias[h][l] || !grads->weight[h][l] || !grads->bias[h][l]) return NR_EINVAL;
-  static bool raised = false;  // (64 rays x 3 heads of activations: more than the default 64 KB of dynamic LDS at 64 inputs)
-  const size_t lds = rh_lds_bytes(in_dim, true);
-  if (!raised && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(radar_heads_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
+  const size_t lds = rh_lds_bytes(in_dim, true);  // (64 rays x 3 heads of activations: > 64 KB at 64 inputs; raised in nr_init)
   hipLaunchKernelGGL(radar_heads_bwd_kernel, dim3((unsigned)nr_cdiv(n, kRhRays)), dim3(kRhThreads), lds, nr_s(stream), *heads, x, in_dim,
                      grad_out, n, grad_x, grad_xyz, *grads);
   NR_LAUNCH_CHECK();

@@ -212,7 +212,7 @@ class Decoders(nn.Module):
         """Rendering: the BasicBlocks' 7 x 7 convolutions on nr_conv7_fwd with their (eval-mode) batch norms FOLDED into weights
         and biases -- BN(conv(x)) = conv'(x) with W' = W gamma / sigma, b' = (b - mean) gamma / sigma + beta -- so that a block is
         two launches: conv + ReLU, conv + residual + ReLU (model_components/cnns.py:21-47 in eval mode).  dtype: the 16-bit
-        operand type (None switches it off).  Re-packed when a parameter or running statistic has changed."""
+        operand type (None switches it off)."""
         from . import ops
 
         blocks = [m for m in self.rgb_decoder.modules() if isinstance(m, BasicBlock)]
@@ -220,29 +220,30 @@ class Decoders(nn.Module):
             for b in blocks:
                 b.conv7_eval = None
             return
-        tensors = [t for b in blocks for t in (*b.main_branch.parameters(), *b.main_branch.buffers())]
-        version = (dtype, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
-        if getattr(self, "_conv7_eval_version", None) == version:
-            return
+        # Folded on EVERY call (once per rendered image): parameters and running statistics change through raw pointers
+        # (nr_adam_step, nr_bn_act_fwd, graph replays), which no version counter sees.  All convolutions at
+        # once: ~15 launches whatever the number of blocks.
         with torch.no_grad():
-            pieces, w_off, b_off, off = [], [], [], 0
-            for b in blocks:
-                conv1, bn1, _, conv2, bn2 = b.main_branch
-                for conv, bn in ((conv1, bn1), (conv2, bn2)):
-                    if conv.kernel_size != (7, 7) or conv.in_channels != 32 or conv.out_channels != 32:
-                        raise NotImplementedError("prepare_conv7_eval: 7 x 7 convolutions 32 -> 32")
-                    k = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
-                    w = (conv.weight.float() * k[:, None, None, None]).permute(0, 2, 3, 1).contiguous()  # [O, kh, kw, I]
-                    bias = ((conv.bias.float() if conv.bias is not None else 0.0) - bn.running_mean.float()) * k + bn.bias.float()
-                    pieces += [w.reshape(-1), bias.reshape(-1)]
-                    w_off.append(off)
-                    b_off.append(off + w.numel())
-                    off += w.numel() + 32
-            flat16 = torch.cat(pieces).to(dtype)
-            images = ops.conv7_pack(flat16, w_off, b_off)
+            pairs = [(cv, bn) for b in blocks for cv, bn in ((b.main_branch[0], b.main_branch[1]), (b.main_branch[3], b.main_branch[4]))]
+            for conv, _ in pairs:
+                if conv.kernel_size != (7, 7) or conv.in_channels != 32 or conv.out_channels != 32:
+                    raise NotImplementedError("prepare_conv7_eval: 7 x 7 convolutions 32 -> 32")
+            n_c = len(pairs)
+            dev = pairs[0][0].weight.device
+            W = torch.stack([cv.weight.float().permute(0, 2, 3, 1) for cv, _ in pairs])  # [n, O, kh, kw, I] (a view per conv, one copy)
+            cb = torch.stack([cv.bias.float() if cv.bias is not None else torch.zeros(32, device=dev) for cv, _ in pairs])
+            gamma, beta = torch.stack([bn.weight.float() for _, bn in pairs]), torch.stack([bn.bias.float() for _, bn in pairs])
+            mean, var = torch.stack([bn.running_mean.float() for _, bn in pairs]), torch.stack([bn.running_var.float() for _, bn in pairs])
+            eps = torch.tensor([bn.eps for _, bn in pairs], device=dev)[:, None]
+            k = gamma / torch.sqrt(var + eps)                                    # [n, O]
+            flat = torch.cat([(W * k[:, :, None, None, None]).reshape(n_c, -1), (cb - mean) * k + beta], dim=1)  # [n, 32*49*32 + 32]
+            per = flat.shape[1]
+            w_off, b_off = [i * per for i in range(n_c)], [i * per + per - 32 for i in range(n_c)]
+            flat16 = flat.reshape(-1).to(dtype)
+            images = ops.conv7_pack(flat16, w_off, b_off, getattr(self, "_conv7_eval_images", None))
+            self._conv7_eval_images = images
         for i, b in enumerate(blocks):
             b.conv7_eval = (images[2 * i, 0], images[2 * i + 1, 0], dtype)
-        self._conv7_eval_version = version
 
     def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int,
                      seed_epoch: Optional[Tensor] = None) -> Tensor:

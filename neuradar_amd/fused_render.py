@@ -46,25 +46,31 @@ class FusedRenderer:
         self.C = c.field.nff_out_dim
         Sm = self.S[2]
         self.feature, self.sdf, self.alpha = torch.empty(B * Sm, self.C, **f32), torch.empty(B * Sm, **f32), torch.empty(B * Sm, **f32)
-        self._field_version = None
+        self.field_struct = self.field_image = None
 
-    def _field(self) -> NrField:
-        """The field's parameter struct and weight image; the image is rebuilt when a parameter changed (version counters)."""
+    def refresh(self) -> NrField:
+        """The field's parameter struct and packed weight image, REBUILT (one small launch).  Call it once per rendered reading,
+        before the chunks' render() calls: the optimizers of this package write parameters through raw pointers (nr_adam_step,
+        nr_apply_delta16, graph replays), which torch's `_version` counters never see -- a cache keyed on them served a stale
+        MLP image beside current hash tables after render -> train -> render."""
         fld = self.model.field
         gw, gb = fld.mlp_geo.weights()
         fw, fb = fld.mlp_feature.weights()
-        version = tuple(t._version for t in (*gw, *gb, *fw, *fb, fld.sdf_to_density.beta)) + (fld.config.mlp_dtype,)
-        if version != self._field_version:
-            fs = NrField()
-            fs.geo, fs.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
-            fs.beta = fld.sdf_to_density.beta.data_ptr()
-            fs.dtype = _lib.NR_DTYPES[fld.config.mlp_dtype]
-            fs.grad_scale = 1.0
-            self.field_image = torch.empty(self.lib.nr_field_image_floats(byref(fs)), device=self.dev)
-            fs.packed = self.field_image.data_ptr()
-            check(self.lib.nr_field_pack(byref(fs), ops._p(self.field_image), ops._stream()), "field_pack")
-            self.field_struct, self._field_version = fs, version
-        return self.field_struct
+        fs = NrField()
+        fs.geo, fs.feat = ops._mlp_struct(gw, gb), ops._mlp_struct(fw, fb)
+        fs.beta = fld.sdf_to_density.beta.data_ptr()
+        fs.dtype = _lib.NR_DTYPES[fld.config.mlp_dtype]
+        fs.grad_scale = 1.0
+        n_img = self.lib.nr_field_image_floats(byref(fs))
+        if getattr(self, "field_image", None) is None or self.field_image.numel() != n_img:
+            self.field_image = torch.empty(n_img, device=self.dev)
+        fs.packed = self.field_image.data_ptr()
+        check(self.lib.nr_field_pack(byref(fs), ops._p(self.field_image), ops._stream()), "field_pack")
+        self.field_struct = fs
+        return fs
+
+    def _field(self) -> NrField:
+        return self.field_struct if getattr(self, "field_struct", None) is not None else self.refresh()
 
     @torch.no_grad()
     def render(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Optional[Tensor], out: Dict[str, Tensor], lo: int) -> None:

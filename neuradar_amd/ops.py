@@ -21,7 +21,9 @@ def _p(t: Optional[Tensor]):
 
 
 def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream()
+    _lib.ensure_device(st.device_index)  # (nr_init once per device)
+    return c_void_p(st.cuda_stream)
 
 
 def _f32(t: Tensor, what: str) -> Tensor:

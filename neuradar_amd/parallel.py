@@ -8,11 +8,23 @@ are packed into a single fused bucket, and unused parameters (proposal_fields[0]
 all-reduced as zeros instead of DDP's find_unused_parameters bitmap exchange.
 """
 import os
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 from torch import nn
+
+# reducers with a deferred table all-gather possibly in flight (shard_step(defer=True)): whatever reads a table outside the
+# fused step -- the rendering entry, state_dict(), optimizer checkpoints -- calls wait_all_table_syncs() first instead of relying
+# on its caller to remember reducer.flush() (ADVICE r04).  A stream-side wait: no host block, no-op when nothing is pending.
+_DEFERRED = weakref.WeakSet()
+
+
+def wait_all_table_syncs() -> None:
+    for r in list(_DEFERRED):
+        r.wait_table_sync()
+
 
 SMALL_PARAM_NUMEL = 1 << 16
 
@@ -79,6 +91,7 @@ class GradAllReducer:
         self.last_sparse: dict = {}
         self.sparse_group = dist.new_group() if (self.world > 1 and sparse_tables and separate_sparse_group) else group
         self.table_dtype = table_dtype
+        self.dense_probe_every = 50  # reduce_sparse: dense steps between two re-counts of the touched rows
         self._flat: Optional[torch.Tensor] = None
         if buffers is not None:
             self.params = [_GradHolder(b) for b in buffers]
@@ -199,6 +212,7 @@ class GradAllReducer:
             if comm is not None:
                 self._table_sync = torch.cuda.Event()
                 self._table_sync.record(comm)
+                _DEFERRED.add(self)
         if transport is None:  # (the bf16 send pass has cleared the local gradient already)
             if lo > 0:
                 g[:lo].zero_()
@@ -276,16 +290,31 @@ class GradAllReducer:
             st["event"] = None
         count, idx, val = st["count"], st["idx"], st["val"]
         first = prev is None
-        dense = (not first) and prev > cap  # lists no longer pay (decided from the last known counts, alike on every rank)
+        # lists no longer pay (decided from the last known counts, alike on every rank); coming BACK from dense needs 2x room
+        dense = (not first) and (prev > cap or (st.get("dense_steps", 0) > 0 and 2 * prev > cap))
         m = cap if first else min(cap, max(256, (2 * prev + 255) // 256 * 256))
         if dense:
             # (a gradient kept from an overflowed step is part of `grad` and travels with it)
-            # (and from here on it stays dense: the touched-row count of a training run only grows)
+            # Dense is not for ever: one outlier batch must not turn every later step into a full all-reduce.  Every
+            # `dense_probe_every` dense steps the non-zero rows are counted again (one read of the gradient) and all-gathered;
+            # the host sees them one step later, like the lists' counts, and the exchange returns to lists once they fit twice.
+            st["dense_steps"] = st.get("dense_steps", 0) + 1
+            if st["dense_steps"] % self.dense_probe_every == 0:
+                count.copy_((grad.view(-1, row_width) != 0).any(dim=1).sum().to(torch.int32).reshape(1))
+                self._all_gather(st["counts"], count)
+                if grad.is_cuda:
+                    st["host"].copy_(st["counts"], non_blocking=True)
+                    st["event"] = torch.cuda.Event()
+                    st["event"].record()
+                else:
+                    st["host"].copy_(st["counts"])
+                    prev = int(st["host"].max())
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.sparse_group)
             st["prev_max"] = prev
             st["flag"].zero_()
             self.last_sparse = {"mode": "dense", "rows": None, "bytes": grad.numel() * 4, "flag": st["flag"]}
             return self.last_sparse
+        st["dense_steps"] = 0
         count.zero_()
         compact(grad, row_width, idx[:m], val[:m * row_width], count)  # rows beyond m stay in grad; count = ALL non-zero rows
         self._all_gather(st["counts"], count)

@@ -74,6 +74,12 @@ class HotPathConfig:
     render_decoders_in_training_dtype: bool = True
 
 
+def _wait_table_syncs_hook(module, prefix, keep_vars) -> None:
+    from .parallel import wait_all_table_syncs
+
+    wait_all_table_syncs()
+
+
 class NeuRadarHotPath(nn.Module):
     def __init__(self, config: HotPathConfig, actors=None) -> None:
         """actors: a `DynamicActors` module shared by the main and the proposal fields (neuradar.py:196-208,293-300)."""
@@ -89,6 +95,8 @@ class NeuRadarHotPath(nn.Module):
         # late-binding lambda, so BOTH proposal rounds evaluate proposal_fields[1]; proposal_fields[0]
         # exists (state_dict, optimizer, all-reduce) but never runs.  Reproduced on purpose.
         last = self.proposal_fields[-1]
+        # state_dict() of a model whose main table a sharded data-parallel step is still all-gathering: wait (stream side) first
+        self.register_state_dict_pre_hook(_wait_table_syncs_hook)
         self._flips = (None, None, None)  # injected per-ray actor flips of (round 0, round 1, main field); None = draw
         self.density_fns = [lambda rs, i=i: last.get_density(rs, flip=self._flips[i])[0] for i in range(len(self.proposal_fields))]
         self.sampler = ProposalNetworkSampler(
@@ -238,6 +246,9 @@ class NeuRadarHotPath(nn.Module):
         rgb [H, W, 3] (camera), intensity and ray_drop_logits / ray_drop_prob (every ray, "intensity_for_cam"),
         radar_output [scans, n, 7] (radar)."""
         assert not self.training, "rendering runs in eval mode (deterministic samplers, no carving masks)"
+        from .parallel import wait_all_table_syncs
+
+        wait_all_table_syncs()  # (a sharded data-parallel step may still be all-gathering the table it updated)
         n_all = len(bundle)
         take = None
         if image_shape is None:  # lidar or radar
@@ -276,6 +287,7 @@ class NeuRadarHotPath(nn.Module):
             dev = rays.origins.device
             C = self.config.field.nff_out_dim
             flat = {"features": torch.empty(n, C, device=dev), **{k: torch.empty(n, 1, device=dev) for k in keep[1:]}}
+            fused.refresh()  # this reading's MLP weight image (parameters change through raw pointers between renders)
             for lo in range(0, n, chunk):
                 hi = min(lo + chunk, n)
                 fused.render(rays.origins[lo:hi], rays.directions[lo:hi], rays.pixel_area[lo:hi],
@@ -324,19 +336,27 @@ class NeuRadarHotPath(nn.Module):
         return outputs
 
     def _fused_renderer(self, max_rays: int):
-        """The forward-only launch chain of the rendering entry (fused_render.FusedRenderer), built once per chunk size; None
-        where it does not apply (dynamic actors, density branch, tcnn-layout tables, NR_FUSED_RENDER=0): the modular path."""
+        """The forward-only launch chain of the rendering entry (fused_render.FusedRenderer); None where it does not apply
+        (dynamic actors, density branch, tcnn-layout tables, NR_FUSED_RENDER=0): the modular path.  ONE renderer sized
+        eval_num_rays_per_chunk serves every reading that fits it (render() takes any n <= its size; ~20 KB of buffers per ray);
+        only a radar scan LONGER than a chunk (its decoder attends over the whole scan, so it is rendered in one piece) gets a
+        larger one, rounded up to a power of two, and only the latest of those is kept -- evaluating many scans of varying
+        length no longer grows GPU memory with every new ray count."""
         if os.environ.get("NR_FUSED_RENDER", "1") == "0":
             return None
         cache = self.__dict__.setdefault("_fused_render_cache", {})
-        if max_rays not in cache:
+        base = int(self.config.eval_num_rays_per_chunk)
+        size = base if max_rays <= base else 1 << (max_rays - 1).bit_length()
+        if size not in cache:
             from .fused_render import FusedRenderer
 
+            for k in [k for k in cache if k != base]:  # at most one oversize renderer alive
+                del cache[k]
             try:
-                cache[max_rays] = FusedRenderer(self, max_rays)
+                cache[size] = FusedRenderer(self, size)
             except NotImplementedError:
-                cache[max_rays] = None
-        return cache[max_rays]
+                cache[size] = None
+        return cache[size]
 
     def decode_lidar(self, features: Tensor, is_lidar: Tensor):
         """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the
@@ -625,6 +645,9 @@ class FlatAdam:
         elements [lo, hi) only: `shards` records (lo, hi, numel) per such buffer, so a checkpoint written by one rank is not
         mistaken for the whole table -- `gather_state_dict()` assembles the full moments on every rank for a checkpoint that
         any world size can load."""
+        from .parallel import wait_all_table_syncs
+
+        wait_all_table_syncs()
         sh = getattr(self, "shards", {})
         return {"exp_avg": [m.reshape(-1).clone() for m, _ in self.state], "exp_avg_sq": [v.reshape(-1).clone() for _, v in self.state],
                 "step_t": self.step_t.clone(), "hyper": self.hyper.clone(),

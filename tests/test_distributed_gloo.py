@@ -147,6 +147,22 @@ def _sparse_worker(rank, world, port):
     assert float(info["flag"]) == 0.0 and info["mode"] in ("sparse", "dense"), info
     assert torch.allclose(buf.view(rows, F), want, rtol=1e-6, atol=1e-6)
     identical(buf)
+    # (e) dense is not for ever: one outlier batch sends the exchange dense; the touched rows are re-counted every
+    # `dense_probe_every` dense steps and the exchange returns to lists once they fit again (with 2x room)
+    red = GradAllReducer(None, buffers=[])
+    red.dense_probe_every = 2
+    modes = []
+    for k, density in enumerate((0.5, 0.01, 0.01, 0.01, 0.01)):
+        buf.zero_()
+        buf.view(rows, F).add_(grads(400 + k, density))
+        want = buf.view(rows, F).clone()
+        dist.all_reduce(want)
+        info = red.reduce_sparse(buf, F, ops=ops_)
+        modes.append(info["mode"])
+        assert float(info["flag"]) == 0.0
+        assert torch.allclose(buf.view(rows, F), want, rtol=1e-6, atol=1e-6), (k, info["mode"])
+        identical(buf)
+    assert modes[0] == "dense" and modes[1] == "dense" and modes[-1] == "sparse", modes
     dist.barrier()
     dist.destroy_process_group()
 

@@ -6,6 +6,7 @@ configs[4] transformer in the step):
   * the lidar loss kernels against the oracle on ragged / degenerate inputs;
   * FusedTrainStep.set_decoders: loss and EVERY parameter gradient of the fused step against the modular HIP path for the
     field part + the CPU oracle (oracle/decoder_losses.py) for everything behind the rendered features."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -324,6 +325,10 @@ def test_cnn_16_bit_working_copies_equal_autocast(dtype, monkeypatch):
     res = {}
     for mode in ("copies", "autocast", "fp32"):
         monkeypatch.setenv("NR_CNN_SHADOW", "1" if mode == "copies" else "0")
+        if os.environ.get("NR_TEST_TRACE"):  # tools/repro_abort.sh: which leg, and where the allocator's segments end
+            torch.cuda.synchronize()
+            segs = sorted((s_["address"], s_["total_size"]) for s_ in torch.cuda.memory_snapshot())
+            print(f"[leg] {dtype} {mode} segments: " + " ".join(f"{a:x}+{n:x}" for a, n in segs), flush=True)
         torch.manual_seed(0)
         dec, m = _decoder_model(48)
         _load_reference_parameters(dec)

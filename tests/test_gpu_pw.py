@@ -48,12 +48,13 @@ def test_head_conv1x1_relu_from_fp32_rows(dtype, P, H, W):
 @pytest.mark.parametrize("mfma", ["1", "0"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("P,H,W", [(8, 32, 32), (2, 3, 5), (1, 7, 9)])
-def test_transposed_convolution_3x3_stride_3(monkeypatch, dtype, P, H, W, mfma):
+def test_transposed_convolution_3x3_stride_3(request, dtype, P, H, W, mfma):
     """Forward and data gradient on the matrix cores (nine 32 x 32 GEMMs per 32 pixels) and on the generic pointwise kernels
-    (NR_PW_MFMA=0); the weight gradient is the generic kernel's in both."""
-    from neuradar_amd import ops
+    (nr_set_tuning NR_TUNE_PW_MFMA_OFF); the weight gradient is the generic kernel's in both."""
+    from neuradar_amd import _lib, ops
 
-    monkeypatch.setenv("NR_PW_MFMA", mfma)
+    _lib.set_tuning("NR_PW_MFMA_OFF", 0 if mfma == "1" else 1)
+    request.addfinalizer(lambda: _lib.set_tuning("NR_PW_MFMA_OFF", 0))
     torch.manual_seed(P * H)
     u = U[dtype]
     x = torch.randn(P, 32, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)

@@ -132,3 +132,52 @@ def test_fused_render_chain_equals_the_modular_eval_path(mlp_dtype, monkeypatch)
             _check(a[k].reshape(-1, a[k].shape[-1]).cpu(), b[k].reshape(-1, b[k].shape[-1]).cpu(), f"{what} {k} ({mlp_dtype})", rtol=1e-4, floor=1e-5,
                    few=5e-3)
     _check(outs["1"][0]["rgb"].reshape(-1, 3).cpu(), outs["0"][0]["rgb"].reshape(-1, 3).cpu(), "rgb", rtol=1e-3, floor=1e-4, few=5e-3)
+
+
+@pytest.mark.parametrize("mlp_dtype", ["bfloat16", "float32"])
+def test_render_after_raw_pointer_optimizer_steps_sees_the_new_parameters(mlp_dtype, monkeypatch):
+    """render -> FlatAdam steps -> render.  FlatAdam (nr_adam_step) and the batch norms' running statistics
+    (nr_bn_act_fwd) write through raw pointers, so torch's `_version` counters never move: the fused renderer's packed MLP image
+    and the CNN's BN-folded 7 x 7 images are rebuilt per rendered reading instead of being cached on those counters.  The second
+    fused render must equal the modular eval path (NR_FUSED_RENDER=0, which packs per call) on the UPDATED parameters -- and differ
+    from the first render."""
+    from neuradar_amd.step import FlatAdam
+
+    H, W = 23, 40
+    model = _model(chunk=101)
+    model.field.config.mlp_dtype = mlp_dtype
+    cam = lambda: _camera_rays(H, W, torch.Generator().manual_seed(7))  # noqa: E731
+    monkeypatch.setenv("NR_FUSED_RENDER", "1")
+    first = model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))
+    # "training": every field / decoder parameter moves through nr_adam_step on a synthetic gradient; running statistics of
+    # the CNN's batch norms move through nr_bn_act_fwd itself
+    params = [p for n_, p in model.named_parameters() if "hash_table" not in n_ and p.requires_grad]
+    opt = FlatAdam(params, lr=5e-2, warmup_steps=0)
+    versions = [p._version for p in params]
+    torch.manual_seed(11)
+    for _ in range(3):
+        for _, g in opt.buffers:
+            g.copy_(torch.randn_like(g))
+        opt.advance()
+        for i in range(len(opt.buffers)):
+            opt.step_buffer(i)
+    assert [p._version for p in params] == versions, "the premise: raw-pointer updates do not bump version counters"
+    from neuradar_amd import ops
+
+    for m_ in model._decoders.rgb_decoder.modules():
+        if isinstance(m_, torch.nn.BatchNorm2d):  # a training-mode nr_bn_act_fwd: running statistics move, their version does not
+            v0 = (m_.running_mean._version, m_.running_var._version)
+            x = (3.0 * torch.randn(2, m_.num_features, 8, 8, device=DEV) + 1.0).contiguous(memory_format=torch.channels_last)
+            with torch.no_grad():
+                ops.bn_act(x, m_.weight, m_.bias, m_.running_mean, m_.running_var, None, 0.5, m_.eps, True)
+            assert (m_.running_mean._version, m_.running_var._version) == v0
+    torch.cuda.synchronize()
+    second = model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))
+    monkeypatch.setenv("NR_FUSED_RENDER", "0")
+    modular = model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))
+    for k in ("features", "depth", "accumulation", "intensity"):
+        _check(second[k].reshape(-1, second[k].shape[-1]).cpu(), modular[k].reshape(-1, modular[k].shape[-1]).cpu(),
+               f"{k} after the update ({mlp_dtype})", rtol=1e-4, floor=1e-5, few=5e-3)
+    _check(second["rgb"].reshape(-1, 3).cpu(), modular["rgb"].reshape(-1, 3).cpu(), "rgb after the update", rtol=1e-3, floor=1e-4, few=5e-3)
+    assert float((second["features"] - first["features"]).abs().max()) > 1e-3, "the update did not reach the rendered features"
+    assert float((second["rgb"] - first["rgb"]).abs().max()) > 1e-3, "the update did not reach the image"

@@ -6,7 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from neuradar_amd import ops  # noqa: E402
+from neuradar_amd import _lib, ops  # noqa: E402
 from neuradar_amd.fused_step import FusedTrainStep  # noqa: E402
 
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cam4096_l16f2_w64"]
@@ -33,18 +33,18 @@ if only:
     torch.cuda.synchronize()
     sys.exit(0)
 for fb in os.environ.get("FWD_BLOCKS", "256,512").split(","):
-    os.environ["NR_FIELD_FWD_BLOCKS"] = fb
+    _lib.set_tuning("NR_FIELD_FWD_BLOCKS", int(fb))
     t = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, B, n, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
     print(f"field_fwd blocks={fb}: {t * 1e6:7.1f} us")
 for bb in os.environ.get("BWD_BLOCKS", "128,256").split(","):
-    os.environ["NR_FIELD_BWD_BLOCKS"] = bb
+    _lib.set_tuning("NR_FIELD_BWD_BLOCKS", int(bb))
     t = bench.time_kernel(lambda: lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, B, n, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s()), 20)
     print(f"field_bwd blocks={bb}: {t * 1e6:7.1f} us")
 # fixed cost vs per-tile cost: shrink n at a fixed grid
 for frac in (1.0, 0.5, 0.25, 0.125, 1.0 / 64):
     nn = int(n * frac) // 32 * 32
-    os.environ["NR_FIELD_FWD_BLOCKS"] = "512"
-    os.environ["NR_FIELD_BWD_BLOCKS"] = "256"
+    _lib.set_tuning("NR_FIELD_FWD_BLOCKS", int("512"))
+    _lib.set_tuning("NR_FIELD_BWD_BLOCKS", int("256"))
     tf = bench.time_kernel(lambda: lib.nr_field_fwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 0, nn, p(st.feature), p(st.sdf), p(st.alpha), s()), 20)
     tb = bench.time_kernel(lambda: lib.nr_field_bwd(byref(st.field_struct), p(st.feats[2]), F, n * F, F, p(d), 32, 0, nn, p(st.g_feature), p(st.g_alpha), None, p(st.g_feats[2]), byref(st.field_grads), p(st.field_ws), s()), 20)
     print(f"n={nn:7d} ({nn // 32} tiles): field_fwd {tf * 1e6:7.1f} us   field_bwd {tb * 1e6:7.1f} us")

@@ -8,10 +8,10 @@ l=json.loads(sys.stdin.readlines()[-1]); print('$label', l['ms_per_step'], l['co
 C="--no-cpu-baseline --secondary= --full-model= --no-roofline --regime trained --trained-steps 400 --no-render"
 W="$C --workload mixed16384_neuradar_full_fp16"
 run fp16_mfma A=1
-run fp16_valu NR_PW_MFMA=0
+run fp16_valu NR_PW_MFMA_OFF=1
 run fp16_lib NR_PW=0
 run fp16_mfma_skipradar NR_DECODER_SKIP=radar
-run fp16_valu_skipradar NR_DECODER_SKIP=radar NR_PW_MFMA=0
+run fp16_valu_skipradar NR_DECODER_SKIP=radar NR_PW_MFMA_OFF=1
 run fp16_lib_skipradar NR_DECODER_SKIP=radar NR_PW=0
 W="$C --workload mixed16384_neuradar_full"
 run bf16_mfma A=1
