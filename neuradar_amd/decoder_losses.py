@@ -294,15 +294,26 @@ class DecoderLossHead:
                     # rows, transposed 3 x 3, tail 1 x 1 + sigmoid to fp32) on nr_pw_*, the blocks' 7 x 7 on nr_conv7_*
                     prm, subs = sh["params"], sh["pointwise"]
                     n_p, ph = xs.shape[0] // (self.patch * self.patch), self.patch
+                    tap = getattr(self, "stage_tap", None)  # tests: the activation after every stage of the decoder ([P, C, H, W])
                     h = ops.pointwise(xs, prm["0.weight"], prm.get("0.bias"), act=1, grad_scale=None if scale is None else scale[1])
                     h = h.view(n_p, ph, ph, h.shape[1]).permute(0, 3, 1, 2)
+                    if tap is not None:
+                        tap.append(h.detach().float())
                     for i_ in (2, 3):
                         h = torch.func.functional_call(m.rgb_decoder[i_], subs[i_], (h,))
+                        if tap is not None:
+                            tap.append(h.detach().float())
                     h = ops.conv_transpose3(h, prm["4.weight"], prm.get("4.bias"))
+                    if tap is not None:
+                        tap.append(h.detach().float())
                     for i_ in (5, 6):
                         h = torch.func.functional_call(m.rgb_decoder[i_], subs[i_], (h,))
+                        if tap is not None:
+                            tap.append(h.detach().float())
                     rgb = ops.pointwise(h.permute(0, 2, 3, 1).reshape(-1, h.shape[1]), prm["7.weight"], prm.get("7.bias"), act=2, out_f32=True)
                     rgb = rgb.view(n_p, 3 * ph, 3 * ph, rgb.shape[1])
+                    if tap is not None:
+                        tap.append(rgb.detach().permute(0, 3, 1, 2).float())
                     nhwc = True
                 else:
                     if scale is not None:  # d loss / d patches leaves the 16-bit backward scaled: divided back here

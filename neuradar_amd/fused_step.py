@@ -45,6 +45,75 @@ def flatten_parameters(params: List[nn.Parameter]) -> Dict[str, Tensor]:
     return {"param": flat, "grad": flat_grad}
 
 
+class SegmentedStep:
+    """A data-parallel training step as hipGraph SEGMENTS cut where the host must act (world > 1).
+
+    torch.distributed collectives cannot sit inside a captured hipGraph portably (gloo is host-driven; capture of RCCL launches
+    cannot be verified on a one-GPU box), so a step with a reducer was launched eagerly: fine for the 29-launch headline step,
+    host-bound for the 186-launch decoder workloads (5.5 ms of host time per step against 3.6 ms of GPU time).  Here the step
+    function runs ONCE under stream capture; every host-side action inside it -- FusedTrainStep._host(fn): the wait for a
+    deferred all-gather, the main table's gradient exchange + Adam, the remaining all-reduces + Adam launches -- ends the
+    current graph, is RECORDED (not executed: nothing executes during capture) and, unless it is the last one, starts the next
+    graph.  replay() then alternates graph launches and the recorded host actions:
+
+        g0 [rays -> sampling rounds]  |host: wait for the previous step's table all-gather|
+        g1 [main gather ... render, decoders, field backward, main scatter]  |host: main table exchange + Adam on the comm stream|
+        g2 [proposal scatters -- beside that exchange]  |host: proposal table / small parameters / other optimizers|
+
+    Every cut is a point where all forked streams have joined (FusedTrainStep joins them in front of each _host call when a
+    recorder is attached).  Reference behaviour: one DDP all-reduce per step overlapped with the backward,
+    pipelines/base_pipeline.py:305-307, scripts/train.py:104,145."""
+
+    def __init__(self, stepper: "FusedTrainStep") -> None:
+        self.stepper = stepper
+        self.parts: List[tuple] = []  # (graph or None, host action or None), in order
+        self._graph = None
+        self._pool = None
+        self.host_ms = None
+
+    # ---- recorder protocol (called by FusedTrainStep._host during capture)
+    def _begin(self) -> None:
+        self._graph = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        self._graph.capture_begin(pool=self._pool)
+
+    def cut(self, fn, final: bool) -> None:
+        self._graph.capture_end()
+        self.parts.append((self._graph, fn))
+        self._graph = None
+        if not final:
+            self._begin()
+
+    def capture(self, step_fn) -> "SegmentedStep":
+        """step_fn(): one call of the step (FusedTrainStep.forward_backward with optimizers and reducer) on static buffers.  Run
+        a few eager steps first (lazy allocations, MIOpen's search).  Nothing is executed here."""
+        assert not self.parts, "already captured"
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        self.stepper._segmenter = self
+        try:
+            with torch.cuda.stream(cap):
+                self._begin()
+                step_fn()
+                if self._graph is not None:  # the step ended without a final host action
+                    self._graph.capture_end()
+                    self.parts.append((self._graph, None))
+                    self._graph = None
+        finally:
+            self.stepper._segmenter = None
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        return self
+
+    def replay(self) -> None:
+        for graph, fn in self.parts:
+            graph.replay()
+            if fn is not None:
+                fn()
+
+
 class FusedTrainStep:
     def __init__(self, model: NeuRadarHotPath, n_rays: int, overlap: bool = True, coherent_rays: Optional[int] = None) -> None:
         """coherent_rays: number of LEADING rays that come in spatially coherent groups (camera patches); their
@@ -53,6 +122,8 @@ class FusedTrainStep:
         c = model.config
         self.overlap = overlap and os.environ.get("NR_STEP_OVERLAP", "1") != "0"  # tuning knob
         self._streams = None
+        self._segmenter = None  # SegmentedStep while it captures this step (world > 1): see _host
+        self._comm = None
         self.timers = None  # dict name -> [(start, end) events]: set by a caller that wants in-step kernel times (eager only)
         assert len(c.num_proposal_samples) == 2
         if not c.field.use_sdf:
@@ -333,6 +404,19 @@ class FusedTrainStep:
                                          self.S[0], c.power_lambda, c.power_scaling, self.model.field.hashgrid.static_scale,
                                          self.sm, p(sl["sp"]), p(sl["eu"]), p(sl["x01"]), p(sl["std"]), ops._stream()), "power_bins")
 
+    def _adam_stream(self):
+        if getattr(self, "_adam_s", None) is None:
+            self._adam_s = torch.cuda.Stream(device=self.dev)
+        return self._adam_s
+
+    def _host(self, fn, final: bool = False) -> None:
+        """A host-side action of the step (a collective, a wait for one, optimizer launches ordered behind one): executed in
+        place -- or, while a SegmentedStep captures the step, recorded as the boundary between two graph segments."""
+        if self._segmenter is None:
+            fn()
+        else:
+            self._segmenter.cut(fn, final)
+
     def forward_backward(self, origins: Tensor, directions: Tensor, pixel_area: Tensor, fars: Tensor,
                          target_features: Tensor, target_depth: Tensor, t_rand: Tensor, jitter1: Tensor,
                          jitter2: Tensor, optimizers=None, reducer=None, after_sampling=None, slot: int = 0,
@@ -474,8 +558,12 @@ class FusedTrainStep:
         # 32-wide stack on 16-bit operands, no actor rows to patch in between.  NR_FUSE_MAIN_GATHER=0: two launches.
         fuse_gather = (mg.num_levels == 8 and F == 4 and self.field_struct.dtype != 0 and self.model.field.config.geo_hidden_dim == 32
                        and not self.n_actors and os.environ.get("NR_FUSE_MAIN_GATHER", "1") != "0")
+        seg = self._segmenter if (reducer is not None and optimizers is not None) else None
         if reducer is not None:
-            reducer.wait_table_sync()  # a deferred all-gather of the previous step's sharded table update lands here: first read
+            # a deferred all-gather of the previous step's sharded table update lands here: first read of the main table
+            if seg is not None and side[0] is not main:
+                main.wait_stream(side[0])  # (a graph segment ends here: every forked stream joined)
+            self._host(reducer.wait_table_sync)
         if not fuse_gather:
             check(self._timed(f"hash_encode_fwd[main_s{Sm}]", lambda: lib.nr_hash_encode_fwd(
                 p(self.x01[2]), p(self.std[2]), p(mg.hash_table), p(mg.scalings), mg.num_levels, F, mg.log2_hashmap_size,
@@ -557,6 +645,8 @@ class FusedTrainStep:
         # 537 MB dense all-reduce) can then start ~0.6 ms earlier and run beside the proposal scatters instead of after
         # them.  Reasoned from the single-GPU timeline like the early fork above, not measured (one GPU per call here).
         order = os.environ.get("NR_SCATTER_ORDER", "main_first" if reducer is not None and early == 0 else "concurrent")
+        if self._segmenter is not None and reducer is not None and optimizers is not None:
+            order = "main_first"  # (graph segments: the main table's exchange is cut in between the main and the proposal scatters)
 
         # proposal levels whose density-head backward rides inside the binned scatter (nr_prop_density_scatter_binned): all
         # rows binned, no actor rows to patch into the feature gradients -- the [L, n, F] gradient buffer is then never touched
@@ -591,6 +681,10 @@ class FusedTrainStep:
                 t_opt.marked[i_m] = True
         if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
             optimizers[0].marked.clear()
+        # main table: scatter and Adam pipelined level by level (single GPU, marked Adam, block-shared scatter; NR_MAIN_LEVEL_PIPELINE)
+        level_pipeline = (mark_seen is not None and self.main_shared and self.amp is None
+                          and os.environ.get("NR_MAIN_LEVEL_PIPELINE", "0") == "1")
+        level_pipeline_buffer = optimizers[0].buffer_of(mg.hash_table) if level_pipeline else None
 
         def scatter(lvl, grid, tag):
             """grad_table += scatter of g_feats[lvl] on the current stream: the merging kernel on the coherent rows, the
@@ -615,6 +709,27 @@ class FusedTrainStep:
                     # NeuRadar's main grid in a step on 16-bit MLP operands: the block-shared vertex-keyed LDS table on 32-bit
                     # integer atomics (grid_shared.hip) for every row -- two waves per SIMD and a third of the merging kernel's
                     # instructions; marks the optimizer's `seen` bytes itself when the marked Adam follows
+                    if level_pipeline:
+                        # one launch per LEVEL, and the level's Adam on a stream of its own as soon as its scatter is done, beside
+                        # the next level's scatter: the step's critical path (main scatter 700 us -> main Adam 514 us, nothing
+                        # beside the Adam) becomes ~ scatter + one level of Adam
+                        T4 = (1 << grid.log2_hashmap_size) * Fg  # floats per level
+                        cur_ = torch.cuda.current_stream()
+                        adam_s = self._adam_stream()
+                        for l_ in range(grid.num_levels):
+                            rc = lib.nr_hash_encode_bwd_shared(
+                                p(self.x01[lvl]), p(self.std[lvl]), c_void_p(grid.scalings.data_ptr() + 4 * l_), 1, Fg, grid.log2_hashmap_size,
+                                c_void_p(self.g_feats[lvl].data_ptr() + 4 * l_ * nl * Fg), Fg, nl * Fg,
+                                c_void_p(grid.hash_table.grad.data_ptr() + 4 * l_ * T4), nl,
+                                c_void_p(mark_seen.data_ptr() + l_ * T4 // 4), sp_)
+                            if rc != 0:
+                                return rc
+                            ev_ = torch.cuda.Event()
+                            ev_.record(cur_)
+                            adam_s.wait_event(ev_)
+                            with torch.cuda.stream(adam_s):
+                                optimizers[0].step_buffer(level_pipeline_buffer, 1.0, part=(l_ * T4, (l_ + 1) * T4))
+                        return 0
                     return lib.nr_hash_encode_bwd_shared(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
                                                          grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
                                                          p(grid.hash_table.grad), nl, p(mark_seen), sp_)
@@ -708,11 +823,12 @@ class FusedTrainStep:
         if self.amp is not None and optimizers is not None:
             # the found-inf flags of the tables' optimizer are final once the field backward has run: the proposal table's Adam
             # (a side stream that may have started before nr_field_bwd) waits for this point, the main table's follows it anyway
-            if reducer is not None:  # every rank must take the same decision: SUM of the ranks' flags (non-zero = found)
+            if reducer is not None and seg is None:  # every rank must take the same decision: SUM of the ranks' flags (non-zero = found)
                 reducer.start(self.amp.buf[self.amp._F:self.amp._F + 8])
                 reducer.wait_all()
-            amp_ev = torch.cuda.Event()
-            amp_ev.record(main)
+            if seg is None:  # (segmented: the flags are summed by the first host action behind the backward, see host_main_table)
+                amp_ev = torch.cuda.Event()
+                amp_ev.record(main)
         for i_, (lvl, stream) in enumerate(chains):
             late = i_ not in before
             if not (late or (split_reduce and i_ == 0)):
@@ -733,58 +849,53 @@ class FusedTrainStep:
             with torch.cuda.stream(side[1]):
                 merged_scatter()
         scatter(2, mg, "main")
-        if order == "main_first":
-            if merged and not before:
-                if side[1] is not main:
-                    side[1].wait_stream(main)
-                with torch.cuda.stream(side[1]):
-                    merged_scatter()
-            for i_, (lvl, stream) in enumerate(chains):
-                if i_ in before or merged:
-                    continue
-                if stream is not main:
-                    stream.wait_stream(main)
-                with torch.cuda.stream(stream):
-                    chain_scatter(lvl)
+
+        def join_all():
+            for s_ in side:
+                if s_ is not main:
+                    main.wait_stream(s_)
+
+        table_opt = field_opt = None
         if optimizers is not None:
             table_opt, field_opt = optimizers[:2]
             scale = 1.0 if reducer is None else 1.0 / reducer.world
             i_prop, i_main = table_opt.buffer_of(pg.hash_table), table_opt.buffer_of(mg.hash_table)
             shared = i_prop == i_main  # tiny tables (<= 65536 elements) live in ONE flat buffer: reduce and step it once,
             #                            after both tables' scatters (below, on side[0])
-            # main table first: its list exchange holds the step's only host read, and issuing it before the
-            # proposal table's all-reduce keeps the CPU from parking behind the proposal chains
-            if not shared:
-                if reducer is not None and reducer.table_mode == "shard" and i_main in getattr(table_opt, "shards", {}):
-                    # reduce-scatter -> Adam on this rank's 1/world of the rows -> all-gather (parallel.shard_step)
-                    # (reducer.table_delta / defer_gather: the update deltas in bf16, the all-gather deferred into the next step)
-                    reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype,
-                                       delta_dtype=getattr(reducer, "table_delta", None), defer=getattr(reducer, "defer_gather", False))
-                else:
-                    keep = None
-                    if reducer is not None:
-                        if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
-                            # (flag = 2 where a rank's list overflowed: the table's Adam then skips this step and keeps the gradient)
-                            keep = reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level).get("flag")
-                        else:
-                            reducer.start(table_opt.buffers[i_main][1])
-                            reducer.wait_all()
-                    table_opt.step_buffer(i_main, scale, skip_extra=keep)
-            if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
-                side[0].wait_stream(side[1])
-                if shared:
-                    side[0].wait_stream(main)
-            with torch.cuda.stream(side[0]):
+
+        def amp_flags_sum():
+            if self.amp is not None and reducer is not None:  # every rank must take the same decision: SUM of the ranks' flags
+                reducer.start(self.amp.buf[self.amp._F:self.amp._F + 8])
+                reducer.wait_all()
+
+        def main_table_step():
+            """The main table's gradient exchange and Adam, on the current stream."""
+            if reducer is not None and reducer.table_mode == "shard" and i_main in getattr(table_opt, "shards", {}):
+                # reduce-scatter -> Adam on this rank's 1/world of the rows -> all-gather (parallel.shard_step)
+                # (reducer.table_delta / defer_gather: the update deltas in bf16, the all-gather deferred into the next step)
+                reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype,
+                                   delta_dtype=getattr(reducer, "table_delta", None), defer=getattr(reducer, "defer_gather", False))
+            else:
+                keep = None
                 if reducer is not None:
-                    reducer.start(table_opt.buffers[i_prop][1])
-                    reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
-                if amp_ev is not None and side[0] is not main:
-                    side[0].wait_event(amp_ev)
-                table_opt.step_buffer(i_prop, scale)
-        for s_ in side:
-            if s_ is not main:
-                main.wait_stream(s_)
-        if optimizers is not None:
+                    if reducer.sparse_tables:  # a step touches ~1 % of the main table's rows: exchange those only
+                        # (flag = 2 where a rank's list overflowed: the table's Adam then skips this step and keeps the gradient)
+                        keep = reducer.reduce_sparse(table_opt.buffers[i_main][1], mg.features_per_level).get("flag")
+                    else:
+                        reducer.start(table_opt.buffers[i_main][1])
+                        reducer.wait_all()
+                if level_pipeline:
+                    torch.cuda.current_stream().wait_stream(self._adam_stream())  # (the levels' Adam launches followed their scatters)
+                else:
+                    table_opt.step_buffer(i_main, scale, skip_extra=keep)
+
+        def prop_table_step():
+            if reducer is not None:
+                reducer.start(table_opt.buffers[i_prop][1])
+                reducer.wait_all()  # stream-level wait: the stream continues once RCCL is done
+            table_opt.step_buffer(i_prop, scale)
+
+        def small_and_other_steps():
             if reducer is not None:  # small parameters: need field_bwd and both prop_density_bwd
                 for _, g_ in field_opt.buffers:
                     reducer.start(g_)
@@ -809,6 +920,75 @@ class FusedTrainStep:
                 o_.step_buffer(i, scale)
             if self.amp is not None:
                 self.amp.update()
+
+        # ---- graph segments (SegmentedStep, world > 1): the optimizer tail as recorded host actions between graphs
+        main_table_cut = False
+        if seg is not None:
+            scatters_pending = (merged and not before) or any(i_ not in before and not merged for i_ in range(len(chains)))
+            if scatters_pending and not shared:
+                # cut between the main grid's scatter and the proposal scatters: the main table's exchange (the step's largest
+                # collective) runs on the communication stream BESIDE the next segment
+                join_all()
+
+                def host_main_table():
+                    cur = torch.cuda.current_stream()
+                    if self._comm is None:
+                        self._comm = torch.cuda.Stream(device=self.dev)
+                    amp_flags_sum()
+                    self._comm.wait_stream(cur)
+                    with torch.cuda.stream(self._comm):
+                        main_table_step()
+
+                self._host(host_main_table)
+                main_table_cut = True
+        if order == "main_first":
+            if merged and not before:
+                if side[1] is not main:
+                    side[1].wait_stream(main)
+                with torch.cuda.stream(side[1]):
+                    merged_scatter()
+            for i_, (lvl, stream) in enumerate(chains):
+                if i_ in before or merged:
+                    continue
+                if stream is not main:
+                    stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    chain_scatter(lvl)
+        if seg is not None:
+            join_all()
+
+            def host_tail():
+                cur = torch.cuda.current_stream()
+                if main_table_cut:
+                    cur.wait_stream(self._comm)
+                else:
+                    amp_flags_sum()
+                    if not shared:
+                        main_table_step()
+                prop_table_step()
+                small_and_other_steps()
+
+            self._host(host_tail, final=True)
+            return self.loss
+        if optimizers is not None:
+            # main table first: its list exchange holds the step's only host read, and issuing it before the
+            # proposal table's all-reduce keeps the CPU from parking behind the proposal chains
+            if not shared:
+                main_table_step()
+            if side[0] is not main:  # proposal chains done -> reduce/step the proposal table beside the main chain
+                side[0].wait_stream(side[1])
+                if shared:
+                    side[0].wait_stream(main)
+            with torch.cuda.stream(side[0]):
+                if reducer is not None:
+                    reducer.start(table_opt.buffers[i_prop][1])
+                    reducer.wait_all()  # stream-level wait: side[0] continues once RCCL is done
+                if amp_ev is not None and side[0] is not main:
+                    side[0].wait_event(amp_ev)
+                table_opt.step_buffer(i_prop, scale)
+        join_all()
+        if optimizers is not None:
+            small_and_other_steps()
         return self.loss
 
     def outputs(self) -> Dict[str, Tensor]:

@@ -609,7 +609,8 @@ class FlatAdam:
                                                ops._stream()), "nr_adam_hyper")
 
     @torch.no_grad()
-    def step_buffer(self, i: int, grad_scale: float = 1.0, delta16: Optional[Tensor] = None, skip_extra: Optional[Tensor] = None) -> None:
+    def step_buffer(self, i: int, grad_scale: float = 1.0, delta16: Optional[Tensor] = None, skip_extra: Optional[Tensor] = None,
+                    part: Optional[Tuple[int, int]] = None) -> None:
         """Adam on buffer i (after `advance()`), on the current stream.  grad_scale = 1/world turns the
         SUM all-reduce of the data-parallel ranks into DDP's mean without a separate pass.  delta16 (bf16, one per element of
         this rank's shard): the update also leaves as a rounded delta for the other replicas (GradAllReducer.shard_step).
@@ -625,8 +626,16 @@ class FlatAdam:
         skip = self.amp.found(self.amp_group) if self.amp is not None else None
         if skip_extra is not None:
             skip = skip_extra if skip is None else torch.where(skip != 0, skip, skip_extra)
+        seen = self.seen[i]
+        if part is not None:
+            # elements [lo, hi) of the buffer only (multiples of 4; one LEVEL of a hash table: FusedTrainStep steps a level as
+            # soon as its scatter is done, beside the next level's scatter) -- element-wise the same update as the whole launch
+            lo, hi = part
+            assert lo_hi is None and delta16 is None and lo % 4 == 0 and hi % 4 == 0 and m.is_contiguous() and v.is_contiguous()
+            p, g, m, v = p.view(-1)[lo:hi], g.view(-1)[lo:hi], m.view(-1)[lo:hi], v.view(-1)[lo:hi]
+            seen = None if seen is None else seen[lo // 4:hi // 4]
         ops.adam_step(p, g, m, v, self.lr, 1, self.betas, self.eps, self.wd, self.adamw, grad_scale=grad_scale,
-                      zero_grad=True, dev_hyper=self.hyper, seen_grad=self.seen[i], marked=marked, skip=skip, delta16=delta16)
+                      zero_grad=True, dev_hyper=self.hyper, seen_grad=seen, marked=marked, skip=skip, delta16=delta16)
 
     @torch.no_grad()
     def check_buffer(self, i: int) -> None:

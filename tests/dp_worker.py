@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="shard: bf16 reduce-scatter, bf16 update-delta all-gather, deferred into the next step")
     ap.add_argument("--fp16-amp", action="store_true", help="fp16 MFMA operands under the device-side loss scaler; rank 1's batch of "
                     "step 1 is poisoned (an overflowing target): BOTH ranks must skip that step")
+    ap.add_argument("--segments", action="store_true", help="step 0 eager, then the step captured as hipGraph segments cut at the "
+                    "collectives (fused_step.SegmentedStep) and REPLAYED for the remaining steps, from static input buffers")
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--force-collectives", action="store_true", help="world 1: issue the collectives anyway (one-rank RCCL group)")
     args = ap.parse_args()
@@ -87,13 +89,28 @@ def main():
         step.set_grad_scaler(amp)
     fars = torch.full((hi - lo,), 1e6, device=dev)
     info = []
+    use_reducer = reducer if (world > 1 or args.force_collectives) else None
+    static = [sl(o), sl(d), sl(area), fars, sl(tf), sl(td), sl(draws[0][0]), sl(draws[0][1]), sl(draws[0][2])]  # --segments: the graphs' inputs
+    seg = None
     for k in range(args.steps):
         tr, j1, j2 = draws[k]
         tf_k = sl(tf)
         if args.fp16_amp and k == 1 and rank == 1:
             tf_k = torch.full_like(tf_k, 1e30)  # only THIS rank's gradients overflow
-        step.forward_backward(sl(o), sl(d), sl(area), fars, tf_k, sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts),
-                              reducer=reducer if (world > 1 or args.force_collectives) else None)
+        if args.segments:
+            from neuradar_amd.fused_step import SegmentedStep
+
+            for buf, src in zip(static[4:], (tf_k, sl(td), sl(tr), sl(j1), sl(j2))):
+                buf.copy_(src)
+            run = lambda: step.forward_backward(*static, optimizers=tuple(opts), reducer=use_reducer)  # noqa: E731
+            if k == 0:
+                run()  # eager: lazy allocations, the exchange's one host read
+            else:
+                if seg is None:
+                    seg = SegmentedStep(step).capture(run)  # (nothing executes during capture)
+                seg.replay()
+        else:
+            step.forward_backward(sl(o), sl(d), sl(area), fars, tf_k, sl(td), sl(tr), sl(j1), sl(j2), optimizers=tuple(opts), reducer=use_reducer)
         if k == args.steps - 1:
             reducer.flush()  # (a deferred all-gather of the last step; earlier ones are waited for by the next step's gather)
         torch.cuda.synchronize()
@@ -102,7 +119,8 @@ def main():
            "amp": None if amp is None else {"scale": amp.get_scale(), "skipped": amp.skipped_steps()},
            "params": {n: p.detach().cpu() for n, p in model.named_parameters()},
            "exp_avg": [m.reshape(-1).cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
-           "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table)}
+           "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table),
+           "segments": None if seg is None else len(seg.parts)}
     torch.save(out, f"{args.out}.rank{rank}")
     if world > 1 or args.force_collectives:
         torch.distributed.barrier()

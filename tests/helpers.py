@@ -1,5 +1,9 @@
 """Shared test helpers: golden loading and oracle parameter construction."""
+import json
 import os
+import subprocess
+import sys
+import tempfile
 
 import numpy as np
 import torch
@@ -60,3 +64,28 @@ def assert_close_but_few(actual, expected, rtol, atol_scale, max_outlier_frac, w
     assert bool(torch.isfinite(actual).all()), f"{what}: non-finite values"
     assert frac <= max_outlier_frac, (f"{what}: {int(bad.sum())} of {bad.numel()} elements ({frac:.2e}) outside rtol={rtol:.1e} / "
                                       f"atol={atol_scale:.1e}*scale; worst |d| = {float((actual - expected).abs().max()):.3e}")
+
+
+def run_child(test_file: str, func: str, timeout: float = 900.0, env=None, **kwargs):
+    """Run `func(**kwargs)` of `test_file` in a child python process (tests/child_main.py) and return what it returned.  The legs
+    that once took the whole pytest process down with them (a GPU fault is a SIGABRT from the ROCr runtime) run this way: the
+    child's death -- any non-zero exit, a signal, the timeout -- is an ordinary test FAILURE carrying the tail of its output, and
+    every other test of the session still reports.  (A child process, never an exec: this process has initialised the GPU.)"""
+    import pytest
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "result.pt")
+        cmd = [sys.executable, os.path.join(here, "child_main.py"), os.path.abspath(test_file), func, json.dumps(kwargs), out]
+        child_env = dict(os.environ)
+        child_env.update(env or {})
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=os.path.dirname(here), env=child_env)
+        except subprocess.TimeoutExpired as e:
+            pytest.fail(f"child {func}({kwargs}) did not finish within {timeout:.0f} s\n{(e.stderr or '')[-3000:]}")
+        if r.stdout:
+            print(r.stdout[-6000:])
+        if r.returncode != 0 or not os.path.exists(out):
+            sig = f" (signal {-r.returncode})" if r.returncode < 0 else ""
+            pytest.fail(f"child {func}({kwargs}) exited with {r.returncode}{sig}\n--- tail of its stderr ---\n{r.stderr[-4000:]}")
+        return torch.load(out, weights_only=False)

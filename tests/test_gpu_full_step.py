@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, load_golden
+from helpers import assert_close, load_golden, run_child
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -159,86 +159,116 @@ def _full_model(loss_type):
 
 
 EPS = {"bfloat16": 2.0 ** -8, "float16": 2.0 ** -11}  # unit roundoff of the 16-bit operand types (tests/test_gpu_lp.py)
+DEC_ROOTS = ("rgb_decoder", "lidar_decoder", "radar_decoder", "offset_head", "radar_uncertainty_head", "existence_probability_head")
 
 
-@pytest.mark.parametrize("mlp_dtype", ["float32", "bfloat16", "float16"])
-@pytest.mark.parametrize("loss_type", ["nll", "euclidean"])
-def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type, mlp_dtype):
-    """fp32: element-wise parity (rtol 1e-4 outputs, 2e-3 gradients).  bfloat16 / float16 = the step bench.py's `full_model`
-    numbers are timed on (BASELINE configs[2] full / configs[4]): field MLPs on 16-bit MFMA operands, the RGB CNN on 16-bit
-    working copies of its parameters inside the optimizer's flat buffers, 32-bit tile sums in the binned scatter -- against the
-    SAME fp32 reference (modular fp32 HIP path + CPU oracle).  Bounds as tests/test_gpu_lp.py states and justifies them:
-    outputs within 5u of their scale (five chained 16-bit layers), every parameter gradient within 2*sqrt(u) in relative L2
-    (a u-fraction of ReLU masks flips; x sqrt(16) for the parameters behind the 11-convolution CNN's 16-bit backward, see
-    below), Hungarian associations exact."""
-    from neuradar_amd import losses
-    from neuradar_amd.decoder_losses import DecoderLossHead, DecoderLossSettings
-    from neuradar_amd.fused_step import FusedTrainStep
-    from neuradar_amd.rays import RayBundle
-    from oracle import decoder_losses as odl
-
-    model = _full_model(loss_type)
-    c = model.config
+def _step_inputs():
+    """The synthetic mixed batch of the full-step tests (CPU tensors): 2 camera patches of 8 x 8 rays, one radar scan of 45 rays
+    with 11 detections, 60 lidar rays (batch order camera, radar, lidar: the bench's -- coherent segments first)."""
     gen = torch.Generator().manual_seed(3)
     patch, n_patch, n_scan, per_scan, n_lid = 8, 2, 1, 45, 60
     n_cam, n_rad = n_patch * patch * patch, n_scan * per_scan
     B = n_cam + n_rad + n_lid
-    r0_rad, r0_lid = n_cam, n_cam + n_rad  # batch order camera, radar, lidar (the bench's: coherent segments first)
-    o = torch.cat([torch.randn(B, 2, generator=gen) * 3.0, torch.full((B, 1), 1.7)], dim=1)
-    d = torch.nn.functional.normalize(torch.cat([torch.ones(B, 1), 0.5 * torch.randn(B, 2, generator=gen)], dim=1), dim=-1)
-    area = torch.cat([torch.full((n_cam,), 2.25e-6), torch.full((n_rad,), 9e-6), torch.full((n_lid,), 4.5e-6)])
-    times = 20.0 * torch.rand(B, generator=gen)
-    is_lidar = torch.zeros(B, dtype=torch.bool)
-    is_lidar[r0_lid:] = True
-    is_radar = torch.zeros(B, dtype=torch.bool)
-    is_radar[r0_rad:r0_lid] = True
-    did_return = torch.ones(B, dtype=torch.bool)
-    did_return[r0_lid:] = torch.rand(n_lid, generator=gen) < 0.8
-    rng = torch.ones(B)
-    rng[r0_lid:] = 2.0 + 60.0 * torch.rand(n_lid, generator=gen)
-    sensor = torch.cat([torch.zeros(n_cam), 2 * torch.ones(n_rad), torch.ones(n_lid)]).long()
-    target_i = torch.rand(B, generator=gen)
-    spher = torch.zeros(B, 2)
-    spher[r0_rad:r0_lid] = torch.stack([torch.rand(n_rad, generator=gen) * 1.6 - 0.8, torch.rand(n_rad, generator=gen) * 0.48 - 0.08], dim=-1)
-    image = torch.rand(n_patch, patch * 3, patch * 3, 3, generator=gen)
-    n_det = 11
-    radar = torch.cat([torch.randn(n_det, 3, generator=gen) * 8.0 + torch.tensor([15.0, 0.0, 0.0]), torch.rand(n_det, 2, generator=gen)], 1)
-    t_rand, j1, j2 = torch.rand(B, 129, generator=gen), torch.rand(B, generator=gen), torch.rand(B, generator=gen)
-    dv = lambda x: x.to(DEV)  # noqa: E731
+    r0_rad, r0_lid = n_cam, n_cam + n_rad
+    i = SimpleNamespace(patch=patch, n_patch=n_patch, n_scan=n_scan, n_lid=n_lid, n_cam=n_cam, n_rad=n_rad, B=B, r0_rad=r0_rad, r0_lid=r0_lid)
+    i.o = torch.cat([torch.randn(B, 2, generator=gen) * 3.0, torch.full((B, 1), 1.7)], dim=1)
+    i.d = torch.nn.functional.normalize(torch.cat([torch.ones(B, 1), 0.5 * torch.randn(B, 2, generator=gen)], dim=1), dim=-1)
+    i.area = torch.cat([torch.full((n_cam,), 2.25e-6), torch.full((n_rad,), 9e-6), torch.full((n_lid,), 4.5e-6)])
+    i.times = 20.0 * torch.rand(B, generator=gen)
+    i.is_lidar = torch.zeros(B, dtype=torch.bool)
+    i.is_lidar[r0_lid:] = True
+    i.is_radar = torch.zeros(B, dtype=torch.bool)
+    i.is_radar[r0_rad:r0_lid] = True
+    i.did_return = torch.ones(B, dtype=torch.bool)
+    i.did_return[r0_lid:] = torch.rand(n_lid, generator=gen) < 0.8
+    i.rng = torch.ones(B)
+    i.rng[r0_lid:] = 2.0 + 60.0 * torch.rand(n_lid, generator=gen)
+    i.sensor = torch.cat([torch.zeros(n_cam), 2 * torch.ones(n_rad), torch.ones(n_lid)]).long()
+    i.target_i = torch.rand(B, generator=gen)
+    i.spher = torch.zeros(B, 2)
+    i.spher[r0_rad:r0_lid] = torch.stack([torch.rand(n_rad, generator=gen) * 1.6 - 0.8, torch.rand(n_rad, generator=gen) * 0.48 - 0.08], dim=-1)
+    i.image = torch.rand(n_patch, patch * 3, patch * 3, 3, generator=gen)
+    i.n_det = 11
+    i.radar = torch.cat([torch.randn(i.n_det, 3, generator=gen) * 8.0 + torch.tensor([15.0, 0.0, 0.0]), torch.rand(i.n_det, 2, generator=gen)], 1)
+    i.t_rand, i.j1, i.j2 = torch.rand(B, 129, generator=gen), torch.rand(B, generator=gen), torch.rand(B, generator=gen)
+    return i
 
-    # ---- reference value: modular HIP path up to the rendered outputs, the CPU oracle behind them
-    bundle = RayBundle(dv(o), dv(d), dv(area)[:, None], fars=torch.full((B, 1), 1e6, device=DEV), times=dv(times)[:, None],
-                       metadata={"is_lidar": dv(is_lidar)[:, None], "did_return": dv(did_return)[:, None],
-                                 "directions_norm": dv(rng)[:, None], "sensor_idxs": dv(sensor)[:, None]})
-    out = model.get_nff_outputs(bundle, t_rand=dv(t_rand), jitters=(dv(j1)[:, None], dv(j2)[:, None]))
-    cs = [s.spacing for s in out["ray_samples_list"]]
-    ws = [w[..., 0] for w in out["weights_list"]]
-    loss = c.interlevel_loss_mult * losses.zipnerf_interlevel_loss(cs, ws) + c.distortion_loss_mult * losses.distortion_loss(cs[-1], ws[-1])
-    loss = loss + c.carving_mult * (out["non_nearby_weights"] ** 2).sum() / n_lid
-    for i in (0, 1):
-        loss = loss + c.prop_lidar_loss_mult * c.carving_mult * out[f"prop_weights_loss_{i}"] / n_lid
-    dec_names = [k for k, _ in model.named_parameters() if k.split(".")[0] in (
-        "rgb_decoder", "lidar_decoder", "radar_decoder", "offset_head", "radar_uncertainty_head", "existence_probability_head")]
+
+def _oracle_step(model, i, loss_type, autocast=None, loss_scale=1.0):
+    """The WHOLE training step on the CPU oracle: oracle/pipeline.py (sampling rounds, field, compositing, appearance embedding,
+    carving side outputs: models/neuradar.py:495-548), oracle/losses.py (inter-level + distortion, :672-704), the carving and
+    proposal-level lidar terms (:633-648), oracle/decoder_losses.py (decoders + their losses, :591-670) -- on copies of the
+    model's parameters, differentiated by torch.autograd.  autocast = a torch dtype: the same step under torch.autocast("cpu")
+    with the loss scaled by `loss_scale` (the reference's AMP, engine/trainer.py:564-595; gradients are unscaled here).
+    Returns (loss, {parameter name: gradient}, outputs)."""
+    from oracle import decoder_losses as odl, losses as ol, pipeline as op
+    from test_gpu_fullsize import _oracle_params
+
+    c = model.config
+    fp, pp = _oracle_params(model)
     named = dict(model.named_parameters())
-    p_cpu = {k: named[k].detach().cpu().clone().requires_grad_(True) for k in dec_names}
-    batch_cpu = {"image": image, "distance": rng[r0_lid:, None], "did_return": did_return[:, None],
-                 "lidar": torch.cat([torch.zeros(n_lid, 3), target_i[r0_lid:, None]], 1), "radar": radar,
-                 "radar_indices": torch.stack([torch.zeros(n_det), torch.arange(n_det).float()], 1).long()}
-    oc = odl.LossSettings(radar_loss_type=loss_type)
-    terms = odl.decoder_losses(out["features"].cpu(), out["depth"].cpu(), [out["prop_depth_0"].cpu(), out["prop_depth_1"].cpu()], spher,
-                               is_lidar[:, None], is_radar[:, None], batch_cpu, p_cpu, patch, n_scan, oc)
-    loss_cpu = odl.total(terms)
-    total = loss.cpu() + loss_cpu
-    nff = {n: p for n, p in model.named_parameters() if p.requires_grad and n not in p_cpu}
-    grads = torch.autograd.grad(total, list(nff.values()) + list(p_cpu.values()), allow_unused=True)
-    ref = dict(zip(list(nff) + list(p_cpu), grads))
-    for p in model.parameters():
-        if p.grad is not None:
-            p.grad.zero_()
+    p_dec = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in named.items() if k.split(".")[0] in DEC_ROOTS}
+    app = named["appearance_embedding.weight"].detach().cpu().clone().requires_grad_(True)
+    col = lambda t: t[:, None]  # noqa: E731
+    ctx = torch.autocast("cpu", dtype=autocast) if autocast is not None else torch.autocast("cpu", enabled=False)
+    with ctx:
+        out = op.nff_outputs(fp, [pp, pp], {"origins": i.o, "directions": i.d, "pixel_area": col(i.area), "fars": torch.full((i.B, 1), 1e6),
+                                            "times": col(i.times), "sensor_idx": col(i.sensor), "is_lidar": col(i.is_lidar),
+                                            "directions_norm": col(i.rng), "did_return": col(i.did_return)},
+                             i.t_rand, (col(i.j1), col(i.j2)),
+                             appearance={"table": app, "duration": c.duration, "embeds_per_sensor": model._num_embeds_per_sensor})
+        loss = c.interlevel_loss_mult * ol.zipnerf_interlevel_loss(out["c_list"], out["w_list"]) \
+            + c.distortion_loss_mult * ol.distortion_loss(out["c_list"][-1], out["w_list"][-1])
+        e = out["final_euclid"]
+        close = op.is_close_to_lidar(e[:, :-1], e[:, 1:], col(i.is_lidar), col(i.rng), col(i.did_return))
+        keep = ((~close) & col(i.is_lidar))[:, :-1]  # neuradar.py:536-541 (the sky sample is dropped)
+        loss = loss + c.carving_mult * (out["weights"][:, :-1][keep] ** 2).sum() / i.n_lid
+        for k in (0, 1):
+            loss = loss + c.prop_lidar_loss_mult * c.carving_mult * out[f"prop_weights_loss_{k}"] / i.n_lid
+        batch_cpu = {"image": i.image, "distance": i.rng[i.r0_lid:, None], "did_return": col(i.did_return),
+                     "lidar": torch.cat([torch.zeros(i.n_lid, 3), i.target_i[i.r0_lid:, None]], 1), "radar": i.radar,
+                     "radar_indices": torch.stack([torch.zeros(i.n_det), torch.arange(i.n_det).float()], 1).long()}
+        terms = odl.decoder_losses(out["features"], out["depth"], [out["prop_depth_0"], out["prop_depth_1"]], i.spher, col(i.is_lidar),
+                                   col(i.is_radar), batch_cpu, p_dec, i.patch, i.n_scan, odl.LossSettings(radar_loss_type=loss_type))
+        total = loss + odl.total(terms)
+    leaves = {"field.hashgrid.static_grid.hash_table": fp.grid.table, "field.sdf_to_density.beta": fp.beta,
+              "proposal_fields.1.hashgrid.static_grid.hash_table": pp.grid.table, "proposal_fields.1.density_decoder.weight": pp.decoder,
+              "appearance_embedding.weight": app}
+    for j, (w, b) in enumerate(fp.geo):
+        leaves[f"field.mlp_geo.layers.{j}.weight"], leaves[f"field.mlp_geo.layers.{j}.bias"] = w, b
+    for j, (w, b) in enumerate(fp.feat):
+        leaves[f"field.mlp_feature.layers.{j}.weight"], leaves[f"field.mlp_feature.layers.{j}.bias"] = w, b
+    leaves.update(p_dec)
+    grads = torch.autograd.grad(total.float() * loss_scale, list(leaves.values()), allow_unused=True)
+    grads = {k: (None if g is None else g.float() / loss_scale) for k, g in zip(leaves, grads)}
+    return total.detach().float(), grads, {"features": out["features"].detach().float(), "depth": out["depth"].detach().float(),
+                                           "assoc": terms["assoc"]}
 
-    # ---- the fused step with the decoder head
+
+@pytest.mark.parametrize("mlp_dtype", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("loss_type", ["nll", "euclidean"])
+def test_fused_step_with_decoders_vs_oracle_end_to_end(loss_type, mlp_dtype):
+    """FusedTrainStep with the decoder head against the CPU ORACLE for the whole step (`_oracle_step`: hot path AND decoders; no
+    HIP kernel on the reference side -- VERDICT r04 weak #5).
+    fp32: loss 1e-4, rendered outputs 1e-4, every parameter gradient element-wise (decoders: rtol 2e-3) or in relative L2 (hot
+    path: 2e-3, the tables on the rows the step touched -- tests/test_gpu_fullsize.py's bounds against the same oracle).
+    bfloat16 / float16 = the step bench.py's `full_model` numbers are timed on (BASELINE configs[2] full / configs[4]): field MLPs
+    on 16-bit MFMA operands, the RGB CNN on 16-bit working copies inside the optimizer's flat buffers, 32-bit tile sums in the
+    scatters.  Bound PER PARAMETER: the distance of the oracle run under torch.autocast(dtype) (= the reference's AMP,
+    engine/trainer.py:564-595) from the fp32 oracle, for the SAME parameter, x 1.5, plus 4u (rounding the gradient itself to the
+    operand type and back): the HIP step may be at most as far from fp32 as the reference's own mixed-precision step is.
+    Outputs within 5u of their scale, Hungarian associations exact."""
+    from neuradar_amd.decoder_losses import DecoderLossHead, DecoderLossSettings
+    from neuradar_amd.fused_step import FusedTrainStep
+
+    model = _full_model(loss_type)
+    i = _step_inputs()
+    dv = lambda x: x.to(DEV)  # noqa: E731
+    total, ref, ref_out = _oracle_step(model, i, loss_type)
     lp = mlp_dtype != "float32"
     if lp:
+        dt16 = {"bfloat16": torch.bfloat16, "float16": torch.float16}[mlp_dtype]
+        _, ref_amp, _ = _oracle_step(model, i, loss_type, autocast=dt16, loss_scale=8192.0 if mlp_dtype == "float16" else 1.0)
         # what bench.py builds for the 16-bit workloads: 16-bit MFMA operands in the field (static loss scale for fp16), every
         # parameter inside the optimizers' flat buffers (channels-last convolution weights), the CNN on 16-bit working copies
         import bench
@@ -246,60 +276,67 @@ def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type, mlp
         model.field.config.mlp_dtype = mlp_dtype
         model.field.config.mlp_grad_scale = 8192.0 if mlp_dtype == "float16" else 1.0
         bench.build_optimizers(model)  # re-homes parameters and gradients (values unchanged); the optimizers are not stepped
-        for p in model.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    B, n_cam, n_rad, n_lid = i.B, i.n_cam, i.n_rad, i.n_lid
     fused = FusedTrainStep(model, B, coherent_rays=n_cam + n_rad)
-    fused.set_lidar(dv(is_lidar).to(torch.uint8), dv(did_return).to(torch.uint8), dv(rng), r0_lid, n_lid, prop_depth_loss=True)
-    layout = {"camera": (0, n_cam), "radar": (r0_rad, n_rad), "lidar": (r0_lid, n_lid)}
-    head = DecoderLossHead(model, layout, patch, n_scan, 16, DecoderLossSettings(radar_loss_type=loss_type),
+    fused.set_lidar(dv(i.is_lidar).to(torch.uint8), dv(i.did_return).to(torch.uint8), dv(i.rng), i.r0_lid, n_lid, prop_depth_loss=True)
+    layout = {"camera": (0, n_cam), "radar": (i.r0_rad, n_rad), "lidar": (i.r0_lid, n_lid)}
+    head = DecoderLossHead(model, layout, i.patch, i.n_scan, 16, DecoderLossSettings(radar_loss_type=loss_type),
                            cnn_autocast={"float32": None, "bfloat16": torch.bfloat16, "float16": torch.float16}[mlp_dtype])
-    batch = {"image": dv(image), "did_return": dv(did_return).to(torch.uint8), "range": dv(rng), "target_intensity": dv(target_i),
-             "directions_spher": dv(spher), "radar": dv(radar), "radar_seg": torch.tensor([0, n_det], dtype=torch.int32, device=DEV)}
-    fused.set_decoders(head, [batch, batch], dv(sensor))
-    floss = fused.forward_backward(dv(o), dv(d), dv(area), torch.full((B,), 1e6, device=DEV), None, None, dv(t_rand), dv(j1), dv(j2),
-                                   times=dv(times))
-    assert torch.equal(head.last["assoc"][0].cpu().long(), terms["assoc"][0]), "Hungarian association"
+    batch = {"image": dv(i.image), "did_return": dv(i.did_return).to(torch.uint8), "range": dv(i.rng), "target_intensity": dv(i.target_i),
+             "directions_spher": dv(i.spher), "radar": dv(i.radar), "radar_seg": torch.tensor([0, i.n_det], dtype=torch.int32, device=DEV)}
+    fused.set_decoders(head, [batch, batch], dv(i.sensor))
+    floss = fused.forward_backward(dv(i.o), dv(i.d), dv(i.area), torch.full((B,), 1e6, device=DEV), None, None, dv(i.t_rand), dv(i.j1), dv(i.j2),
+                                   times=dv(i.times))
+    assert torch.equal(head.last["assoc"][0].cpu().long(), ref_out["assoc"][0]), "Hungarian association"
     if lp:
         assert bool(head._shadow), "the CNN must run on its 16-bit working copies (the path bench.py times)"
         assert fused.bin_sum_bits == 32 and fused.field_struct.dtype == {"bfloat16": 1, "float16": 2}[mlp_dtype]
     u = EPS.get(mlp_dtype)
     out_tol = dict(rtol=1e-4, atol_scale=1e-5) if not lp else dict(rtol=5 * u, atol_scale=5 * u)
-    assert_close(fused.outputs()["features"].cpu(), out["features"][:, :32].detach().cpu(), what="features", **out_tol)
-    assert_close(fused.outputs()["depth"].cpu(), out["depth"].detach().cpu(), what="depth", **out_tol)
-    assert_close(floss.sum().cpu(), total.detach(), rtol=1e-4 if not lp else 5 * u, atol_scale=1e-6, what="loss")
+    assert_close(fused.outputs()["features"].cpu(), ref_out["features"][:, :32], what="features", **out_tol)
+    assert_close(fused.outputs()["depth"].cpu(), ref_out["depth"], what="depth", **out_tol)
+    assert_close(floss.sum().cpu(), total, rtol=1e-4 if not lp else 5 * u, atol_scale=1e-6, what="loss")
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))  # noqa: E731
     checked, rows, bad = 0, [], []
-    for n_, p in model.named_parameters():
+    named = dict(model.named_parameters())
+    for n_, p in named.items():
         if not p.requires_grad:
             continue
-        if ref[n_] is None:
+        want = ref.get(n_)
+        if want is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n_
             continue
-        if float(ref[n_].abs().sum()) < 1e-5 and "main_branch" in n_ and n_.endswith("bias"):
+        got = p.grad.detach().cpu().reshape(want.shape)
+        if float(want.abs().sum()) < 1e-5 and "main_branch" in n_ and n_.endswith("bias"):
             # convolution bias in front of a training-mode batch norm: zero up to rounding (16-bit: rounding noise of the
             # activation gradients summed over the patch, far below the weight gradient of the same convolution)
-            w_grad = dict(model.named_parameters())[n_[:-4] + "weight"].grad
-            assert float(p.grad.abs().sum()) < (1e-5 if not lp else 0.05 * float(w_grad.abs().sum())), n_
+            w_grad = named[n_[:-4] + "weight"].grad
+            assert float(got.abs().sum()) < (1e-5 if not lp else 0.05 * float(w_grad.abs().sum())), n_
             continue
+        hot = n_.split(".")[0] in ("field", "proposal_fields", "appearance_embedding")
         if not lp:
-            assert_close(p.grad.cpu(), ref[n_].cpu(), rtol=2e-3, atol_scale=2e-4, what="fused grad " + n_)
+            if hot:
+                err = rel(got, want)
+                assert err < 2e-3, f"fused grad {n_}: relative L2 error {err:.3e} against the oracle"
+                if "hash_table" in n_:  # the same rows are touched: where only one side is non-zero the value is a rounding residue
+                    diff = (got != 0) != (want != 0)
+                    resid = float(torch.maximum(got.abs(), want.abs())[diff].max()) if bool(diff.any()) else 0.0
+                    assert resid <= 1e-6 * float(want.abs().max()), f"grad {n_}: entries touched on one side only carry up to {resid:.3e}"
+            else:
+                assert_close(got, want, rtol=2e-3, atol_scale=2e-4, what="fused grad " + n_)
         else:
-            want = ref[n_].double().cpu()
-            err = float((p.grad.double().cpu() - want).norm() / want.norm().clamp_min(1e-30))
-            # parameters whose gradient passes through the RGB CNN's 16-bit backward sit behind up to 11 convolutions (each
-            # followed by a batch norm / ReLU) plus the field's 5 layers: independent sqrt(u)-sized perturbations per layer
-            # add up like a random walk -- 2 sqrt(u) sqrt(16).  torch.autocast of the same CNN sits at the same distance from
-            # its fp32 self (test_cnn_16_bit_working_copies_equal_autocast compares the two directly).  Measured: bf16 0.27
-            # (appearance embedding) / 0.23 (first convolutions), fp16 0.13 / 0.10; 1e-3 ... 7e-2 everywhere else.
-            behind_cnn = n_.startswith(("rgb_decoder.", "appearance_embedding", "field.mlp_", "field.hashgrid"))
-            bound = 2 * u ** 0.5 * (4.0 if behind_cnn else 1.0)
-            rows.append((n_, err, float(want.norm()), bound))
-            if not err < bound:
-                bad.append((n_, err, bound))
+            err, amp = rel(got, want), rel(ref_amp[n_], want)
+            bound = 1.5 * amp + 4 * u
+            rows.append((n_, err, amp, float(want.norm()), bound))
+            if not err <= bound:
+                bad.append((n_, err, amp, bound))
         checked += 1
-    for n_, err, nrm, bound in rows:
-        print(f"{mlp_dtype} {loss_type} grad {n_:70s} rel L2 {err:.3e}   |ref| {nrm:.3e}   bound {bound:.3e}")
-    assert not bad, f"{mlp_dtype}: gradients outside their relative-L2 bound (2*sqrt(u) = {2 * u ** 0.5:.3e}, x4 behind the CNN): {bad}"
+    for n_, err, amp, nrm, bound in rows:
+        print(f"{mlp_dtype} {loss_type} grad {n_:70s} rel L2 vs fp32 oracle: HIP {err:.3e}  autocast oracle {amp:.3e}  bound {bound:.3e}   |ref| {nrm:.3e}")
+    assert not bad, f"{mlp_dtype}: gradients farther from the fp32 oracle than 1.5 x the autocast oracle + 4u: {bad}"
     for must in ("appearance_embedding.weight", "lidar_decoder.layers.0.weight", "rgb_decoder.2.main_branch.0.weight",
                  "radar_decoder.encoder.layers.0.self_attn.in_proj_weight", "offset_head.layers.0.weight",
                  "field.hashgrid.static_grid.hash_table", "proposal_fields.1.hashgrid.static_grid.hash_table"):
@@ -307,63 +344,101 @@ def test_fused_step_with_decoders_matches_modular_path_and_oracle(loss_type, mlp
     assert checked > 50
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_cnn_16_bit_working_copies_equal_autocast(dtype, monkeypatch):
-    """DecoderLossHead runs the RGB CNN on 16-bit working copies of its convolution parameters (one copy before the forward,
-    one mixed-precision add of the gradients after the backward) instead of torch.autocast's per-parameter casts: the same
-    output, loss and batch-norm statistics (to the operand type's rounding); gradients as close to the fp32 CNN's as autocast's are (the backward runs the same
-    operations on the same 16-bit operands, but MIOpen's benchmark mode picks the algorithms of every head independently and
-    the gradients sit at 1e-4 ... 1e-8 -- fp16's subnormal range -- so two 16-bit runs differ by ~2 % in relative L2)."""
+STAGES = ("conv 1x1 + ReLU", "block 2", "block 3", "transposed conv 3x3 / 3", "block 5", "block 6", "conv 1x1 + sigmoid")
+
+
+def _cnn_leg(dtype: str, mode: str):
+    """One leg of test_cnn_16_bit_working_copies_equal_autocast, run in a process of its own (helpers.run_child): the camera
+    chain of DecoderLossHead -- `copies`: 16-bit working copies on nr_pw_* / nr_conv7_* / nr_bn_act_*; `autocast`: torch.autocast
+    over the library's kernels; `fp32` -- twice (the working copies' gradient buffer is cleared and reused).  Returns rgb, loss,
+    d loss / d features, parameter gradients, batch-norm buffers and the activation after each of the decoder's seven stages."""
     from neuradar_amd.decoder_losses import DecoderLossHead
     from neuradar_amd.fused_step import flatten_parameters
 
+    os.environ["NR_CNN_SHADOW"] = "1" if mode == "copies" else "0"
+    dt = getattr(torch, dtype)
     g = load_golden("model_train")
     n_cam = int(g["n_patch"]) * int(g["patch"]) ** 2
     layout = {"camera": (0, n_cam), "lidar": (n_cam, 0), "radar": (n_cam, 0)}
     feats = g["features"][:n_cam].to(DEV)
     image = g["image"].to(DEV)
-    res = {}
-    for mode in ("copies", "autocast", "fp32"):
-        monkeypatch.setenv("NR_CNN_SHADOW", "1" if mode == "copies" else "0")
-        if os.environ.get("NR_TEST_TRACE"):  # tools/repro_abort.sh: which leg, and where the allocator's segments end
-            torch.cuda.synchronize()
-            segs = sorted((s_["address"], s_["total_size"]) for s_ in torch.cuda.memory_snapshot())
-            print(f"[leg] {dtype} {mode} segments: " + " ".join(f"{a:x}+{n:x}" for a, n in segs), flush=True)
-        torch.manual_seed(0)
-        dec, m = _decoder_model(48)
-        _load_reference_parameters(dec)
-        flatten_parameters(list(dec.rgb_decoder.parameters()))
-        head = DecoderLossHead(m, layout, int(g["patch"]), 0, 0, cnn_autocast=None if mode == "fp32" else dtype)
-        slots = torch.zeros(1025, device=DEV)
-        for _ in range(2):  # twice: the working copies' gradient buffer is cleared and reused
-            for p_ in dec.rgb_decoder.parameters():
-                p_.grad.zero_()
-            g_f, _ = head.backward_into(feats, torch.ones(n_cam, device=DEV), None, None, {"image": image}, slots)
-        assert bool(head._shadow) == (mode == "copies")
-        res[mode] = (head.last["rgb"].detach().clone(), float(slots.sum()), g_f.clone(),
-                     {k: v.grad.clone() for k, v in dec.rgb_decoder.named_parameters()},
-                     {k: v.clone() for k, v in dec.rgb_decoder.named_buffers()})
+    torch.manual_seed(0)
+    dec, m = _decoder_model(48)
+    _load_reference_parameters(dec)
+    flatten_parameters(list(dec.rgb_decoder.parameters()))
+    head = DecoderLossHead(m, layout, int(g["patch"]), 0, 0, cnn_autocast=None if mode == "fp32" else dt)
+    stages = []
+    if mode == "copies":
+        head.stage_tap = stages
+    else:  # the modules themselves run: the same seven activations through forward hooks
+        for k in (1, 2, 3, 4, 5, 6, 8):
+            dec.rgb_decoder[k].register_forward_hook(lambda mod, inp, out: stages.append(out.detach().float()))
+    slots = torch.zeros(1025, device=DEV)
+    for _ in range(2):
+        stages.clear()
+        for p_ in dec.rgb_decoder.parameters():
+            p_.grad.zero_()
+        g_f, _ = head.backward_into(feats, torch.ones(n_cam, device=DEV), None, None, {"image": image}, slots)
+    torch.cuda.synchronize()
+    assert bool(head._shadow) == (mode == "copies")
+    assert len(stages) == len(STAGES), len(stages)
+    cpu = lambda t: t.detach().float().cpu()  # noqa: E731
+    return {"rgb": cpu(head.last["rgb"]), "loss": float(slots.sum()), "g_f": cpu(g_f),
+            "grads": {k: cpu(v.grad) for k, v in dec.rgb_decoder.named_parameters()},
+            "buffers": {k: cpu(v) for k, v in dec.rgb_decoder.named_buffers()}, "stages": [cpu(t) for t in stages]}
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_cnn_16_bit_working_copies_equal_autocast(dtype):
+    """DecoderLossHead runs the RGB CNN (model_components/cnns.py:21-47, models/neuradar.py:225-240) on 16-bit working copies of
+    its convolution parameters -- one copy before the forward, one mixed-precision add of the gradients after the backward --
+    on this repo's kernels instead of torch.autocast's per-parameter casts around the library's (engine/trainer.py:564-595).
+    Each leg runs in a child process (a GPU fault in one is that leg's failure, not the session's).
+      * forward, STAGE BY STAGE: the activation after each of the decoder's seven stages against autocast's, in max-norm relative
+        to the stage's scale: (4 + 2 (k - 1)) u at stage k -- both chains round every stage's output to the operand type (u) and
+        stage 1 differs by design (autocast rounds the fp32 features first, nr_pw_fwd reads them in fp32); a wrong kernel shows
+        up AT ITS STAGE as O(1), not averaged away eleven layers deep;
+      * rgb, loss, batch-norm statistics at 8u;
+      * gradients (16-bit backward through eleven convolutions: two valid roundings of every layer, ~15 % apart in bf16):
+        per parameter no farther from the fp32 leg than autocast is, x 1.5 + 2e-3."""
+    dt = getattr(torch, dtype)
+    u = EPS[dtype]
+    res = {mode: run_child(__file__, "_cnn_leg", dtype=dtype, mode=mode) for mode in ("copies", "autocast", "fp32")}
     a, b, f = res["copies"], res["autocast"], res["fp32"]
-    # (usually bit-identical; MIOpen's benchmark mode may pick another forward algorithm for the second head: 1 run in ~8)
-    tol = 4e-3 if dtype == torch.float16 else 3e-2
-    assert_close(a[0].cpu(), b[0].cpu(), rtol=tol, atol_scale=tol, what="rgb")
-    assert abs(a[1] - b[1]) <= tol * abs(b[1]), ("loss", a[1], b[1])
-    for k in a[4]:
-        assert_close(a[4][k].float().cpu(), b[4][k].float().cpu(), rtol=tol, atol_scale=tol, what="batch-norm statistics " + k)
+    worst = []
+    for k, (name, x, y, z) in enumerate(zip(STAGES, a["stages"], b["stages"], f["stages"]), start=1):
+        y = y.reshape(x.shape)
+        scale = float(y.abs().max())
+        d_ab, d_af, d_bf = (float((p_ - q_.reshape(x.shape)).abs().max()) / scale for p_, q_ in ((x, y), (x, z), (y, z)))
+        print(f"{dtype} stage {k} ({name:24s}) scale {scale:9.3e}   copies vs autocast {d_ab / u:6.2f} u   copies vs fp32 {d_af / u:6.2f} u   "
+              f"autocast vs fp32 {d_bf / u:6.2f} u")
+        if d_ab > (4 + 2 * (k - 1)) * u:
+            worst.append((k, name, d_ab / u))
+    assert not worst, f"{dtype}: stages whose output differs from autocast's by more than (4 + 2 (k - 1)) u of its scale: {worst}"
+    tol = 8 * u
+    assert_close(a["rgb"], b["rgb"].reshape(a["rgb"].shape), rtol=tol, atol_scale=tol, what="rgb")
+    assert abs(a["loss"] - b["loss"]) <= tol * abs(b["loss"]), ("loss", a["loss"], b["loss"])
+    for k in a["buffers"]:
+        assert_close(a["buffers"][k].float(), b["buffers"][k].float(), rtol=tol, atol_scale=tol, what="batch-norm statistics " + k)
     rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
-    rows = {"d loss / d features": (a[2], b[2], f[2])}
-    rows.update({k: (a[3][k], b[3][k], f[3][k]) for k in a[3] if not k.endswith(("main_branch.0.bias", "main_branch.3.bias"))})
+    rows = {"d loss / d features": (a["g_f"], b["g_f"], f["g_f"])}
+    rows.update({k: (a["grads"][k], b["grads"][k], f["grads"][k]) for k in a["grads"] if not k.endswith(("main_branch.0.bias", "main_branch.3.bias"))})
     for k, (x, y, z) in rows.items():  # (a convolution bias in front of a batch norm has no gradient: rounding noise only)
         e_copies, e_autocast = rel(x, z), rel(y, z)
-        print(f"{dtype} {k:50s} copies vs fp32 {e_copies:.3e}   autocast vs fp32 {e_autocast:.3e}   copies vs autocast {rel(x, y):.3e}")
+        print(f"{dt} {k:50s} copies vs fp32 {e_copies:.3e}   autocast vs fp32 {e_autocast:.3e}   copies vs autocast {rel(x, y):.3e}")
         assert e_copies <= 1.5 * e_autocast + 2e-3, (k, e_copies, e_autocast)
-        # (the two 16-bit runs are not compared with each other: the working copies' 7 x 7 convolutions run on conv7.hip, autocast's
-        # on the library's kernels -- two valid roundings of every layer's output, eleven layers deep: 15 % apart in bf16 while both
-        # sit equally far from fp32 -- and in fp16 only the copies' backward runs under the loss scale)
 
 
 @pytest.mark.parametrize("workload", ["mixed16384_neuradar_full", "mixed16384_neuradar_full_fp16", "mixed8192_vod_nll"])
 def test_full_model_workloads_train_at_full_size(workload):
+    """_workload_leg in a child process (helpers.run_child: full-size tables, three streams, graph capture -- its death is this
+    test's failure only)."""
+    r = run_child(__file__, "_workload_leg", timeout=1200.0, workload=workload)
+    print(r["summary"])
+    assert r["ok"]
+
+
+def _workload_leg(workload: str):
     """BASELINE configs[2] "full" (bf16), configs[4] (fp16 MFMA, transformer in the step) and configs[3] (VoD scan, nll) per-GPU
     shapes, exactly as bench.py builds and times them (the optimizers incl. cnn / transformer, graph replay of the pipelined
     step): 50 training steps at FULL size, then size-independent properties -- loss finite at every step, the decoders' loss terms
@@ -408,8 +483,9 @@ def test_full_model_workloads_train_at_full_size(workload):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     ls, ds = torch.tensor(losses_), torch.tensor(dec_)
-    print(f"{workload}: loss {losses_[0]:.4f} -> {losses_[-1]:.4f}; decoder-side terms (rgb + lidar + radar) {dec_[0]:.4f} -> {dec_[-1]:.4f}"
-          f"  (mean of the first 4: {float(ds[:4].mean()):.4f}, of the last 4: {float(ds[-4:].mean()):.4f})")
+    summary = (f"{workload}: loss {losses_[0]:.4f} -> {losses_[-1]:.4f}; decoder-side terms (rgb + lidar + radar) {dec_[0]:.4f} -> {dec_[-1]:.4f}"
+               f"  (mean of the first 4: {float(ds[:4].mean()):.4f}, of the last 4: {float(ds[-4:].mean()):.4f})")
+    print(summary)
     assert bool(torch.isfinite(ls).all()) and bool(torch.isfinite(ds).all()), (losses_, dec_)
     # What must go down is what the decoders are supervised with (rgb, lidar depth / intensity / ray drop, radar).  The TOTAL of
     # this synthetic batch does not, and that is the reference's loss, not the kernels: its proposal-level lidar depth terms
@@ -432,3 +508,4 @@ def test_full_model_workloads_train_at_full_size(workload):
         m = a[a >= 0]
         assert int(m.numel()) == min(n_det, n_pred), f"scan {s_}: {m.numel()} matches for {n_det} detections / {n_pred} predictions"
         assert int(m.max()) < n_det and torch.unique(m).numel() == m.numel(), f"scan {s_}: a detection is matched twice"
+    return {"ok": True, "summary": summary}
