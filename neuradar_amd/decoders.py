@@ -288,17 +288,19 @@ class Decoders(nn.Module):
         rad = is_radar[..., 0] if is_radar is not None else torch.zeros(n, dtype=torch.bool, device=features.device)
         cam = ~(lid | rad)
         intensity = ray_drop_logit = rgb = radar_output = None
-        lf = features[lid]
+        from .ops import rows_where  # (= features[mask]; see its note on the backward of boolean-mask indexing)
+
+        lf = rows_where(features, lid)
         if lf.numel() > 0:
             intensity, ray_drop_logit = self.lidar_decoder(lf).split(1, dim=-1)
             intensity = intensity.sigmoid()
-        cf = features[cam]
+        cf = rows_where(features, cam)
         if cf.numel() > 0:
             patches = cf.view(-1, *patch_size, cf.shape[-1]).permute(0, 3, 1, 2)
             rgb = self.rgb_decoder(patches).permute(0, 2, 3, 1)
-        rf = features[rad]
+        rf = rows_where(features, rad)
         if rf.numel() > 0:
-            radar_output = self.decode_radar(rf, depth[rad], directions_spher[rad], num_radar_scans or 1)
+            radar_output = self.decode_radar(rf, rows_where(depth, rad), rows_where(directions_spher, rad), num_radar_scans or 1)
         return rgb, intensity, ray_drop_logit, radar_output
 
 

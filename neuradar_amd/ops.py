@@ -26,6 +26,18 @@ def _stream():
     return c_void_p(st.cuda_stream)
 
 
+def rows_where(t: Tensor, mask: Tensor) -> Tensor:
+    """`t[mask]` for a boolean mask over t's first dimension (or over all of t: the result is then 1-D), same values in the same
+    order -- through nonzero + index_select, whose backward is index_add_.  The backward of ATen's boolean-mask indexing
+    (`indexing_backward_kernel_small_stride`, torch 2.10 / ROCm 7.2) reads behind the end of a tensor: harmless until that tensor is
+    the last block of an allocator segment, then a GPU page fault (found with the guard allocator of tests/test_gpu_redzone.py on
+    the reference's own `features[is_lidar[..., 0]]`, models/neuradar.py:432-452)."""
+    if mask.shape == t.shape and t.dim() != 1:
+        return t.reshape(-1).index_select(0, mask.reshape(-1).nonzero().reshape(-1))
+    assert mask.dim() == 1 and mask.shape[0] == t.shape[0], "row mask"
+    return t.index_select(0, mask.nonzero().reshape(-1))
+
+
 def _f32(t: Tensor, what: str) -> Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{what} must be a GPU tensor: neuradar_amd has no CPU path (the oracle is test-only)")
@@ -786,8 +798,14 @@ _BN_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 _BN_WS: dict = {}
 
 
+def _ws_key(device):
+    """Partials workspaces are per (device, STREAM): two launches that reduce through one workspace on different streams would
+    race (the decoder chains run on three streams; a weight gradient launched beside its chain would be a fourth)."""
+    return (str(device), torch.cuda.current_stream(device).cuda_stream)
+
+
 def _bn_workspace(device) -> Tensor:
-    key = str(device)
+    key = _ws_key(device)
     if key not in _BN_WS:
         _BN_WS[key] = torch.empty(int(_lib.lib().nr_bn_act_workspace_floats(1, 64)), device=device, dtype=torch.float32)
     return _BN_WS[key]
@@ -991,9 +1009,9 @@ def conv7_wgrad(x: Tensor, grad_y: Tensor, want_bias: bool = True, into: Optiona
     P, C, H, W = x.shape
     assert C == 32 and x.dtype in _DT16 and grad_y.dtype == x.dtype and grad_y.shape == x.shape
     assert x.is_contiguous(memory_format=torch.channels_last) and grad_y.is_contiguous(memory_format=torch.channels_last)
-    ws = _conv7_ws.get(x.device)
+    ws = _conv7_ws.get(_ws_key(x.device))
     if ws is None:
-        ws = _conv7_ws[x.device] = torch.empty(_lib.lib().nr_conv7_wgrad_workspace_bytes(), device=x.device, dtype=torch.uint8)
+        ws = _conv7_ws[_ws_key(x.device)] = torch.empty(_lib.lib().nr_conv7_wgrad_workspace_bytes(), device=x.device, dtype=torch.uint8)
     if into is not None:
         check(_lib.lib().nr_conv7_wgrad(_p(x), _p(grad_y), _p(into[0]), _p(into[1]), 1, _p(ws), P, H, W, _DT16[x.dtype], _stream()),
               "nr_conv7_wgrad")
@@ -1083,9 +1101,9 @@ class _Pointwise(torch.autograd.Function):
             check(lib.nr_pw_bwd_data(_p(g), _p(y), int(out_f32), _p(weight), _p(gx), x_f32, P, K, O, act, int(transposed), H, W, _p(scale),
                                      dt, _stream()), "nr_pw_bwd_data")
         w_, b_ = ctx.param_refs
-        ws = _pw_ws.get(x2d.device)
+        ws = _pw_ws.get(_ws_key(x2d.device))
         if ws is None:
-            ws = _pw_ws[x2d.device] = torch.empty(lib.nr_pw_workspace_bytes(), device=x2d.device, dtype=torch.uint8)
+            ws = _pw_ws[_ws_key(x2d.device)] = torch.empty(lib.nr_pw_workspace_bytes(), device=x2d.device, dtype=torch.uint8)
         direct = (_DIRECT_PARAM_GRADS and w_.is_leaf and w_.grad is not None and w_.grad.dtype == w_.dtype and w_.grad.stride() == w_.stride()
                   and (b_ is None or (b_.is_leaf and b_.grad is not None and b_.grad.dtype == b_.dtype and b_.grad.is_contiguous())))
         if direct:  # added straight into the parameters' .grad buffers (same memory layout as the parameters)

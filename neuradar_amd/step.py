@@ -223,7 +223,8 @@ class NeuRadarHotPath(nn.Module):
         if lidar:  # :537-541: weights of lidar samples away from the measured return (carving loss input)
             md = rs.metadata
             m = ((~md["is_close_to_lidar"][:, :-1]) & md["is_lidar"][:, :-1]).squeeze(-1)
-            out["non_nearby_weights"] = weights[:, :-1][m]
+            w_ = weights[:, :-1]  # [B, S - 1, 1]; = w_[m] ([k, 1]) of the reference
+            out["non_nearby_weights"] = ops.rows_where(w_.reshape(-1, w_.shape[-1]) if w_.dim() == 3 else w_.reshape(-1), m.reshape(-1))
         # the sky sample is dropped from the lists the regularisers see (:515,534-535)
         out["weights_list"] = prop_w + [weights[:, :-1]]
         out["ray_samples_list"] = prop_rs + [rs.drop_last()]
@@ -362,7 +363,7 @@ class NeuRadarHotPath(nn.Module):
         """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the
         decoder MLP (MFMA kernels) -> (intensity in (0,1) [n_lidar,1], ray_drop_logit [n_lidar,1]); (None, None)
         when the batch holds no lidar ray."""
-        lidar_features = features[is_lidar[..., 0]]
+        lidar_features = ops.rows_where(features, is_lidar[..., 0])
         if lidar_features.numel() == 0:
             return None, None
         intensity, ray_drop_logit = self.lidar_decoder(lidar_features).split(1, dim=-1)
@@ -377,11 +378,12 @@ class NeuRadarHotPath(nn.Module):
         far = torch.tensor(c.non_return_lidar_distance, device=pred_depth.device)
         target[~did_return] = pred_depth.detach()[~did_return].maximum(far)
         unreduced = (target - pred_depth).abs()
-        unreduced[~did_return] = unreduced[~did_return] * c.non_return_loss_mult
+        # (`unreduced[~did_return] *= mult` of the reference as a select: same values, no masked write in the autograd graph)
+        unreduced = torch.where(did_return.reshape(-1, *([1] * (unreduced.dim() - 1))), unreduced, unreduced * c.non_return_loss_mult)
         mask = (unreduced < torch.quantile(unreduced, c.quantile_threshold)).squeeze(-1)
         qr = mask & did_return
-        return {"depth_loss": c.depth_mult * unreduced[mask].mean(),
-                "intensity_loss": c.intensity_mult * ((points_intensities[qr] - intensity[qr]) ** 2).mean(),
+        return {"depth_loss": c.depth_mult * ops.rows_where(unreduced, mask).mean(),
+                "intensity_loss": c.intensity_mult * ((ops.rows_where(points_intensities, qr) - ops.rows_where(intensity, qr)) ** 2).mean(),
                 "ray_drop_loss": c.ray_drop_loss_mult * torch.nn.functional.binary_cross_entropy_with_logits(
                     ray_drop_logits, (~did_return).unsqueeze(-1).to(ray_drop_logits))}
 

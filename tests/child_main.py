@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main() -> int:
+    import faulthandler
+
+    faulthandler.enable()  # a fatal signal (the ROCr fault handler's SIGABRT) dumps every python thread's stack to stderr
     path, func, kwargs, out = sys.argv[1:5]
     for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
         if p not in sys.path:

@@ -26,6 +26,8 @@ LAST = ("test_gpu_amp.py", "test_gpu_full_step.py", "test_gpu_graph_replay.py", 
 
 
 def _gpu_visible() -> bool:
+    if os.environ.get("NR_TEST_ASSUME_GPU") == "1":  # (exercising this file's GPU-session plumbing on a CPU box)
+        return True
     import torch
 
     return torch.cuda.is_available()
@@ -39,6 +41,7 @@ def pytest_configure(config):
     global _CONFIG
     _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _c_level_stderr_to_the_log(config)
     want = os.environ.get("NR_TEST_XDIST", "auto")
     if want == "0" or _is_worker(config) or not config.pluginmanager.hasplugin("xdist"):
         return
@@ -51,6 +54,26 @@ def pytest_configure(config):
         config.option.numprocesses = 1
         config.option.dist = "load"
         config.option.tx = ["popen"]
+
+
+def _c_level_stderr_to_the_log(config) -> None:
+    """On a GPU box: python-level capture only (`--capture=sys` semantics) instead of pytest's default fd capture, in the
+    controller and in every xdist worker.  What C code writes to fd 2 -- the ROCr runtime's "Memory access fault by GPU node ...",
+    glibc's "free(): invalid pointer", a HIP `guarantee` -- then reaches the session's log at once, next to the node id of the
+    crashed test; under fd capture it dies with the process inside pytest's temporary file (round 4: two aborts, no message)."""
+    if os.environ.get("NR_TEST_CAPTURE", "sys") != "sys" or getattr(config.option, "capture", "fd") != "fd" or not _gpu_visible():
+        return
+    capman = config.pluginmanager.getplugin("capturemanager")
+    if capman is None or getattr(capman, "_method", None) != "fd":
+        return
+    try:
+        capman.stop_global_capturing()
+        capman._method = "sys"
+        capman.start_global_capturing()
+        capman.suspend_global_capture()  # (the state pytest is in at this point: suspended until a test runs; the terminal reporter
+        #                                   created after this hook must get the REAL sys.stdout)
+    except Exception:  # noqa: BLE001 -- a pytest whose capture manager looks different: keep its default
+        pass
 
 
 def _rank(item) -> int:

