@@ -682,8 +682,8 @@ class FusedTrainStep:
         if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
             optimizers[0].marked.clear()
         # main table: scatter and Adam pipelined level by level (single GPU, marked Adam, block-shared scatter; NR_MAIN_LEVEL_PIPELINE)
-        level_pipeline = (mark_seen is not None and self.main_shared and self.amp is None
-                          and os.environ.get("NR_MAIN_LEVEL_PIPELINE", "0") == "1")
+        level_pipeline = int(os.environ.get("NR_MAIN_LEVEL_PIPELINE", "0")) if (mark_seen is not None and self.main_shared and self.amp is None) else 0
+        level_pipeline = min(level_pipeline, mg.num_levels)  # number of level GROUPS (0 = off: one scatter launch, then one Adam launch)
         level_pipeline_buffer = optimizers[0].buffer_of(mg.hash_table) if level_pipeline else None
 
         def scatter(lvl, grid, tag):
@@ -710,15 +710,17 @@ class FusedTrainStep:
                     # integer atomics (grid_shared.hip) for every row -- two waves per SIMD and a third of the merging kernel's
                     # instructions; marks the optimizer's `seen` bytes itself when the marked Adam follows
                     if level_pipeline:
-                        # one launch per LEVEL, and the level's Adam on a stream of its own as soon as its scatter is done, beside
-                        # the next level's scatter: the step's critical path (main scatter 700 us -> main Adam 514 us, nothing
+                        # one launch per GROUP of levels, and the group's Adam on a stream of its own as soon as its scatter is done,
+                        # beside the next group's scatter: the step's critical path (main scatter 700 us -> main Adam 514 us, nothing
                         # beside the Adam) becomes ~ scatter + one level of Adam
                         T4 = (1 << grid.log2_hashmap_size) * Fg  # floats per level
                         cur_ = torch.cuda.current_stream()
                         adam_s = self._adam_stream()
-                        for l_ in range(grid.num_levels):
+                        per = -(-grid.num_levels // level_pipeline)  # levels per launch
+                        for l_ in range(0, grid.num_levels, per):
+                            k_ = min(per, grid.num_levels - l_)
                             rc = lib.nr_hash_encode_bwd_shared(
-                                p(self.x01[lvl]), p(self.std[lvl]), c_void_p(grid.scalings.data_ptr() + 4 * l_), 1, Fg, grid.log2_hashmap_size,
+                                p(self.x01[lvl]), p(self.std[lvl]), c_void_p(grid.scalings.data_ptr() + 4 * l_), k_, Fg, grid.log2_hashmap_size,
                                 c_void_p(self.g_feats[lvl].data_ptr() + 4 * l_ * nl * Fg), Fg, nl * Fg,
                                 c_void_p(grid.hash_table.grad.data_ptr() + 4 * l_ * T4), nl,
                                 c_void_p(mark_seen.data_ptr() + l_ * T4 // 4), sp_)
@@ -728,7 +730,7 @@ class FusedTrainStep:
                             ev_.record(cur_)
                             adam_s.wait_event(ev_)
                             with torch.cuda.stream(adam_s):
-                                optimizers[0].step_buffer(level_pipeline_buffer, 1.0, part=(l_ * T4, (l_ + 1) * T4))
+                                optimizers[0].step_buffer(level_pipeline_buffer, 1.0, part=(l_ * T4, (l_ + k_) * T4))
                         return 0
                     return lib.nr_hash_encode_bwd_shared(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
                                                          grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
