@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 25
+#define NR_ABI_VERSION 26
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -991,6 +991,25 @@ int nr_gen_rays_camera_patches(const float* u, int64_t n_patches, int n_cams, in
  * pixel_samplers.py): counter-based, value i of draw number *epoch (a device-resident float counter, e.g.
  * the optimizer's step; NULL = 0) for this seed.  24 random bits per value, like torch's float32 rand. */
 int nr_uniform_fill(float* out, int64_t n, uint32_t seed, const float* epoch, nr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI v26: the main table's optimizer step in two launches around the scatter.
+ *   nr_hash_mark_vertices   stamp[level * T + entry] = value for the 8 vertices (floor, floor + 1 per axis) of every row's cell on
+ *                           every level: the entries this step's gradient can reach (a superset of what the scatter writes).
+ *                           x [n,3] in [0,1], scalings [L], stamp uint8 [L * T] (one byte per 4-float group of an F = 4 table).
+ *   nr_adam_step_split      nr_adam_step_marked's update (no weight decay, no skip flag), phase 1: groups with seen_grad != 0 whose
+ *                           stamp differs from the step's value -- zero gradient, the gradient buffer is neither read nor written;
+ *                           phase 2: groups stamped with the step's value -- full update, gradient cleared.  Together: exactly one
+ *                           update per group, bit-identical to the single launch.  Phase 1 may run before / beside the step's
+ *                           forward and backward (it writes only groups the step does not read).
+ *   value = (int)epoch[0] % 255 + 1, epoch = a device float that counts steps (FlatAdam.step_t[1]): graph replays stamp every step
+ *   differently without a host-side argument.  lr and the bias corrections come from dev_hyper (nr_adam_hyper).
+ * ---------------------------------------------------------------------------------------------- */
+int nr_hash_mark_vertices(const float* x, const float* scalings, int L, int log2T, int64_t n, uint8_t* stamp, const float* epoch,
+                          nr_stream_t stream);
+int nr_adam_step_split(float* param, float* grad, float* m, float* v, int64_t n, float beta1, float beta2, float eps, float grad_scale,
+                       const float* dev_hyper, const uint8_t* seen_grad, const uint8_t* stamp, const float* epoch, int phase,
+                       int state_stride, nr_stream_t stream);
 
 #ifdef __cplusplus
 }

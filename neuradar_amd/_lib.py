@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 25
+NR_ABI_VERSION = 26
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -78,6 +78,8 @@ PROTOTYPES = {
     "nr_abi_version": [],
     "nr_target_arch": [],
     "nr_init": [],
+    "nr_hash_mark_vertices": [P, P, I, I, L, P, P, P],
+    "nr_adam_step_split": [P, P, P, P, L, F, F, F, F, P, P, P, P, I, I, P],
     "nr_set_tuning": [I, I],
     "nr_hash_encode_fwd": [P, P, P, P, I, I, I, P, L, L, L, I, P],
     "nr_hash_encode_bwd": [P, P, P, I, I, I, P, L, L, P, L, I, P],

@@ -331,6 +331,26 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
 #endif
 }
 
+// Stamp every table group (entry) that the rows' gradients can reach on any level: the 8 vertices (floor, floor + 1 per axis --
+// this file's scatter's) of every row's cell.  One byte per entry of the [L * T] table; the value comes from a device-resident step
+// counter.  A superset of what the scatter writes (vertices with weight 0, rows with a zero gradient) is fine: see adam_split_kernel.
+__global__ void __launch_bounds__(256)
+hash_mark_kernel(const float* __restrict__ x, const float* __restrict__ scalings, int L, int log2T, int64_t n, uint8_t* __restrict__ stamp,
+                 const float* __restrict__ epoch) {
+  const uint8_t now = (uint8_t)nr_stamp_value(epoch);
+  const uint32_t mask = (1u << log2T) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float px = x[i * 3], py = x[i * 3 + 1], pz = x[i * 3 + 2];
+    for (int l = 0; l < L; ++l) {
+      const float s = scalings[l];
+      const int lx = (int)floorf(px * s), ly = (int)floorf(py * s), lz = (int)floorf(pz * s);
+      uint8_t* base = stamp + ((int64_t)l << log2T);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) base[nr_hash3(lx + (c & 1), ly + ((c >> 1) & 1), lz + (c >> 2), mask)] = now;
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef NR_SHARED_CLOCKS
@@ -363,6 +383,17 @@ extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const
   else
     hipLaunchKernelGGL(scatter_shared_kernel<false>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,
                        sl, grad_table, n, tiles, seen_grad);
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_hash_mark_vertices(const float* x, const float* scalings, int L, int log2T, int64_t n, uint8_t* stamp, const float* epoch,
+                                     nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!x || !scalings || !stamp || !epoch || n < 0 || L < 1 || log2T < 1 || log2T > 30) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n, 256);
+  hipLaunchKernelGGL(hash_mark_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, nr_s(stream), x, scalings, L, log2T, n, stamp,
+                     epoch);
   NR_LAUNCH_CHECK();
   return 0;
 }

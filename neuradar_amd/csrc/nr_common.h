@@ -53,6 +53,10 @@ __device__ __forceinline__ uint32_t nr_hash3(int ix, int iy, int iz, uint32_t ma
   return (((uint32_t)ix * 1u) ^ ((uint32_t)iy * 2654435761u) ^ ((uint32_t)iz * 805459861u)) & mask;
 }
 
+// ---- the step's stamp value (nr_hash_mark_vertices / nr_adam_step_split): 1 ... 255 from a device-resident step counter, so
+// that a replayed hipGraph stamps every step differently; 0 = never stamped
+__device__ __forceinline__ int nr_stamp_value(const float* __restrict__ epoch) { return ((int)epoch[0]) % 255 + 1; }
+
 // ---- loss partial sums ---------------------------------------------------------------------------
 // Every wave adds its loss into slot (global wave index mod NR_LOSS_SLOTS).  Same-address float atomics
 // are applied one after the other at the memory side (~0.4 us each, measured): with 64 slots the

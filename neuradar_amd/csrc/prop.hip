@@ -336,6 +336,65 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
   }
 }
 
+// ---- the marked update in TWO launches around the scatter -----------------------------------------
+// The step's critical path ended scatter (700 us) -> Adam (514 us) with nothing beside the Adam.  Which groups of the table THIS
+// step's gradient can reach is known long before the backward: the vertices of the step's samples, i.e. what the forward gather
+// reads (nr_hash_mark_vertices stamps them with the step's epoch value as soon as the sampling rounds are done).  So:
+//   PHASE 1  groups with a history (seen) that this step does NOT touch (stamp != value): their gradient is exactly 0 -- the
+//            zero-gradient update (moments decay, the parameter moves) runs BESIDE the forward and the field backward, on its own
+//            stream; the gradient is neither read nor written (96 instead of 128 bytes per group);
+//   PHASE 2  the groups stamped this step, after the scatter: the full update.
+// Every group gets exactly one update per step, with the arithmetic of adam_marked_kernel on the same operands: bit-identical to
+// the single launch (tests/test_gpu_adam_split.py).  A stale stamp (the 8-bit value comes round every 255 steps; a vertex whose
+// weight is 0) only sends a group to phase 2 with a zero gradient.  Phase 1 writes only parameters the step's forward does not
+// read.  No loss-scaler skip (the flags are not known when phase 1 runs): the caller keeps the single launch under a scaler.
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+adam_split_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                  float beta1, float beta2, float eps, float grad_scale, const float* __restrict__ dev_hyper,
+                  const uint8_t* __restrict__ seen_grad, const uint8_t* __restrict__ stamp, const float* __restrict__ epoch, int ss) {
+  const float lr = dev_hyper[0], bc1 = dev_hyper[1], bc2_sqrt = dev_hyper[2];
+  const uint8_t now = (uint8_t)nr_stamp_value(epoch);
+  const int64_t n4 = n / 4;
+  float4* p4 = reinterpret_cast<float4*>(param);
+  float4* g4 = reinterpret_cast<float4*>(grad);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  const float step_size = lr / bc1;
+  auto upd = [&](float& p, float g, float& mm, float& vv) {  // adam_marked_kernel's arithmetic, operand for operand
+    const float gr = g * grad_scale;
+    mm = mm + (gr - mm) * (1.0f - beta1);
+    vv = vv * beta2 + (1.0f - beta2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p = p - step_size * (mm / denom);
+  };
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto ld = [](const float4* q) { f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(q)); return make_float4(t.x, t.y, t.z, t.w); };
+  auto stv = [](float4* q, float4 x) { f4 t = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4*>(q)); };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto live = [&](int64_t j) -> bool {  // (the thread's next two bytes are requested one trip ahead)
+    if (j >= n4) return false;
+    const uint8_t st = stamp[j];
+    return PHASE == 1 ? (st != now && seen_grad[j] != 0) : st == now;
+  };
+  bool cur = live(i);
+  for (; i < n4; i += stride) {
+    const bool mine = cur;
+    cur = live(i + stride);
+    if (!mine) continue;
+    float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (PHASE == 2) g = ld(g4 + i);
+    float4 mm = ld(m4 + i * ss), vv = ld(v4 + i * ss), pp = ld(p4 + i);
+    const bool had = g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f;
+    if (!had && mm.x == 0.0f && mm.y == 0.0f && mm.z == 0.0f && mm.w == 0.0f && vv.x == 0.0f && vv.y == 0.0f && vv.z == 0.0f && vv.w == 0.0f)
+      continue;  // fixed point: no stores
+    upd(pp.x, g.x, mm.x, vv.x); upd(pp.y, g.y, mm.y, vv.y); upd(pp.z, g.z, mm.z, vv.z); upd(pp.w, g.w, mm.w, vv.w);
+    stv(p4 + i, pp); stv(m4 + i * ss, mm); stv(v4 + i * ss, vv);
+    if (PHASE == 2 && had) stv(g4 + i, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  }
+}
+
 // One-thread kernel: advances the optimizer step counter and refreshes {lr, 1-beta1^t, sqrt(1-beta2^t)}
 // (ExponentialDecayScheduler, engine/schedulers.py:112-143; LambdaLR applies func(k-1) to step k).
 __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict__ hyper, float lr, float lr_final,
@@ -591,6 +650,27 @@ extern "C" int nr_grad_apply(const int* idx, const float* val, const int* count,
     default: return NR_EINVAL;
   }
 #undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_adam_step_split(float* param, float* grad, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                                  float grad_scale, const float* dev_hyper, const uint8_t* seen_grad, const uint8_t* stamp,
+                                  const float* epoch, int phase, int state_stride, nr_stream_t stream) {
+  if (n == 0) return 0;
+  if (!param || !grad || !m || !v || !dev_hyper || !seen_grad || !stamp || !epoch || n < 0 || (n & 3) != 0 || (phase != 1 && phase != 2))
+    return NR_EINVAL;
+  if (state_stride != 1 && !(state_stride == 2 && v == m + 4)) return NR_EINVAL;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) != 0) return NR_EINVAL;
+  const int64_t want = nr_cdiv(n / 4 + 1, 256);
+  const int64_t cap = nr_tuning().adam_blocks > 0 ? nr_tuning().adam_blocks : 4096;
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
+  if (phase == 1)
+    hipLaunchKernelGGL(adam_split_kernel<1>, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, beta1, beta2, eps, grad_scale,
+                       dev_hyper, seen_grad, stamp, epoch, state_stride);
+  else
+    hipLaunchKernelGGL(adam_split_kernel<2>, dim3(blocks), dim3(256), 0, nr_s(stream), param, grad, m, v, n, beta1, beta2, eps, grad_scale,
+                       dev_hyper, seen_grad, stamp, epoch, state_stride);
   NR_LAUNCH_CHECK();
   return 0;
 }

@@ -528,6 +528,25 @@ class FusedTrainStep:
             if optimizers is not None:
                 for o_ in optimizers:
                     o_.advance()
+        # The main table's `seen` bytes set by its scatter (single GPU, fused optimizer, every row through the merging kernel; the
+        # optimizer's buffer must be exactly the static table -- the actors' tables live in a buffer of their own):
+        # NR_ADAM_MARKED=0 disables
+        mark_seen = None
+        if (optimizers is not None and reducer is None and self.binned_ws[2] is None and not grads_accumulated
+                and os.environ.get("NR_ADAM_MARKED", "1") != "0"):
+            t_opt = optimizers[0]
+            i_m = t_opt.buffer_of(self.mgrid.hash_table)
+            if (t_opt.seen[i_m] is not None and t_opt.buffers[i_m][0].data_ptr() == self.mgrid.hash_table.data_ptr()
+                    and t_opt.buffers[i_m][0].numel() == self.mgrid.hash_table.numel() and i_m not in getattr(t_opt, "shards", {})):
+                mark_seen = t_opt.seen[i_m]
+                if not hasattr(t_opt, "marked"):
+                    t_opt.marked = {}
+                t_opt.marked[i_m] = True
+        if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
+            optimizers[0].marked.clear()
+        # ... and its Adam in two launches around the scatter (FlatAdam.step_buffer_split; NR_ADAM_SPLIT=0: one launch after it)
+        adam_split = (mark_seen is not None and self.main_shared and self.amp is None and self.overlap
+                      and os.environ.get("NR_ADAM_SPLIT", "1") != "0")
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
@@ -572,6 +591,21 @@ class FusedTrainStep:
             actor_overwrite(2, mg)
         if side[0] is not main:
             main.wait_stream(side[0])
+        if adam_split:
+            # the sampling rounds are done (the main samples' positions are final) and the optimizers' schedule kernels have run:
+            # stamp the table entries this step can touch and give every OTHER entry with a history its zero-gradient update now,
+            # on a stream of its own beside the field's forward and backward -- the main table's Adam behind the scatter (the end of
+            # the step's critical path) then only walks the stamped entries
+            if getattr(self, "_stamp", None) is None:
+                self._stamp = torch.zeros(mg.hash_table.numel() // 4, device=self.dev, dtype=torch.uint8)
+            ev_ = torch.cuda.Event()
+            ev_.record(main)
+            adam_s = self._adam_stream()
+            adam_s.wait_event(ev_)
+            with torch.cuda.stream(adam_s):
+                check(lib.nr_hash_mark_vertices(p(self.x01[2]), p(mg.scalings), mg.num_levels, mg.log2_hashmap_size, n, p(self._stamp),
+                                                c_void_p(optimizers[0].step_t.data_ptr() + 4), ops._stream()), "hash_mark_vertices")
+                optimizers[0].step_buffer_split(optimizers[0].buffer_of(mg.hash_table), 1, self._stamp)
         if after_sampling is not None:
             if side[1] is not main:
                 side[1].wait_stream(main)
@@ -665,24 +699,9 @@ class FusedTrainStep:
                 check(lib.nr_prop_density_bwd(p(self.feats[lvl]), Fp, nl * Fp, Fp, p(w_dec), w_dec.numel(), nl, S, self.sm, p(self.dens[lvl]),
                                               p(self.g_dens[lvl]), p(self.g_feats[lvl]), p(w_dec.grad), sp_), "prop_density_bwd")
 
-        # The main table's `seen` bytes set by its scatter (single GPU, fused optimizer, every row through the merging kernel; the
-        # optimizer's buffer must be exactly the static table -- the actors' tables live in a buffer of their own):
-        # NR_ADAM_MARKED=0 disables
-        mark_seen = None
-        if (optimizers is not None and reducer is None and self.binned_ws[2] is None and not grads_accumulated
-                and os.environ.get("NR_ADAM_MARKED", "1") != "0"):
-            t_opt = optimizers[0]
-            i_m = t_opt.buffer_of(mg.hash_table)
-            if (t_opt.seen[i_m] is not None and t_opt.buffers[i_m][0].data_ptr() == mg.hash_table.data_ptr()
-                    and t_opt.buffers[i_m][0].numel() == mg.hash_table.numel() and i_m not in getattr(t_opt, "shards", {})):
-                mark_seen = t_opt.seen[i_m]
-                if not hasattr(t_opt, "marked"):
-                    t_opt.marked = {}
-                t_opt.marked[i_m] = True
-        if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
-            optimizers[0].marked.clear()
         # main table: scatter and Adam pipelined level by level (single GPU, marked Adam, block-shared scatter; NR_MAIN_LEVEL_PIPELINE)
-        level_pipeline = int(os.environ.get("NR_MAIN_LEVEL_PIPELINE", "0")) if (mark_seen is not None and self.main_shared and self.amp is None) else 0
+        level_pipeline = int(os.environ.get("NR_MAIN_LEVEL_PIPELINE", "0")) if (mark_seen is not None and self.main_shared and self.amp is None
+                                                                                 and not adam_split) else 0
         level_pipeline = min(level_pipeline, mg.num_levels)  # number of level GROUPS (0 = off: one scatter launch, then one Adam launch)
         level_pipeline_buffer = optimizers[0].buffer_of(mg.hash_table) if level_pipeline else None
 
@@ -856,6 +875,8 @@ class FusedTrainStep:
             for s_ in side:
                 if s_ is not main:
                     main.wait_stream(s_)
+            if adam_split:
+                main.wait_stream(self._adam_stream())
 
         table_opt = field_opt = None
         if optimizers is not None:
@@ -888,6 +909,8 @@ class FusedTrainStep:
                         reducer.wait_all()
                 if level_pipeline:
                     torch.cuda.current_stream().wait_stream(self._adam_stream())  # (the levels' Adam launches followed their scatters)
+                elif adam_split:
+                    table_opt.step_buffer_split(i_main, 2, self._stamp)  # the stamped entries; the rest was stepped beside the forward
                 else:
                     table_opt.step_buffer(i_main, scale, skip_extra=keep)
 

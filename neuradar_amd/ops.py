@@ -1180,6 +1180,26 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
                                   _p(dev_hyper), _p(seen_grad), _p(skip), _p(delta16), stride, _stream()), "nr_adam_step")
 
 
+def hash_mark_vertices(x: Tensor, scalings: Tensor, log2_hashmap_size: int, stamp: Tensor, epoch: Tensor) -> None:
+    """nr_hash_mark_vertices: stamp (uint8 [L * T]) <- the step's value at every table entry the rows' gradients can reach."""
+    assert stamp.dtype == torch.uint8 and stamp.numel() >= scalings.numel() << log2_hashmap_size and epoch.dtype == torch.float32
+    check(_lib.lib().nr_hash_mark_vertices(_p(x), _p(scalings), scalings.numel(), log2_hashmap_size, x.shape[0], _p(stamp), _p(epoch), _stream()),
+          "nr_hash_mark_vertices")
+
+
+def adam_step_split(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, betas, eps: float, grad_scale: float, dev_hyper: Tensor,
+                    seen_grad: Tensor, stamp: Tensor, epoch: Tensor, phase: int) -> None:
+    """nr_adam_step_split: phase 1 = the zero-gradient update of the groups with a history that this step does not touch (may run
+    beside the step's forward / backward); phase 2 = the full update of the groups stamped this step (after the scatter)."""
+    stride = 1
+    if not exp_avg.is_contiguous():
+        assert exp_avg.dim() == 2 and exp_avg.stride() == (8, 1) and exp_avg_sq.data_ptr() == exp_avg.data_ptr() + 16
+        stride = 2
+    assert param.numel() % 4 == 0 and seen_grad.numel() >= param.numel() // 4 and stamp.numel() >= param.numel() // 4
+    check(_lib.lib().nr_adam_step_split(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), betas[0], betas[1], eps, grad_scale,
+                                        _p(dev_hyper), _p(seen_grad), _p(stamp), _p(epoch), int(phase), stride, _stream()), "nr_adam_step_split")
+
+
 def apply_delta16(param: Tensor, delta16: Tensor, lo: int, hi: int) -> None:
     """param[i] += float(delta16[i]) outside [lo, hi): the receiving side of the sharded table step (nr_apply_delta16)."""
     assert delta16.dtype == torch.bfloat16 and delta16.numel() == param.numel() and param.is_contiguous() and delta16.is_contiguous()

@@ -640,6 +640,16 @@ class FlatAdam:
                       zero_grad=True, dev_hyper=self.hyper, seen_grad=seen, marked=marked, skip=skip, delta16=delta16)
 
     @torch.no_grad()
+    def step_buffer_split(self, i: int, phase: int, stamp: Tensor) -> None:
+        """The marked update of buffer i (a hash table whose `seen` bytes this step's scatter sets) in two launches around the
+        scatter -- ops.adam_step_split: phase 1 (groups with a history that `stamp` says this step does not touch: zero gradient)
+        any time after `advance()`, e.g. beside the forward; phase 2 (the stamped groups) after the scatter.  No loss scaler, no
+        shards, no weight decay: FusedTrainStep falls back to step_buffer otherwise."""
+        (p, g), (m, v) = self.buffers[i], self.state[i]
+        assert self.amp is None and i not in getattr(self, "shards", {}) and self.seen[i] is not None and self.wd == 0.0
+        ops.adam_step_split(p.view(-1), g.view(-1), m, v, self.betas, self.eps, 1.0, self.hyper, self.seen[i], stamp, self.step_t[1:], phase)
+
+    @torch.no_grad()
     def check_buffer(self, i: int) -> None:
         """With a loss scaler attached: raise this optimizer's found-inf flag if gradient buffer i holds an inf / NaN (one
         small launch; meant for the flat buffer of the small parameters -- the tables' gradients are flagged by their
