@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float16": 2500.0, "float32": 157.0}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
     # BASELINE.json configs[1]: camera-only, L=16/F=2 hash + 64-wide MLP, 4096 rays
@@ -922,6 +923,21 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             roof["limiter"] = ("LDS capacity and LDS-atomic issue of the on-chip merge (bin pass 48 KB per block, apply pass 132 KB), plus the "
                                "memory side's float-atomic path it shares with the two other scatters running beside it -- not HBM bandwidth")
         roof["mfma_busy_frac"] = pmc_mfma_busy(workload)
+        # the field MLPs in FLOP terms (a busy fraction alone does not say it): 2 * in * out per linear layer
+        # and main sample forward, x 3 for forward + both backward products, over the field kernels' own time in the step
+        if mlp_times:
+            fld = model.field
+            flop_fwd = sum(2 * l.weight.shape[0] * l.weight.shape[1] for mm_ in (fld.mlp_geo, fld.mlp_feature) for l in mm_.layers)
+            flop_step = 3 * flop_fwd * n_rays * model.config.num_nerf_samples
+            t_field = sum(v for k, v in mlp_times.items() if k.startswith("field"))
+            if t_field > 0:
+                peak = MFMA_PEAK_TFLOPS.get(mlp_dtype, MFMA_PEAK_TFLOPS["float32"])
+                roof["mfma"] = {"flop_per_step": int(flop_step), "field_kernels_us": round(t_field * 1e6, 2),
+                                "achieved_tflops": round(flop_step / t_field / 1e12, 2), "peak_tflops_dense": peak,
+                                "frac": round(flop_step / t_field / 1e12 / peak, 5), "operands": mlp_dtype,
+                                "note": "layers of width 32-64 on 32x32x16 MFMA tiles: one tile row per layer, operands re-staged per layer; the forward "
+                                        "kernel is a 537-MB gather with an MLP attached -- the north star's >= 50 % MFMA is out of reach for this "
+                                        "network by two orders of magnitude at ANY kernel quality (17.8 GFLOP per step = 7 us at the dense peak)"}
         bwd = [r for r in rows if "bwd" in r["kernel"]]
         if stepper is not None and len(bwd) in (2, 3):
             # the three scatters start within ~80 us of each other and share the chip (and HBM) until the longest ends:

@@ -544,9 +544,12 @@ class FusedTrainStep:
                 t_opt.marked[i_m] = True
         if mark_seen is None and optimizers is not None and hasattr(optimizers[0], "marked"):
             optimizers[0].marked.clear()
-        # ... and its Adam in two launches around the scatter (FlatAdam.step_buffer_split; NR_ADAM_SPLIT=0: one launch after it)
+        # ... and, opt-in (NR_ADAM_SPLIT=1), its Adam in two launches around the scatter (FlatAdam.step_buffer_split).  Bit-identical
+        # to the single launch and MEASURED SLOWER (2.15 -> 2.50 ms per step, same box, three interleaved repetitions): the
+        # zero-gradient phase streams 0.8 GB beside the forward, whose gathers then take twice as long (field_fwd_gather 152 -> 325 us,
+        # render 50 -> 367 us), and is still running when the scatter starts -- DESIGN.md section 13.  Default: one launch behind it.
         adam_split = (mark_seen is not None and self.main_shared and self.amp is None and self.overlap
-                      and os.environ.get("NR_ADAM_SPLIT", "1") != "0")
+                      and os.environ.get("NR_ADAM_SPLIT", "0") == "1")
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):

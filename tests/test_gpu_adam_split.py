@@ -119,16 +119,24 @@ def _train(split: str, steps: int, monkeypatch):
 
 
 def test_training_steps_with_the_split_adam_equal_the_single_launch(monkeypatch):
-    """Six optimizer steps of the fused step (block-shared main scatter, marked Adam) with the Adam split around the scatter and
-    with the single launch behind it, different batches every step: the main table, both of its moments and every other parameter
-    agree to the rounding of the scatters' float atomics (two runs of the SAME configuration differ by as much); moments of groups
-    a later step no longer touches keep decaying (the zero-gradient phase did run)."""
-    a, b = _train("1", 6, monkeypatch), _train("0", 6, monkeypatch)
+    """Six optimizer steps of the fused step (block-shared main scatter, marked Adam) with the Adam split around the scatter
+    (NR_ADAM_SPLIT=1) and with the single launch behind it, different batches every step.  The scatters' float atomics make two
+    runs of the SAME configuration differ (and Adam turns the rounding of a near-zero gradient into a visible difference of that
+    entry's update), so the yardstick is measured: the split run may differ from a single-launch run in at most twice as many
+    entries as two single-launch runs differ from each other (+ 1e-4 of the table), for the table and both of its moments; every
+    other parameter within the usual tolerance; moments of groups a later step no longer touches keep decaying (the
+    zero-gradient phase did run)."""
+    a, b, b2 = _train("1", 6, monkeypatch), _train("0", 6, monkeypatch), _train("0", 6, monkeypatch)
     assert a["split"] and not b["split"]
+
+    def off(x, y):
+        x, y = x.reshape(-1), y.reshape(-1)
+        return float(((x - y).abs() > 1e-6 * float(y.abs().max()) + 1e-3 * y.abs()).float().mean())
+
     for key in ("table", "m", "v"):
-        x, y = a[key].reshape(-1), b[key].reshape(-1)
-        off = (x - y).abs() > 1e-6 * float(y.abs().max()) + 1e-3 * y.abs()
-        assert float(off.float().mean()) <= 1e-4, f"{key}: {int(off.sum())} of {off.numel()} entries differ"
+        noise, got = off(b2[key], b[key]), off(a[key], b[key])
+        print(f"{key}: entries off -- split vs single {got:.3e}, single vs single {noise:.3e}")
+        assert got <= 2.0 * noise + 1e-4, f"{key}: {got:.3e} of the entries differ (two single-launch runs: {noise:.3e})"
     for n_, p in a["others"].items():
         torch.testing.assert_close(p, b["others"][n_], rtol=2e-3, atol=1e-5, msg=lambda m, n_=n_: f"{n_}: {m}")
     assert float((a["m"] != 0).float().mean()) > 0.01
