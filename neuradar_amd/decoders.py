@@ -234,7 +234,10 @@ class Decoders(nn.Module):
             cb = torch.stack([cv.bias.float() if cv.bias is not None else torch.zeros(32, device=dev) for cv, _ in pairs])
             gamma, beta = torch.stack([bn.weight.float() for _, bn in pairs]), torch.stack([bn.bias.float() for _, bn in pairs])
             mean, var = torch.stack([bn.running_mean.float() for _, bn in pairs]), torch.stack([bn.running_var.float() for _, bn in pairs])
-            eps = torch.tensor([bn.eps for _, bn in pairs], device=dev)[:, None]
+            eps_key = tuple(bn.eps for _, bn in pairs)
+            if getattr(self, "_conv7_eps", (None, None))[0] != eps_key:  # (constants: one host-to-device copy, not one per image)
+                self._conv7_eps = (eps_key, torch.tensor(eps_key, device=dev)[:, None])
+            eps = self._conv7_eps[1]
             k = gamma / torch.sqrt(var + eps)                                    # [n, O]
             flat = torch.cat([(W * k[:, :, None, None, None]).reshape(n_c, -1), (cb - mean) * k + beta], dim=1)  # [n, 32*49*32 + 32]
             per = flat.shape[1]

@@ -321,3 +321,47 @@ def test_kernel_tests_under_the_guard_allocator(files):
     r = run_child(__file__, "_guarded_pytest", timeout=1500, files=files)
     print(f"{files}: {r['allocations']} guarded allocations")
     assert r["canary_failures"] == 0
+
+
+def _guarded_workload(workload: str, steps: int = 3):
+    """bench.py's own step for `workload` at FULL size -- model, optimizers, device-side batch assembly, the pipelined fused step
+    with its side streams (and, for the decoder workloads, the decoder segment) -- launched eagerly under the guard allocator."""
+    lib = _install_guard_allocator()
+    import bench
+    from neuradar_amd.parallel import GradAllReducer
+
+    dev = torch.device(DEV)
+    wl = bench.WORKLOADS[workload]
+    n_rays = wl["rays"]
+    mlp_dtype = wl.get("mlp_dtype", "bfloat16")
+    model = bench.build_model(wl, dev, mlp_dtype, 8192.0 if mlp_dtype == "float16" else 1.0)
+    opts = bench.build_optimizers(model)
+    reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()])
+    scene = bench.SyntheticScene(dev, seed=1000, radar=wl.get("radar", "zod"))
+    torch.manual_seed(1234)
+    targets = (0.1 * torch.randn(n_rays, 32, device=dev), 5.0 + 50.0 * torch.rand(n_rays, 1, device=dev))
+    fwd_bwd, _, stepper = bench.make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_optimizer=True,
+                                          mixed=wl if "cam_rays" in wl else None)
+    losses_ = []
+    for _ in range(steps):
+        fwd_bwd()
+        torch.cuda.synchronize()
+        losses_.append(float(stepper.loss.sum()))
+    assert all(x == x and abs(x) < 1e30 for x in losses_), losses_
+    for n_, p_ in model.named_parameters():
+        assert bool(torch.isfinite(p_).all()), f"parameter {n_}"
+    return {"allocations": int(lib.guard_allocations()), "canary_failures": int(lib.guard_canary_failures()), "losses": losses_}
+
+
+@pytest.mark.parametrize("workload", ["mixed16384_neuradar", "cam4096_l16f2_w64", "mixed16384_neuradar_full_fp16", "mixed8192_vod_nll"])
+def test_bench_workloads_at_full_size_under_the_guard_allocator(workload):
+    """BASELINE configs[2] (the headline), configs[1], configs[4] and configs[3] per-GPU shapes, exactly as bench.py builds them, three
+    optimizer steps each with every tensor at the end of its own mapped region: no kernel of the timed path -- batch assembly,
+    gathers, field, render, the three scatters (binned, block-shared), Adam, the decoder segment and its losses -- reads or writes
+    behind a buffer at the sizes the numbers are quoted on (a size-independent property: a fault kills the child)."""
+    if os.environ.get("NR_TEST_GUARD_SWEEP", "1") == "0":
+        pytest.skip("NR_TEST_GUARD_SWEEP=0")
+    r = run_child(__file__, "_guarded_workload", timeout=1200, workload=workload)
+    print(f"{workload}: {r['allocations']} guarded allocations, losses {r['losses']}")
+    assert r["canary_failures"] == 0
+
