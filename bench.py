@@ -385,7 +385,7 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
             return stepper.forward_backward(o_, d_, a_, f_, None if decoders else tf_k, None if decoders else td_k,
                                             r[:n_t].view(n_rays, S0 + 1), r[n_t:n_t + n_rays], r[n_t + n_rays:n_t + 2 * n_rays],
                                             optimizers=opts if fuse_optimizer else None,
-                                            reducer=reducer if (fuse_optimizer and reducer.world > 1) else None,
+                                            reducer=reducer if (fuse_optimizer and (reducer.world > 1 or getattr(reducer, "force_collectives", False))) else None,
                                             after_sampling=tail, slot=k, prepared=True,
                                             times=times_of[k] if (has_actors or decoders) else None,
                                             flips=list(flip_buf[k]) if has_actors else None)
@@ -646,12 +646,14 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     # sharded table step: fp32 on both halves of the exchange (the reference's DDP all-reduces fp32 gradients and its Adam
     # writes fp32 parameters; --table-transport bf16 / --table-delta bf16 are opt-in and named in the line), the all-gather
     # deferred into the next step by default (--no-defer-gather: the round-3 behaviour)
+    one_rank = bool(getattr(args, "one_rank_collectives", False))
+    reducer.force_collectives = one_rank
     reducer.table_delta = torch.bfloat16 if args.table_delta == "bf16" else None
     reducer.defer_gather = not args.no_defer_gather
     if mode == "shard" and args.table_transport == "bf16":
         reducer.table_dtype = torch.bfloat16
-    if mode == "shard" and world > 1:
-        if opts[0].shard_buffer(opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table), rank, world) is None:
+    if mode == "shard" and (world > 1 or one_rank):
+        if opts[0].shard_buffer(opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table), rank, world, force=one_rank) is None:
             reducer.table_mode, reducer.sparse_tables = "dense", False
     scene = SyntheticScene(device, seed=1000 + rank, radar=wl.get("radar", "zod"))  # seed + rank, like scripts/train.py:104
     torch.manual_seed(1234 + rank)
@@ -664,7 +666,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
 
     # world > 1: the RCCL collectives are issued between kernels of the step, so the step is launched
     # eagerly (the fused step is 29 launches: the CPU stays ahead of the GPU)
-    use_graph = not args.no_graph and world == 1
+    use_graph = not args.no_graph and world == 1 and not one_rank
     graphs = []
     segmented = 0  # world > 1: graph segments per step (0 = eager launches)
     if use_graph:
@@ -734,7 +736,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                 g_opt.replay()
             elif not fuse_opt:
                 optim()
-    elif world > 1 and not args.no_graph and not args.autograd and fuse_opt and stepper is not None and os.environ.get("NR_SEGMENTS", "1") != "0":
+    elif (world > 1 or one_rank) and not args.no_graph and not args.autograd and fuse_opt and stepper is not None and os.environ.get("NR_SEGMENTS", "1") != "0":
         # world > 1: the step as hipGraph SEGMENTS cut at the collectives (fused_step.SegmentedStep) -- the decoder workloads'
         # 186 dependent launches per step are host-bound when launched eagerly.  One captured step per buffer set of the
         # pipelined batches; every rank captures after the same eager steps (the exchanges' lazy state and first host read).
@@ -1029,6 +1031,9 @@ def main():
                     "--single-device lets the multi-rank code path be exercised on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (functional testing only)")
     ap.add_argument("--check-replicas", action="store_true", help="after the run, verify that all ranks hold identical parameters")
+    ap.add_argument("--one-rank-collectives", action="store_true", help="--gpus 1 only: run the DATA-PARALLEL step (reducer, sharded table "
+                    "exchange, graph segments) in a one-rank RCCL group -- every collective is issued for real and returns at once, so "
+                    "host_ms_per_step is what launching the world > 1 step costs the host (two gloo ranks on one device block in every collective)")
     args = ap.parse_args()
 
     from neuradar_amd import _lib
@@ -1036,6 +1041,16 @@ def main():
 
     _lib.lib()  # fail loudly if the HIP extension is missing
     rank, world, local_rank = init_distributed(args.dist_backend)
+    if args.one_rank_collectives:
+        if world != 1:
+            raise SystemExit("--one-rank-collectives is for --gpus 1")
+        import socket
+
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group(backend=args.dist_backend or "nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     if args.single_device:
         local_rank = 0
     if world != args.gpus:

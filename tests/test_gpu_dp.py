@@ -175,3 +175,25 @@ def test_two_rank_step_replayed_as_graph_segments_equals_the_eager_step(tmp_path
     if path == "amp":
         for r in seg:
             assert r["amp"] == eager[0]["amp"], (r["amp"], eager[0]["amp"])
+
+
+def test_segment_replay_takes_the_host_out_of_the_data_parallel_decoder_step():
+    """What graph segments are for, measured where it can be measured on one GPU: bench.py --one-rank-collectives runs the
+    DATA-PARALLEL step of a decoder workload (reducer, sharded table exchange, all-reduces of every optimizer's buffers) in a
+    one-rank RCCL group -- every collective is issued for real and returns at once -- replayed as hipGraph segments.  The host
+    spends well under the step's duration launching it (measured: 1.0 of 3.2 ms; launched eagerly, NR_SEGMENTS=0: 3.6 of 3.7 ms,
+    host-bound -- profiles/r05_host_ms_per_step.txt)."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--one-rank-collectives", "--workload", "mixed8192_vod_nll", "--steps", "20",
+           "--warmup", "20", "--secondary", "", "--full-model", "", "--trained-steps", "0", "--min-seconds", "0.3", "--no-cpu-baseline",
+           "--no-roofline", "--no-render"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = line["config"]
+    print(f"one-rank RCCL group: {cfg['graph_segments_per_step']} segments, host {cfg['host_ms_per_step']} ms / step, step {line['ms_per_step']} ms")
+    assert cfg["graph_segments_per_step"] == 3
+    assert cfg["host_ms_per_step"] < 0.6 * line["ms_per_step"], (cfg["host_ms_per_step"], line["ms_per_step"])
+
