@@ -35,8 +35,17 @@ namespace {
 
 constexpr int kRows = 256;          // threads per block = rows per tile
 constexpr int kWaves = kRows / NR_WAVE;
-constexpr int kSlots = 3840;        // 15 x 256: load factor <= 0.54 when no two of the tile's 2 048 corners coincide
-constexpr int kMaxOcc = kRows * 8;  // distinct vertices of a tile on one level
+#ifndef NR_SHARED_SLOTS
+#define NR_SHARED_SLOTS 3840
+#endif
+#ifndef NR_SHARED_PROBES
+#define NR_SHARED_PROBES NR_SHARED_SLOTS
+#endif
+constexpr int kSlots = NR_SHARED_SLOTS;  // 3 840 = 15 x 256: load factor <= 0.54 when no two of the tile's 2 048 corners coincide.  (A/B
+                                         // builds: a smaller table -- more blocks per CU in the same LDS -- with NR_SHARED_PROBES bounding the
+                                         // linear probing; a vertex that finds no slot goes to the table directly)
+constexpr int kMaxProbes = NR_SHARED_PROBES;
+constexpr int kMaxOcc = kRows * 8 < kSlots ? kRows * 8 : kSlots;  // distinct vertices of a tile on one level (at most one per slot)
 constexpr int kFixBits = 21;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kMaxLevels = 8;
@@ -251,7 +260,7 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
             const uint32_t o2 = atomicCAS(&keys[sc], kEmpty, idx[c]);
             if (o2 == kEmpty) { claimed |= 1u << c; break; }
             if (o2 == idx[c]) break;
-            if (++probes >= kSlots) { sc = kEmpty; break; }  // (cannot happen: at most 2 048 keys for 3 840 slots)
+            if (++probes >= kMaxProbes) { sc = kEmpty; break; }  // (default build: cannot happen, at most 2 048 keys for 3 840 slots)
           }
           s[c] = sc;
         }
