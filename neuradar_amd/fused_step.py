@@ -76,7 +76,12 @@ class SegmentedStep:
         self._graph = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        self._graph.capture_begin(pool=self._pool)
+        # thread_local: with a process group alive, torch's NCCL / RCCL watchdog thread polls events of earlier collectives while
+        # this thread captures; under the default "global" capture mode such a call from ANOTHER thread invalidates the capture
+        # and the watchdog takes the process down ("operation not permitted when stream is capturing" -- seen once in four runs
+        # of bench.py --one-rank-collectives).  Launches of the decoders' autograd threads onto the capturing streams are
+        # captured in either mode.
+        self._graph.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def cut(self, fn, final: bool) -> None:
         self._graph.capture_end()
