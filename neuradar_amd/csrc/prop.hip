@@ -295,7 +295,11 @@ adam_marked_kernel(float* __restrict__ param, float* __restrict__ grad, float* _
   };
   typedef float f4 __attribute__((ext_vector_type(4)));
   auto ld = [](const float4* q) { f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(q)); return make_float4(t.x, t.y, t.z, t.w); };
+#ifdef NR_ADAM_TEMPORAL_STORES  // (A/B build: plain stores, which the L2 may merge into whole lines before they leave)
+  auto stv = [](float4* q, float4 x) { *q = x; };
+#else
   auto stv = [](float4* q, float4 x) { f4 t = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(t, reinterpret_cast<f4*>(q)); };
+#endif
 #ifndef NR_ADAMM_U
 #define NR_ADAMM_U 1
 #endif
