@@ -88,7 +88,7 @@ def main():
         amp = GradScalerState(dev, init_scale=1024.0).attach(opts)
         step.set_grad_scaler(amp)
     fars = torch.full((hi - lo,), 1e6, device=dev)
-    info = []
+    info, losses = [], []
     use_reducer = reducer if (world > 1 or args.force_collectives) else None
     static = [sl(o), sl(d), sl(area), fars, sl(tf), sl(td), sl(draws[0][0]), sl(draws[0][1]), sl(draws[0][2])]  # --segments: the graphs' inputs
     seg = None
@@ -115,12 +115,13 @@ def main():
             reducer.flush()  # (a deferred all-gather of the last step; earlier ones are waited for by the next step's gather)
         torch.cuda.synchronize()
         info.append(dict(reducer.last_sparse))
+        losses.append(float(step.loss.sum()))
     out = {"rank": rank, "world": world, "exchange": [{k_: v_ for k_, v_ in e.items() if k_ != "flag"} for e in info],
            "amp": None if amp is None else {"scale": amp.get_scale(), "skipped": amp.skipped_steps()},
            "params": {n: p.detach().cpu() for n, p in model.named_parameters()},
            "exp_avg": [m.reshape(-1).cpu() for o_ in opts for m, _ in o_.state], "shard": shard,
            "main_buffer": opts[0].buffer_of(model.field.hashgrid.static_grid.hash_table),
-           "segments": None if seg is None else len(seg.parts)}
+           "segments": None if seg is None else len(seg.parts), "losses": losses}
     torch.save(out, f"{args.out}.rank{rank}")
     if world > 1 or args.force_collectives:
         torch.distributed.barrier()

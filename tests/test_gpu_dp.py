@@ -198,3 +198,33 @@ def test_segment_replay_takes_the_host_out_of_the_data_parallel_decoder_step():
     assert cfg["graph_segments_per_step"] == 3
     assert cfg["host_ms_per_step"] < 0.6 * line["ms_per_step"], (cfg["host_ms_per_step"], line["ms_per_step"])
 
+
+def test_two_rank_bf16_table_exchange_trains_like_the_fp32_exchange(tmp_path):
+    """The opt-in bf16 variant of the sharded table exchange (bf16 reduce-scatter, bf16 update-delta all-gather, deferred) against
+    the default fp32 one over 150 optimizer steps on two ranks (a reduced-precision exchange needs more than a
+    3-step tolerance check before anyone turns it on): the loss follows the same trajectory -- every step within 15 %, the mean of the last 20 within 3 % -- and the
+    tables end up as far from the fp32 run's as a SECOND fp32 run does (measured: 0.120 vs 0.119 in relative L2 after 150 steps --
+    the scatters' float atomics make this sensitive trajectory diverge between identical runs; the bf16 exchange adds nothing
+    visible on top; what it rounds is 2^-9 of every update and of every partial gradient sum)."""
+    base = ["--log2t", "16", "--rays", "512", "--shard", "--steps", "150"]
+    f32 = _run(str(tmp_path), "f32", 2, base)
+    f32b = _run(str(tmp_path), "f32b", 2, base)  # the yardstick: a second fp32 run (the scatters' float atomics make runs differ)
+    b16 = _run(str(tmp_path), "b16", 2, base + ["--bf16"])
+    lf, lb = torch.tensor(f32[0]["losses"]), torch.tensor(b16[0]["losses"])
+    print(f"loss fp32 exchange {float(lf[:5].mean()):.5f} -> {float(lf[-20:].mean()):.5f}; bf16 exchange {float(lb[:5].mean()):.5f} -> {float(lb[-20:].mean()):.5f}")
+    # (the worker's per-ray random targets cannot be fitted -- its loss moves by an order of magnitude over the run, which makes it
+    # a sensitive trajectory: what is asserted is that the two exchanges FOLLOW THE SAME ONE, step for step)
+    assert float((lf - lf[0]).abs().max()) > 0.5 * float(lf[0]), "the parameters did not move"
+    dev_ = ((lb - lf).abs() / lf.abs().clamp_min(1e-6))
+    print(f"largest per-step relative deviation of the loss {float(dev_.max()):.3e}, over the last 20 steps {float(dev_[-20:].mean()):.3e}")
+    # (measured: 5.0e-2 at the worst step, 1.8e-2 over the last 20; two fp32 runs differ by 0.5 % in the last-20 mean -- float atomics)
+    assert float(dev_.max()) <= 0.15 and abs(float(lb[-20:].mean()) - float(lf[-20:].mean())) <= 0.03 * float(lf[-20:].mean())
+    t32 = f32[0]["params"]["field.hashgrid.static_grid.hash_table"].double()
+    t16 = b16[0]["params"]["field.hashgrid.static_grid.hash_table"].double()
+    t32b = f32b[0]["params"]["field.hashgrid.static_grid.hash_table"].double()
+    rel, noise = float((t16 - t32).norm() / t32.norm()), float((t32b - t32).norm() / t32.norm())
+    print(f"main table after 150 steps: relative L2 distance bf16 vs fp32 exchange {rel:.3e}; two fp32 runs {noise:.3e}")
+    assert rel <= 3.0 * noise + 2e-2, (rel, noise)
+    for n, p in b16[0]["params"].items():
+        assert torch.equal(p, b16[1]["params"][n]), f"bf16 exchange: parameter {n} differs between the ranks"
+
