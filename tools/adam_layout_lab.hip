@@ -55,6 +55,43 @@ __global__ void __launch_bounds__(256) adam_records(f4* p, f4* rec, const uint8_
   }
 }
 
+// (c) today's arrays, but a lane owns a whole 64-byte LINE (4 groups, their 4 seen bytes as one word): 4 x 16 B per array and lane
+__global__ void __launch_bounds__(256) adam_arrays_line(f4* p, f4* g, f4* m, f4* v, const uint32_t* seen4, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t mk = i < n16 ? seen4[i] : 0u;
+  for (; i < n16; i += stride) {
+    const uint32_t cur = mk;
+    mk = i + stride < n16 ? seen4[i + stride] : 0u;
+    if (!cur) continue;
+    f4 gg[4], mm[4], vv[4], pp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((cur >> (8 * k)) & 0xFFu) { gg[k] = ldnt(g + 4 * i + k); mm[k] = ldnt(m + 4 * i + k); vv[k] = ldnt(v + 4 * i + k); pp[k] = ldnt(p + 4 * i + k); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((cur >> (8 * k)) & 0xFFu) {
+        const bool had = gg[k][0] != 0.0f || gg[k][1] != 0.0f || gg[k][2] != 0.0f || gg[k][3] != 0.0f;
+        upd(pp[k], gg[k], mm[k], vv[k]);
+        stnt(p + 4 * i + k, pp[k]); stnt(m + 4 * i + k, mm[k]); stnt(v + 4 * i + k, vv[k]);
+        if (had) stnt(g + 4 * i + k, gg[k]);
+      }
+  }
+}
+// (d) as (a) with TWO groups per lane and trip, a whole wave-width apart (more loads in flight per lane)
+__global__ void __launch_bounds__(256) adam_arrays_x2(f4* p, f4* g, f4* m, f4* v, const uint8_t* seen, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const int64_t j = i + stride;
+    const uint8_t a = seen[i], b = j < n4 ? seen[j] : 0;
+    f4 g0, m0, v0, p0, g1, m1, v1, p1;
+    if (a) { g0 = ldnt(g + i); m0 = ldnt(m + i); v0 = ldnt(v + i); p0 = ldnt(p + i); }
+    if (b) { g1 = ldnt(g + j); m1 = ldnt(m + j); v1 = ldnt(v + j); p1 = ldnt(p + j); }
+    if (a) { upd(p0, g0, m0, v0); stnt(p + i, p0); stnt(m + i, m0); stnt(v + i, v0); stnt(g + i, g0); }
+    if (b) { upd(p1, g1, m1, v1); stnt(p + j, p1); stnt(m + j, m1); stnt(v + j, v1); stnt(g + j, g1); }
+  }
+}
+
 int main(int argc, char** argv) {
   const int64_t n4 = 33554432;  // NeuRadar's main table: 8 levels x 2^22 entries
   const size_t bytes = (size_t)n4 * 16;
@@ -76,19 +113,21 @@ int main(int argc, char** argv) {
         for (int64_t i = 0; i < n4; i += 4) { const uint8_t b = rnd() < dens; for (int k = 0; k < 4; ++k) h[i + k] = b; live += 4 * b; }
       }
       hipMemcpy(seen, h.data(), n4, hipMemcpyHostToDevice);
-      for (int variant = 0; variant < 2; ++variant) {
+      for (int variant = 0; variant < 4; ++variant) {
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
           hipEventRecord(e0);
           if (variant == 0) hipLaunchKernelGGL(adam_arrays, dim3(4096), dim3(256), 0, 0, p, g, m, v, seen, n4);
-          else hipLaunchKernelGGL(adam_records, dim3(4096), dim3(256), 0, 0, p, rec, seen, n4);
+          else if (variant == 1) hipLaunchKernelGGL(adam_records, dim3(4096), dim3(256), 0, 0, p, rec, seen, n4);
+          else if (variant == 2) hipLaunchKernelGGL(adam_arrays_line, dim3(4096), dim3(256), 0, 0, p, g, m, v, reinterpret_cast<const uint32_t*>(seen), n4 / 4);
+          else hipLaunchKernelGGL(adam_arrays_x2, dim3(4096), dim3(256), 0, 0, p, g, m, v, seen, n4);
           hipEventRecord(e1); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1);
           if (rep > 0 && ms < best) best = ms;
         }
-        const double moved = (double)live * (variant == 0 ? 112.0 : 128.0) + (double)n4;  // bytes the kernel asks for
+        const double moved = (double)live * (variant == 1 ? 128.0 : 112.0) + (double)n4;  // bytes the kernel asks for
         printf("%s live %.2f (%s): %-26s %7.1f us  %6.2f TB/s of requested bytes\n", pattern == 0 ? "random groups" : "whole lines  ", dens,
-               pattern == 0 ? "16-B granules" : "64-B granules", variant == 0 ? "four arrays (today)" : "p + [g|m|v|pad] records", best * 1e3, moved / (best * 1e-3) / 1e12);
+               pattern == 0 ? "16-B granules" : "64-B granules", variant == 0 ? "four arrays (today)" : variant == 1 ? "p + [g|m|v|pad] records" : variant == 2 ? "four arrays, lane = line" : "four arrays, 2 groups/trip", best * 1e3, moved / (best * 1e-3) / 1e12);
       }
     }
   return 0;
