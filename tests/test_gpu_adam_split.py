@@ -140,6 +140,8 @@ def test_training_steps_with_the_split_adam_equal_the_single_launch(monkeypatch)
         noise, got = off(b2[key], b[key]), off(a[key], b[key])
         print(f"{key}: entries off -- split vs single {got:.3e}, single vs single {noise:.3e}")
         assert got <= 3.0 * noise + floor[key], f"{key}: {got:.3e} of the entries differ (two single-launch runs: {noise:.3e})"
-    for n_, p in a["others"].items():
-        torch.testing.assert_close(p, b["others"][n_], rtol=2e-3, atol=1e-5, msg=lambda m, n_=n_: f"{n_}: {m}")
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp_min(1e-30))  # noqa: E731
+    for n_, p in a["others"].items():  # (the same yardstick: MLP weights of two single-launch runs differ too -- 16-bit operands, float atomics, Adam)
+        noise, got = rel(b2["others"][n_], b["others"][n_]), rel(p, b["others"][n_])
+        assert got <= 3.0 * noise + 1e-3, f"{n_}: relative L2 distance {got:.3e} (two single-launch runs: {noise:.3e})"
     assert float((a["m"] != 0).float().mean()) > 0.01
