@@ -404,7 +404,7 @@ def test_cnn_16_bit_working_copies_equal_autocast(dtype):
         2.8 u in fp16, 0.9 / 2.1 / 2.2 / 3.1 / 3.7 / 4.4 / 2.7 u in bf16 -- each chain sits 0.7 ... 4.3 u from the fp32 chain;
       * rgb, loss, batch-norm statistics at 8u;
       * gradients (16-bit backward through eleven convolutions: two valid roundings of every layer, ~15 % apart in bf16):
-        per parameter no farther from the fp32 leg than autocast is, x 1.5 + 2e-3."""
+        per parameter no farther from the fp32 leg than autocast is, x 1.5 + max(2e-3, 8u)."""
     dt = getattr(torch, dtype)
     u = EPS[dtype]
     res = {mode: run_child(__file__, "_cnn_leg", dtype=dtype, mode=mode) for mode in ("copies", "autocast", "fp32")}
@@ -430,7 +430,9 @@ def test_cnn_16_bit_working_copies_equal_autocast(dtype):
     for k, (x, y, z) in rows.items():  # (a convolution bias in front of a batch norm has no gradient: rounding noise only)
         e_copies, e_autocast = rel(x, z), rel(y, z)
         print(f"{dt} {k:50s} copies vs fp32 {e_copies:.3e}   autocast vs fp32 {e_autocast:.3e}   copies vs autocast {rel(x, y):.3e}")
-        assert e_copies <= 1.5 * e_autocast + 2e-3, (k, e_copies, e_autocast)
+        # (+ 8u: autocast's own distance from fp32 moves with the algorithms MIOpen picks for that leg -- 0.073 ... 0.112 for the
+        # 32-number `4.bias` over this round's runs -- and a ratio of two such numbers needs an absolute part of the operand type's size)
+        assert e_copies <= 1.5 * e_autocast + max(2e-3, 8 * u), (k, e_copies, e_autocast)
 
 
 @pytest.mark.parametrize("workload", ["mixed16384_neuradar_full", "mixed16384_neuradar_full_fp16", "mixed8192_vod_nll"])
