@@ -8,8 +8,9 @@ tables, MLP weight grads) -> dense Adam on every parameter.  Weak scaling: every
 full batch (the reference's semantics), gradients are mean-all-reduced over RCCL.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N --steps K --warmup W          (starts its own N rank processes, one per GPU: launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      (the driver's form: the ranks come from the environment)
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant hash-grid
 kernel, HIP-event timed on its launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample).
@@ -780,13 +781,17 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         for _ in range(args.steps):
             step()
         host = time.perf_counter() - t0  # launch loop only: how far the CPU runs ahead of the GPU
+        own = None
+        if world > 1:
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0  # this rank's own K steps, before it waits for the others
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([el], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             el = float(tt.item())
-        return el, host
+        return el, host, own
 
     # the K-step block is repeated until >= min_seconds have been timed (every block is exactly K steps): a 20-step block
     # is 10-50 ms, too short for one sample to be trusted -- the line reports the MEDIAN block and the spread
@@ -805,6 +810,13 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     elapsed = statistics.median(per_block)
     host_elapsed = statistics.median(b[1] for b in blocks)
     reducer.flush()  # (a deferred all-gather of the last step)
+    per_rank_ms = None
+    if world > 1:
+        # every rank's own median block (its K steps up to its own device synchronisation, before the closing barrier)
+        mine = torch.tensor([statistics.median(b[2] for b in blocks) / args.steps * 1e3], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank_ms = [round(float(t_), 4) for t_ in allr]
     if args.gate_ms > 0 and world == 1:
         # for a kernel trace: under rocprofv3 the host needs longer to submit a replay than the GPU to run it, and the trace
         # shows the submission order instead of the step.  Hold the stream with a spinning kernel, submit a few replays behind it,
@@ -836,7 +848,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         reducer.world = 1  # make_step's closure passes `reducer` only while reducer.world > 1
         for _ in range(4):
             step()
-        t_off, _ = timed_block()
+        t_off = timed_block()[0]
         reducer.world = keep
         ms_off = t_off / args.steps * 1e3
         exchange = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
@@ -845,7 +857,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                     "exposed_ms_per_step": round(ms_per_step - ms_off, 4),
                     # per GPU and step, from the collectives' sizes: each half of the main table's exchange, the proposal
                     # table's dense all-reduce (2 (w-1)/w of its bytes), the small-parameter bucket
-                    "main_table": {k_: v_ for k_, v_ in (reducer.last_sparse or {}).items() if k_ != "rows"},
+                    "main_table": {k_: v_ for k_, v_ in (reducer.last_sparse or {}).items() if k_ != "rows" and not torch.is_tensor(v_)},
                     "proposal_table_allreduce_bytes_per_gpu": int(2 * (world - 1) / world * model.proposal_fields[1].hashgrid.static_grid.hash_table.numel()
                                                                   * (2 if reducer.table_dtype is not None else 4))}
 
@@ -969,14 +981,116 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
               "ms_p10": per_block[int(0.1 * (n_blocks - 1) + 0.5)] / args.steps * 1e3, "ms_p90": per_block[int(0.9 * (n_blocks - 1) + 0.5)] / args.steps * 1e3,
               "allreduce_bytes": (reducer.bytes_per_step() - (model.field.hashgrid.static_grid.hash_table.numel() * 4
                                                              if reducer.last_sparse.get("mode") == "sparse" else 0)) if world > 1 else 0,
-              "exchange": (reducer.last_sparse or "dense") if world > 1 else None,
+              "exchange": ({k_: v_ for k_, v_ in reducer.last_sparse.items() if not torch.is_tensor(v_)} if reducer.last_sparse else "dense") if world > 1 else None,
               "exchange_dtypes": ({"gradient_transport": "bfloat16" if reducer.table_dtype == torch.bfloat16 else "float32",
                                    "update_all_gather": "bfloat16 deltas" if (reducer.table_mode == "shard" and reducer.table_delta is not None) else "float32 parameters"}
                                   if world > 1 else None), "decoders_us": decoders_us, "mlp_dtype": mlp_dtype,
-              "exchange_cost": exchange, "loss": float(stepper.loss.sum()) if stepper is not None else None}
+              "exchange_cost": exchange, "per_rank_ms": per_rank_ms, "loss": float(stepper.loss.sum()) if stepper is not None else None}
     del graphs, stepper, fwd_bwd, optim, model, opts, reducer, scene
     torch.cuda.empty_cache()
     return result
+
+
+def launch_ranks(n, argv, limit_s=0.0):
+    """`python bench.py --gpus N` without a launcher: start N CHILD processes of this file, one per GPU, with the environment
+    torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / MASTER_PORT = a free port),
+    wait for them and return the worst exit code.  Children, never an exec, and this process makes no HIP / torch.cuda call: it
+    only launches and waits.  Rank 0 inherits this process's stdout (its one JSON line IS this command's one JSON line); every
+    rank inherits stderr.  When a rank dies the others are stopped (the exact PIDs started here): a collective that waits for a
+    dead peer would otherwise hang the run until the driver's limit."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cpus = os.cpu_count() or n
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   NR_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, cpus // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stdin=subprocess.DEVNULL))
+
+    def stop_all(sig):
+        for p_ in procs:
+            if p_.poll() is None:
+                try:
+                    p_.send_signal(sig)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):  # the driver's timeout / Ctrl-C reaches the ranks too
+        stop_all(signal.SIGTERM)
+        raise SystemExit(128 + signum)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+    t0, worst, failed = time.monotonic(), 0, None
+    try:
+        while any(p_.poll() is None for p_ in procs):
+            for r, p_ in enumerate(procs):
+                rc = p_.poll()
+                if rc is not None and rc != 0 and failed is None:
+                    failed = (r, rc)
+            if failed is None and limit_s > 0 and time.monotonic() - t0 > limit_s:
+                failed = (-1, 124)
+                print(f"[bench] launcher: {limit_s:.0f} s limit reached, stopping the ranks", file=sys.stderr, flush=True)
+            if failed is not None:
+                if failed[0] >= 0:
+                    print(f"[bench] launcher: rank {failed[0]} exited with code {failed[1]}; stopping the other ranks", file=sys.stderr, flush=True)
+                stop_all(signal.SIGTERM)
+                t1 = time.monotonic()
+                while any(p_.poll() is None for p_ in procs) and time.monotonic() - t1 < 15.0:
+                    time.sleep(0.1)
+                stop_all(signal.SIGKILL)
+                for p_ in procs:
+                    p_.wait()
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all(signal.SIGKILL)
+    for p_ in procs:
+        rc = p_.wait()
+        rc = 128 - rc if rc < 0 else rc  # (killed by signal s: 128 + s, like a shell reports it)
+        worst = max(worst, rc)
+    if failed is not None:
+        worst = max(worst, failed[1] if failed[1] > 0 else 1)
+    return worst
+
+
+def launch_check(args):
+    """--launch-check: what the launcher must get right, without the workload -- every rank joins the group over the backend
+    asked for, one all-reduce crosses it, rank 0 prints the world it saw."""
+    import torch.distributed as dist
+
+    from neuradar_amd.parallel import init_distributed
+
+    rank, world, local_rank = init_distributed(args.dist_backend)
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    seen = world
+    if world > 1:
+        dev = torch.device("cuda", 0 if args.single_device else local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([float(rank + 1)], device=dev)
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2, float(t)
+        seen = dist.get_world_size()
+    if os.environ.get("NR_BENCH_FAIL_RANK") == str(rank):  # (tests: one rank dies, the launcher must stop the others)
+        return 7
+    if os.environ.get("NR_BENCH_HANG_RANK") == str(rank):
+        time.sleep(3600)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": seen, "backend": dist.get_backend() if world > 1 else None,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -1034,7 +1148,22 @@ def main():
     ap.add_argument("--one-rank-collectives", action="store_true", help="--gpus 1 only: run the DATA-PARALLEL step (reducer, sharded table "
                     "exchange, graph segments) in a one-rank RCCL group -- every collective is issued for real and returns at once, so "
                     "host_ms_per_step is what launching the world > 1 step costs the host (two gloo ranks on one device block in every collective)")
+    ap.add_argument("--exchange-variants", default="auto", help="world > 1: after the headline (default fp32 exchange) time the same "
+                    "workload again with these main-table exchanges, comma-separated out of bf16 (bf16 transport + bf16 update deltas); "
+                    "'auto' = bf16 when the default exchange is the fp32 sharded step, '' = none.  The exchange switched OFF is always "
+                    "timed (gradient_exchange.ms_per_step_without_exchange)")
+    ap.add_argument("--launch-check", action="store_true", help="every rank joins the process group, all-reduces one number over it and "
+                    "rank 0 prints {n_gpus, ranks}: the launcher by itself (no GPU needed with --dist-backend gloo)")
+    ap.add_argument("--rank-timeout", type=float, default=0.0, help="self-launched ranks (--gpus N without WORLD_SIZE): kill the job "
+                    "after this many seconds (0 = no limit)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher of N rank processes and touches no GPU itself
+        # (the reference starts one process per GPU by itself too: scripts/train.py:167-230, mp.spawn at :211)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
+    if args.launch_check:
+        raise SystemExit(launch_check(args))
 
     from neuradar_amd import _lib
     from neuradar_amd.parallel import init_distributed
@@ -1059,6 +1188,36 @@ def main():
     torch.cuda.set_device(device)
     main_res = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, not args.no_cpu_baseline,
                        args.min_seconds, trained_steps=args.trained_steps if args.regime == "trained" else 0)
+    if rank == 0 and world > 1:
+        # (stderr: stdout carries ONE line at the end; should a later block of a first-ever N-GPU run fail, the headline is on record)
+        print("[bench] headline (world %d): %.1f rays/s, %.4f ms/step, exchange %s" % (world, main_res["value"], main_res["ms_per_step"],
+              json.dumps({k_: v_ for k_, v_ in (main_res["exchange"] or {}).items() if k_ not in ("rows", "flag")} if isinstance(main_res["exchange"], dict) else main_res["exchange"])),
+              file=sys.stderr, flush=True)
+    exchange_variants = None
+    if world > 1 and not args.autograd:
+        # one multi-GPU run answers every question about the exchange: the headline above used the default (fp32 on both halves);
+        # the same workload once more per variant, same timing rules (shorter: >= 0.5 s of timed blocks)
+        want = args.exchange_variants
+        if want == "auto":
+            want = "bf16" if (isinstance(main_res["exchange"], dict) and main_res["exchange"].get("mode") in ("shard", "shard_lists")
+                              and args.table_transport == "fp32" and args.table_delta == "fp32") else ""
+        exchange_variants = {}
+        for v_ in [w_ for w_ in want.split(",") if w_]:
+            if v_ != "bf16":
+                raise SystemExit(f"--exchange-variants: unknown variant {v_!r}")
+            a2 = argparse.Namespace(**vars(args))
+            a2.table_transport, a2.table_delta = "bf16", "bf16"
+            vr = measure(a2, args.workload, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
+            exchange_variants["bf16_transport_bf16_delta"] = {
+                "value": round(vr["value"], 1), "unit": "rays/s", "ms_per_step": round(vr["ms_per_step"], 4), "timed_blocks": vr["blocks"],
+                "ms_per_step_per_rank": vr["per_rank_ms"], "main_table_exchange_dtypes": vr["exchange_dtypes"],
+                "main_table": {k_: v2 for k_, v2 in (vr["exchange"] or {}).items() if k_ not in ("rows", "flag")} if isinstance(vr["exchange"], dict) else vr["exchange"],
+                "exposed_ms_per_step": (vr["exchange_cost"] or {}).get("exposed_ms_per_step")}
+        ec = main_res["exchange_cost"] or {}
+        exchange_variants["exchange_off"] = {"ms_per_step": ec.get("ms_per_step_without_exchange"),
+                                             "value": (round(world * main_res["n_rays"] / (ec["ms_per_step_without_exchange"] * 1e-3), 1)
+                                                       if ec.get("ms_per_step_without_exchange") else None), "unit": "rays/s",
+                                             "what": "the same K steps with every collective skipped (each rank steps on its own gradient; after the timed region)"}
     secondary = None
     if args.secondary and args.secondary != args.workload and not args.autograd:
         # BASELINE.json configs[1] (the configuration the north star's >= 2 M rays/s target is phrased on) beside the
@@ -1135,7 +1294,10 @@ def main():
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}", "regime": args.regime,
                        "grad_allreduce_bytes": r["allreduce_bytes"], "main_table_exchange": r["exchange"], "main_table_exchange_dtypes": r["exchange_dtypes"],
-                       "gradient_exchange": r["exchange_cost"]},
+                       "gradient_exchange": r["exchange_cost"], "exchange_variants": exchange_variants,
+                       "ms_per_step_per_rank": r["per_rank_ms"],
+                       "ms_per_step_rank_min_max": [min(r["per_rank_ms"]), max(r["per_rank_ms"])] if r["per_rank_ms"] else None,
+                       "launcher": "self (python bench.py --gpus N)" if os.environ.get("NR_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if world > 1 else None)},
             "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,
         }
         print(json.dumps(line), flush=True)

@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 26
+#define NR_ABI_VERSION 27
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -56,10 +56,8 @@ enum {
   NR_TUNE_FIELD_BWD_BLOCKS = 4,  /* blocks (= gradient slabs) of nr_field_bwd* (default 256 fp32 / 512 16-bit) */
   NR_TUNE_PDBWD_BLOCKS = 5,      /* blocks of nr_prop_density_bwd (default 256) */
   NR_TUNE_ADAM_BLOCKS = 6,       /* blocks of nr_adam_step* (default 4096) */
-  NR_TUNE_PW_MFMA_OFF = 7,       /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
-  NR_TUNE_PROP_SHARED_OFF = 8,   /* 1: proposal-table scatters on the binned kernels instead of the block-shared table */
-  NR_TUNE_PROP_SHARED_BLOCKS = 9 /* blocks of the block-shared proposal scatter */
-};
+  NR_TUNE_PW_MFMA_OFF = 7        /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+};                               /* (v27: knobs 8 / 9 of v26 -- NR_TUNE_PROP_SHARED_* -- are gone: nothing read them) */
 int nr_init(void);
 int nr_set_tuning(int knob, int value);
 
@@ -971,6 +969,28 @@ int nr_grad_apply(const int* idx, const float* val, const int* count, int64_t ca
  * the same counts and takes the same branch. */
 int nr_grad_apply_guarded(const int* idx, const float* val, const int* counts, int world, int list_rank, int own_rank, int64_t m,
                           int row_width, float* grad, float* flag, nr_stream_t stream);
+
+/* Row lists to the SHARD OWNERS: the gradient half of the sharded data-parallel table step (ABI v27).  The table's rows are
+ * owned in `world` contiguous shards of rows_per_shard rows; instead of a dense reduce-scatter every rank sends each owner the
+ * rows of that owner's shard it has a gradient for (9-22 % of the rows per rank on the mixed batch), the owner adds the lists
+ * in rank order with plain adds (fp32, exact, the same sums whatever the arrival order) -- the reduction half of the
+ * reference's DDP all-reduce (pipelines/base_pipeline.py:305-307) for a gradient that is sparse.
+ * nr_grad_compact_shards: grad [world * rows_per_shard, F]; for every destination d the non-zero rows of shard d move to segment
+ *   d of (idx, val) -- segment d starts at row sum(caps[0..d)) of the lists and holds caps[d] rows; idx = row - d * rows_per_shard
+ *   -- and are zeroed in grad; counts[d] += ALL non-zero rows of the shard (the caller zeroes counts; rows beyond caps[d] stay
+ *   in grad).  caps, counts: device int32 [world].
+ * nr_grad_lists_apply: on the owner `own_rank`: the list received from `src_rank` (capacity list_cap = caps[own_rank]) is added
+ *   onto `shard` (the rank's own rows of the gradient), guarded by the all-gathered counts [world, world] (source-major): if ANY
+ *   list of the exchange overflowed its destination's capacity nothing is applied and flag[0] = 2.0f (nr_adam_step's "skip and
+ *   keep the gradient"); otherwise flag[0] = 0.  Launch once per source, in rank order.
+ * nr_grad_lists_restore: overflow only (a no-op otherwise): every segment of the rank's own send lists is added back onto its
+ *   local gradient, which is then whole again and carries over into the next step.  max_cap = max(caps). */
+int nr_grad_compact_shards(float* grad, int64_t rows_per_shard, int row_width, int world, const int* caps, int* idx, float* val,
+                           int* counts, nr_stream_t stream);
+int nr_grad_lists_apply(const int* idx, const float* val, int64_t list_cap, const int* counts, const int* caps, int world,
+                        int src_rank, int own_rank, int row_width, float* shard, float* flag, nr_stream_t stream);
+int nr_grad_lists_restore(const int* idx, const float* val, int64_t max_cap, const int* counts, const int* caps, int world,
+                          int own_rank, int64_t rows_per_shard, int row_width, float* grad, nr_stream_t stream);
 
 /* On-device batch assembly for camera patches (the reference samples patches
  * in data/pixel_samplers.py and generates rays on CPU workers): u [n_patches,3] uniform [0,1) ->

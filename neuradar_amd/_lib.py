@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 26
+NR_ABI_VERSION = 27
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -187,6 +187,9 @@ PROTOTYPES = {
     "nr_grad_compact": [P, L, I, L, P, P, P, P],
     "nr_grad_apply": [P, P, P, L, I, P, P],
     "nr_grad_apply_guarded": [P, P, P, I, I, I, L, I, P, P, P],
+    "nr_grad_compact_shards": [P, L, I, I, P, P, P, P, P],
+    "nr_grad_lists_apply": [P, P, L, P, P, I, I, I, I, P, P, P],
+    "nr_grad_lists_restore": [P, P, L, P, P, I, I, L, I, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
@@ -228,6 +231,9 @@ def lib() -> ctypes.CDLL:
             fn.restype = _RESTYPES.get(name, c_int)
         if handle.nr_abi_version() != NR_ABI_VERSION:
             raise RuntimeError("libneuradar_hip.so ABI version mismatch")
+        for env, hint in RETIRED_ENV.items():
+            if os.environ.get(env):
+                raise RuntimeError(f"{env} is set but this build no longer reads it ({hint})")
         for knob, (env, _) in enumerate(TUNING):  # launch-shape knobs for A/B runs: read ONCE, here (the library never reads the environment)
             value = os.environ.get(env)
             if value:
@@ -241,8 +247,10 @@ def lib() -> ctypes.CDLL:
 TUNING = (("NR_CONV7_BLOCKS", "persistent blocks of nr_conv7_fwd"), ("NR_BIN_BLOCKS_PER_CU", "bin blocks per half CU"),
           ("NR_SHARED_BLOCKS", "blocks of nr_hash_encode_bwd_shared"), ("NR_FIELD_FWD_BLOCKS", "blocks of nr_field_fwd*"),
           ("NR_FIELD_BWD_BLOCKS", "blocks of nr_field_bwd*"), ("NR_PDBWD_BLOCKS", "blocks of nr_prop_density_bwd"),
-          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"),
-          ("NR_PROP_SHARED_OFF", "1: binned kernels for the proposal scatters"), ("NR_PROP_SHARED_BLOCKS", "blocks of the shared proposal scatter"))
+          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"))
+# variables earlier rounds read and this build ignores: setting one is an A/B run that compares identical code -- refuse it loudly
+RETIRED_ENV = {"NR_PW_MFMA": "use NR_PW_MFMA_OFF=1", "NR_PROP_SHARED_OFF": "no kernel ever read it (removed in ABI v27)",
+               "NR_PROP_SHARED_BLOCKS": "no kernel ever read it (removed in ABI v27)"}
 
 def set_tuning(env_name: str, value: int) -> None:
     """nr_set_tuning by the knob's environment-variable name (tests / probes switching a knob inside one process)."""

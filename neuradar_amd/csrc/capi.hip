@@ -31,8 +31,6 @@ extern "C" int nr_set_tuning(int knob, int value) {
     case NR_TUNE_PDBWD_BLOCKS: g_tuning.pdbwd_blocks = value; break;
     case NR_TUNE_ADAM_BLOCKS: g_tuning.adam_blocks = value; break;
     case NR_TUNE_PW_MFMA_OFF: g_tuning.pw_mfma_off = value; break;
-    case NR_TUNE_PROP_SHARED_OFF: g_tuning.prop_shared_off = value; break;
-    case NR_TUNE_PROP_SHARED_BLOCKS: g_tuning.prop_shared_blocks = value; break;
     default: return NR_EINVAL;
   }
   return 0;

@@ -29,8 +29,6 @@ struct NrTuning {
   int pdbwd_blocks;        // NR_TUNE_PDBWD_BLOCKS: blocks of nr_prop_density_bwd
   int adam_blocks;         // NR_TUNE_ADAM_BLOCKS
   int pw_mfma_off;         // NR_TUNE_PW_MFMA_OFF: 1 = the transposed convolution on the generic pointwise kernels
-  int prop_shared_off;     // NR_TUNE_PROP_SHARED_OFF: 1 = the proposal scatters on the binned kernels (A/B)
-  int prop_shared_blocks;  // NR_TUNE_PROP_SHARED_BLOCKS
 };
 const NrTuning& nr_tuning();
 // per-file attribute setup, called by nr_init()

@@ -602,6 +602,117 @@ grad_apply_guarded_kernel(const int* __restrict__ idx, const float* __restrict__
   }
 }
 
+// ---- row lists to the SHARD OWNERS (sharded data-parallel table step, parallel.GradAllReducer.shard_step) ---------------
+// The table's rows are owned in `world` contiguous shards of rows_per_shard rows.  compact_shards: one launch, blockIdx.y = the
+// destination shard d; the non-zero rows of that shard go, as (row - d * rows_per_shard, values), into segment d of the send
+// lists -- segment d starts at sum(caps[0..d)) and holds caps[d] rows -- and are cleared in the table; counts[d] = ALL non-zero
+// rows of shard d (rows beyond caps[d] stay in the table).  Same two-pass scheme as grad_compact_kernel.
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_compact_shards_kernel(float* __restrict__ grad_all, int64_t rows, const int* __restrict__ caps, int* __restrict__ idx_all,
+                           float* __restrict__ val_all, int* __restrict__ counts) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int d = blockIdx.y;
+  int64_t off = 0;
+  for (int k = 0; k < d; ++k) off += caps[k];
+  const int64_t cap = caps[d];
+  float* __restrict__ grad = grad_all + (int64_t)d * rows * F;
+  int* __restrict__ idx = idx_all + off;
+  float* __restrict__ val = val_all + off * F;
+  int* __restrict__ count = counts + d;
+  const int lane = nr_lane(), wave = threadIdx.x >> 6;
+  const int64_t per_wave = nr_cdiv_dev(nr_cdiv_dev(rows, (int64_t)gridDim.x * 4), NR_WAVE) * NR_WAVE;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * per_wave, r1 = r0 + per_wave < rows ? r0 + per_wave : rows;
+  auto nonzero = [&](int64_t r, float (&v)[F]) {
+    bool nz = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      v[f] = r < r1 ? grad[r * F + f] : 0.0f;
+      nz |= v[f] != 0.0f;
+    }
+    return nz;
+  };
+  int mine = 0;  // wave-uniform
+  for (int64_t base = r0; base < r1; base += NR_WAVE) {
+    float v[F];
+    mine += __popcll(__ballot(nonzero(base + lane, v)));
+  }
+  if (lane == 0) s_wave[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = total > 0 ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
+  int64_t pos = s_base;
+  for (int k = 0; k < wave; ++k) pos += s_wave[k];
+  if (mine == 0) return;
+  for (int64_t base = r0; base < r1; base += NR_WAVE) {
+    const int64_t r = base + lane;
+    float v[F];
+    const bool nz = nonzero(r, v);
+    const unsigned long long m = __ballot(nz);
+    const int64_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
+    if (nz && at < cap) {
+      idx[at] = (int)r;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        val[at * F + f] = v[f];
+        grad[r * F + f] = 0.0f;
+      }
+    }
+    pos += __popcll(m);
+  }
+}
+
+// did ANY (source, destination) list overflow?  counts [world, world] (source-major, as all-gathered), caps [world] (per destination)
+__device__ __forceinline__ bool nr_lists_overflowed(const int* __restrict__ counts, const int* __restrict__ caps, int world) {
+  bool ovf = false;
+  for (int k = 0; k < world * world; ++k) ovf = ovf || counts[k] > caps[k % world];
+  return ovf;
+}
+
+// Owner side: the list that source rank `src` sent to this rank (`own`), added onto the rank's shard of the gradient with plain
+// adds -- the caller launches it for src = 0 ... world-1 IN THAT ORDER, so the owner's sums do not depend on anything but the
+// lists.  Nothing is applied if any list of the exchange overflowed (every rank sees the same counts: the same branch everywhere);
+// flag[0] = 2 then makes the owner's Adam launch skip the step (nr_adam_step's skip = 2), and restore (below) puts every rank's
+// own rows back into its local gradient, which the next step's scatter adds onto.
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_lists_apply_kernel(const int* __restrict__ idx, const float* __restrict__ val, const int* __restrict__ counts,
+                        const int* __restrict__ caps, int world, int src, int own, float* __restrict__ shard, float* __restrict__ flag) {
+  const bool ovf = nr_lists_overflowed(counts, caps, world);
+  if (flag != nullptr && src == 0 && blockIdx.x == 0 && threadIdx.x == 0) flag[0] = ovf ? 2.0f : 0.0f;
+  if (ovf) return;
+  const int64_t n = counts[src * world + own];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) shard[r * F + f] += val[i * F + f];
+  }
+}
+
+// Sender side, overflow only: every segment of the rank's own send lists goes back where it came from (blockIdx.y = destination).
+template <int F>
+__global__ void __launch_bounds__(256)
+grad_lists_restore_kernel(const int* __restrict__ idx_all, const float* __restrict__ val_all, const int* __restrict__ counts,
+                          const int* __restrict__ caps, int world, int own, int64_t rows, float* __restrict__ grad_all) {
+  if (!nr_lists_overflowed(counts, caps, world)) return;
+  const int d = blockIdx.y;
+  int64_t off = 0;
+  for (int k = 0; k < d; ++k) off += caps[k];
+  const int64_t have = counts[own * world + d], n = have < caps[d] ? have : caps[d];
+  const int* __restrict__ idx = idx_all + off;
+  const float* __restrict__ val = val_all + off * F;
+  float* __restrict__ grad = grad_all + (int64_t)d * rows * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx[i];
+#pragma unroll
+    for (int f = 0; f < F; ++f) grad[r * F + f] += val[i * F + f];
+  }
+}
+
 }  // namespace
 
 extern "C" int nr_grad_apply_guarded(const int* idx, const float* val, const int* counts, int world, int list_rank, int own_rank,
@@ -629,6 +740,66 @@ extern "C" int nr_grad_compact(float* grad, int64_t rows, int F, int64_t cap, in
   if (!grad || !idx || !val || !count || rows < 0 || rows > 0x7fffffff || cap < 1) return NR_EINVAL;
   const unsigned blocks = (unsigned)(nr_cdiv(rows, 256) < 1024 ? nr_cdiv(rows, 256) : 1024);
 #define CALL(FF) hipLaunchKernelGGL(grad_compact_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), grad, rows, cap, idx, val, count)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_grad_compact_shards(float* grad, int64_t rows_per_shard, int F, int world, const int* caps, int* idx, float* val,
+                                      int* counts, nr_stream_t stream) {
+  if (rows_per_shard == 0) return 0;
+  if (!grad || !caps || !idx || !val || !counts || rows_per_shard < 0 || rows_per_shard > 0x7fffffff || world < 1 || world > 64)
+    return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(rows_per_shard, 256) < 1024 ? nr_cdiv(rows_per_shard, 256) : 1024);
+#define CALL(FF) hipLaunchKernelGGL(grad_compact_shards_kernel<FF>, dim3(blocks, (unsigned)world), dim3(256), 0, nr_s(stream), grad, \
+                                    rows_per_shard, caps, idx, val, counts)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_grad_lists_apply(const int* idx, const float* val, int64_t list_cap, const int* counts, const int* caps, int world,
+                                   int src_rank, int own_rank, int F, float* shard, float* flag, nr_stream_t stream) {
+  if (!idx || !val || !counts || !caps || !shard || list_cap < 1 || world < 1 || world > 64 || src_rank < 0 || src_rank >= world ||
+      own_rank < 0 || own_rank >= world)
+    return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(list_cap, 256) < 1024 ? nr_cdiv(list_cap, 256) : 1024);
+#define CALL(FF) hipLaunchKernelGGL(grad_lists_apply_kernel<FF>, dim3(blocks), dim3(256), 0, nr_s(stream), idx, val, counts, caps, \
+                                    world, src_rank, own_rank, shard, flag)
+  switch (F) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    default: return NR_EINVAL;
+  }
+#undef CALL
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_grad_lists_restore(const int* idx, const float* val, int64_t max_cap, const int* counts, const int* caps, int world,
+                                     int own_rank, int64_t rows_per_shard, int F, float* grad, nr_stream_t stream) {
+  if (!idx || !val || !counts || !caps || !grad || max_cap < 1 || world < 1 || world > 64 || own_rank < 0 || own_rank >= world ||
+      rows_per_shard < 1)
+    return NR_EINVAL;
+  const unsigned blocks = (unsigned)(nr_cdiv(max_cap, 256) < 256 ? nr_cdiv(max_cap, 256) : 256);
+#define CALL(FF) hipLaunchKernelGGL(grad_lists_restore_kernel<FF>, dim3(blocks, (unsigned)world), dim3(256), 0, nr_s(stream), idx, val, \
+                                    counts, caps, world, own_rank, rows_per_shard, grad)
   switch (F) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;

@@ -101,7 +101,19 @@ class SegmentedStep:
         try:
             with torch.cuda.stream(cap):
                 self._begin()
-                step_fn()
+                try:
+                    step_fn()
+                except BaseException:
+                    # a step that raises mid-capture must not leave the stream capturing (every later launch on it would fail with
+                    # "operation not permitted when stream is capturing") nor a half-recorded list of segments behind
+                    if self._graph is not None:
+                        try:
+                            self._graph.capture_end()
+                        except Exception:  # noqa: BLE001 -- the capture may already be invalidated; ending it is best effort
+                            pass
+                        self._graph = None
+                    self.parts = []
+                    raise
                 if self._graph is not None:  # the step ended without a final host action
                     self._graph.capture_end()
                     self.parts.append((self._graph, None))
@@ -417,7 +429,9 @@ class FusedTrainStep:
     def _host(self, fn, final: bool = False) -> None:
         """A host-side action of the step (a collective, a wait for one, optimizer launches ordered behind one): executed in
         place -- or, while a SegmentedStep captures the step, recorded as the boundary between two graph segments."""
-        if self._segmenter is None:
+        # (a segmenter cuts only the step the joins in front of the cuts are written for -- reducer AND fused optimizers: `seg` in
+        # forward_backward; with a reducer alone the streams forked there would be unjoined at the cut)
+        if self._segmenter is None or not getattr(self, "_seg_active", True):
             fn()
         else:
             self._segmenter.cut(fn, final)
@@ -553,8 +567,9 @@ class FusedTrainStep:
         # to the single launch and MEASURED SLOWER (2.15 -> 2.50 ms per step, same box, three interleaved repetitions): the
         # zero-gradient phase streams 0.8 GB beside the forward, whose gathers then take twice as long (field_fwd_gather 152 -> 325 us,
         # render 50 -> 367 us), and is still running when the scatter starts -- DESIGN.md section 13.  Default: one launch behind it.
+        # (nr_adam_step_split has no weight-decay term: a table optimizer with weight decay stays on the single launch)
         adam_split = (mark_seen is not None and self.main_shared and self.amp is None and self.overlap
-                      and os.environ.get("NR_ADAM_SPLIT", "0") == "1")
+                      and optimizers[0].wd == 0.0 and os.environ.get("NR_ADAM_SPLIT", "0") == "1")
         jit = (jitter1, jitter2)
         pg, w_dec = self.pgrid, self.prop.density_decoder.weight
         for lvl in range(2):
@@ -586,6 +601,7 @@ class FusedTrainStep:
         fuse_gather = (mg.num_levels == 8 and F == 4 and self.field_struct.dtype != 0 and self.model.field.config.geo_hidden_dim == 32
                        and not self.n_actors and os.environ.get("NR_FUSE_MAIN_GATHER", "1") != "0")
         seg = self._segmenter if (reducer is not None and optimizers is not None) else None
+        assert self._segmenter is None or seg is not None, "SegmentedStep captures the data-parallel step with fused optimizers (reducer and optimizers given)"
         if reducer is not None:
             # a deferred all-gather of the previous step's sharded table update lands here: first read of the main table
             if seg is not None and side[0] is not main:
@@ -905,7 +921,8 @@ class FusedTrainStep:
                 # reduce-scatter -> Adam on this rank's 1/world of the rows -> all-gather (parallel.shard_step)
                 # (reducer.table_delta / defer_gather: the update deltas in bf16, the all-gather deferred into the next step)
                 reducer.shard_step(table_opt, i_main, scale, transport=reducer.table_dtype,
-                                   delta_dtype=getattr(reducer, "table_delta", None), defer=getattr(reducer, "defer_gather", False))
+                                   delta_dtype=getattr(reducer, "table_delta", None), defer=getattr(reducer, "defer_gather", False),
+                                   row_width=mg.features_per_level)
             else:
                 keep = None
                 if reducer is not None:

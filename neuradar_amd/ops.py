@@ -1274,6 +1274,33 @@ def grad_apply_guarded(idx: Tensor, val: Tensor, counts: Tensor, list_rank: int,
                                            _p(grad), _p(flag), _stream()), "nr_grad_apply_guarded")
 
 
+def grad_compact_shards(grad: Tensor, row_width: int, world: int, caps: Tensor, idx: Tensor, val: Tensor, counts: Tensor) -> None:
+    """nr_grad_compact_shards: the non-zero rows of each of the `world` equal row shards of grad move into that destination's
+    segment of (idx, val) (segment d: caps[d] rows starting at sum(caps[:d]); indices relative to the shard) and are cleared;
+    counts[d] += all non-zero rows of shard d."""
+    g = _f32(grad, "grad")
+    if g.data_ptr() != grad.data_ptr() or g.numel() % (world * row_width) != 0:
+        raise RuntimeError("grad_compact_shards works in place on a contiguous float32 gradient of world equal row shards")
+    check(_lib.lib().nr_grad_compact_shards(_p(g), g.numel() // (world * row_width), row_width, world, _p(caps), _p(idx), _p(val), _p(counts),
+                                            _stream()), "nr_grad_compact_shards")
+
+
+def grad_lists_apply(idx: Tensor, val: Tensor, counts: Tensor, caps: Tensor, src_rank: int, own_rank: int, row_width: int,
+                     shard: Tensor, flag: Optional[Tensor]) -> None:
+    """nr_grad_lists_apply: the list received from src_rank onto this rank's shard of the gradient, unless any list of the
+    exchange overflowed (then flag = 2: the owner's Adam skips the step and the gradient is kept)."""
+    world = caps.numel()
+    check(_lib.lib().nr_grad_lists_apply(_p(idx), _p(val), idx.numel(), _p(counts), _p(caps), world, int(src_rank), int(own_rank), row_width,
+                                         _p(shard), _p(flag), _stream()), "nr_grad_lists_apply")
+
+
+def grad_lists_restore(idx: Tensor, val: Tensor, max_cap: int, counts: Tensor, caps: Tensor, own_rank: int, row_width: int, grad: Tensor) -> None:
+    """nr_grad_lists_restore: after an overflowed exchange the rank's own send lists go back into its local gradient (no-op otherwise)."""
+    world = caps.numel()
+    check(_lib.lib().nr_grad_lists_restore(_p(idx), _p(val), int(max_cap), _p(counts), _p(caps), world, int(own_rank),
+                                           grad.numel() // (world * row_width), row_width, _p(grad), _stream()), "nr_grad_lists_restore")
+
+
 def uniform_fill(out: Tensor, seed: int, epoch: Optional[Tensor] = None) -> Tensor:
     """out <- U[0,1), draw number `epoch[0]` (device float counter) of the stream `seed` (nr_uniform_fill)."""
     check(_lib.lib().nr_uniform_fill(_p(_f32(out, "out")), out.numel(), seed & 0xFFFFFFFF, _p(epoch), _stream()), "nr_uniform_fill")

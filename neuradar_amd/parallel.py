@@ -124,7 +124,8 @@ class GradAllReducer:
 
     # ---- sharded table step: reduce-scatter -> Adam on the owned rows -> all-gather ------------------
     def shard_step(self, opt, i: int, grad_scale: float, transport: Optional[torch.dtype] = None,
-                   delta_dtype: Optional[torch.dtype] = None, defer: bool = False, kernels=None) -> dict:
+                   delta_dtype: Optional[torch.dtype] = None, defer: bool = False, kernels=None, row_width: Optional[int] = None,
+                   list_kernels=None) -> dict:
         """The data-parallel step of ONE big table whose gradient is dense across the ranks (the mixed batch touches 9-22 % of
         the main table's rows per rank: the union over 8 ranks is most of the table, so row lists no longer pay).  Instead of
         all-reduce + a replicated Adam over the whole table on every GPU:
@@ -146,7 +147,14 @@ class GradAllReducer:
         550 at 8 ranks), so nothing is gained by pipelining it against a chunked exchange: what matters is where the wire time
         of the two halves hides (the reduce-scatter behind the proposal scatters, the all-gather in the next step).
         No host read, no allocation after the first call.  opt: step.FlatAdam with shard_buffer(i) applied.
-        kernels: (to16_clear, apply_delta16) callables; default = the HIP kernels (CPU tests pass torch stand-ins)."""
+        kernels: (to16_clear, apply_delta16) callables; default = the HIP kernels (CPU tests pass torch stand-ins).
+
+        row_width (the table's features per row) given, fp32 transport and self.shard_lists (the default): step 1 is NOT a
+        dense reduce-scatter -- the gradient is sparse (9-22 % of the rows per rank on the mixed batch), so every rank sends
+        each owner the (row, values) lists of that owner's shard (_lists_to_owners: one compaction launch, one all-to-all of
+        the index parts and one of the value parts, the owner adds the lists in rank order with plain fp32 adds -- exact, no
+        rounding of partial sums, the same sum whatever the arrival order), with the dense reduce-scatter as the fallback
+        when the lists stop paying and a device-side guard for a list that overflows."""
         p, g = opt.buffers[i]
         if self.world == 1 and not self.force_collectives:
             opt.step_buffer(i, grad_scale)
@@ -173,7 +181,13 @@ class GradAllReducer:
                 st["mine"] = torch.empty(per, device=g.device, dtype=delta_dtype or torch.float32)
             self._shard_state[key] = st
         # 1. reduce-scatter
-        if transport is not None:
+        lists, keep = None, None
+        if transport is None and row_width is not None and getattr(self, "shard_lists", True) and per % row_width == 0:
+            lists = self._lists_to_owners(g, lo, hi, int(row_width), list_kernels)  # None: this step goes dense
+            keep = None if lists is None else lists["flag"]
+        if lists is not None:
+            pass
+        elif transport is not None:
             to16_clear(g, st["low"])  # low = bf16(g); g = 0
             if nccl:
                 dist.reduce_scatter_tensor(st["low_out"], st["low"], op=dist.ReduceOp.SUM, group=self.group)
@@ -188,10 +202,11 @@ class GradAllReducer:
         # 2. the owner's Adam (zeroes g[lo:hi]).  With a delta buffer it must not be overwritten while a deferred all-gather of
         #    the previous step still reads it (and the receivers' apply of that step must be done before this step's arrives)
         self.wait_table_sync()
+        extra = {} if keep is None else {"skip_extra": keep}  # (an overflowed list exchange: the step is skipped, the gradient kept)
         if delta_dtype is not None:
-            opt.step_buffer(i, grad_scale, delta16=st["delta"][lo:hi])
+            opt.step_buffer(i, grad_scale, delta16=st["delta"][lo:hi], **extra)
         else:
-            opt.step_buffer(i, grad_scale)
+            opt.step_buffer(i, grad_scale, **extra)
         # 3. all-gather of the updated rows (parameters, or their bf16 update deltas), 4. optionally on its own stream
         cur = torch.cuda.current_stream() if g.is_cuda else None
         comm = None
@@ -213,7 +228,7 @@ class GradAllReducer:
                 self._table_sync = torch.cuda.Event()
                 self._table_sync.record(comm)
                 _DEFERRED.add(self)
-        if transport is None:  # (the bf16 send pass has cleared the local gradient already)
+        if transport is None and lists is None:  # (the bf16 send pass / the compaction has cleared the local gradient already)
             if lo > 0:
                 g[:lo].zero_()
             if hi < n:
@@ -224,8 +239,137 @@ class GradAllReducer:
         self.last_sparse = {"mode": "shard", "rows": [per] * self.world, "bytes": int(f * n * (e_rs + e_ag)),
                             "reduce_scatter_bytes_per_gpu": int(f * n * e_rs), "all_gather_bytes_per_gpu": int(f * n * e_ag),
                             "reduce_scatter_dtype": "float32" if transport is None else "bfloat16",
-                            "all_gather": "float32 parameters" if delta_dtype is None else "bfloat16 update deltas", "deferred": bool(comm is not None)}
+                            "all_gather": "float32 parameters" if delta_dtype is None else "bfloat16 update deltas", "deferred": bool(comm is not None),
+                            "gradient_half": "dense reduce-scatter"}
+        if lists is not None:
+            self.last_sparse.update({"gradient_half": "row lists to the shard owners (all-to-all, fp32, owner adds in rank order)",
+                                     "reduce_scatter_bytes_per_gpu": lists["bytes"], "bytes": lists["bytes"] + int(f * n * e_ag),
+                                     "list_rows_per_destination": lists["caps"], "dense_reduce_scatter_would_be": int(f * n * 4)})
         return self.last_sparse
+
+    def _lists_to_owners(self, g: torch.Tensor, lo: int, hi: int, F: int, kernels=None) -> Optional[dict]:
+        """The gradient half of the sharded step for a SPARSE gradient: afterwards g[lo:hi] holds the sum over the ranks of the
+        rows this rank owns and the rest of g is zero -- what the dense reduce-scatter (+ clearing) leaves -- without moving
+        the zeros.  g: flat [world * per] fp32 gradient of a [rows, F] table, shard d = elements [d * per, (d + 1) * per).
+
+          1. nr_grad_compact_shards: ONE launch; destination d's non-zero rows -> segment d (capacity caps[d] rows) of the send
+             lists, cleared in g; counts[d] = all non-zero rows of shard d.
+          2. the counts are all-gathered ([world, world] on every rank) and copied to pinned host memory asynchronously: they
+             size the NEXT step's segments (1.3 x the largest list a destination received, kept while it stays within
+             [1.1, 1.6] x; 2.3 x after an overflow, whose kept gradient the next step adds onto) and decide, one step late and alike on every rank, to fall back to the dense reduce-scatter when a
+             list would exceed half a shard's rows (there the lists' 4 + 4F bytes per row stop paying against 4F per row of
+             the dense ring).  No host read after the first call (which counts once, synchronously, before any timed region).
+          3. all-to-all of the index parts, all-to-all of the value parts (fixed sizes known to every rank: segment d of every
+             rank goes to rank d).
+          4. nr_grad_lists_apply per source rank, IN RANK ORDER, plain adds onto g[lo:hi]: every owner computes a sum that
+             depends on the lists only -- fp32, exact to the addition order 0 .. world-1, identical however the ranks' lists
+             arrive.  (The dense ring adds in an order that depends on the ring position; both are fp32 sums of the same
+             `world` addends.)
+          5. a step whose count jumps past a segment's capacity is caught on the device from the gathered counts: nobody applies
+             anything, nr_grad_lists_restore puts every rank's own rows back, the returned flag (= 2) makes the owner's Adam skip
+             the step and keep the gradient; the next step's scatter adds onto it and the next exchange (sized from the counts
+             known by then) carries both.  Replicas stay bit-identical, nothing is lost.
+        Returns {"flag", "bytes" (per GPU on the wire), "caps"} or None when this step is to go dense (the caller then runs the
+        reduce-scatter).  Reference semantics: the fp32 gradient mean of DDP, pipelines/base_pipeline.py:305-307."""
+        world, per = self.world, hi - lo
+        rows = per // F  # rows per shard
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        if kernels is None:
+            from . import ops as hip_ops
+            kernels = (hip_ops.grad_compact_shards, hip_ops.grad_lists_apply, hip_ops.grad_lists_restore)
+        compact_shards, lists_apply, lists_restore = kernels
+        dev = g.device
+        key = ("lists", g.data_ptr(), F)
+        st = self.__dict__.setdefault("_lists_state", {}).get(key)
+        i32 = dict(device=dev, dtype=torch.int32)
+        if st is None:
+            st = dict(counts=torch.zeros(world, **i32), cm=torch.zeros(world * world, **i32), flag=torch.zeros(1, device=dev, dtype=torch.float32),
+                      host=(torch.zeros(world * world, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(world * world, dtype=torch.int32)),
+                      zero_caps=torch.zeros(world, **i32), event=None, need=None, caps=None, caps_dev=None, dense_steps=0,
+                      idx_s=None, val_s=None, idx_r=None, val_r=None)
+            self._lists_state[key] = st
+        cap_max = max(rows // 2, 1)
+
+        def gather_counts(sync: bool):
+            self._all_gather_g(st["cm"], st["counts"])
+            if dev.type == "cuda" and not sync:
+                st["host"].copy_(st["cm"], non_blocking=True)
+                st["event"] = torch.cuda.Event()
+                st["event"].record()
+            else:
+                st["host"].copy_(st["cm"])
+                st["event"] = None
+                st["need"] = st["host"].view(world, world).max(dim=0).values.tolist()
+
+        if st["event"] is not None:  # the previous step's counts (copied a whole step ago)
+            st["event"].synchronize()
+            st["event"] = None
+            st["need"] = st["host"].view(world, world).max(dim=0).values.tolist()
+        if st["need"] is None:  # first call: count once, synchronously (rows stay where they are: capacities of zero)
+            st["counts"].zero_()
+            compact_shards(g, F, world, st["zero_caps"], st["zero_caps"], st["flag"], st["counts"])
+            gather_counts(sync=True)
+        need = st["need"]
+        dense = max(need) > cap_max or (st["dense_steps"] > 0 and 2 * max(need) > cap_max)  # (coming back needs 2x room)
+        if dense:
+            st["dense_steps"] += 1
+            if st["dense_steps"] % self.dense_probe_every == 0:  # dense is not for ever: re-count now and then (one read of g)
+                st["counts"].zero_()
+                compact_shards(g, F, world, st["zero_caps"], st["zero_caps"], st["flag"], st["counts"])
+                gather_counts(sync=False)
+            return None
+        st["dense_steps"] = 0
+        caps = st["caps"]
+        if caps is not None and any(nd > c for nd, c in zip(need, caps)):
+            # the previous step overflowed: its gradient was kept and this step's scatter has added onto it -- room for the union
+            gr = int(getattr(self, "list_granularity", 1024))
+            caps = [min(cap_max, max(gr, (int(2.3 * nd) + gr - 1) // gr * gr)) for nd in need]
+            st["caps"], st["caps_dev"] = caps, torch.tensor(caps, dtype=torch.int32).to(dev)
+        elif caps is None or any(not (1.1 * nd <= c) or c > max(1.6 * nd, int(getattr(self, "list_granularity", 1024))) for nd, c in zip(need, caps)):
+            gr = int(getattr(self, "list_granularity", 1024))
+            caps = [min(cap_max, max(gr, (int(1.3 * nd) + gr - 1) // gr * gr)) for nd in need]
+            st["caps"], st["caps_dev"] = caps, torch.tensor(caps, dtype=torch.int32).to(dev)
+        total, mine = sum(caps), caps[rank]
+        if st["idx_s"] is None or st["idx_s"].numel() < total or st["idx_r"].numel() < world * mine:
+            grow = lambda n_: (int(1.25 * n_) + 1023) // 1024 * 1024  # noqa: E731  (room for the next few re-sizings)
+            st["idx_s"], st["val_s"] = torch.zeros(grow(total), **i32), torch.zeros(grow(total), F, device=dev, dtype=torch.float32)
+            st["idx_r"], st["val_r"] = torch.zeros(grow(world * mine), **i32), torch.zeros(grow(world * mine), F, device=dev, dtype=torch.float32)
+        idx_s, val_s = st["idx_s"][:total], st["val_s"][:total]
+        idx_r, val_r = st["idx_r"][:world * mine], st["val_r"][:world * mine]
+        st["counts"].zero_()
+        compact_shards(g, F, world, st["caps_dev"], idx_s, val_s, st["counts"])
+        gather_counts(sync=False)
+        self._all_to_all_rows(idx_r, idx_s, caps, mine)
+        self._all_to_all_rows(val_r, val_s, caps, mine)
+        shard = g[lo:hi]
+        for src in range(world):  # rank order, plain adds
+            lists_apply(idx_r[src * mine:(src + 1) * mine], val_r[src * mine:(src + 1) * mine], st["cm"], st["caps_dev"], src, rank, F,
+                        shard, st["flag"])
+        lists_restore(idx_s, val_s, max(caps), st["cm"], st["caps_dev"], rank, F, g)
+        return {"flag": st["flag"], "bytes": (total - mine) * (4 + 4 * F), "caps": list(caps)}
+
+    def _all_gather_g(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        """out [world * len(mine)] <- every rank's `mine` in rank order, over self.group (flat form on RCCL, list form on gloo)."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            n = mine.numel()
+            dist.all_gather([out[r * n:(r + 1) * n] for r in range(self.world)], mine, group=self.group)
+
+    def _all_to_all_rows(self, out: torch.Tensor, inp: torch.Tensor, caps, mine: int) -> None:
+        """Segment d (caps[d] leading-dimension rows) of every rank's `inp` goes to rank d; `out` receives world segments of
+        `mine` = caps[own rank] rows in rank order.  RCCL: one all_to_all_single with the split sizes every rank knows.  gloo (the
+        CPU / one-GPU tests): every rank gathers all send buffers and copies its own segments out -- same result."""
+        world = self.world
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all_single(out, inp, output_split_sizes=[mine] * world, input_split_sizes=list(caps), group=self.group)
+            return
+        rank = dist.get_rank(self.group)
+        parts = [torch.empty_like(inp) for _ in range(world)]
+        dist.all_gather(parts, inp.contiguous(), group=self.group)
+        off = sum(caps[:rank])
+        for r in range(world):
+            out[r * mine:(r + 1) * mine].copy_(parts[r][off:off + mine])
 
     def wait_table_sync(self) -> None:
         """Make the current stream wait for a deferred all-gather (+ delta apply) of the previous sharded step: call it in
@@ -262,9 +406,13 @@ class GradAllReducer:
         `ops`: (compact, apply_guarded) callables; default = the HIP kernels (neuradar_amd.ops)."""
         if self.world == 1 and not self.force_collectives:
             return {"mode": "single", "flag": None}
+        count_rows = None
         if ops is None:
             from . import ops as hip_ops
             ops = (hip_ops.grad_compact, hip_ops.grad_apply_guarded)
+
+            def count_rows(count_, st_):  # count-only pass of the compaction kernel (capacity 0: nothing moves, no temporaries)
+                hip_ops.grad_compact_shards(grad, row_width, 1, st_["zero_cap"], st_["zero_cap"], st_["flag"], count_)
         compact, apply_guarded = ops
         rows = grad.numel() // row_width
         cap = int(cap_rows) if cap_rows is not None else max(rows * row_width // ((1 + row_width) * self.world), 1)
@@ -278,7 +426,7 @@ class GradAllReducer:
                       count=torch.zeros(1, device=dev, dtype=torch.int32), counts=torch.zeros(world, device=dev, dtype=torch.int32),
                       out_idx=torch.zeros(world * cap, device=dev, dtype=torch.int32),
                       out_val=torch.zeros(world * cap * row_width, device=dev, dtype=torch.float32),
-                      flag=torch.zeros(1, device=dev, dtype=torch.float32),
+                      flag=torch.zeros(1, device=dev, dtype=torch.float32), zero_cap=torch.zeros(1, device=dev, dtype=torch.int32),
                       host=torch.zeros(world, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(world, dtype=torch.int32),
                       event=None, prev_max=None)
             self.__dict__.setdefault("_sparse_state", {})[key] = st
@@ -300,7 +448,11 @@ class GradAllReducer:
             # the host sees them one step later, like the lists' counts, and the exchange returns to lists once they fit twice.
             st["dense_steps"] = st.get("dense_steps", 0) + 1
             if st["dense_steps"] % self.dense_probe_every == 0:
-                count.copy_((grad.view(-1, row_width) != 0).any(dim=1).sum().to(torch.int32).reshape(1))
+                if count_rows is not None:
+                    count.zero_()
+                    count_rows(count, st)
+                else:  # (torch stand-ins of the CPU tests)
+                    count.copy_((grad.view(-1, row_width) != 0).any(dim=1).sum().to(torch.int32).reshape(1))
                 self._all_gather(st["counts"], count)
                 if grad.is_cuda:
                     st["host"].copy_(st["counts"], non_blocking=True)

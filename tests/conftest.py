@@ -22,7 +22,7 @@ if ROOT not in sys.path:
 FIRST = ("test_gpu_parity.py", "test_gpu_lp.py", "test_gpu_renderers.py", "test_gpu_fullsize.py", "test_gpu_fused_actors.py")
 # ... and the multi-stream / full-size / subprocess tests last (~90 of 361: >= 270 tests are reported before the first of them)
 LAST = ("test_gpu_amp.py", "test_gpu_full_step.py", "test_gpu_graph_replay.py", "test_gpu_dp.py", "test_gpu_bench_line.py",
-        "test_gpu_convergence.py", "test_gpu_adam_split.py", "test_gpu_redzone.py")  # (the last two: an opt-in kernel, test tooling)
+        "test_gpu_convergence.py", "test_gpu_adam_split.py", "test_bench_launcher.py", "test_gpu_redzone.py")  # (the last two: an opt-in kernel, test tooling)
 
 
 def _gpu_visible() -> bool:

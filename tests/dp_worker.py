@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--shard", action="store_true", help="main table: reduce-scatter -> Adam on this rank's rows -> all-gather")
+    ap.add_argument("--dense-shard", action="store_true", help="shard: dense fp32 reduce-scatter instead of row lists to the owners")
     ap.add_argument("--bf16", action="store_true", help="shard: bf16 reduce-scatter, bf16 update-delta all-gather, deferred into the next step")
     ap.add_argument("--fp16-amp", action="store_true", help="fp16 MFMA operands under the device-side loss scaler; rank 1's batch of "
                     "step 1 is poisoned (an overflowing target): BOTH ranks must skip that step")
@@ -58,6 +59,7 @@ def main():
     reducer = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()],
                              table_mode="shard" if args.shard else ("dense" if args.dense else "sparse"))
     reducer.force_collectives = args.force_collectives
+    reducer.shard_lists = not args.dense_shard
     if args.bf16:
         reducer.table_dtype, reducer.table_delta, reducer.defer_gather = torch.bfloat16, torch.bfloat16, True
     shard = None

@@ -257,6 +257,142 @@ def test_two_rank_sharded_table_step_fp32_gradient_bf16_delta():
     mp.spawn(_shard_worker, args=(2, _free_port(), False, True), nprocs=2, join=True)
 
 
+# ---- the sharded step's gradient half as row lists to the shard owners (GradAllReducer._lists_to_owners) --------------------
+def _torch_compact_shards(g, F, world, caps, idx, val, counts):
+    """nr_grad_compact_shards in torch: the non-zero rows of shard d -> segment d of the lists (capacity caps[d]), cleared in g."""
+    G = g.view(world, -1, F)
+    off = 0
+    for d in range(world):
+        nz = (G[d] != 0).any(dim=1).nonzero().flatten()
+        counts[d] += nz.numel()
+        take = nz[:int(caps[d])]
+        if take.numel():
+            idx[off:off + take.numel()] = take.to(torch.int32)
+            val[off:off + take.numel()] = G[d][take]
+            G[d][take] = 0
+        off += int(caps[d])
+
+
+def _lists_overflowed(cm, caps):
+    w = caps.numel()
+    return bool((cm.view(w, w) > caps.view(1, w)).any())
+
+
+def _torch_lists_apply(idx, val, cm, caps, src, own, F, shard, flag):
+    ovf = _lists_overflowed(cm, caps)
+    if src == 0:
+        flag[0] = 2.0 if ovf else 0.0
+    if ovf:
+        return
+    n = int(cm[src * caps.numel() + own])
+    shard.view(-1, F).index_add_(0, idx[:n].long(), val[:n])  # (unique rows within one list)
+
+
+def _torch_lists_restore(idx, val, max_cap, cm, caps, own, F, g):
+    if not _lists_overflowed(cm, caps):
+        return
+    w = caps.numel()
+    G = g.view(w, -1, F)
+    off = 0
+    for d in range(w):
+        n = min(int(cm[own * w + d]), int(caps[d]))
+        G[d].index_add_(0, idx[off:off + n].long(), val[off:off + n])
+        off += int(caps[d])
+
+
+class _StubOptSkip(_StubOpt):
+    """_StubOpt + nr_adam_step's skip flag: 2 = no update, the gradient is KEPT (zero deltas for the replicas)."""
+
+    def step_buffer(self, i, grad_scale, delta16=None, skip_extra=None):
+        if skip_extra is not None and float(skip_extra[0]) == 2.0:
+            if delta16 is not None:
+                delta16.zero_()
+            return
+        super().step_buffer(i, grad_scale, delta16=delta16)
+
+
+def _lists_worker(rank, world, port, delta, densities):
+    """Steps with the given fraction of non-zero rows per rank.  Checked every step: replicas bit-identical; the parameters equal the
+    replicated step on the all-reduced gradient (world 2: a + b is the same float in either order, so EXACTLY); the exchange mode
+    that ran; a step whose lists overflow moves nothing and its gradient arrives with the next step's."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neuradar_amd.parallel import GradAllReducer, init_distributed
+
+    init_distributed(backend="gloo")
+    F, rows = 4, 1 << 12
+    n = rows * F
+    p = torch.linspace(-1, 1, n).clone()
+    p0 = p.clone()
+    red = GradAllReducer(None, buffers=[], table_mode="shard")
+    red.list_granularity = 16
+    red.dense_probe_every = 2
+    grad = torch.zeros(n)
+    opt = _StubOptSkip(p, grad, rank, world)
+    modes = []
+    for stepno, dens in enumerate(densities):
+        g = torch.Generator().manual_seed(10 * stepno + rank)
+        hit = torch.rand(rows, generator=g) < dens
+        fresh = torch.where(hit[:, None], torch.randn(rows, F, generator=g), torch.zeros(rows, F)).reshape(-1)
+        grad += fresh  # (the scatter ADDS onto whatever an overflowed step left behind)
+        total = grad.clone()  # what the exchange must deliver if it delivers: the sum of the ranks' local gradients
+        dist.all_reduce(total)
+        info = red.shard_step(opt, 0, 1.0 / world, delta_dtype=torch.bfloat16 if delta else None, defer=True, row_width=F,
+                              kernels=(_torch_to16_clear, _torch_apply_delta),
+                              list_kernels=(_torch_compact_shards, _torch_lists_apply, _torch_lists_restore))
+        st = next(iter(red._lists_state.values()))
+        overflowed = info["gradient_half"].startswith("row lists") and float(st["flag"][0]) == 2.0
+        modes.append("overflow" if overflowed else ("lists" if info["gradient_half"].startswith("row lists") else "dense"))
+        if overflowed:
+            assert float(grad.abs().max()) > 0, "an overflowed step must keep the local gradient"
+            kept = grad.clone()
+            dist.all_reduce(kept)
+            assert torch.equal(kept, total), "an overflowed step must leave every rank's gradient whole"
+        else:
+            upd = -0.1 / world * total
+            p0 += upd.to(torch.bfloat16).float() if delta else upd
+            assert float(grad.abs().max()) == 0.0, "the local gradient must be cleared everywhere"
+            if modes[-1] == "lists":
+                f = (world - 1) / world
+                assert info["reduce_scatter_bytes_per_gpu"] == sum(c for d, c in enumerate(info["list_rows_per_destination"]) if d != rank) * (4 + 4 * F)
+                assert info["reduce_scatter_bytes_per_gpu"] < info["dense_reduce_scatter_would_be"] == int(f * n * 4)
+        gathered = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(gathered, p)
+        assert all(torch.equal(t, gathered[0]) for t in gathered), f"replicas differ after step {stepno} ({modes[-1]})"
+        assert torch.equal(p, p0), (stepno, modes[-1], float((p - p0).abs().max()))
+    red.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+    return modes
+
+
+def _lists_entry(rank, world, port, delta, densities, check):
+    modes = _lists_worker(rank, world, port, delta, densities)
+    if check == "all_lists":
+        assert modes == ["lists"] * len(densities), modes
+    else:  # the overflow story (see the test's docstring)
+        assert modes[:4] == ["lists", "lists", "overflow", "lists"], modes
+        assert modes[5] == "overflow" and "dense" in modes[6:] and modes[-1] == "lists", modes
+
+
+def test_two_rank_sharded_step_gradient_as_row_lists_to_the_owners():
+    """15 % of the rows per rank, steady: every step goes as lists, results EXACTLY the replicated step's."""
+    mp.spawn(_lists_entry, args=(2, _free_port(), False, [0.15] * 4, "all_lists"), nprocs=2, join=True)
+
+
+def test_two_rank_row_lists_with_bf16_update_deltas():
+    mp.spawn(_lists_entry, args=(2, _free_port(), True, [0.15] * 3, "all_lists"), nprocs=2, join=True)
+
+
+def test_two_rank_row_lists_overflow_keeps_the_gradient_then_dense_then_back():
+    """0.1 -> 0.14 of the rows: the lists sized from the 0.1 steps (x 1.3) overflow -- nothing moves, every rank's gradient stays
+    whole, the next step's scatter adds onto it and its lists (sized 2.3 x the overflowed step's true counts) carry the union.
+    -> 0.7: overflow again, then -- beyond half a shard's rows -- the dense reduce-scatter, decided one step late; back to lists
+    once a re-count (every 2 dense steps here) sees the 0.05 steps."""
+    dens = [0.1, 0.1, 0.14, 0.14, 0.14, 0.7, 0.7, 0.05, 0.05, 0.05, 0.05, 0.05]
+    mp.spawn(_lists_entry, args=(2, _free_port(), False, dens, "overflow_story"), nprocs=2, join=True)
+
+
 def test_two_rank_sparse_table_exchange():
     mp.spawn(_sparse_worker, args=(2, _free_port()), nprocs=2, join=True)
 

@@ -50,6 +50,8 @@ def _run(tmp, tag, world, extra):
 @pytest.mark.parametrize("path,extra", [("sparse", ["--log2t", "20", "--rays", "256"]), ("dense_fallback", ["--log2t", "14", "--rays", "512"]),
                                         ("dense", ["--log2t", "16", "--rays", "512", "--dense"]),
                                         ("shard", ["--log2t", "16", "--rays", "512", "--shard"]),
+                                        ("shard_lists", ["--log2t", "20", "--rays", "256", "--shard"]),
+                                        ("shard_dense", ["--log2t", "20", "--rays", "256", "--shard", "--dense-shard"]),
                                         ("shard_bf16", ["--log2t", "16", "--rays", "512", "--shard", "--bf16"])])
 def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
     dp = _run(str(tmp_path), "dp", 2, extra)
@@ -60,7 +62,15 @@ def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
         assert torch.equal(p, dp[1]["params"][n]), f"{path}: parameter {n} differs between the ranks after 3 steps"
     # (3) the exchange path that was meant to run did run
     modes = {e.get("mode") for e in dp[0]["exchange"]}
-    want = {"sparse": {"sparse"}, "dense_fallback": {"dense"}, "dense": {None}, "shard": {"shard"}, "shard_bf16": {"shard"}}[path]
+    want = {"sparse": {"sparse"}, "dense_fallback": {"dense"}, "dense": {None}, "shard": {"shard"}, "shard_bf16": {"shard"},
+            "shard_lists": {"shard"}, "shard_dense": {"shard"}}[path]
+    if path in ("shard_lists", "shard_dense"):
+        # the gradient half of the sharded step: (row, values) lists to the shard owners by default (a step touches a few per cent
+        # of this table's rows), the dense fp32 reduce-scatter on request; the lists move a fraction of the dense bytes
+        for e in dp[0]["exchange"]:
+            assert e["gradient_half"].startswith("row lists" if path == "shard_lists" else "dense reduce-scatter"), e
+            if path == "shard_lists":
+                assert e["reduce_scatter_bytes_per_gpu"] < 0.5 * e["dense_reduce_scatter_would_be"], e
     if path == "shard_bf16":  # bf16 on both halves of the exchange, the all-gather deferred (and still: replicas identical, above)
         e0 = dp[0]["exchange"][0]
         assert e0["reduce_scatter_dtype"] == "bfloat16" and e0["all_gather"].startswith("bfloat16") and e0["deferred"]
@@ -74,7 +84,7 @@ def test_two_rank_fused_step_on_one_gpu(tmp_path, path, extra):
             assert (lo0, hi1) == (0, b.numel()) and hi0 == lo1 and a.numel() == hi0 - lo0
             both = torch.cat([a, first[1]["exp_avg"][i]])
             err = float((both - b.reshape(-1)).norm() / b.norm().clamp_min(1e-30))
-            tol = 1e-4 if path == "shard" else 2.0 ** -8  # (the gradient travelled in bf16: 2^-9 per entry)
+            tol = 1e-4 if path != "shard_bf16" else 2.0 ** -8  # (the gradient travelled in bf16: 2^-9 per entry)
             assert err < tol, f"{path}: Adam first moment of the main table: relative L2 error {err:.3e} against the single-process run"
             continue
         err = float((a - b).norm() / b.norm().clamp_min(1e-30))
@@ -88,14 +98,17 @@ def test_rccl_branches_in_a_one_rank_group(tmp_path):
     row lists, the in-place reduce_scatter_tensor / all_gather_into_tensor of the sharded table step in fp32 and with bf16 on both
     halves (bf16 send buffer, bf16 update deltas gathered in place on the communication stream and applied, deferred into the next
     step) -- executed for real in a one-rank RCCL group (force_collectives): same result as the step without any collective."""
-    base = ["--log2t", "16", "--rays", "256", "--steps", "2"]
+    base = ["--log2t", "18", "--rays", "256", "--steps", "2"]
     plain = _run(str(tmp_path), "plain", 1, base)[0]
     env_port = str(_free_port())
     os.environ["MASTER_PORT"] = env_port
     try:
-        for tag, extra in (("rccl_sparse", []), ("rccl_shard", ["--shard"]), ("rccl_shard_bf16", ["--shard", "--bf16"])):
+        for tag, extra in (("rccl_sparse", []), ("rccl_shard", ["--shard"]), ("rccl_shard_dense", ["--shard", "--dense-shard"]),
+                           ("rccl_shard_bf16", ["--shard", "--bf16"])):
             got = _run(str(tmp_path), tag, 1, base + extra + ["--backend", "nccl", "--force-collectives"])[0]
             assert {e.get("mode") for e in got["exchange"]} == ({"shard"} if extra else {"sparse"}), got["exchange"]
+            if tag == "rccl_shard":  # the row lists' all_to_all_single (+ the counts' all_gather_into_tensor) ran on RCCL
+                assert all(e["gradient_half"].startswith("row lists") for e in got["exchange"]), got["exchange"]
             for n, p in plain["params"].items():  # (float atomics: two runs agree to rounding, not bitwise)
                 torch.testing.assert_close(got["params"][n], p, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{tag}: parameter {n}: {m}")
     finally:
@@ -149,6 +162,7 @@ def test_two_rank_loss_scaler_skips_on_every_rank(tmp_path):
 
 
 @pytest.mark.parametrize("path,extra", [("shard", ["--log2t", "16", "--rays", "512", "--shard"]),
+                                        ("shard_lists", ["--log2t", "20", "--rays", "256", "--shard"]),
                                         ("shard_bf16_deferred", ["--log2t", "16", "--rays", "512", "--shard", "--bf16"]),
                                         ("sparse", ["--log2t", "20", "--rays", "256"]),
                                         ("amp", ["--log2t", "16", "--rays", "512", "--shard", "--fp16-amp"])])
