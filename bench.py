@@ -360,11 +360,34 @@ def make_step(model, scene, opts, reducer, targets, n_rays, fused=True, fuse_opt
                     col = 0.5 + 0.5 * torch.sin((o_[sl_] + depth[sl_, None] * d_[sl_]) @ Wf[:, :3] * 2.0)
                     dec_batches[slot]["image"].copy_(col.view(n_p, scene.PATCH, scene.PATCH, 3).repeat_interleave(3, 1).repeat_interleave(3, 2))
 
+        # experiment (VERDICT r05 next #4a): the lidar rows in spatial order -- the sampler draws lidar points i.i.d.
+        # (data/pixel_samplers.py:538-587: randperm over the scans at :551, uniform points at :559) and the losses are sums over
+        # rays, so the order carries no meaning; key = the 8-m cell of the ray's end point (x major), one argsort + seven
+        # gathers on the assembly's side stream.  NR_LIDAR_SORT=1; result in DESIGN.md section 5.
+        lidar_sort = n_lidar > 0 and os.environ.get("NR_LIDAR_SORT", "0") == "1"
+
+        def sort_lidar_rows(slot):
+            s_ = asm.slots[slot]
+            sl_ = asm.seg("lidar")
+            end = s_["origins"][sl_] + s_["directions"][sl_] * s_["directions_norm"][sl_].clamp(max=150.0)[:, None]
+            cell = torch.floor(end / 8.0).to(torch.int64) + 512
+            perm = torch.argsort((cell[:, 0] * 1024 + cell[:, 1]) * 1024 + cell[:, 2])
+            for name in ("origins", "directions", "pixel_area", "times", "directions_norm", "did_return"):
+                s_[name][sl_] = s_[name][sl_][perm]
+            s_["lidar_indices"][:n_lidar] = s_["lidar_indices"][:n_lidar][perm]
+            if scene_targets:
+                for t_ in tgt_slots[slot]:
+                    t_[sl_] = t_[sl_][perm]
+            if decoders:
+                dec_batches[slot]["target_intensity"][sl_] = dec_batches[slot]["target_intensity"][sl_][perm]
+
         def head(slot):
             rays[slot] = assemble(slot)
             o_, d_, a_, f_ = rays[slot]
             if scene_targets:
                 canyon(slot, o_, d_)
+            if lidar_sort:
+                sort_lidar_rows(slot)
             stepper.prepare(slot, o_, d_, a_, f_, r[:n_t].view(n_rays, S0 + 1))
             ready[slot] = True
 
@@ -498,14 +521,14 @@ def pmc_traffic(workload, kernel):
         if "launch_sites" in doc:
             site = doc["launch_sites"].get(kernel)
             if site and site.get("traffic_bytes"):
-                return int(site["traffic_bytes"])
+                return int(site["traffic_bytes"]), os.path.basename(path)
             continue
         tag = kernel[kernel.index("[") + 1:-1]  # round-1 layout: one entry per kernel
         kind = "bwd" if "bwd" in kernel else "fwd"
         for name, c in doc["kernels"].items():
             if kind in name and tag in name:
-                return int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-    return None
+                return int((c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.basename(path)
+    return None, None
 
 
 def pmc_mfma_busy(workload):
@@ -915,10 +938,14 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         longest = max(r["seconds"] for r in rows)
         dom = max((r for r in rows if r["seconds"] >= 0.97 * longest), key=lambda r: r["bytes"])
         achieved = dom["bytes"] / dom["seconds"] / 1e9
+        traffic, traffic_src = pmc_traffic(workload, dom["kernel"])
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(workload, dom["kernel"]),
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (f"profiles/{traffic_src}: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this workload, read "
+                                   "back from the committed file -- NOT measured in this run (bench.py does not run the profiler)") if traffic_src else None,
                 "avg_us": round(dom["seconds"] * 1e6, 2), "bytes_per_launch": dom["bytes"],
-                "timing": "HIP events around the launch inside the running step (other streams' kernels overlap it)"
+                "timing": "IN-STEP bracket: HIP events around the launch site inside the running step -- the site shares the chip with the "
+                          "other streams' kernels, so this is how long the site is in flight, not what its kernels cost (see `serialised`)"
                 if stepper is not None else "HIP events, kernel alone",
                 "all_hash_kernels": [{"kernel": r["kernel"], "us": round(r["seconds"] * 1e6, 2),
                                       "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1)} for r in rows],
@@ -928,6 +955,26 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
             roof["serialised_us"] = round(ser * 1e6, 2)
             roof["frac_serialised"] = round(dom["bytes"] / ser / 1e9 / HBM_PEAK_GBS, 4)
             roof["all_hash_kernels_serialised_us"] = {k: round(v * 1e6, 2) for k, v in times_serial.items() if k.startswith("hash_encode")}
+            # The reproducible figures: the same step with every launch on ONE stream -- a site's bracket is then
+            # its kernels' own duration (what rocprofv3's per-kernel averages add up to).  The dominant site BY ITSELF is the longest
+            # there (the main grid's scatter; in the overlapped step the proposal scatters stay in flight longer because they share
+            # the chip with it and with Adam), and `frac` / `achieved` / `avg_us` / `kernel` of this object are taken from THIS
+            # bracket; the in-step bracket of the site that is in flight longest moves to `in_step`.
+            by_bytes = {r["kernel"]: r["bytes"] for r in rows}
+            ser_rows = [(k, v) for k, v in times_serial.items() if k in by_bytes]
+            k_ser, t_ser = max(ser_rows, key=lambda kv: kv[1])
+            tr_ser, tr_src = pmc_traffic(workload, k_ser)
+            roof["in_step"] = {"kernel": dom["kernel"], "avg_us": roof["avg_us"], "achieved": roof["achieved"], "frac": roof["frac"],
+                               "bytes_per_launch": dom["bytes"], "serialised_us": roof["serialised_us"], "frac_serialised": roof["frac_serialised"],
+                               "timing": roof["timing"]}
+            roof.update({"kernel": k_ser, "avg_us": round(t_ser * 1e6, 2), "bytes_per_launch": by_bytes[k_ser],
+                         "achieved": round(by_bytes[k_ser] / t_ser / 1e9, 1), "frac": round(by_bytes[k_ser] / t_ser / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": tr_ser, "traffic_source": (f"profiles/{tr_src}: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this "
+                                                               "workload, read back from the committed file -- NOT measured in this run") if tr_src else None,
+                         "timing": "SERIALISED bracket: HIP events around the launch site with the step's launches on one stream (the site's kernels "
+                                   "alone on the chip, on the step's own rows and gradients); the in-step bracket is under `in_step`",
+                         "serialised_us": round(t_ser * 1e6, 2), "frac_serialised": round(by_bytes[k_ser] / t_ser / 1e9 / HBM_PEAK_GBS, 4)})
+            dom = dict(dom, kernel=k_ser)
         # `bound` is the contract's field (hbm | mfma); what actually limits the dominant launch site is neither: the traffic
         # (FETCH + WRITE) is 0.6 x the algorithmic bytes, MFMA plays no role
         if "main_s32" in dom["kernel"] and stepper is not None and stepper.main_shared:
@@ -1165,9 +1212,11 @@ def main():
     if args.launch_check:
         raise SystemExit(launch_check(args))
 
+    import neuradar_amd
     from neuradar_amd import _lib
     from neuradar_amd.parallel import init_distributed
 
+    neuradar_amd.apply_miopen_workaround()  # (the fp32 workloads' CNN backward goes through MIOpen; explicit since round 6)
     _lib.lib()  # fail loudly if the HIP extension is missing
     rank, world, local_rank = init_distributed(args.dist_backend)
     if args.one_rank_collectives:

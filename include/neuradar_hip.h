@@ -984,13 +984,17 @@ int nr_grad_apply_guarded(const int* idx, const float* val, const int* counts, i
  *   list of the exchange overflowed its destination's capacity nothing is applied and flag[0] = 2.0f (nr_adam_step's "skip and
  *   keep the gradient"); otherwise flag[0] = 0.  Launch once per source, in rank order.
  * nr_grad_lists_restore: overflow only (a no-op otherwise): every segment of the rank's own send lists is added back onto its
- *   local gradient, which is then whole again and carries over into the next step.  max_cap = max(caps). */
+ *   local gradient, which is then whole again and carries over into the next step.  max_cap = max(caps).  found_inf (nullable;
+ *   the loss scaler's flag of the table's optimizer, already summed over the ranks): when it is raised the step's gradient is
+ *   rejected, not kept -- nothing is restored and a second launch clears the whole local gradient (the rows the lists had no
+ *   room for are still in it), so that the skipped step leaves no inf / NaN behind on any rank. */
 int nr_grad_compact_shards(float* grad, int64_t rows_per_shard, int row_width, int world, const int* caps, int* idx, float* val,
                            int* counts, nr_stream_t stream);
 int nr_grad_lists_apply(const int* idx, const float* val, int64_t list_cap, const int* counts, const int* caps, int world,
                         int src_rank, int own_rank, int row_width, float* shard, float* flag, nr_stream_t stream);
 int nr_grad_lists_restore(const int* idx, const float* val, int64_t max_cap, const int* counts, const int* caps, int world,
-                          int own_rank, int64_t rows_per_shard, int row_width, float* grad, nr_stream_t stream);
+                          int own_rank, int64_t rows_per_shard, int row_width, float* grad, const float* found_inf,
+                          nr_stream_t stream);
 
 /* On-device batch assembly for camera patches (the reference samples patches
  * in data/pixel_samplers.py and generates rays on CPU workers): u [n_patches,3] uniform [0,1) ->

@@ -189,7 +189,7 @@ PROTOTYPES = {
     "nr_grad_apply_guarded": [P, P, P, I, I, I, L, I, P, P, P],
     "nr_grad_compact_shards": [P, L, I, I, P, P, P, P, P],
     "nr_grad_lists_apply": [P, P, L, P, P, I, I, I, I, P, P, P],
-    "nr_grad_lists_restore": [P, P, L, P, P, I, I, L, I, P, P],
+    "nr_grad_lists_restore": [P, P, L, P, P, I, I, L, I, P, P, P],
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }

@@ -697,8 +697,10 @@ grad_lists_apply_kernel(const int* __restrict__ idx, const float* __restrict__ v
 template <int F>
 __global__ void __launch_bounds__(256)
 grad_lists_restore_kernel(const int* __restrict__ idx_all, const float* __restrict__ val_all, const int* __restrict__ counts,
-                          const int* __restrict__ caps, int world, int own, int64_t rows, float* __restrict__ grad_all) {
+                          const int* __restrict__ caps, int world, int own, int64_t rows, float* __restrict__ grad_all,
+                          const float* __restrict__ found_inf) {
   if (!nr_lists_overflowed(counts, caps, world)) return;
+  if (found_inf != nullptr && found_inf[0] != 0.0f) return;  // (a gradient the loss scaler rejects is not kept: discard below)
   const int d = blockIdx.y;
   int64_t off = 0;
   for (int k = 0; k < d; ++k) off += caps[k];
@@ -711,6 +713,25 @@ grad_lists_restore_kernel(const int* __restrict__ idx_all, const float* __restri
 #pragma unroll
     for (int f = 0; f < F; ++f) grad[r * F + f] += val[i * F + f];
   }
+}
+
+// Overflowed exchange of a step the loss scaler rejects (found-inf raised on some rank): the optimizer skips the step and CLEARS
+// its gradient instead of keeping it -- so must every rank's local gradient, of which the compaction has left the rows beyond the
+// lists' capacities in place (an inf / NaN loss makes every touched vertex non-zero, zero-weight corners included: the row count
+// jumps exactly on such a step).  A no-op unless both conditions hold.
+__global__ void __launch_bounds__(256)
+grad_lists_discard_kernel(float* __restrict__ grad, int64_t n, const int* __restrict__ counts, const int* __restrict__ caps, int world,
+                          const float* __restrict__ found_inf) {
+  if (found_inf[0] == 0.0f || !nr_lists_overflowed(counts, caps, world)) return;
+  float4* g4 = reinterpret_cast<float4*>(grad);
+  const int64_t n4 = n / 4;
+  const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 g = g4[i];
+    if (g.x != 0.0f || g.y != 0.0f || g.z != 0.0f || g.w != 0.0f) g4[i] = z;  // (NaN != 0)
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) grad[i] = 0.0f;
 }
 
 }  // namespace
@@ -793,13 +814,14 @@ extern "C" int nr_grad_lists_apply(const int* idx, const float* val, int64_t lis
 }
 
 extern "C" int nr_grad_lists_restore(const int* idx, const float* val, int64_t max_cap, const int* counts, const int* caps, int world,
-                                     int own_rank, int64_t rows_per_shard, int F, float* grad, nr_stream_t stream) {
+                                     int own_rank, int64_t rows_per_shard, int F, float* grad, const float* found_inf,
+                                     nr_stream_t stream) {
   if (!idx || !val || !counts || !caps || !grad || max_cap < 1 || world < 1 || world > 64 || own_rank < 0 || own_rank >= world ||
-      rows_per_shard < 1)
+      rows_per_shard < 1 || (((uintptr_t)grad) & 15u) != 0)
     return NR_EINVAL;
   const unsigned blocks = (unsigned)(nr_cdiv(max_cap, 256) < 256 ? nr_cdiv(max_cap, 256) : 256);
 #define CALL(FF) hipLaunchKernelGGL(grad_lists_restore_kernel<FF>, dim3(blocks, (unsigned)world), dim3(256), 0, nr_s(stream), idx, val, \
-                                    counts, caps, world, own_rank, rows_per_shard, grad)
+                                    counts, caps, world, own_rank, rows_per_shard, grad, found_inf)
   switch (F) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;
@@ -808,6 +830,9 @@ extern "C" int nr_grad_lists_restore(const int* idx, const float* val, int64_t m
     default: return NR_EINVAL;
   }
 #undef CALL
+  if (found_inf != nullptr)
+    hipLaunchKernelGGL(grad_lists_discard_kernel, dim3(4096), dim3(256), 0, nr_s(stream), grad, (int64_t)world * rows_per_shard * F, counts,
+                       caps, world, found_inf);
   NR_LAUNCH_CHECK();
   return 0;
 }

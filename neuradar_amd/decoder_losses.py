@@ -110,6 +110,11 @@ class DecoderLossHead:
         self.model, self.layout, self.patch, self.n_scans, self.max_det = model, layout, patch, n_scans, max_detections
         self.c = settings or DecoderLossSettings()
         self.cnn_autocast = cnn_autocast
+        if cnn_autocast is None or os.environ.get("NR_CNN_SHADOW", "1") == "0":
+            # the RGB decoder's convolutions (and their channels-last BACKWARDS) go through MIOpen on this configuration
+            from . import apply_miopen_workaround
+
+            apply_miopen_workaround()
         # fp16 CNN: its backward runs on fp16 activations and gradients, and d loss / d rgb ~ 1e-5 sits below fp16's smallest
         # normal (6e-5) -- the reference trains under GradScaler.  `amp` (step.GradScalerState, set by
         # FusedTrainStep.set_grad_scaler): the camera chain's gradient is multiplied by the dynamic scale where it enters the

@@ -429,9 +429,9 @@ class FusedTrainStep:
     def _host(self, fn, final: bool = False) -> None:
         """A host-side action of the step (a collective, a wait for one, optimizer launches ordered behind one): executed in
         place -- or, while a SegmentedStep captures the step, recorded as the boundary between two graph segments."""
-        # (a segmenter cuts only the step the joins in front of the cuts are written for -- reducer AND fused optimizers: `seg` in
-        # forward_backward; with a reducer alone the streams forked there would be unjoined at the cut)
-        if self._segmenter is None or not getattr(self, "_seg_active", True):
+        # (a segmenter cuts only the step the joins in front of the cuts are written for -- reducer AND fused optimizers:
+        # forward_backward asserts it)
+        if self._segmenter is None:
             fn()
         else:
             self._segmenter.cut(fn, final)

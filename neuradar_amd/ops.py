@@ -1294,11 +1294,14 @@ def grad_lists_apply(idx: Tensor, val: Tensor, counts: Tensor, caps: Tensor, src
                                          _p(shard), _p(flag), _stream()), "nr_grad_lists_apply")
 
 
-def grad_lists_restore(idx: Tensor, val: Tensor, max_cap: int, counts: Tensor, caps: Tensor, own_rank: int, row_width: int, grad: Tensor) -> None:
-    """nr_grad_lists_restore: after an overflowed exchange the rank's own send lists go back into its local gradient (no-op otherwise)."""
+def grad_lists_restore(idx: Tensor, val: Tensor, max_cap: int, counts: Tensor, caps: Tensor, own_rank: int, row_width: int, grad: Tensor,
+                       found_inf: Optional[Tensor] = None) -> None:
+    """nr_grad_lists_restore: after an overflowed exchange the rank's own send lists go back into its local gradient (no-op
+    otherwise) -- unless the loss scaler's flag `found_inf` is raised: then the whole local gradient is cleared instead."""
     world = caps.numel()
     check(_lib.lib().nr_grad_lists_restore(_p(idx), _p(val), int(max_cap), _p(counts), _p(caps), world, int(own_rank),
-                                           grad.numel() // (world * row_width), row_width, _p(grad), _stream()), "nr_grad_lists_restore")
+                                           grad.numel() // (world * row_width), row_width, _p(grad), _p(found_inf), _stream()),
+          "nr_grad_lists_restore")
 
 
 def uniform_fill(out: Tensor, seed: int, epoch: Optional[Tensor] = None) -> Tensor:

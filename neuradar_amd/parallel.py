@@ -183,7 +183,9 @@ class GradAllReducer:
         # 1. reduce-scatter
         lists, keep = None, None
         if transport is None and row_width is not None and getattr(self, "shard_lists", True) and per % row_width == 0:
-            lists = self._lists_to_owners(g, lo, hi, int(row_width), list_kernels)  # None: this step goes dense
+            amp = getattr(opt, "amp", None)  # (the loss scaler's found-inf flag of this optimizer, summed over the ranks by now)
+            lists = self._lists_to_owners(g, lo, hi, int(row_width), list_kernels,
+                                          found_inf=None if amp is None else amp.found(opt.amp_group))  # None: this step goes dense
             keep = None if lists is None else lists["flag"]
         if lists is not None:
             pass
@@ -247,7 +249,7 @@ class GradAllReducer:
                                      "list_rows_per_destination": lists["caps"], "dense_reduce_scatter_would_be": int(f * n * 4)})
         return self.last_sparse
 
-    def _lists_to_owners(self, g: torch.Tensor, lo: int, hi: int, F: int, kernels=None) -> Optional[dict]:
+    def _lists_to_owners(self, g: torch.Tensor, lo: int, hi: int, F: int, kernels=None, found_inf=None) -> Optional[dict]:
         """The gradient half of the sharded step for a SPARSE gradient: afterwards g[lo:hi] holds the sum over the ranks of the
         rows this rank owns and the rest of g is zero -- what the dense reduce-scatter (+ clearing) leaves -- without moving
         the zeros.  g: flat [world * per] fp32 gradient of a [rows, F] table, shard d = elements [d * per, (d + 1) * per).
@@ -268,7 +270,9 @@ class GradAllReducer:
           5. a step whose count jumps past a segment's capacity is caught on the device from the gathered counts: nobody applies
              anything, nr_grad_lists_restore puts every rank's own rows back, the returned flag (= 2) makes the owner's Adam skip
              the step and keep the gradient; the next step's scatter adds onto it and the next exchange (sized from the counts
-             known by then) carries both.  Replicas stay bit-identical, nothing is lost.
+             known by then) carries both.  Replicas stay bit-identical, nothing is lost.  Exception: a step the loss scaler
+             rejects (found_inf raised: the optimizer skips AND clears) -- an inf / NaN loss makes every touched vertex non-zero,
+             so the count jumps on exactly such a step; its gradient is then discarded on every rank instead of kept.
         Returns {"flag", "bytes" (per GPU on the wire), "caps"} or None when this step is to go dense (the caller then runs the
         reduce-scatter).  Reference semantics: the fp32 gradient mean of DDP, pipelines/base_pipeline.py:305-307."""
         world, per = self.world, hi - lo
@@ -345,7 +349,7 @@ class GradAllReducer:
         for src in range(world):  # rank order, plain adds
             lists_apply(idx_r[src * mine:(src + 1) * mine], val_r[src * mine:(src + 1) * mine], st["cm"], st["caps_dev"], src, rank, F,
                         shard, st["flag"])
-        lists_restore(idx_s, val_s, max(caps), st["cm"], st["caps_dev"], rank, F, g)
+        lists_restore(idx_s, val_s, max(caps), st["cm"], st["caps_dev"], rank, F, g, found_inf)
         return {"flag": st["flag"], "bytes": (total - mine) * (4 + 4 * F), "caps": list(caps)}
 
     def _all_gather_g(self, out: torch.Tensor, mine: torch.Tensor) -> None:

@@ -338,26 +338,34 @@ class NeuRadarHotPath(nn.Module):
 
     def _fused_renderer(self, max_rays: int):
         """The forward-only launch chain of the rendering entry (fused_render.FusedRenderer); None where it does not apply
-        (dynamic actors, density branch, tcnn-layout tables, NR_FUSED_RENDER=0): the modular path.  ONE renderer sized
-        eval_num_rays_per_chunk serves every reading that fits it (render() takes any n <= its size; ~20 KB of buffers per ray);
-        only a radar scan LONGER than a chunk (its decoder attends over the whole scan, so it is rendered in one piece) gets a
-        larger one, rounded up to a power of two, and only the latest of those is kept -- evaluating many scans of varying
-        length no longer grows GPU memory with every new ray count."""
+        (dynamic actors, density branch, tcnn-layout tables, NR_FUSED_RENDER=0): the modular path.  ONE renderer is kept, sized to
+        the largest request so far rounded up to a power of two (render() takes any n <= its size; about 20 KB of buffers per
+        ray): a 16-ray lidar reading allocates a 16-ray renderer, a full image one chunk (eval_num_rays_per_chunk = 32 768 rays:
+        650 MB) that then also serves the small readings, a radar scan longer than a chunk (rendered in one piece: its decoder
+        attends over the whole scan) a larger one.  It stays on the model across training steps; release_render_buffers() drops
+        it."""
         if os.environ.get("NR_FUSED_RENDER", "1") == "0":
             return None
         cache = self.__dict__.setdefault("_fused_render_cache", {})
-        base = int(self.config.eval_num_rays_per_chunk)
-        size = base if max_rays <= base else 1 << (max_rays - 1).bit_length()
-        if size not in cache:
-            from .fused_render import FusedRenderer
+        have = cache.get("renderer")
+        if cache.get("unsupported"):
+            return None
+        if have is not None and have.B >= max_rays:
+            return have
+        from .fused_render import FusedRenderer
 
-            for k in [k for k in cache if k != base]:  # at most one oversize renderer alive
-                del cache[k]
-            try:
-                cache[size] = FusedRenderer(self, size)
-            except NotImplementedError:
-                cache[size] = None
-        return cache[size]
+        size = max(16, 1 << (int(max_rays) - 1).bit_length())
+        cache["renderer"] = None  # (the smaller one goes first: never two alive)
+        del have
+        try:
+            cache["renderer"] = FusedRenderer(self, size)
+        except NotImplementedError:
+            cache["unsupported"] = True
+        return cache["renderer"]
+
+    def release_render_buffers(self) -> None:
+        """Free the rendering entry's persistent device buffers (the FusedRenderer; rebuilt by the next rendered reading)."""
+        self.__dict__.pop("_fused_render_cache", None)
 
     def decode_lidar(self, features: Tensor, is_lidar: Tensor):
         """decode_features, lidar branch (neuradar.py:432-452): the lidar rays' rendered features through the

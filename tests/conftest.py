@@ -41,6 +41,11 @@ def pytest_configure(config):
     global _CONFIG
     _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tests' reference legs run channels-last convolution backwards through MIOpen (torch.autocast CNNs): the explicit
+    # workaround for MIOpen 3.5.0's overrunning NHWC backward-data kernels, inherited by every child process the tests start
+    import neuradar_amd
+
+    neuradar_amd.apply_miopen_workaround()
     _c_level_stderr_to_the_log(config)
     want = os.environ.get("NR_TEST_XDIST", "auto")
     if want == "0" or _is_worker(config) or not config.pluginmanager.hasplugin("xdist"):

@@ -288,8 +288,11 @@ def _torch_lists_apply(idx, val, cm, caps, src, own, F, shard, flag):
     shard.view(-1, F).index_add_(0, idx[:n].long(), val[:n])  # (unique rows within one list)
 
 
-def _torch_lists_restore(idx, val, max_cap, cm, caps, own, F, g):
+def _torch_lists_restore(idx, val, max_cap, cm, caps, own, F, g, found_inf=None):
     if not _lists_overflowed(cm, caps):
+        return
+    if found_inf is not None and float(found_inf[0]) != 0.0:  # the loss scaler rejects the step: discard, do not keep
+        g.zero_()
         return
     w = caps.numel()
     G = g.view(w, -1, F)
@@ -391,6 +394,71 @@ def test_two_rank_row_lists_overflow_keeps_the_gradient_then_dense_then_back():
     once a re-count (every 2 dense steps here) sees the 0.05 steps."""
     dens = [0.1, 0.1, 0.14, 0.14, 0.14, 0.7, 0.7, 0.05, 0.05, 0.05, 0.05, 0.05]
     mp.spawn(_lists_entry, args=(2, _free_port(), False, dens, "overflow_story"), nprocs=2, join=True)
+
+
+class _StubAmp:
+    def __init__(self):
+        self.flag = torch.zeros(1)
+
+    def found(self, group):
+        return self.flag
+
+
+def _lists_found_inf_worker(rank, world, port):
+    """A step the loss scaler rejects AND whose lists overflow (an inf loss makes every touched vertex non-zero: the row count jumps
+    on exactly such a step): the optimizer skips and clears -- and so must every rank's whole local gradient, although the exchange
+    alone would have kept it (seen on the GPU: the kept NaN rows poisoned the next step too and the replicas diverged)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neuradar_amd.parallel import GradAllReducer, init_distributed
+
+    init_distributed(backend="gloo")
+    F, rows = 4, 1 << 12
+    n = rows * F
+    p = torch.linspace(-1, 1, n).clone()
+    red = GradAllReducer(None, buffers=[], table_mode="shard")
+    red.list_granularity = 16
+    grad = torch.zeros(n)
+
+    class Opt(_StubOptSkip):
+        def step_buffer(self, i, grad_scale, delta16=None, skip_extra=None):
+            (p_, g_), (lo, hi) = self.buffers[i], self.shards[i]
+            if float(self.amp.flag[0]) != 0.0:  # found-inf takes precedence (FlatAdam.step_buffer): skip and CLEAR the shard's gradient
+                g_[lo:hi] = 0
+                return
+            super().step_buffer(i, grad_scale, delta16=delta16, skip_extra=skip_extra)
+
+    opt = Opt(p, grad, rank, world)
+    opt.amp, opt.amp_group = _StubAmp(), 0
+    kern = dict(kernels=(_torch_to16_clear, _torch_apply_delta), list_kernels=(_torch_compact_shards, _torch_lists_apply, _torch_lists_restore))
+    for stepno, (dens, poisoned) in enumerate([(0.1, False), (0.1, False), (0.3, True), (0.1, False)]):
+        g = torch.Generator().manual_seed(10 * stepno + rank)
+        hit = torch.rand(rows, generator=g) < dens
+        fresh = torch.where(hit[:, None], torch.randn(rows, F, generator=g), torch.zeros(rows, F)).reshape(-1)
+        if poisoned and rank == 1:
+            fresh = torch.where(fresh != 0, torch.full_like(fresh, float("nan")), fresh)
+        grad += fresh
+        opt.amp.flag[0] = 1.0 if poisoned else 0.0  # (already summed over the ranks: raised on both)
+        total = torch.nan_to_num(grad.clone())
+        dist.all_reduce(total)
+        before = p.clone()
+        info = red.shard_step(opt, 0, 1.0 / world, defer=True, row_width=F, **kern)
+        assert info["gradient_half"].startswith("row lists")
+        assert float(grad.abs().nan_to_num(nan=1.0).max()) == 0.0, f"step {stepno}: the local gradient must be clear on every rank"
+        if poisoned:
+            assert float(next(iter(red._lists_state.values()))["flag"][0]) == 2.0, "the poisoned step was meant to overflow the lists"
+            assert torch.equal(p, before)
+        else:
+            assert torch.equal(p, before - 0.1 / world * total)
+        gathered = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(gathered, p)
+        assert all(torch.equal(t, gathered[0]) for t in gathered) and bool(torch.isfinite(p).all())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_lists_overflow_on_a_step_the_loss_scaler_rejects_discards_the_gradient():
+    mp.spawn(_lists_found_inf_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
 def test_two_rank_sparse_table_exchange():

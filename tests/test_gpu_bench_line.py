@@ -33,6 +33,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # round 3: the dominant site by itself, the MFMA counter of the field kernels, the trained regime, the decoder workloads
     assert roof["serialised_us"] > 0 and roof["serialised_us"] <= roof["avg_us"] * 1.25
     assert abs(roof["frac_serialised"] - roof["bytes_per_launch"] / (roof["serialised_us"] * 1e-6) / 1e9 / roof["peak"]) < 1e-3
+    # round 6: `frac` comes from the SERIALISED bracket (the site's kernels alone on the chip: reproducible, what rocprofv3's kernel
+    # averages add up to); the in-step bracket of the site that stays in flight longest is kept under `in_step`; `traffic` names
+    # the committed profile it was read from
+    assert roof["timing"].startswith("SERIALISED") and roof["serialised_us"] == roof["avg_us"] and roof["frac_serialised"] == roof["frac"]
+    ins = roof["in_step"]
+    assert ins["timing"].startswith("IN-STEP") and ins["avg_us"] >= 0.8 * ins["serialised_us"] and abs(ins["frac"] - ins["achieved"] / 8000.0) < 1e-3
+    assert (roof["traffic"] is None) == (roof["traffic_source"] is None) and (roof["traffic"] is None or "NOT measured in this run" in roof["traffic_source"])
     assert roof["mfma_busy_frac"] is None or all(0 <= v <= 1 for k, v in roof["mfma_busy_frac"].items() if k != "source")
     tr = r["trained"]
     assert tr["steps_trained"] == 40 and tr["value"] > 0 and tr["roofline"]["bound"] == "hbm" and tr["roofline"]["serialised_us"] > 0

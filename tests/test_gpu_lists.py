@@ -68,12 +68,13 @@ def test_compact_shards_vs_torch(F, world, caps_frac):
     assert torch.equal(full.reshape(-1), _gradient(rows, F, 0.1, 5 + F + world, dev))
 
 
-@pytest.mark.parametrize("overflow", [False, True])
-def test_lists_apply_and_restore_vs_torch(overflow):
+@pytest.mark.parametrize("overflow,found", [(False, False), (True, False), (True, True), (False, True)])
+def test_lists_apply_and_restore_vs_torch(overflow, found):
     """One rank's view of a 4-rank exchange: its send lists (compacted here), four received lists (made up: each source's rows of
     this rank's shard), the gathered counts.  Without overflow the owner's shard becomes the rank-order sum and restore is a
     no-op; with one overflowing (source, destination) pair NOTHING is applied, the flag says 2 and restore makes the local
-    gradient whole again."""
+    gradient whole again -- unless the loss scaler's found-inf flag is raised as well: then the whole local gradient (here with a
+    few rows the lists had no room for left in it) is cleared instead."""
     from neuradar_amd import ops
 
     dev = torch.device("cuda", 0)
@@ -90,13 +91,12 @@ def test_lists_apply_and_restore_vs_torch(overflow):
     idx_r, val_r = torch.zeros(world * mine, dtype=torch.int32, device=dev), torch.zeros(world * mine, F, device=dev)
     gen = torch.Generator().manual_seed(3)
     for src in range(world):
-        n = 400 + 50 * src
+        n = 400 + 50 * src if src != own else int(counts[own])  # (the own list's length is what the compaction counted)
         rows_ = torch.randperm(per, generator=gen)[:n].to(torch.int32)
         idx_r[src * mine:src * mine + n] = rows_.to(dev)
         val_r[src * mine:src * mine + n] = torch.randn(n, F, generator=gen).to(dev)
         cm[src] = torch.tensor([500, 480, n, 450], dtype=torch.int32)
     cm[own] = counts.cpu()
-    cm[own, own] = 400 + 50 * own
     if overflow:
         cm[1, 3] = int(caps[3]) + 1  # some OTHER pair's list did not fit: every rank must take the same branch
     cm_dev = cm.reshape(-1).to(dev)
@@ -107,11 +107,17 @@ def test_lists_apply_and_restore_vs_torch(overflow):
         ops.grad_lists_apply(idx_r[src * mine:(src + 1) * mine], val_r[src * mine:(src + 1) * mine], cm_dev, caps.to(dev), src, own, F, shard, flag)
         _torch_lists_apply(idx_r[src * mine:(src + 1) * mine].cpu(), val_r[src * mine:(src + 1) * mine].cpu(), cm.reshape(-1), caps, src, own, F,
                            ref_g[own * per * F:(own + 1) * per * F], ref_flag)
-    ops.grad_lists_restore(idx_s, val_s, int(caps.max()), cm_dev, caps.to(dev), own, F, g)
-    _torch_lists_restore(idx_s.cpu(), val_s.cpu(), int(caps.max()), cm.reshape(-1), caps, own, F, ref_g)
+    found_inf = torch.full((1,), 1.0 if found else 0.0, device=dev)
+    if overflow and found:
+        g[5 * F] = float("nan")  # (a row the compaction had no room for)
+        ref_g[5 * F] = float("nan")
+    ops.grad_lists_restore(idx_s, val_s, int(caps.max()), cm_dev, caps.to(dev), own, F, g, found_inf)
+    _torch_lists_restore(idx_s.cpu(), val_s.cpu(), int(caps.max()), cm.reshape(-1), caps, own, F, ref_g, found_inf.cpu())
     assert float(flag) == float(ref_flag) == (2.0 if overflow else 0.0)
     assert torch.equal(g.cpu(), ref_g)
-    if overflow:
+    if overflow and found:
+        assert float(g.abs().max()) == 0.0, "a rejected step's gradient is discarded everywhere"
+    elif overflow:
         assert torch.equal(g, g0), "after an overflowed exchange the local gradient is whole again"
     else:
         assert float(g.view(world, -1)[torch.arange(world) != own].abs().max()) == 0.0
