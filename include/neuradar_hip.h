@@ -56,7 +56,8 @@ enum {
   NR_TUNE_FIELD_BWD_BLOCKS = 4,  /* blocks (= gradient slabs) of nr_field_bwd* (default 256 fp32 / 512 16-bit) */
   NR_TUNE_PDBWD_BLOCKS = 5,      /* blocks of nr_prop_density_bwd (default 256) */
   NR_TUNE_ADAM_BLOCKS = 6,       /* blocks of nr_adam_step* (default 4096) */
-  NR_TUNE_PW_MFMA_OFF = 7        /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+  NR_TUNE_PW_MFMA_OFF = 7,       /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+  NR_TUNE_SHARED_LINE_TABLE = 8  /* 1: nr_hash_encode_bwd_shared on the LINE-keyed table (round-6 experiment, measured slower: DESIGN section 5) */
 };                               /* (v27: knobs 8 / 9 of v26 -- NR_TUNE_PROP_SHARED_* -- are gone: nothing read them) */
 int nr_init(void);
 int nr_set_tuning(int knob, int value);
@@ -214,6 +215,28 @@ typedef struct nr_conv7_list {
   int64_t offset[NR_CONV7_MAX];
   int64_t bias_offset[NR_CONV7_MAX];
 } nr_conv7_list_t;
+/* Rendering (ABI v27): the eval-mode batch norm that follows each of the n convolutions FOLDED into its weights and bias --
+ * W'[o] = W[o] gamma[o] / sqrt(var[o] + eps), b' = (b - mean) gamma / sqrt(var + eps) + beta (model_components/cnns.py:21-47 in
+ * eval mode) -- straight from the fp32 master parameters into images[k][0] (the forward orientation of nr_conv7_pack's array), in
+ * one launch.  weight[k]: fp32, element (o, tap t = ky * 7 + kx, i) at o * stride_o + t * stride_t + i * stride_i (any memory
+ * format); bias[k] nullable.  state: two device uint32 owned by the caller, zero-initialised: the launch EARLY-OUTS on the device
+ * while state[0] matches the device's parameter-generation word (nr_param_generation: bumped by every optimizer step, sharded
+ * delta apply and batch-norm running-statistics update of this library, graph replays included) unless force != 0 (the caller saw
+ * a torch-side change: a version counter, a rebound tensor); state[1] counts the rebuilds. */
+typedef struct {
+  int n;
+  const float* weight[NR_CONV7_MAX];
+  int64_t stride_o[NR_CONV7_MAX], stride_t[NR_CONV7_MAX], stride_i[NR_CONV7_MAX];
+  const float* bias[NR_CONV7_MAX];
+  const float* gamma[NR_CONV7_MAX];
+  const float* beta[NR_CONV7_MAX];
+  const float* mean[NR_CONV7_MAX];
+  const float* var[NR_CONV7_MAX];
+  float eps[NR_CONV7_MAX];
+} nr_conv7_fold_t;
+int nr_conv7_fold_pack(const nr_conv7_fold_t* list, int dtype, void* images, uint32_t* state, int force, nr_stream_t stream);
+/* The device's parameter-generation word (device pointer; NULL before nr_init on this device). */
+const uint32_t* nr_param_generation(void);
 int64_t nr_conv7_image_bytes(void);
 int nr_conv7_pack(const void* weights16, const nr_conv7_list_t* list, int dtype, void* images, nr_stream_t stream);
 int nr_conv7_fwd(const void* x16, const void* image, const void* residual16, int relu, void* y16, int n_images, int height,

@@ -43,6 +43,12 @@ class NrConv7List(Structure):
     _fields_ = [("n", c_int), ("offset", c_int64 * 16), ("bias_offset", c_int64 * 16)]
 
 
+class NrConv7Fold(Structure):
+    _fields_ = [("n", c_int), ("weight", c_void_p * 16), ("stride_o", c_int64 * 16), ("stride_t", c_int64 * 16), ("stride_i", c_int64 * 16),
+                ("bias", c_void_p * 16), ("gamma", c_void_p * 16), ("beta", c_void_p * 16), ("mean", c_void_p * 16), ("var", c_void_p * 16),
+                ("eps", c_float * 16)]
+
+
 _ENC_PARAMS = ("in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias", "linear1_weight", "linear1_bias",
                "linear2_weight", "linear2_bias", "norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias", "norm_weight", "norm_bias")
 
@@ -105,6 +111,8 @@ PROTOTYPES = {
     "nr_radar_heads_bwd": [P, P, I, P, L, P, P, P, P],
     "nr_conv7_image_bytes": [],
     "nr_conv7_pack": [P, POINTER(NrConv7List), I, P, P],
+    "nr_conv7_fold_pack": [POINTER(NrConv7Fold), I, P, P, I, P],
+    "nr_param_generation": [],
     "nr_conv7_fwd": [P, P, P, I, P, I, I, I, I, P],
     "nr_conv7_wgrad_workspace_bytes": [],
     "nr_conv7_wgrad": [P, P, P, P, I, P, I, I, I, I, P],
@@ -193,7 +201,7 @@ PROTOTYPES = {
     "nr_gen_rays_camera_patches": [P, L, I, I, I, I, I, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "nr_uniform_fill": [P, L, c_uint32, P, P],
 }
-_RESTYPES = {"nr_target_arch": c_char_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
+_RESTYPES = {"nr_target_arch": c_char_p, "nr_param_generation": c_void_p, "nr_field_bwd_workspace_floats": c_int64, "nr_field_image_floats": c_int64,
              "nr_field_stash_floats": c_int64, "nr_hash_encode_bwd_binned_workspace_bytes": c_int64,
              "nr_tcnn_grid_param_count": c_int64, "nr_attention_workspace_floats": c_int64,
              "nr_radar_assign_workspace_bytes": c_int64, "nr_radar_assign_status_offset": c_int64,
@@ -247,7 +255,8 @@ def lib() -> ctypes.CDLL:
 TUNING = (("NR_CONV7_BLOCKS", "persistent blocks of nr_conv7_fwd"), ("NR_BIN_BLOCKS_PER_CU", "bin blocks per half CU"),
           ("NR_SHARED_BLOCKS", "blocks of nr_hash_encode_bwd_shared"), ("NR_FIELD_FWD_BLOCKS", "blocks of nr_field_fwd*"),
           ("NR_FIELD_BWD_BLOCKS", "blocks of nr_field_bwd*"), ("NR_PDBWD_BLOCKS", "blocks of nr_prop_density_bwd"),
-          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"))
+          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"),
+          ("NR_SHARED_LINE_TABLE", "1: the main grid's block-shared scatter keyed by 64-byte line (round-6 experiment) instead of by vertex"))
 # variables earlier rounds read and this build ignores: setting one is an A/B run that compares identical code -- refuse it loudly
 RETIRED_ENV = {"NR_PW_MFMA": "use NR_PW_MFMA_OFF=1", "NR_PROP_SHARED_OFF": "no kernel ever read it (removed in ABI v27)",
                "NR_PROP_SHARED_BLOCKS": "no kernel ever read it (removed in ABI v27)"}

@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ residual, int64_t M, int C, const float* __restrict__ partial, int nblk,
                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                 float* __restrict__ running_mean, float* __restrict__ running_var, int relu, T* __restrict__ y,
-                float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+                float* __restrict__ save_mean, float* __restrict__ save_rstd, uint32_t* __restrict__ generation) {
   __shared__ float tot[2][64];
+  if (running_mean != nullptr && blockIdx.x == 0 && threadIdx.x == 0) nr_bump_generation(generation);  // (the running statistics move)
   __shared__ float scale[64], shift[64];
   bn_total(partial, nblk, C, tot);
   const int tid = threadIdx.x;
@@ -231,7 +232,8 @@ extern "C" int nr_bn_act_fwd(const void* x, const void* residual, int64_t M, int
 #define NR_BN_FWD(T)                                                                                                                  \
   hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nblk), dim3(kBnThreads), 0, nr_s(stream), (const T*)x, M, C, workspace);                 \
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(nblk), dim3(kBnThreads), 0, nr_s(stream), (const T*)x, (const T*)residual, M, C,         \
-                     workspace, nblk, gamma, beta, eps, momentum, running_mean, running_var, relu, (T*)y, save_mean, save_rstd)
+                     workspace, nblk, gamma, beta, eps, momentum, running_mean, running_var, relu, (T*)y, save_mean, save_rstd, \
+                     nr_generation_ptr())
   if (dtype == NR_DTYPE_F32) { NR_BN_FWD(float); } else if (dtype == NR_DTYPE_BF16) { NR_BN_FWD(__bf16); } else { NR_BN_FWD(_Float16); }
 #undef NR_BN_FWD
   NR_LAUNCH_CHECK();

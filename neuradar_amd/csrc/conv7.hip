@@ -83,6 +83,48 @@ conv7_pack_kernel(const E* __restrict__ wbase, nr_conv7_list_t list, unsigned ch
   }
 }
 
+// Rendering: BN(conv(x)) of a BasicBlock in eval mode as ONE convolution -- W'[o] = W[o] gamma[o] / sqrt(var[o] + eps),
+// b' = (b - mean) gamma / sqrt(var + eps) + beta (model_components/cnns.py:21-47, torch BatchNorm2d eval) -- folded from the fp32
+// master parameters and written as the forward weight image in one launch, with an EARLY OUT on the device: state[0] holds the
+// parameter generation (+ 1) the images were built from; unless `force`, nothing is done while it still matches the device's
+// generation word (nr_common.h) -- no host read, no version counter that raw-pointer optimizers bypass.  state[1] counts the
+// rebuilds (tests).  A second one-thread launch commits state[0] after every block of the first has read it.
+template <typename E>
+__global__ void __launch_bounds__(256)
+conv7_fold_pack_kernel(nr_conv7_fold_t list, unsigned char* __restrict__ images, const uint32_t* __restrict__ generation,
+                       const uint32_t* __restrict__ state, int force) {
+  if (!force && generation != nullptr && state[0] == *generation + 1u) return;
+  const int conv = blockIdx.y;
+  const float* w = list.weight[conv];
+  const int64_t so = list.stride_o[conv], st = list.stride_t[conv], si = list.stride_i[conv];
+  unsigned char* dst = images + (int64_t)conv * 2 * kImgAll;  // (orientation 0 of the [n, 2, bytes] image array)
+  E* img = reinterpret_cast<E*>(dst);
+  __shared__ float kf[kC];
+  if (threadIdx.x < kC)
+    kf[threadIdx.x] = list.gamma[conv][threadIdx.x] / sqrtf(list.var[conv][threadIdx.x] + list.eps[conv]);
+  __syncthreads();
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kImg / 2; e += gridDim.x * blockDim.x) {
+    const int j = e & 7, lane = (e >> 3) & 63, frag = e >> 9, c = frag & 1, t = frag >> 1;
+    const int r = lane & 31, h = lane >> 5, k = 16 * c + 8 * h + j;
+    img[e] = (E)(w[r * so + t * st + k * si] * kf[r]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < kC) {
+    const int o = threadIdx.x;
+    const float b = list.bias[conv] != nullptr ? list.bias[conv][o] : 0.0f;
+    // (the bias passes through the 16-bit type like the weights do: what the torch-side fold this replaces handed to nr_conv7_pack)
+    reinterpret_cast<float*>(dst + kImg)[o] = (float)(E)((b - list.mean[conv][o]) * kf[o] + list.beta[conv][o]);
+  }
+}
+
+__global__ void conv7_fold_commit_kernel(const uint32_t* __restrict__ generation, uint32_t* __restrict__ state, int force) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t now = generation != nullptr ? *generation + 1u : 0u;
+  if (force || generation == nullptr || state[0] != now) {
+    state[0] = now;
+    state[1] += 1u;
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 conv7_kernel(const typename T::elem* __restrict__ x, const unsigned char* __restrict__ image,
@@ -341,6 +383,26 @@ extern "C" int nr_conv7_pack(const void* weights16, const nr_conv7_list_t* list,
   else
     hipLaunchKernelGGL(conv7_pack_kernel<_Float16>, grid, dim3(256), 0, nr_s(stream), static_cast<const _Float16*>(weights16), *list,
                        static_cast<unsigned char*>(images));
+  NR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int nr_conv7_fold_pack(const nr_conv7_fold_t* list, int dtype, void* images, uint32_t* state, int force, nr_stream_t stream) {
+  if (!list || list->n == 0) return 0;
+  if (!images || !state || list->n < 0 || list->n > NR_CONV7_MAX || (dtype != NR_DTYPE_BF16 && dtype != NR_DTYPE_F16) ||
+      ((uintptr_t)images & 15u) != 0)
+    return NR_EINVAL;
+  for (int k = 0; k < list->n; ++k)
+    if (!list->weight[k] || !list->gamma[k] || !list->beta[k] || !list->mean[k] || !list->var[k]) return NR_EINVAL;
+  const uint32_t* gen = nr_generation_ptr();
+  const dim3 grid(8, (unsigned)list->n);
+  if (dtype == NR_DTYPE_BF16)
+    hipLaunchKernelGGL(conv7_fold_pack_kernel<__bf16>, grid, dim3(256), 0, nr_s(stream), *list, static_cast<unsigned char*>(images), gen, state,
+                       force);
+  else
+    hipLaunchKernelGGL(conv7_fold_pack_kernel<_Float16>, grid, dim3(256), 0, nr_s(stream), *list, static_cast<unsigned char*>(images), gen,
+                       state, force);
+  hipLaunchKernelGGL(conv7_fold_commit_kernel, dim3(1), dim3(64), 0, nr_s(stream), gen, state, force);
   NR_LAUNCH_CHECK();
   return 0;
 }

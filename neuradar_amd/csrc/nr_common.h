@@ -29,8 +29,17 @@ struct NrTuning {
   int pdbwd_blocks;        // NR_TUNE_PDBWD_BLOCKS: blocks of nr_prop_density_bwd
   int adam_blocks;         // NR_TUNE_ADAM_BLOCKS
   int pw_mfma_off;         // NR_TUNE_PW_MFMA_OFF: 1 = the transposed convolution on the generic pointwise kernels
+  int shared_line_table;   // NR_TUNE_SHARED_LINE_TABLE: 1 = the main grid's block-shared scatter keyed by 64-byte line (experiment) instead of by vertex
 };
 const NrTuning& nr_tuning();
+// The device's PARAMETER GENERATION word (capi.hip; allocated by nr_init, NULL before): bumped on the device by every launch that
+// writes parameters through raw pointers (the optimizers' schedule kernel nr_adam_hyper -- once per optimizer step --,
+// nr_apply_delta16, nr_bn_act_fwd's running statistics), graph replays included.  Consumers that cache something derived from
+// parameters (nr_conv7_fold_pack) compare it ON THE DEVICE: no host read, no version counter that raw-pointer writes bypass.
+uint32_t* nr_generation_ptr();
+__device__ __forceinline__ void nr_bump_generation(uint32_t* gen) {
+  if (gen != nullptr) atomicAdd(gen, 1u);
+}
 // per-file attribute setup, called by nr_init()
 int nr_init_conv7();
 int nr_init_encoder();

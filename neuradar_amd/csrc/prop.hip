@@ -215,7 +215,9 @@ adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restri
 // [lo, hi) (the owner's Adam launch has applied its deltas already); zero groups -- most of a table in any one step -- cost
 // their 8 bytes of delta only.
 __global__ void __launch_bounds__(256)
-apply_delta16_kernel(float* __restrict__ p, const __bf16* __restrict__ delta, int64_t n, int64_t lo, int64_t hi) {
+apply_delta16_kernel(float* __restrict__ p, const __bf16* __restrict__ delta, int64_t n, int64_t lo, int64_t hi,
+                     uint32_t* __restrict__ generation) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) nr_bump_generation(generation);
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     if (i * 4 >= lo && i * 4 < hi) continue;  // (shards are whole 16-byte groups)
@@ -403,8 +405,9 @@ adam_split_kernel(float* __restrict__ param, float* __restrict__ grad, float* __
 // (ExponentialDecayScheduler, engine/schedulers.py:112-143; LambdaLR applies func(k-1) to step k).
 __global__ void adam_hyper_kernel(float* __restrict__ step_t, float* __restrict__ hyper, float lr, float lr_final,
                                   int warmup, int max_steps, float beta1, float beta2, const float* __restrict__ amp,
-                                  int amp_group) {
+                                  int amp_group, uint32_t* __restrict__ generation) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  nr_bump_generation(generation);  // an optimizer step is about to rewrite parameters (graph replays pass here too)
   // step_t[0]: scheduler steps so far, step_t[1]: optimizer updates so far.  A step the loss scaler skipped is not counted:
   // the counters were advanced at the top of that step, before its gradients were known, so they are taken back here.
   double step = (double)step_t[0], upd = (double)step_t[1];
@@ -880,7 +883,7 @@ extern "C" int nr_adam_hyper(float* step_t, float* hyper, float lr, float lr_fin
   if (!step_t || !hyper || !(lr > 0.0f) || !(lr_final > 0.0f) || warmup < 0 || max_steps < 1) return NR_EINVAL;
   if (amp != nullptr && (amp_group < 0 || amp_group >= NR_AMP_MAX_GROUPS)) return NR_EINVAL;
   hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, nr_s(stream), step_t, hyper, lr, lr_final, warmup, max_steps,
-                     beta1, beta2, amp, amp_group);
+                     beta1, beta2, amp, amp_group, nr_generation_ptr());
   NR_LAUNCH_CHECK();
   return 0;
 }
@@ -995,7 +998,7 @@ extern "C" int nr_apply_delta16(float* param, const void* delta16, int64_t n, in
     return NR_EINVAL;
   const int64_t want = nr_cdiv(n / 4 + 1, 256);
   hipLaunchKernelGGL(apply_delta16_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, nr_s(stream), param,
-                     static_cast<const __bf16*>(delta16), n, lo, hi);
+                     static_cast<const __bf16*>(delta16), n, lo, hi, nr_generation_ptr());
   NR_LAUNCH_CHECK();
   return 0;
 }

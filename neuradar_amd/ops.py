@@ -988,6 +988,35 @@ def conv7_pack(flat16: Tensor, weight_offsets, bias_offsets, images: Optional[Te
     return images
 
 
+def conv7_fold_pack(pairs, dtype: torch.dtype, images: Optional[Tensor], state: Tensor, force: bool) -> Tensor:
+    """nr_conv7_fold_pack: `pairs` = [(Conv2d 32 -> 32 7 x 7, BatchNorm2d)] in eval mode -> images uint8 [n, 2, bytes / 2] whose
+    [k, 0] is the LDS image of BN_k(conv_k(.)) as ONE convolution, built from the fp32 master parameters in one launch that
+    early-outs ON THE DEVICE while `state[0]` (two device int32 of the caller, zero-initialised) matches the device's
+    parameter-generation word -- unless `force`.  state[1] counts the rebuilds."""
+    n = len(pairs)
+    half = _lib.lib().nr_conv7_image_bytes() // 2
+    dev = pairs[0][0].weight.device
+    if images is None:
+        images = torch.zeros(n, 2, half, device=dev, dtype=torch.uint8)
+        force = True
+    lst = _lib.NrConv7Fold()
+    lst.n = n
+    for k, (cv, bn) in enumerate(pairs):
+        w = cv.weight
+        if w.dtype != torch.float32 or w.shape != (32, 32, 7, 7) or w.stride(2) != 7 * w.stride(3):
+            raise NotImplementedError("conv7_fold_pack: fp32 [32, 32, 7, 7] weights whose taps are one strided axis")
+        for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise NotImplementedError("conv7_fold_pack: fp32 contiguous batch-norm tensors")
+        lst.weight[k], lst.stride_o[k], lst.stride_i[k], lst.stride_t[k] = w.data_ptr(), w.stride(0), w.stride(1), w.stride(3)
+        lst.bias[k] = cv.bias.data_ptr() if cv.bias is not None else None
+        lst.gamma[k], lst.beta[k] = bn.weight.data_ptr(), bn.bias.data_ptr()
+        lst.mean[k], lst.var[k], lst.eps[k] = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps)
+    _stream_ = _stream()  # (also: nr_init on this device -- the generation word exists)
+    check(_lib.lib().nr_conv7_fold_pack(byref(lst), _DT16[dtype], _p(images), _p(state), int(bool(force)), _stream_), "nr_conv7_fold_pack")
+    return images
+
+
 def conv7_forward(x: Tensor, image: Tensor, residual: Optional[Tensor] = None, relu: bool = False) -> Tensor:
     """nr_conv7_fwd on a channels-last 16-bit activation x [P, 32, H, W] (memory [P, H, W, 32]) -> the same shape and format."""
     P, C, H, W = x.shape

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "neuradar_hip.h")
 def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    decls = re.findall(r"\b(?:int64_t|int|const char\*)\s+(nr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    decls = re.findall(r"\b(?:int64_t|int|const char\*|const uint32_t\*)\s+(nr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
     return {name: [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"] for name, args in decls}
 
 

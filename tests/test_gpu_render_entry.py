@@ -138,7 +138,8 @@ def test_fused_render_chain_equals_the_modular_eval_path(mlp_dtype, monkeypatch)
 def test_render_after_raw_pointer_optimizer_steps_sees_the_new_parameters(mlp_dtype, monkeypatch):
     """render -> FlatAdam steps -> render.  FlatAdam (nr_adam_step) and the batch norms' running statistics
     (nr_bn_act_fwd) write through raw pointers, so torch's `_version` counters never move: the fused renderer's packed MLP image
-    and the CNN's BN-folded 7 x 7 images are rebuilt per rendered reading instead of being cached on those counters.  The second
+    is rebuilt per rendered reading (one 23-us launch) and the CNN's BN-folded 7 x 7 images when the library's device-side
+    parameter-generation word has moved (test_cnn_weight_images_are_rebuilt_exactly_when_parameters_moved).  The second
     fused render must equal the modular eval path (NR_FUSED_RENDER=0, which packs per call) on the UPDATED parameters -- and differ
     from the first render."""
     from neuradar_amd.step import FlatAdam
@@ -181,3 +182,108 @@ def test_render_after_raw_pointer_optimizer_steps_sees_the_new_parameters(mlp_dt
     _check(second["rgb"].reshape(-1, 3).cpu(), modular["rgb"].reshape(-1, 3).cpu(), "rgb after the update", rtol=1e-3, floor=1e-4, few=5e-3)
     assert float((second["features"] - first["features"]).abs().max()) > 1e-3, "the update did not reach the rendered features"
     assert float((second["rgb"] - first["rgb"]).abs().max()) > 1e-3, "the update did not reach the image"
+
+
+def test_cnn_weight_images_are_rebuilt_exactly_when_parameters_moved():
+    """Round 6: the BN-folded 7 x 7 weight images of the rendering entry are built by ONE launch
+    (nr_conv7_fold_pack) that early-outs ON THE DEVICE while the library's parameter-generation word -- bumped by every optimizer
+    step (nr_adam_hyper), sharded delta apply and running-statistics update, graph replays included -- is what the images were
+    built from.  Checked through the rebuild counter the kernel keeps (state[1]) and against a forced rebuild:
+    render -> render without training: NO rebuild; after FlatAdam steps (raw pointers, version counters unmoved): one rebuild and
+    the images equal a forced fold of the current parameters; after a training-mode nr_bn_act_fwd alone: rebuilt; after a
+    torch-side in-place write (version counter): rebuilt; after an optimizer step inside a REPLAYED hipGraph: rebuilt."""
+    from neuradar_amd import ops
+    from neuradar_amd.step import FlatAdam
+
+    H, W = 23, 40
+    model = _model(chunk=101)
+    model.field.config.mlp_dtype = "bfloat16"
+    dec = model._decoders
+    cam = lambda: _camera_rays(H, W, torch.Generator().manual_seed(7))  # noqa: E731
+    render = lambda: model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))  # noqa: E731
+
+    def rebuilds():
+        torch.cuda.synchronize()
+        return int(dec._conv7_eval_cache["state"][1])
+
+    def images_are_current():
+        have = dec._conv7_eval_cache["images"][:, 0].clone()
+        dec._conv7_eval_cache["key"] = None  # forces the next fold
+        dec.prepare_conv7_eval(torch.bfloat16)
+        torch.cuda.synchronize()
+        return torch.equal(have, dec._conv7_eval_cache["images"][:, 0])
+
+    first = render()
+    n0 = rebuilds()
+    assert n0 == 1
+    again = render()
+    assert rebuilds() == n0, "render -> render without training must not rebuild the weight images"
+    assert torch.equal(first["rgb"], again["rgb"])
+    params = [p for p in dec.rgb_decoder.parameters() if p.requires_grad]
+    opt = FlatAdam(params, lr=5e-2, warmup_steps=0)
+    n0 = rebuilds()  # (FlatAdam rebinds the parameters into its flat buffer: new data pointers -> the host key forces one rebuild)
+    versions = [p._version for p in params]
+
+    def train_step():
+        for _, g in opt.buffers:
+            g.copy_(torch.randn_like(g))
+        opt.advance()
+        for i in range(len(opt.buffers)):
+            opt.step_buffer(i)
+
+    torch.manual_seed(5)
+    render()
+    n1 = rebuilds()
+    render()
+    assert rebuilds() == n1
+    train_step()
+    assert [p._version for p in params] == versions, "the premise: raw-pointer updates do not bump version counters"
+    second = render()
+    assert rebuilds() == n1 + 1, "an optimizer step through raw pointers must be seen"
+    assert float((second["rgb"] - again["rgb"]).abs().max()) > 1e-3
+    n2 = rebuilds()
+    assert images_are_current()
+    n2 = rebuilds()
+    # running statistics alone
+    bn = next(m for m in dec.rgb_decoder.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    x = (3.0 * torch.randn(2, bn.num_features, 8, 8, device=DEV) + 1.0).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, 0.5, bn.eps, True)
+    render()
+    assert rebuilds() == n2 + 1, "a running-statistics update through nr_bn_act_fwd must be seen"
+    assert images_are_current()
+    n3 = rebuilds()
+    # a torch-side write: the version counter
+    conv7 = next(m for m in dec.rgb_decoder.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (7, 7))
+    with torch.no_grad():
+        conv7.weight.mul_(1.01)
+    render()
+    assert rebuilds() == n3 + 1 and images_are_current()
+    n3 = rebuilds()
+    with torch.no_grad():  # ... and a parameter the images do not depend on (the 1 x 1 head) leaves them alone
+        params[0].mul_(1.01)
+    render()
+    assert rebuilds() == n3
+    n4 = rebuilds()
+    # an optimizer step inside a replayed hipGraph: no Python runs, the device word still moves
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        train_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    render()
+    n5 = rebuilds()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.advance()
+        for i in range(len(opt.buffers)):
+            opt.step_buffer(i)
+    for _, g in opt.buffers:
+        g.copy_(torch.randn_like(g))
+    graph.replay()
+    render()
+    assert rebuilds() == n5 + 1, "an optimizer step inside a replayed graph must be seen"
+    assert images_are_current()
+    assert n4 >= 0
+
