@@ -672,6 +672,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     # deferred into the next step by default (--no-defer-gather: the round-3 behaviour)
     one_rank = bool(getattr(args, "one_rank_collectives", False))
     reducer.force_collectives = one_rank
+    reducer.shard_lists = os.environ.get("NR_SHARD_LISTS", "1") != "0"  # (0: the sharded step's gradient half as a dense reduce-scatter)
     reducer.table_delta = torch.bfloat16 if args.table_delta == "bf16" else None
     reducer.defer_gather = not args.no_defer_gather
     if mode == "shard" and args.table_transport == "bf16":
@@ -800,10 +801,12 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     def timed_block():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
         barrier()
-        t0 = time.perf_counter()
+        t0, w0 = time.perf_counter(), getattr(reducer, "host_wait_s", 0.0)
         for _ in range(args.steps):
             step()
-        host = time.perf_counter() - t0  # launch loop only: how far the CPU runs ahead of the GPU
+        # launch loop only: how far the CPU runs ahead of the GPU -- without the time the row-list exchange holds the host for the
+        # counts of two steps ago once it is two steps ahead (back-pressure by design, parallel.GradAllReducer._lists_to_owners)
+        host = time.perf_counter() - t0 - (getattr(reducer, "host_wait_s", 0.0) - w0)
         own = None
         if world > 1:
             torch.cuda.synchronize()

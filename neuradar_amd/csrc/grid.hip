@@ -274,14 +274,8 @@ hash_encode_bwd_kernel(const float* __restrict__ x, const float* __restrict__ st
                                               nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[1]),
                                               nr_dpp_i<NR_DPP_WAVE_SHR1, 0xF>(INT_MIN, lo[2]));
     int flag = head ? 1 : 0;
-    auto scan_step = [&](auto ctrl, auto rowmask) {
-      constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-      const float take = flag ? 0.0f : 1.0f;
-#pragma unroll
-      for (int corner = 0; corner < 8; ++corner)
-#pragma unroll
-        for (int f = 0; f < F; ++f) v[corner][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, v[corner][f]), take, v[corner][f]);
-      flag |= nr_dpp_i<C, R>(0, flag);
+    auto scan_step = [&](auto ctrl, auto rowmask) {  // (nr_common.h: two vector instructions per element and in-row step)
+      nr_seg_scan_step<decltype(ctrl)::value, decltype(rowmask)::value, 8 * F>(&v[0][0], flag, lane);
     };
     // a step changes nothing once every lane's partial sum has reached its run's head (flag = 1 everywhere: take = 0), so
     // the scan stops there -- no step at all where every lane is a cell of its own (the fine levels), all seven only where

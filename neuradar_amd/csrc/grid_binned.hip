@@ -296,17 +296,11 @@ bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const flo
       const unsigned long long heads = __ballot(head);
       if (heads != ~0ull) {  // (uniform) some run is longer than one lane
         int flag = head ? 1 : 0;
-        auto scan_step = [&](auto ctrl, auto rowmask) {
+        auto scan_step = [&](auto ctrl, auto rowmask) {  // (nr_common.h: two vector instructions per element and in-row step)
           constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-          const float take = flag ? 0.0f : 1.0f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-              va[q][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, va[q][f]), take, va[q][f]);
-              vb[q][f] = __builtin_fmaf(nr_dpp_f<C, R>(0.0f, vb[q][f]), take, vb[q][f]);
-            }
-          flag |= nr_dpp_i<C, R>(0, flag);
+          int f2 = flag;
+          nr_seg_scan_step<C, R, 4 * F>(&va[0][0], f2, lane);
+          nr_seg_scan_step<C, R, 4 * F>(&vb[0][0], flag, lane);
         };
         // (the scan stops once every lane has reached its run's head: the remaining steps would add nothing)
         do {

@@ -230,14 +230,8 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       const unsigned long long heads = __ballot(head);
       if (heads != ~0ull) {  // (uniform) some run is longer than one lane
         int flag = head ? 1 : 0;
-        auto scan_step = [&](auto ctrl, auto rowmask) {
-          constexpr int C = decltype(ctrl)::value, R = decltype(rowmask)::value;
-          const int take = flag ? 0 : -1;
-#pragma unroll
-          for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int f = 0; f < F; ++f) q[c][f] += nr_dpp_i<C, R>(0, q[c][f]) & take;
-          flag |= nr_dpp_i<C, R>(0, flag);
+        auto scan_step = [&](auto ctrl, auto rowmask) {  // (nr_seg_scan_step: two vector instructions per element and in-row step)
+          nr_seg_scan_step<decltype(ctrl)::value, decltype(rowmask)::value, 8 * F>(&q[0][0], flag, lane);
         };
         // (the scan stops once every lane has reached its run's head: the remaining steps would add nothing)
         do {

@@ -176,6 +176,7 @@ __device__ __forceinline__ float nr_dpp_f(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xF, false));
 }
 constexpr int NR_DPP_ROW_SHR = 0x110;   // + n: lane i <- lane i-n inside its row of 16
+constexpr int NR_DPP_ROW_SHL = 0x100;   // + n: lane i <- lane i+n inside its row of 16
 constexpr int NR_DPP_WAVE_SHL1 = 0x130; // lane i <- lane i+1 (whole wave)
 constexpr int NR_DPP_WAVE_SHR1 = 0x138; // lane i <- lane i-1 (whole wave)
 constexpr int NR_DPP_ROW_BCAST15 = 0x142;  // lane 15 of row r -> every lane of row r+1
@@ -186,6 +187,45 @@ __device__ __forceinline__ int nr_xor32_i(int x) {
   return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
 }
 __device__ __forceinline__ float nr_xor32_f(float x) { return __int_as_float(nr_xor32_i(__float_as_int(x))); }
+
+// One step of a SEGMENTED inclusive scan over N values per lane (runs of neighbouring lanes; `flag` != 0 once a lane's partial
+// sums have reached its run's head): lane i adds lane (i - d)'s values unless its flag is set, then the flags propagate.  Used
+// by the three scatter kernels to fold neighbouring lanes in one grid cell before anything touches LDS or memory.
+// R6: an element costs TWO vector instructions per in-row step and ONE per row-broadcast step (round 5: five issue slots --
+// v_mov 0 / s_nop / v_mov_dpp / v_cndmask-or-fma / v_add: the scan was two thirds of the main scatter's instructions):
+//   * in-row steps (C = row_shr:d): the mask moves to the SOURCE side -- lane j offers its values only if lane j + d of its row
+//     still accumulates (flags shifted the other way: one DPP per step) -- so the add itself carries the DPP operand
+//     (v_cndmask + v_add_{u32,f32}_dpp); all offers are formed before the adds (a DPP operand written by the previous
+//     instruction costs two wait states);
+//   * row-broadcast steps (C = row_bcast:15, one source, sixteen destinations with flags of their own): the destinations are
+//     selected by EXEC -- the step's ONE source lane (15 / 31 / 47 for destination row 1 / 2 / 3) stays active (DPP reads active
+//     lanes only; it lies outside the row mask, so it is not written) -- and the add is a bare v_add_*_dpp.
+// Same additions in the same order as the masked form: identical sums (floats: x + 1 * y and x + 0 are exact).
+template <int C, int R> __device__ __forceinline__ int nr_dpp_zero(int src) { return nr_dpp_i<C, R>(0, src); }
+template <int C, int R> __device__ __forceinline__ float nr_dpp_zero(float src) { return nr_dpp_f<C, R>(0.0f, src); }
+template <int C, int R, int N, typename T>
+__device__ __forceinline__ void nr_seg_scan_step(T* __restrict__ x, int& flag, int lane) {
+  if constexpr (C >= NR_DPP_ROW_SHR && C < NR_DPP_ROW_SHR + 16) {
+    constexpr int D = C - NR_DPP_ROW_SHR;
+    const bool offer = nr_dpp_i<NR_DPP_ROW_SHL + D, 0xF>(1, flag) == 0;  // lane j + d of my row still accumulates
+    T m[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      m[k] = offer ? x[k] : (T)0;
+      asm volatile("" : "+v"(m[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] += nr_dpp_zero<C, R>(m[k]);
+  } else {
+    static_assert(C == NR_DPP_ROW_BCAST15 && (R == 0x2 || R == 0x4 || R == 0x8), "row-broadcast steps of the scan: one destination row each");
+    constexpr int kSource = R == 0x2 ? 15 : R == 0x4 ? 31 : 47;  // (a lane of the row BEFORE the destination row: never written)
+    if (flag == 0 || lane == kSource) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) x[k] += nr_dpp_zero<C, R>(x[k]);
+    }
+  }
+  flag |= nr_dpp_i<C, R>(0, flag);
+}
 
 // maximum over the wave, valid in LANE 63 only: six v_max_f32 with DPP operands (prefix maxima inside the rows of 16, then
 // the two row broadcasts) instead of six ds_bpermute round trips

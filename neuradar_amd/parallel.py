@@ -257,8 +257,9 @@ class GradAllReducer:
           1. nr_grad_compact_shards: ONE launch; destination d's non-zero rows -> segment d (capacity caps[d] rows) of the send
              lists, cleared in g; counts[d] = all non-zero rows of shard d.
           2. the counts are all-gathered ([world, world] on every rank) and copied to pinned host memory asynchronously: they
-             size the NEXT step's segments (1.3 x the largest list a destination received, kept while it stays within
-             [1.1, 1.6] x; 2.3 x after an overflow, whose kept gradient the next step adds onto) and decide, one step late and alike on every rank, to fall back to the dense reduce-scatter when a
+             size the segments of the step `count_lag` (2) steps later -- by then the copy has landed long ago and the host is
+             never held within a step of the device -- at 1.3 x the largest list a destination received, kept while it stays
+             within [1.1, 1.6] x; (1 + 1.3 lag) x after an overflow, whose kept gradient the following steps add onto and decide, one step late and alike on every rank, to fall back to the dense reduce-scatter when a
              list would exceed half a shard's rows (there the lists' 4 + 4F bytes per row stop paying against 4F per row of
              the dense ring).  No host read after the first call (which counts once, synchronously, before any timed region).
           3. all-to-all of the index parts, all-to-all of the value parts (fixed sizes known to every rank: segment d of every
@@ -288,27 +289,49 @@ class GradAllReducer:
         i32 = dict(device=dev, dtype=torch.int32)
         if st is None:
             st = dict(counts=torch.zeros(world, **i32), cm=torch.zeros(world * world, **i32), flag=torch.zeros(1, device=dev, dtype=torch.float32),
-                      host=(torch.zeros(world * world, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(world * world, dtype=torch.int32)),
-                      zero_caps=torch.zeros(world, **i32), event=None, need=None, caps=None, caps_dev=None, dense_steps=0,
+                      host=[], pending=[], turn=0,
+                      zero_caps=torch.zeros(world, **i32), need=None, caps=None, caps_dev=None, dense_steps=0,
                       idx_s=None, val_s=None, idx_r=None, val_r=None)
             self._lists_state[key] = st
         cap_max = max(rows // 2, 1)
 
+        lag = max(1, int(getattr(self, "count_lag", 2)))  # a step is sized from the counts of `lag` steps ago
+
         def gather_counts(sync: bool):
             self._all_gather_g(st["cm"], st["counts"])
-            if dev.type == "cuda" and not sync:
-                st["host"].copy_(st["cm"], non_blocking=True)
-                st["event"] = torch.cuda.Event()
-                st["event"].record()
+            if sync:
+                st["host"][0].copy_(st["cm"])
+                st["need"] = st["host"][0].view(world, world).max(dim=0).values.tolist()
+                return
+            buf = st["host"][st["turn"] % len(st["host"])]  # (lag + 1 pinned buffers in turn: the one written now is read `lag` steps on)
+            st["turn"] += 1
+            ev = None
+            if dev.type == "cuda":
+                buf.copy_(st["cm"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
             else:
-                st["host"].copy_(st["cm"])
-                st["event"] = None
-                st["need"] = st["host"].view(world, world).max(dim=0).values.tolist()
+                buf.copy_(st["cm"])
+            st["pending"].append((ev, buf))
 
-        if st["event"] is not None:  # the previous step's counts (copied a whole step ago)
-            st["event"].synchronize()
-            st["event"] = None
-            st["need"] = st["host"].view(world, world).max(dim=0).values.tolist()
+        if len(st["host"]) != lag + 1:
+            mk = lambda: torch.zeros(world * world, dtype=torch.int32)  # noqa: E731
+            st["host"] = [mk().pin_memory() if dev.type == "cuda" else mk() for _ in range(lag + 1)]
+        # The counts that size THIS step: those gathered `lag` steps ago (default 2).  Waiting for the previous step's copy
+        # would hold the host within one step of the device on every step; two steps back the copy has landed long ago and the
+        # host keeps its run-ahead (graph segments: tests/test_gpu_dp.py::test_segment_replay_takes_the_host_out...).  Every
+        # rank applies the same rule, so every rank sizes its segments from the same counts.
+        while len(st["pending"]) >= lag:
+            ev, buf = st["pending"].pop(0)
+            if ev is not None and not ev.query():
+                # the host has run `lag` steps ahead of the device: it waits here for the counts -- back-pressure, not work; the time
+                # is accounted separately (bench.py reports the launch loop's host time without it)
+                import time
+
+                t0 = time.perf_counter()
+                ev.synchronize()
+                self.host_wait_s = getattr(self, "host_wait_s", 0.0) + time.perf_counter() - t0
+            st["need"] = buf.view(world, world).max(dim=0).values.tolist()
         if st["need"] is None:  # first call: count once, synchronously (rows stay where they are: capacities of zero)
             st["counts"].zero_()
             compact_shards(g, F, world, st["zero_caps"], st["zero_caps"], st["flag"], st["counts"])
@@ -324,20 +347,31 @@ class GradAllReducer:
             return None
         st["dense_steps"] = 0
         caps = st["caps"]
+        gr = int(getattr(self, "list_granularity", 1024))
         if caps is not None and any(nd > c for nd, c in zip(need, caps)):
-            # the previous step overflowed: its gradient was kept and this step's scatter has added onto it -- room for the union
-            gr = int(getattr(self, "list_granularity", 1024))
-            caps = [min(cap_max, max(gr, (int(2.3 * nd) + gr - 1) // gr * gr)) for nd in need]
-            st["caps"], st["caps_dev"] = caps, torch.tensor(caps, dtype=torch.int32).to(dev)
-        elif caps is None or any(not (1.1 * nd <= c) or c > max(1.6 * nd, int(getattr(self, "list_granularity", 1024))) for nd, c in zip(need, caps)):
-            gr = int(getattr(self, "list_granularity", 1024))
+            # a step overflowed: its gradient was kept and the following steps' scatters have added onto it -- room for the union
+            caps = [min(cap_max, max(gr, (int((1.0 + 1.3 * lag) * nd) + gr - 1) // gr * gr)) for nd in need]  # (lag more batches pile up meanwhile)
+        elif caps is None or any(not (1.1 * nd <= c) or c > max(1.6 * nd, gr) for nd, c in zip(need, caps)):
             caps = [min(cap_max, max(gr, (int(1.3 * nd) + gr - 1) // gr * gr)) for nd in need]
-            st["caps"], st["caps_dev"] = caps, torch.tensor(caps, dtype=torch.int32).to(dev)
+        if caps != st["caps"]:
+            # new capacities reach the device through a ring of pinned staging buffers and an asynchronous copy on the exchange's
+            # own stream (a pageable host-to-device copy would hold the host until the stream has drained -- and a fresh model's
+            # counts grow by tens of per cent per step for its first hundred steps: measured 9-18 ms of host time per step)
+            if st["caps_dev"] is None:
+                st["caps_dev"] = torch.zeros(world, **i32)
+                mk = lambda: torch.zeros(world, dtype=torch.int32)  # noqa: E731
+                st["caps_stage"] = [mk().pin_memory() if dev.type == "cuda" else mk() for _ in range(8)]
+            stage = st["caps_stage"][st["turn"] % len(st["caps_stage"])]
+            stage.copy_(torch.tensor(caps, dtype=torch.int32))
+            st["caps_dev"].copy_(stage, non_blocking=True)
+            st["caps"] = caps
         total, mine = sum(caps), caps[rank]
-        if st["idx_s"] is None or st["idx_s"].numel() < total or st["idx_r"].numel() < world * mine:
-            grow = lambda n_: (int(1.25 * n_) + 1023) // 1024 * 1024  # noqa: E731  (room for the next few re-sizings)
-            st["idx_s"], st["val_s"] = torch.zeros(grow(total), **i32), torch.zeros(grow(total), F, device=dev, dtype=torch.float32)
-            st["idx_r"], st["val_r"] = torch.zeros(grow(world * mine), **i32), torch.zeros(grow(world * mine), F, device=dev, dtype=torch.float32)
+        if st["idx_s"] is None:
+            # the lists' buffers, ONCE, for the largest capacities the exchange can ever choose (cap_max rows per destination: 20
+            # bytes x rows of the whole table for sending and as much for receiving -- 0.67 GB for the NeuRadar main table, whatever
+            # the world size): re-sizing them as the counts drift re-allocates hundreds of megabytes on the step's critical path
+            st["idx_s"], st["val_s"] = torch.zeros(world * cap_max, **i32), torch.zeros(world * cap_max, F, device=dev, dtype=torch.float32)
+            st["idx_r"], st["val_r"] = torch.zeros(world * cap_max, **i32), torch.zeros(world * cap_max, F, device=dev, dtype=torch.float32)
         idx_s, val_s = st["idx_s"][:total], st["val_s"][:total]
         idx_r, val_r = st["idx_r"][:world * mine], st["val_r"][:world * mine]
         st["counts"].zero_()

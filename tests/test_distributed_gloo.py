@@ -373,8 +373,8 @@ def _lists_entry(rank, world, port, delta, densities, check):
     modes = _lists_worker(rank, world, port, delta, densities)
     if check == "all_lists":
         assert modes == ["lists"] * len(densities), modes
-    else:  # the overflow story (see the test's docstring)
-        assert modes[:4] == ["lists", "lists", "overflow", "lists"], modes
+    else:  # the overflow story (see the test's docstring); a step is sized from the counts of TWO steps earlier (count_lag)
+        assert modes[:5] == ["lists", "lists", "overflow", "overflow", "lists"], modes
         assert modes[5] == "overflow" and "dense" in modes[6:] and modes[-1] == "lists", modes
 
 
@@ -389,9 +389,11 @@ def test_two_rank_row_lists_with_bf16_update_deltas():
 
 def test_two_rank_row_lists_overflow_keeps_the_gradient_then_dense_then_back():
     """0.1 -> 0.14 of the rows: the lists sized from the 0.1 steps (x 1.3) overflow -- nothing moves, every rank's gradient stays
-    whole, the next step's scatter adds onto it and its lists (sized 2.3 x the overflowed step's true counts) carry the union.
-    -> 0.7: overflow again, then -- beyond half a shard's rows -- the dense reduce-scatter, decided one step late; back to lists
-    once a re-count (every 2 dense steps here) sees the 0.05 steps."""
+    whole, the following steps' scatters add onto it.  A step is sized from the counts of TWO steps earlier (count_lag: the host
+    never waits for the previous step's copy), so the step after the overflow overflows too and the third one's lists (sized
+    3.6 x the overflowed step's true counts) carry the union of three batches -- every step's result is still EXACTLY the
+    replicated step's on whatever the gradients held.  -> 0.7: overflow again, then -- beyond half a shard's rows -- the dense
+    reduce-scatter; back to lists once a re-count (every 2 dense steps here) sees the 0.05 steps."""
     dens = [0.1, 0.1, 0.14, 0.14, 0.14, 0.7, 0.7, 0.05, 0.05, 0.05, 0.05, 0.05]
     mp.spawn(_lists_entry, args=(2, _free_port(), False, dens, "overflow_story"), nprocs=2, join=True)
 
