@@ -636,7 +636,7 @@ def measure_render(model, scene, device, reps=5):
                 ts.append(a.elapsed_time(b))
             ms = sorted(ts)[len(ts) // 2]
             n = res["depth"].numel()
-            out[name] = {"rays": n, "ms": round(ms, 3), "rays_per_s": round(n / (ms * 1e-3), 1),
+            out[name] = {"rays": n, "ms": round(ms, 3), "ms_min": round(min(ts), 3), "rays_per_s": round(n / (ms * 1e-3), 1),
                          "outputs": {k: list(v.shape) for k, v in res.items() if k in ("rgb", "depth", "radar_output", "intensity")}}
     out["note"] = ("forward only, eval mode, eager launches (ray generation of the full image included); "
                    "chunks of %d rays" % model.config.eval_num_rays_per_chunk)

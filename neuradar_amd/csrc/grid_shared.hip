@@ -254,6 +254,7 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       // ---- insert-or-add of the run sums.  The first probe of all 8 corners is issued before any is looked at (independent
       // LDS round trips); the adds return nothing; the slots a lane has claimed join the block's list of occupied slots with
       // ONE returning atomic per wave for all 8 corners
+      NR_CLK(6)
       uint32_t nz = 0u;  // bit c: corner c has something to add
 #pragma unroll
       for (int c = 0; c < 8; ++c) nz |= ((q[c][0] | q[c][1] | q[c][2] | q[c][3]) != 0 ? 1u : 0u) << c;
@@ -295,6 +296,7 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
           if (MARK) seen[((int64_t)level << log2T) + idx[c]] = 1;
         }
       }
+      NR_CLK(7)
       {
         // One returning atomic per wave reserves the span of the list for all 8 corners of all its lanes; inside it the entries
         // go lane-major.  (Corner-major -- neighbouring rays' same-numbered corners, i.e. the vertices of one 64-byte table line, on

@@ -244,6 +244,38 @@ class Decoders(nn.Module):
         for i, b in enumerate(blocks):
             b.conv7_eval = (images[2 * i, 0], images[2 * i + 1, 0], dtype)
 
+    @torch.no_grad()
+    def render_rgb16(self, features: Tensor, height: int, width: int, dtype: torch.dtype) -> Optional[Tensor]:
+        """Rendering: the whole RGB decoder (models/neuradar.py:225-240 in eval mode) on the hand-written kernels -- the 1 x 1 head
+        + ReLU straight from the fp32 feature image (nr_pw_fwd), the BasicBlocks as BN-folded 7 x 7 convolutions (prepare_conv7_eval:
+        nr_conv7_fwd), the transposed 3 x 3 / stride-3 convolution (nr_pw_fwd, transposed) and the 1 x 1 tail + sigmoid -- on
+        16-bit copies of the three pointwise layers' parameters made per image (six tiny casts).  features [height * width, C] fp32,
+        row major -> [3 height, 3 width, 3] fp32, or None where the layouts do not fit (the torch path then).
+        Round 5 ran the pointwise layers through torch.autocast -> MIOpen: ConvTranspose2d's FORWARD is a backward-data
+        convolution, and with MIOpen 3.5.0's overrunning NHWC backward-data solver switched off (apply_miopen_workaround) it fell
+        to a slow kernel -- the 1.2 ms per 1080p image that BENCH_r05 lost against BENCH_r04."""
+        from . import ops
+
+        seq = self.rgb_decoder
+        if not (len(seq) == 9 and isinstance(seq[0], nn.Conv2d) and isinstance(seq[4], nn.ConvTranspose2d) and isinstance(seq[7], nn.Conv2d)
+                and all(isinstance(seq[i], BasicBlock) and seq[i].conv7_eval is not None and seq[i].conv7_eval[2] == dtype for i in (2, 3, 5, 6))
+                and features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.is_contiguous()):
+            return None
+        c16 = lambda t: None if t is None else t.detach().to(dtype)  # noqa: E731
+        w0, b0, w7, b7 = c16(seq[0].weight), c16(seq[0].bias), c16(seq[7].weight), c16(seq[7].bias)
+        w4, b4 = c16(seq[4].weight).contiguous(memory_format=torch.channels_last), c16(seq[4].bias)
+        probe16 = torch.empty(1, 32, device=features.device, dtype=dtype)
+        if not (ops.pointwise_ok(features[:1], w0, b0) and ops.pointwise_ok(probe16, w4, b4, True) and ops.pointwise_ok(probe16, w7, b7)
+                and w0.shape[0] == 32 and w4.shape[1] == 32):
+            return None
+        h = ops.pointwise(features, w0, b0, act=1)                                   # [H W, 32] 16-bit
+        h = h.view(1, height, width, 32).permute(0, 3, 1, 2)                         # channels-last [1, 32, H, W]
+        h = seq[3](seq[2](h))
+        h = ops.conv_transpose3(h, w4, b4)                                           # channels-last [1, 32, 3 H, 3 W]
+        h = seq[6](seq[5](h))
+        rgb = ops.pointwise(h.permute(0, 2, 3, 1).reshape(-1, 32), w7, b7, act=2, out_f32=True)
+        return rgb.view(3 * height, 3 * width, w7.shape[0])
+
     def decode_radar(self, radar_features: Tensor, depth: Tensor, directions_spher: Tensor, num_radar_scans: int,
                      seed_epoch: Optional[Tensor] = None) -> Tensor:
         """neuradar.py:463-491: features / depth / (azimuth, elevation) of the radar rays, scan after scan ->

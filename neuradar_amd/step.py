@@ -325,6 +325,12 @@ class NeuRadarHotPath(nn.Module):
             if low is not None and self.config.render_decoders_in_training_dtype and patch.is_cuda:
                 # (the BasicBlocks' 7 x 7 convolutions on the matrix-core kernel with their batch norms folded in: conv7.hip)
                 dec.prepare_conv7_eval(low if os.environ.get("NR_CONV7", "1") != "0" else None)
+                # the whole CNN on the hand-written kernels where the layouts fit (Decoders.render_rgb16); else torch.autocast
+                rgb16 = (dec.render_rgb16(features.contiguous(), patch_size[0], patch_size[1], low)
+                         if os.environ.get("NR_RENDER_PW", "1") != "0" else None)
+                if rgb16 is not None:
+                    outputs["rgb"] = rgb16
+                    return outputs
                 with torch.autocast("cuda", dtype=low):
                     rgb = dec.rgb_decoder(patch).float()
             else:

@@ -287,3 +287,26 @@ def test_cnn_weight_images_are_rebuilt_exactly_when_parameters_moved():
     assert images_are_current()
     assert n4 >= 0
 
+
+@pytest.mark.parametrize("mlp_dtype", ["bfloat16", "float16"])
+def test_rendered_image_on_hand_written_pointwise_layers_equals_the_autocast_path(mlp_dtype, monkeypatch):
+    """Round 6: the rendering entry runs the RGB decoder's three pointwise layers (1 x 1 head + ReLU, transposed 3 x 3 / stride 3,
+    1 x 1 tail + sigmoid) on nr_pw_fwd like the training step does (Decoders.render_rgb16) instead of torch.autocast -> MIOpen
+    (whose backward-data solver -- ConvTranspose2d's forward -- is slow once the overrunning NHWC one is switched off).  Same
+    operands, same 16-bit rounding points: the image equals the autocast path's to a few units of the operand type."""
+    H, W = 24, 42
+    model = _model(chunk=500)
+    model.field.config.mlp_dtype = mlp_dtype
+    cam = lambda: _camera_rays(H, W, torch.Generator().manual_seed(9))  # noqa: E731
+    monkeypatch.setenv("NR_RENDER_PW", "1")
+    a = model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))
+    monkeypatch.setenv("NR_RENDER_PW", "0")
+    b = model.get_outputs_for_camera_ray_bundle(cam(), image_shape=(H, W))
+    assert a["rgb"].shape == b["rgb"].shape == (H, W, 3) and a["rgb"].dtype == torch.float32
+    u = 2.0 ** -8 if mlp_dtype == "bfloat16" else 2.0 ** -11
+    err = (a["rgb"] - b["rgb"]).abs()
+    assert float(err.max()) <= 24 * u and float(err.mean()) <= 2 * u, (float(err.max()), float(err.mean()))
+    assert float(a["rgb"].std()) > 1e-3, "a constant image would pass trivially"
+    for k in ("features", "depth"):
+        assert torch.equal(a[k], b[k])
+

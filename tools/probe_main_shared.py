@@ -62,7 +62,8 @@ for upto in [int(v) for v in os.environ.get("PROBE_STEPS", "6,600").split(",")]:
         lib.nr_debug_shared_clocks(buf, 1)
         c = [int(v) for v in buf]
         tot = max(sum(c), 1)
-        names = ["tile load + setup", "corners, hash, wave max", "barrier A", "insert (cmpst, adds, append)", "barrier B", "flush"]
+        names = ["tile load + setup", "corners, hash, wave max", "barrier A", "append to the occupied list", "barrier B", "flush",
+                 "block max, fixed point, segmented scan", "cmpst round trip, probing, ds_add"]
         print("phase share of wave-cycles: " + "; ".join(f"{n} {100.0 * v / tot:.1f} %" for n, v in zip(names, c)) + f"  [total {tot / 1e6:.1f} M wave-cycles]")
     if os.environ.get("PROBE_LEVELS", "1") == "1":
         for l0 in range(L):

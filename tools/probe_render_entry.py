@@ -13,6 +13,19 @@ dev = torch.device("cuda")
 wl = bench.WORKLOADS["mixed16384_neuradar_full"]
 model = bench.build_model(wl, dev, os.environ.get("PROBE_DTYPE", "bfloat16")).eval()
 scene = bench.SyntheticScene(dev, seed=1000)
+n_train = int(os.environ.get("PROBE_TRAIN_STEPS", "0"))
+if n_train:  # the model as bench.py renders it: after some fused training steps (decoders in the step, optimizers through raw pointers)
+    from neuradar_amd.parallel import GradAllReducer
+
+    model.train()
+    opts = bench.build_optimizers(model)
+    red = GradAllReducer(None, buffers=[g for o in opts for g in o.grad_buffers()])
+    targets = (0.1 * torch.randn(wl["rays"], 32, device=dev), 5.0 + 50.0 * torch.rand(wl["rays"], 1, device=dev))
+    fwd_bwd, optim, st = bench.make_step(model, scene, opts, red, targets, wl["rays"], fused=True, fuse_optimizer=True, mixed=wl)
+    for _ in range(n_train):
+        fwd_bwd()
+    torch.cuda.synchronize()
+    model.eval()
 H, W = scene.H, scene.W
 ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
 idx = torch.stack([torch.full_like(ys, 100), ys, xs], dim=-1).reshape(-1, 3)
@@ -65,3 +78,7 @@ with torch.no_grad():
 print(f"rays {n}: whole entry {t_all:.2f} ms = ray generation of {H * W} rays {t_gen:.2f} + strided selection {t_take:.2f} + field (fused chain, "
       f"{(n + 32767) // 32768} chunks) {t_field:.2f} + lidar decoder {t_lidar:.2f} + RGB CNN {t_cnn:.2f} (channels-last copy first: {t_cnn_cl:.2f}; "
       f"autocast bf16: {t_cnn16:.2f}) ms")
+if os.environ.get("PROBE_BENCH_RENDER", "1") == "1":  # the same entry through bench.py's own measurement, in this process
+    r = bench.measure_render(model, scene, dev)
+    print("bench.measure_render:", r["camera_image"]["ms"], "ms camera image,", r["radar_scan"]["ms"], "ms radar scan")
+
