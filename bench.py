@@ -1342,6 +1342,8 @@ def main():
                        "full_model_ms_per_step": {f_["workload"]: {"fresh": f_["ms_per_step"],
                                                                     "trained": (f_["after_training"] or {}).get("ms_per_step")} for f_ in full_model},
                        "graph": r["use_graph"], "graph_segments_per_step": r["segments"], "steps_per_graph_replay": r["unroll"], "host_ms_per_step": round(r["host_ms"], 4),
+                       "host_ms_per_step_is": "duration of the launch loop per step: once the host is a few replays ahead it includes the back-pressure "
+                                              "of the device's queue -- an upper bound of the host's work, not a measure of it",
                        "timed_blocks": r["blocks"], "ms_per_step_min": round(r["ms_min"], 4), "ms_per_step_max": round(r["ms_max"], 4),
                        "value_is": f"median over {r['blocks']} timed blocks of exactly {args.steps} steps each",
                        "step": "autograd" if args.autograd else "fused", "parallelism": f"dp{world}", "regime": args.regime,
