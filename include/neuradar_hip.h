@@ -56,8 +56,7 @@ enum {
   NR_TUNE_FIELD_BWD_BLOCKS = 4,  /* blocks (= gradient slabs) of nr_field_bwd* (default 256 fp32 / 512 16-bit) */
   NR_TUNE_PDBWD_BLOCKS = 5,      /* blocks of nr_prop_density_bwd (default 256) */
   NR_TUNE_ADAM_BLOCKS = 6,       /* blocks of nr_adam_step* (default 4096) */
-  NR_TUNE_PW_MFMA_OFF = 7,       /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
-  NR_TUNE_SHARED_LINE_TABLE = 8  /* 1: nr_hash_encode_bwd_shared on the LINE-keyed table (round-6 experiment, measured slower: DESIGN section 5) */
+  NR_TUNE_PW_MFMA_OFF = 7        /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
 };                               /* (v27: knobs 8 / 9 of v26 -- NR_TUNE_PROP_SHARED_* -- are gone: nothing read them) */
 int nr_init(void);
 int nr_set_tuning(int knob, int value);

@@ -255,8 +255,7 @@ def lib() -> ctypes.CDLL:
 TUNING = (("NR_CONV7_BLOCKS", "persistent blocks of nr_conv7_fwd"), ("NR_BIN_BLOCKS_PER_CU", "bin blocks per half CU"),
           ("NR_SHARED_BLOCKS", "blocks of nr_hash_encode_bwd_shared"), ("NR_FIELD_FWD_BLOCKS", "blocks of nr_field_fwd*"),
           ("NR_FIELD_BWD_BLOCKS", "blocks of nr_field_bwd*"), ("NR_PDBWD_BLOCKS", "blocks of nr_prop_density_bwd"),
-          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"),
-          ("NR_SHARED_LINE_TABLE", "1: the main grid's block-shared scatter keyed by 64-byte line (round-6 experiment) instead of by vertex"))
+          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"))
 # variables earlier rounds read and this build ignores: setting one is an A/B run that compares identical code -- refuse it loudly
 RETIRED_ENV = {"NR_PW_MFMA": "use NR_PW_MFMA_OFF=1", "NR_PROP_SHARED_OFF": "no kernel ever read it (removed in ABI v27)",
                "NR_PROP_SHARED_BLOCKS": "no kernel ever read it (removed in ABI v27)"}

@@ -33,17 +33,11 @@
 
 namespace {
 
-// R6 EXPERIMENT (NR_TUNE_SHARED_LINE_TABLE=1; measured SLOWER, off by default -- DESIGN.md section 5): the table keyed by the
-// 64-BYTE LINE of the gradient table (4 neighbouring entries = 16 floats) instead of by vertex.
-// tools/atomic_group_lab.hip: the memory side's float-atomic rate is a rate of (wave instruction, 64-byte line) REQUESTS -- 20 G/s
-// whether a request carries 1, 4, 8 or 16 floats (4 B: 84 GB/s; one 16-byte vertex: 334 GB/s; an aligned x-pair of vertices:
-// 660 GB/s; a whole line: 1 290 GB/s) -- and two halves of a line in two instructions are two requests.  The scatter alone runs AT
-// that rate (14.5 M vertex requests / 20.7 G/s = 700 us).  The vertices of a cell's x-pairs are neighbours in the table whenever
-// x mod 4 != 3 (entry = (x ^ h(y, z)) mod T), and neighbouring rays' cells line up along x: a bucket = one line, the 16 lanes of a
-// bucket leave in ONE atomic instruction = one request for up to four vertices.  Same integer sums per (tile, level, vertex) as the
-// vertex-keyed table: the value added to the table is bit for bit the same.  Result: 870 vs 698 us alone, step 2.70 vs 2.31 ms
-// (same box, interleaved): a bucket holds ~1.5 vertices on these batches, so the flush issues ~2.7x the wave instructions (16 lanes
-// per bucket, most of them idle) for ~1/3 fewer requests -- the kernel is not bound by the request rate alone.
+// R6 experiments, measured and NOT adopted (code in git history, commit bbf50ab): the table keyed by the
+// 64-byte LINE of the gradient table (one atomic request per line instead of per vertex: -21 % requests, but +6 % wave-cycles:
+// 870 vs 698 us alone, step 2.70 vs 2.31 ms); two blocks per CU on a 3 328-slot table (alone 441 -> 292 us, in the step +2..5 %:
+// the bin blocks of the proposal scatters lose their LDS); the three scatters one after the other (+15 %); two features' sums in one
+// 64-bit integer (16 ds_add_u64 instead of 32 ds_add_u32 per row: alone -4 % / -1.5 %, step +-0).
 constexpr int kRows = 256;          // threads per block = rows per tile
 constexpr int kWaves = kRows / NR_WAVE;
 #ifndef NR_SHARED_SLOTS
@@ -82,33 +76,21 @@ __device__ unsigned long long g_shared_clocks[8];
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t key) { return __umulhi(key * 2654435761u, (uint32_t)kSlots); }
 
-// ---- line-keyed table: kBuckets buckets of 4 entries x F sums; a tile's 2 048 corners fall into at most 2 048 lines (every corner
-// a line of its own), typically ~1 300 for incoherent rows (an x-pair shares its line three times out of four) and a few hundred
-// for coherent ones; a line that finds no bucket within kLineProbes goes to the table directly
-#ifndef NR_SHARED_BUCKETS
-#define NR_SHARED_BUCKETS 2048
-#endif
-constexpr int kBuckets = NR_SHARED_BUCKETS;
-constexpr int kLineProbes = 64;
-constexpr int kLinePlane = kBuckets * 4 + 16;  // floats of one feature's plane: entry e of bucket b, feature f at f * kLinePlane + 4 b + e
-__device__ __forceinline__ uint32_t bucket_of(uint32_t line) { return __umulhi(line * 2654435761u, (uint32_t)kBuckets); }
-
-template <bool MARK, bool LINES>
+template <bool MARK>
 __global__ void __launch_bounds__(kRows)
 scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L,
                       int log2T, const float* __restrict__ gout, int64_t sl, float* __restrict__ gtable, int64_t n,
                       int64_t n_tiles, unsigned char* __restrict__ seen) {
   constexpr int F = 4;
-  constexpr int kKeys = LINES ? kBuckets : kSlots, kValPlane = LINES ? kLinePlane : kPlane, kOcc = LINES ? kBuckets : kMaxOcc;
-  __shared__ __attribute__((aligned(16))) uint32_t keys[kKeys];  // LINES: the bucket's line (entry index >> 2)
-  __shared__ __attribute__((aligned(16))) uint32_t vals[kValPlane * F];
-  __shared__ uint16_t occ[kOcc];
+  __shared__ __attribute__((aligned(16))) uint32_t keys[kSlots];
+  __shared__ __attribute__((aligned(16))) uint32_t vals[kPlane * F];
+  __shared__ uint16_t occ[kMaxOcc];
   __shared__ uint32_t count[2];
   __shared__ float wmax[kWaves];
   const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1), wave = tid >> 6;
   const uint32_t mask = (1u << log2T) - 1u;
-  for (int i = tid; i < kKeys; i += kRows) keys[i] = kEmpty;
-  for (int i = tid; i < kValPlane * F; i += kRows) vals[i] = 0u;
+  for (int i = tid; i < kSlots; i += kRows) keys[i] = kEmpty;
+  for (int i = tid; i < kPlane * F; i += kRows) vals[i] = 0u;
   if (tid < 2) count[tid] = 0u;
   __syncthreads();
 
@@ -259,37 +241,33 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
 #pragma unroll
       for (int c = 0; c < 8; ++c) nz |= ((q[c][0] | q[c][1] | q[c][2] | q[c][3]) != 0 ? 1u : 0u) << c;
       const bool ins = ins_row && tail;
-      // (LINES: the key is the corner's 64-byte line, s[] its BUCKET; the sums of entry e = idx & 3 live at 4 * bucket + e.  The
-      // second corner of an x-pair that shares the first one's line finds the bucket its own lane has just claimed.)
-      uint32_t s[8], old[8], key[8];
+      uint32_t s[8], old[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        key[c] = LINES ? idx[c] >> 2 : idx[c];
-        s[c] = LINES ? bucket_of(key[c]) : slot_of(key[c]);
-        old[c] = (ins && ((nz >> c) & 1u)) ? atomicCAS(&keys[s[c]], kEmpty, key[c]) : key[c];  // ds_cmpst_rtn_b32
+        s[c] = slot_of(idx[c]);
+        old[c] = (ins && ((nz >> c) & 1u)) ? atomicCAS(&keys[s[c]], kEmpty, idx[c]) : idx[c];  // ds_cmpst_rtn_b32
       }
-      uint32_t claimed = 0u;  // bit c: this lane created the slot (bucket) of corner c
+      uint32_t claimed = 0u;  // bit c: this lane created the slot of corner c
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const bool act = ins && ((nz >> c) & 1u);
         if (act && old[c] == kEmpty) claimed |= 1u << c;
-        if (act && old[c] != kEmpty && old[c] != key[c]) {  // taken by another vertex (line): linear probing
+        if (act && old[c] != kEmpty && old[c] != idx[c]) {  // taken by another vertex: linear probing
           uint32_t sc = s[c];
           int probes = 0;
           while (true) {
-            sc = sc + 1u == (uint32_t)kKeys ? 0u : sc + 1u;
-            const uint32_t o2 = atomicCAS(&keys[sc], kEmpty, key[c]);
+            sc = sc + 1u == (uint32_t)kSlots ? 0u : sc + 1u;
+            const uint32_t o2 = atomicCAS(&keys[sc], kEmpty, idx[c]);
             if (o2 == kEmpty) { claimed |= 1u << c; break; }
-            if (o2 == key[c]) break;
-            if (++probes >= (LINES ? kLineProbes : kMaxProbes)) { sc = kEmpty; break; }  // (vertex table, default build: cannot happen)
+            if (o2 == idx[c]) break;
+            if (++probes >= kMaxProbes) { sc = kEmpty; break; }  // (default build: cannot happen, at most 2 048 keys for 3 840 slots)
           }
           s[c] = sc;
         }
         if (act && s[c] != kEmpty) {
-          const uint32_t at = LINES ? s[c] * 4u + (idx[c] & 3u) : s[c];
 #pragma unroll
           for (int f = 0; f < F; ++f)
-            if (q[c][f] != 0) atomicAdd(&vals[f * kValPlane + at], (uint32_t)q[c][f]);  // ds_add_u32
+            if (q[c][f] != 0) atomicAdd(&vals[f * kPlane + s[c]], (uint32_t)q[c][f]);  // ds_add_u32
         } else if (act) {  // (no slot: see above)
 #pragma unroll
           for (int f = 0; f < F; ++f) unsafeAtomicAdd(base + (int64_t)idx[c] * F + f, (float)q[c][f] * inv_fix);
@@ -325,41 +303,6 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       NR_CLK(4)
       // ---- flush: lane = (occupied slot, feature); the slot is empty again afterwards.  Four slots per lane and trip, their LDS
       // reads issued together
-      if (LINES) {
-        // lane = (occupied bucket, entry, feature): the 16 lanes of a bucket are 16 consecutive floats of the table = ONE request
-        const uint32_t n_items = *cnt * 16u;
-        if (tid == 0) count[(unit + 1u) & 1u] = 0u;
-        for (uint32_t item0 = (uint32_t)tid; item0 < n_items; item0 += kRows * 4) {
-          uint32_t b[4], line[4];
-          int qq[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t item = item0 + (uint32_t)k * kRows;
-            b[k] = item < n_items ? occ[item >> 4] : kEmpty;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t ef = (item0 + (uint32_t)k * kRows) & 15u;
-            line[k] = b[k] != kEmpty ? keys[b[k]] : 0u;
-            qq[k] = b[k] != kEmpty ? (int)vals[(ef & 3u) * kValPlane + b[k] * 4u + (ef >> 2)] : 0;
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t ef = (item0 + (uint32_t)k * kRows) & 15u;
-            if (b[k] == kEmpty) continue;
-            if (ef == 0u) keys[b[k]] = kEmpty;  // (the 16 lanes of a bucket sit in one wave instruction: all have read the key)
-            if (qq[k] != 0) {
-              vals[(ef & 3u) * kValPlane + b[k] * 4u + (ef >> 2)] = 0u;
-              const uint32_t entry = (line[k] << 2) | (ef >> 2);
-              unsafeAtomicAdd(base + (int64_t)entry * F + (ef & 3u), (float)qq[k] * inv_fix);
-              if (MARK) seen[((int64_t)level << log2T) + entry] = 1;
-            }
-          }
-        }
-        NR_CLK(5)
-        ++unit;
-        continue;
-      }
       const uint32_t n_items = *cnt * F;
       if (tid == 0) count[(unit + 1u) & 1u] = 0u;  // (the other counter: last read in the previous unit's flush)
       for (uint32_t item0 = (uint32_t)tid; item0 < n_items; item0 += kRows * 4) {
@@ -444,15 +387,12 @@ extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const
   // beats two per CU by 4.5 % per step, same call (2.27 -> 2.17 ms fresh; 384 / 192 / 128 blocks: 2.24 / 2.20 / 2.45 ms)
   const int cap = nr_tuning().shared_blocks > 0 ? nr_tuning().shared_blocks : 256;
   const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
-#define CALL(MARK, LINES) hipLaunchKernelGGL((scatter_shared_kernel<MARK, LINES>), dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, \
-                                             L, log2T, grad_out, sl, grad_table, n, tiles, seen_grad)
-  const bool lines = nr_tuning().shared_line_table != 0;
-  if (seen_grad != nullptr) {
-    if (lines) CALL(true, true); else CALL(true, false);
-  } else {
-    if (lines) CALL(false, true); else CALL(false, false);
-  }
-#undef CALL
+  if (seen_grad != nullptr)
+    hipLaunchKernelGGL(scatter_shared_kernel<true>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,
+                       sl, grad_table, n, tiles, seen_grad);
+  else
+    hipLaunchKernelGGL(scatter_shared_kernel<false>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,
+                       sl, grad_table, n, tiles, seen_grad);
   NR_LAUNCH_CHECK();
   return 0;
 }

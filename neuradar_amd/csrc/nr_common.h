@@ -29,7 +29,6 @@ struct NrTuning {
   int pdbwd_blocks;        // NR_TUNE_PDBWD_BLOCKS: blocks of nr_prop_density_bwd
   int adam_blocks;         // NR_TUNE_ADAM_BLOCKS
   int pw_mfma_off;         // NR_TUNE_PW_MFMA_OFF: 1 = the transposed convolution on the generic pointwise kernels
-  int shared_line_table;   // NR_TUNE_SHARED_LINE_TABLE: 1 = the main grid's block-shared scatter keyed by 64-byte line (experiment) instead of by vertex
 };
 const NrTuning& nr_tuning();
 // The device's PARAMETER GENERATION word (capi.hip; allocated by nr_init, NULL before): bumped on the device by every launch that

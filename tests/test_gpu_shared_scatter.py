@@ -172,62 +172,3 @@ def test_shared_scatter_argument_checks_empty_input_and_nonfinite_rows():
     assert lib.nr_hash_encode_bwd_shared(p(x), p(sd), p(sc), L, 4, log2t, p(g3), 4, n * 4, p(gt3), n, None, st()) == 0
     rows_bad = bad.any(dim=1)
     assert_close(gt2[~rows_bad].cpu(), gt3[~rows_bad].cpu(), rtol=1e-5, atol_scale=1e-6, what="finite rows beside non-finite ones")
-
-
-def test_line_keyed_table_equals_the_vertex_keyed_table_bit_for_bit():
-    """Round 6 experiment: the table keyed by the 64-byte LINE of the gradient table (a bucket = 4 neighbouring entries, flushed as one
-    atomic request) instead of by vertex.  The integer sum of a (tile, level, vertex) is the same in both, so with ONE tile per
-    level -- every entry receives exactly one float add -- the two tables must produce the same bits.  The line-keyed table is an
-    opt-in experiment (NR_TUNE_SHARED_LINE_TABLE: measured slower); the default is the round-4 vertex table."""
-    from neuradar_amd import _lib
-    from oracle import hashgrid
-
-    torch.manual_seed(3)
-    L, log2t = 8, 18
-    sc = hashgrid.level_scalings(L, 32, 8192).to(DEV)
-    for n, spread in ((256, 1.0), (256, 1e-3), (200, 0.05)):  # incoherent rows / all rows within a few coarse cells / a ragged tile
-        x = (0.4 + spread * torch.rand(n, 3)).clamp(0, 1).to(DEV)
-        std = (0.002 * torch.rand(n)).to(DEV)
-        gout = torch.randn(n, L * 4).to(DEV)
-        seen_a, seen_b = (torch.zeros(L << log2t, dtype=torch.uint8, device=DEV) for _ in range(2))
-        a = _shared(x, std, sc, log2t, gout, seen_a)
-        try:
-            _lib.set_tuning("NR_SHARED_LINE_TABLE", 1)
-            b = _shared(x, std, sc, log2t, gout, seen_b)
-        finally:
-            _lib.set_tuning("NR_SHARED_LINE_TABLE", 0)
-        assert torch.equal(a, b), f"n={n} spread={spread}: {int((a != b).sum())} entries differ, worst {float((a - b).abs().max()):.3e}"
-        assert torch.equal(seen_a, seen_b)
-        assert float(a.abs().max()) > 0
-
-
-def test_line_keyed_table_when_every_corner_is_a_line_of_its_own():
-    """The adversarial geometry for the line-keyed table: every row's cell has x mod 4 == 3, so NO x-pair shares a line, and the
-    rows are incoherent -- 2 048 distinct lines per tile for 2 048 buckets: the probe limit is reached and the overflow goes to
-    the table directly.  Against the oracle, same bound as above."""
-    from oracle import hashgrid
-
-    torch.manual_seed(11)
-    n, log2t, res = 4096, 19, 512.0
-    sc = torch.tensor([res])
-    cell_x = (torch.randint(0, int(res) // 4, (n,)) * 4 + 3).float()
-    x = torch.stack([(cell_x + 0.05 + 0.9 * torch.rand(n)) / res, torch.rand(n), torch.rand(n)], dim=1).clamp(0, 1 - 1e-6)
-    assert bool(((torch.floor(x[:, 0] * res).long() % 4) == 3).all())
-    std = torch.zeros(n)
-    gout = torch.randn(n, 4)
-    table = hashgrid.init_table(1, log2t, 4, scale=1.0).requires_grad_(True)
-    ref = hashgrid.encode(x, table, sc, 2**log2t).view(n, 1, 4)
-    (gref,) = torch.autograd.grad(ref, table, gout.view(n, 1, 4))
-    from neuradar_amd import _lib
-
-    try:
-        _lib.set_tuning("NR_SHARED_LINE_TABLE", 1)
-        gt = _shared(x.to(DEV), std.to(DEV), sc.to(DEV), log2t, gout.to(DEV)).cpu()
-    finally:
-        _lib.set_tuning("NR_SHARED_LINE_TABLE", 0)
-    n_add = _addends(x.to(DEV), sc.to(DEV), log2t, torch.ones(n, 1, dtype=torch.bool, device=DEV)).cpu().double()[:, None]
-    bound = 1e-4 * gref.abs() + (n_add + 1.0) * (2.0 ** -21 + 2e-7) * float(gout.abs().max())
-    err = (gt - gref).abs()
-    assert bool((err <= bound).all()), f"worst excess {float((err - bound).max()):.3e}"
-    assert not bool(((gt != 0) & (gref == 0)).any())
-
