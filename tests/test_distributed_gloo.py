@@ -338,8 +338,13 @@ def _lists_worker(rank, world, port, delta, densities):
         hit = torch.rand(rows, generator=g) < dens
         fresh = torch.where(hit[:, None], torch.randn(rows, F, generator=g), torch.zeros(rows, F)).reshape(-1)
         grad += fresh  # (the scatter ADDS onto whatever an overflowed step left behind)
-        total = grad.clone()  # what the exchange must deliver if it delivers: the sum of the ranks' local gradients
-        dist.all_reduce(total)
+        # what the exchange must deliver if it delivers: the sum of the ranks' local gradients IN RANK ORDER (the owner adds the lists
+        # 0, 1, ..., world - 1 with plain adds; for two ranks any order gives the same float)
+        parts = [torch.empty_like(grad) for _ in range(world)]
+        dist.all_gather(parts, grad.clone())
+        total = torch.zeros_like(grad)
+        for part in parts:
+            total += part
         info = red.shard_step(opt, 0, 1.0 / world, delta_dtype=torch.bfloat16 if delta else None, defer=True, row_width=F,
                               kernels=(_torch_to16_clear, _torch_apply_delta),
                               list_kernels=(_torch_compact_shards, _torch_lists_apply, _torch_lists_restore))
@@ -381,6 +386,12 @@ def _lists_entry(rank, world, port, delta, densities, check):
 def test_two_rank_sharded_step_gradient_as_row_lists_to_the_owners():
     """15 % of the rows per rank, steady: every step goes as lists, results EXACTLY the replicated step's."""
     mp.spawn(_lists_entry, args=(2, _free_port(), False, [0.15] * 4, "all_lists"), nprocs=2, join=True)
+
+
+def test_four_rank_row_lists_exact_in_rank_order():
+    """Four ranks: per-destination segment sizes and offsets that differ (shard d of rank s holds what it holds), the owner's
+    sum in rank order -- bit for bit the sum 0 + g0 + g1 + g2 + g3."""
+    mp.spawn(_lists_entry, args=(4, _free_port(), False, [0.12] * 4, "all_lists"), nprocs=4, join=True)
 
 
 def test_two_rank_row_lists_with_bf16_update_deltas():
