@@ -289,7 +289,7 @@ class GradAllReducer:
         i32 = dict(device=dev, dtype=torch.int32)
         if st is None:
             st = dict(counts=torch.zeros(world, **i32), cm=torch.zeros(world * world, **i32), flag=torch.zeros(1, device=dev, dtype=torch.float32),
-                      host=[], pending=[], turn=0,
+                      host=[], pending=[], turn=0, calls=0,
                       zero_caps=torch.zeros(world, **i32), need=None, caps=None, caps_dev=None, dense_steps=0,
                       idx_s=None, val_s=None, idx_r=None, val_r=None)
             self._lists_state[key] = st
@@ -312,7 +312,7 @@ class GradAllReducer:
                 ev.record()
             else:
                 buf.copy_(st["cm"])
-            st["pending"].append((ev, buf))
+            st["pending"].append((st["calls"], ev, buf))
 
         if len(st["host"]) != lag + 1:
             mk = lambda: torch.zeros(world * world, dtype=torch.int32)  # noqa: E731
@@ -321,8 +321,9 @@ class GradAllReducer:
         # would hold the host within one step of the device on every step; two steps back the copy has landed long ago and the
         # host keeps its run-ahead (graph segments: tests/test_gpu_dp.py::test_segment_replay_takes_the_host_out...).  Every
         # rank applies the same rule, so every rank sizes its segments from the same counts.
-        while len(st["pending"]) >= lag:
-            ev, buf = st["pending"].pop(0)
+        st["calls"] += 1
+        while st["pending"] and st["pending"][0][0] <= st["calls"] - lag:  # (by call number: the same entries on every rank)
+            _, ev, buf = st["pending"].pop(0)
             if ev is not None and not ev.query():
                 # the host has run `lag` steps ahead of the device: it waits here for the counts -- back-pressure, not work; the time
                 # is accounted separately (bench.py reports the launch loop's host time without it)
