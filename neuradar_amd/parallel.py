@@ -259,9 +259,10 @@ class GradAllReducer:
           2. the counts are all-gathered ([world, world] on every rank) and copied to pinned host memory asynchronously: they
              size the segments of the step `count_lag` (2) steps later -- by then the copy has landed long ago and the host is
              never held within a step of the device -- at 1.3 x the largest list a destination received, kept while it stays
-             within [1.1, 1.6] x; (1 + 1.3 lag) x after an overflow, whose kept gradient the following steps add onto and decide, one step late and alike on every rank, to fall back to the dense reduce-scatter when a
-             list would exceed half a shard's rows (there the lists' 4 + 4F bytes per row stop paying against 4F per row of
-             the dense ring).  No host read after the first call (which counts once, synchronously, before any timed region).
+             within [1.1, 1.6] x; (1 + 1.3 lag) x after an overflow, whose kept gradient the following steps add onto.  The same
+             counts decide, `count_lag` steps late and alike on every rank, to fall back to the dense reduce-scatter when a list
+             would exceed half a shard's rows (there the lists' 4 + 4F bytes per row stop paying against 4F per row of the dense
+             ring).  No host read after the first call (which counts once, synchronously, before any timed region).
           3. all-to-all of the index parts, all-to-all of the value parts (fixed sizes known to every rank: segment d of every
              rank goes to rank d).
           4. nr_grad_lists_apply per source rank, IN RANK ORDER, plain adds onto g[lo:hi]: every owner computes a sum that
