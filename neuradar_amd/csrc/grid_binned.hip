@@ -146,8 +146,10 @@ struct BinSegment {
   int n_samples;
 };
 
+// (F = 1 on 32-bit sums: 48 KB of LDS per block = THREE blocks per CU, which needs six waves per SIMD = at most 80 VGPRs; left alone
+// the compiler took 84 -- five waves per SIMD, two resident blocks per CU, and the launch's third block per CU ran as a tail)
 template <int F, bool HEAD, typename SumT>
-__global__ void __launch_bounds__(BinCfg<F>::ROWS)
+__global__ void __launch_bounds__(BinCfg<F>::ROWS) __attribute__((amdgpu_waves_per_eu((F == 1 && sizeof(SumT) == 4) ? 6 : 1)))
 bin_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L, int level0,
            int log2T, const float* __restrict__ gout, int64_t sn, int64_t sl, float* __restrict__ gtable, int64_t n, int ns,
            int shift, int cap_log2, int64_t nb, uint32_t* __restrict__ rkey, SumT* __restrict__ rsum,
