@@ -644,6 +644,62 @@ def measure_render(model, scene, device, reps=5):
     return out
 
 
+FALLBACKS: list = []  # world > 1: what failed on the way and what ran instead (in the line as config.fallbacks)
+
+
+def note_fallback(what, exc, instead):
+    """A block of a multi-GPU run failed with an exception every rank sees (an argument RCCL refuses, a capture error): say so
+    on stderr, keep it for the line, and let the caller go on with `instead`.  (A rank that fails ALONE leaves the others in a
+    collective: nothing in-process recovers that -- the process group's timeout ends the job.)"""
+    import traceback
+
+    FALLBACKS.append({"failed": what, "error": f"{type(exc).__name__}: {exc}"[:300], "instead": instead})
+    print(f"[bench] {what} failed ({type(exc).__name__}: {exc}); {instead}", file=sys.stderr, flush=True)
+    traceback.print_exc(file=sys.stderr)
+
+
+def measure_headline(args, rank, world, device):
+    """The headline block.  world == 1: exceptions surface as they are.  world > 1 -- a first run on a real node must not be
+    lost to one refusing call -- a ladder: as configured -> the sharded step's gradient half as a dense reduce-scatter
+    (NR_SHARD_LISTS=0) -> the plain dense all-reduce (--table-exchange dense) -> that without graph segments; args / environment
+    stay degraded for the blocks that follow, config.fallbacks names every rung taken."""
+    import gc
+
+    def run():
+        return measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, not args.no_cpu_baseline,
+                       args.min_seconds, trained_steps=args.trained_steps if args.regime == "trained" else 0)
+
+    if world == 1:
+        return run()
+
+    def lists_off():
+        os.environ["NR_SHARD_LISTS"] = "0"
+
+    def dense():
+        args.table_exchange = "dense"
+
+    def eager():
+        args.no_graph = True
+
+    ladder = [("sharded step with a dense reduce-scatter (NR_SHARD_LISTS=0)", lists_off), ("dense all-reduce (--table-exchange dense)", dense),
+              ("dense all-reduce, eager launches (--no-graph)", eager)]
+    while True:
+        try:
+            return run()
+        except Exception as e:  # noqa: BLE001
+            if not ladder:
+                raise
+            instead, apply = ladder.pop(0)
+            note_fallback("headline block", e, instead)
+            apply()
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            gc.collect()
+            torch.cuda.empty_cache()
+
+
 def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_cpu, min_seconds, trained_steps=0, min_blocks=1):
     """Build `workload`, warm up, time it (see timed_block) and, on request, collect the roofline / CPU-baseline blocks.
     trained_steps > 0: the "trained" regime -- scene-consistent targets (make_step), that many training steps before the timed
@@ -673,6 +729,8 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     one_rank = bool(getattr(args, "one_rank_collectives", False))
     reducer.force_collectives = one_rank
     reducer.shard_lists = os.environ.get("NR_SHARD_LISTS", "1") != "0"  # (0: the sharded step's gradient half as a dense reduce-scatter)
+    if "lists" in os.environ.get("NR_BENCH_INJECT", "").split(",") and reducer.shard_lists and mode == "shard" and world > 1:
+        raise RuntimeError("injected failure (NR_BENCH_INJECT=lists)")  # (tests: the headline ladder)
     reducer.table_delta = torch.bfloat16 if args.table_delta == "bf16" else None
     reducer.defer_gather = not args.no_defer_gather
     if mode == "shard" and args.table_transport == "bf16":
@@ -772,13 +830,22 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
         torch.cuda.synchronize()
         slots = getattr(fwd_bwd, "state", None)
         seg_steps = {}
-        for _ in range(2 if slots is not None else 1):
-            k = slots["k"] if slots is not None else 0
-            seg_steps[k] = SegmentedStep(stepper).capture(fwd_bwd)  # (fwd_bwd flips slots["k"]; nothing executes during capture)
-        segmented = sum(len(v.parts) for v in seg_steps.values()) // len(seg_steps)
+        try:
+            if "segments" in os.environ.get("NR_BENCH_INJECT", "").split(","):
+                raise RuntimeError("injected failure (NR_BENCH_INJECT=segments)")
+            for _ in range(2 if slots is not None else 1):
+                k = slots["k"] if slots is not None else 0
+                seg_steps[k] = SegmentedStep(stepper).capture(fwd_bwd)  # (fwd_bwd flips slots["k"]; nothing executes during capture)
+            segmented = sum(len(v.parts) for v in seg_steps.values()) // len(seg_steps)
+        except Exception as e:  # noqa: BLE001  (SegmentedStep.capture has ended the capture and dropped its parts)
+            note_fallback(f"{workload}: graph segments", e, "eager launches")
+            seg_steps = {}
+            torch.cuda.synchronize()
 
         def step():
-            if slots is not None:
+            if not seg_steps:
+                fwd_bwd()
+            elif slots is not None:
                 k = slots["k"]
                 slots["k"] = 1 - k
                 seg_steps[k].replay()
@@ -1041,7 +1108,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     return result
 
 
-def launch_ranks(n, argv, limit_s=0.0):
+def launch_ranks(n, argv, limit_s=0.0, extra_env=None, stdout0=None):
     """`python bench.py --gpus N` without a launcher: start N CHILD processes of this file, one per GPU, with the environment
     torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / MASTER_PORT = a free port),
     wait for them and return the worst exit code.  Children, never an exec, and this process makes no HIP / torch.cuda call: it
@@ -1060,10 +1127,10 @@ def launch_ranks(n, argv, limit_s=0.0):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                   NR_BENCH_SELF_LAUNCHED="1")
+                   NR_BENCH_SELF_LAUNCHED="1", **(extra_env or {}))
         env.setdefault("OMP_NUM_THREADS", str(max(1, cpus // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL, stdin=subprocess.DEVNULL))
+                                      stdout=stdout0 if r == 0 else subprocess.DEVNULL, stdin=subprocess.DEVNULL))
 
     def stop_all(sig):
         for p_ in procs:
@@ -1112,6 +1179,34 @@ def launch_ranks(n, argv, limit_s=0.0):
     return worst
 
 
+def launch_with_retries(n, argv, limit_s=0.0, retry=True):
+    """launch_ranks, and when the job FAILS (a rank raised, or RCCL's watchdog ended a hung collective after NR_DIST_TIMEOUT_S)
+    the same command once more per rung of the ladder measure_headline climbs in-process: row lists off, dense all-reduce, dense
+    all-reduce launched eagerly.  Rank 0's stdout goes through a file and only the LAST attempt's is relayed, so the command
+    prints one JSON line whatever happened on the way; the line's config.fallbacks names the attempts that failed."""
+    import tempfile
+
+    rungs = [({}, []), ({"NR_SHARD_LISTS": "0"}, []), ({"NR_SHARD_LISTS": "0"}, ["--table-exchange", "dense"]),
+             ({"NR_SHARD_LISTS": "0", "NR_SEGMENTS": "0"}, ["--table-exchange", "dense", "--no-graph"])]
+    if not retry:
+        rungs = rungs[:1]
+    history, rc = [], 1
+    for k, (env_k, argv_k) in enumerate(rungs):
+        with tempfile.TemporaryFile(mode="w+b") as out0:
+            t0 = time.monotonic()
+            rc = launch_ranks(n, [*argv, *argv_k], limit_s, dict(env_k, NR_BENCH_LAUNCH_ATTEMPT=str(k), NR_BENCH_LAUNCH_HISTORY=json.dumps(history)), out0)
+            last = k == len(rungs) - 1 or rc in (0, 124)
+            if last:
+                out0.seek(0)
+                sys.stdout.buffer.write(out0.read())
+                sys.stdout.flush()
+                return rc
+        history.append({"failed": f"launch attempt {k}: env {env_k} args {argv_k}", "error": f"exit code {rc} after {time.monotonic() - t0:.0f} s",
+                        "instead": f"env {rungs[k + 1][0]} args {rungs[k + 1][1]}"})
+        print(f"[bench] launcher: attempt {k} failed (exit code {rc}); once more with env {rungs[k + 1][0]} args {rungs[k + 1][1]}", file=sys.stderr, flush=True)
+    return rc
+
+
 def launch_check(args):
     """--launch-check: what the launcher must get right, without the workload -- every rank joins the group over the backend
     asked for, one all-reduce crosses it, rank 0 prints the world it saw."""
@@ -1119,10 +1214,12 @@ def launch_check(args):
 
     from neuradar_amd.parallel import init_distributed
 
-    rank, world, local_rank = init_distributed(args.dist_backend)
+    rank, world, local_rank = init_distributed(args.dist_backend, timeout_s=float(os.environ.get("NR_DIST_TIMEOUT_S", "300")))
     if world != args.gpus:
         print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         return 2
+    attempt = int(os.environ.get("NR_BENCH_LAUNCH_ATTEMPT", "0"))
+    failing = attempt < int(os.environ.get("NR_BENCH_FAIL_ATTEMPTS", "1000"))  # (tests: the first k attempts fail, the next one passes)
     seen = world
     if world > 1:
         dev = torch.device("cuda", 0 if args.single_device else local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -1130,12 +1227,13 @@ def launch_check(args):
         dist.all_reduce(t)
         assert float(t) == world * (world + 1) / 2, float(t)
         seen = dist.get_world_size()
-    if os.environ.get("NR_BENCH_FAIL_RANK") == str(rank):  # (tests: one rank dies, the launcher must stop the others)
+    if failing and os.environ.get("NR_BENCH_FAIL_RANK") == str(rank):  # (tests: one rank dies, the launcher must stop the others)
         return 7
-    if os.environ.get("NR_BENCH_HANG_RANK") == str(rank):
+    if failing and os.environ.get("NR_BENCH_HANG_RANK") == str(rank):
         time.sleep(3600)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": seen, "backend": dist.get_backend() if world > 1 else None,
+                          "launch_attempt": attempt, "fallbacks": json.loads(os.environ.get("NR_BENCH_LAUNCH_HISTORY", "[]")),
                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
     if world > 1:
         dist.barrier()
@@ -1206,12 +1304,14 @@ def main():
                     "rank 0 prints {n_gpus, ranks}: the launcher by itself (no GPU needed with --dist-backend gloo)")
     ap.add_argument("--rank-timeout", type=float, default=0.0, help="self-launched ranks (--gpus N without WORLD_SIZE): kill the job "
                     "after this many seconds (0 = no limit)")
+    ap.add_argument("--no-launch-retry", action="store_true", help="self-launched ranks: do not run the command again on a simpler "
+                    "gradient exchange when the job fails (default: up to three more attempts, named in config.fallbacks)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: this process becomes the launcher of N rank processes and touches no GPU itself
         # (the reference starts one process per GPU by itself too: scripts/train.py:167-230, mp.spawn at :211)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
+        raise SystemExit(launch_with_retries(args.gpus, sys.argv[1:], args.rank_timeout, retry=not args.no_launch_retry))
     if args.launch_check:
         raise SystemExit(launch_check(args))
 
@@ -1221,7 +1321,10 @@ def main():
 
     neuradar_amd.apply_miopen_workaround()  # (the fp32 workloads' CNN backward goes through MIOpen; explicit since round 6)
     _lib.lib()  # fail loudly if the HIP extension is missing
-    rank, world, local_rank = init_distributed(args.dist_backend)
+    # (a hung collective ends the job after NR_DIST_TIMEOUT_S instead of the backends' 10 / 30 minutes; no block of this file keeps
+    # a rank away from the others for longer than tens of seconds)
+    rank, world, local_rank = init_distributed(args.dist_backend, timeout_s=float(os.environ.get("NR_DIST_TIMEOUT_S", "300")))
+    FALLBACKS.extend(json.loads(os.environ.get("NR_BENCH_LAUNCH_HISTORY", "[]")))
     if args.one_rank_collectives:
         if world != 1:
             raise SystemExit("--one-rank-collectives is for --gpus 1")
@@ -1238,13 +1341,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    main_res = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, not args.no_cpu_baseline,
-                       args.min_seconds, trained_steps=args.trained_steps if args.regime == "trained" else 0)
+    main_res = measure_headline(args, rank, world, device)
     if rank == 0 and world > 1:
         # (stderr: stdout carries ONE line at the end; should a later block of a first-ever N-GPU run fail, the headline is on record)
         print("[bench] headline (world %d): %.1f rays/s, %.4f ms/step, exchange %s" % (world, main_res["value"], main_res["ms_per_step"],
               json.dumps({k_: v_ for k_, v_ in (main_res["exchange"] or {}).items() if k_ not in ("rows", "flag")} if isinstance(main_res["exchange"], dict) else main_res["exchange"])),
               file=sys.stderr, flush=True)
+    def guard(what, fn):
+        # (world > 1: a later block failing on every rank must not take the measured headline with it)
+        if world == 1:
+            return fn()
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            note_fallback(what, e, "left out of the line")
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            return None
+
     exchange_variants = None
     if world > 1 and not args.autograd:
         # one multi-GPU run answers every question about the exchange: the headline above used the default (fp32 on both halves);
@@ -1259,8 +1375,8 @@ def main():
                 raise SystemExit(f"--exchange-variants: unknown variant {v_!r}")
             a2 = argparse.Namespace(**vars(args))
             a2.table_transport, a2.table_delta = "bf16", "bf16"
-            vr = measure(a2, args.workload, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
-            exchange_variants["bf16_transport_bf16_delta"] = {
+            vr = guard("exchange variant bf16", lambda: measure(a2, args.workload, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5)))
+            exchange_variants["bf16_transport_bf16_delta"] = None if vr is None else {
                 "value": round(vr["value"], 1), "unit": "rays/s", "ms_per_step": round(vr["ms_per_step"], 4), "timed_blocks": vr["blocks"],
                 "ms_per_step_per_rank": vr["per_rank_ms"], "main_table_exchange_dtypes": vr["exchange_dtypes"],
                 "main_table": {k_: v2 for k_, v2 in (vr["exchange"] or {}).items() if k_ not in ("rows", "flag")} if isinstance(vr["exchange"], dict) else vr["exchange"],
@@ -1274,8 +1390,8 @@ def main():
     if args.secondary and args.secondary != args.workload and not args.autograd:
         # BASELINE.json configs[1] (the configuration the north star's >= 2 M rays/s target is phrased on) beside the
         # headline configs[2] shape, same precision, same timing rules, in the same JSON line
-        sec = measure(args, args.secondary, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5))
-        secondary = {"workload": sec["workload"], "value": round(sec["value"], 1), "unit": "rays/s", "ms_per_step": round(sec["ms_per_step"], 4),
+        sec = guard("secondary block", lambda: measure(args, args.secondary, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5)))
+        secondary = None if sec is None else {"workload": sec["workload"], "value": round(sec["value"], 1), "unit": "rays/s", "ms_per_step": round(sec["ms_per_step"], 4),
                      "ms_per_step_min": round(sec["ms_min"], 4), "ms_per_step_max": round(sec["ms_max"], 4), "timed_blocks": sec["blocks"],
                      "rays_per_gpu_per_step": sec["n_rays"], "main_grid": sec["wl"]["grid"], "mlp_width": sec["wl"]["hidden"]}
     full_model = []
@@ -1284,7 +1400,9 @@ def main():
         # (RGB CNN, lidar MLP, radar transformer + heads, Hungarian-matched radar loss), same timing rules, reported beside the headline
         for w_ in args.full_model.split(","):
             # (>= 12 timed blocks each, median + p10 / p90 in the line: four blocks with a 2.6x spread are not a measurement -- VERDICT r04 weak #7)
-            fr = measure(args, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5), min_blocks=12)
+            fr = guard(f"full_model block {w_}", lambda: measure(args, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5), min_blocks=12))
+            if fr is None:
+                continue
             full_model.append({"workload": w_, "value": round(fr["value"], 1), "unit": "rays/s", "ms_per_step": round(fr["ms_per_step"], 4),
                                "ms_per_step_min": round(fr["ms_min"], 4), "ms_per_step_max": round(fr["ms_max"], 4),
                                "ms_per_step_p10": round(fr["ms_p10"], 4), "ms_per_step_p90": round(fr["ms_p90"], 4),
@@ -1304,9 +1422,9 @@ def main():
                 # can say what the trained model renders -- `quality`; the radar detections stay synthetic points)
                 a2 = argparse.Namespace(**vars(args))
                 a2.no_render = True
-                ft = measure(a2, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5),
-                             trained_steps=args.full_model_trained_steps, min_blocks=12)
-                full_model[-1]["after_training"] = {"steps_trained": -(-args.full_model_trained_steps // 2) * 2, "value": round(ft["value"], 1),
+                ft = guard(f"full_model block {w_} after training", lambda: measure(a2, w_, args.mlp_dtype, rank, world, device, False, False, min(args.min_seconds, 0.5),
+                                                                                    trained_steps=args.full_model_trained_steps, min_blocks=12))
+                full_model[-1]["after_training"] = None if ft is None else {"steps_trained": -(-args.full_model_trained_steps // 2) * 2, "value": round(ft["value"], 1),
                                                     "unit": "rays/s", "ms_per_step": round(ft["ms_per_step"], 4),
                                                     "ms_per_step_min": round(ft["ms_min"], 4), "ms_per_step_max": round(ft["ms_max"], 4),
                                                     "ms_per_step_p10": round(ft["ms_p10"], 4), "ms_per_step_p90": round(ft["ms_p90"], 4), "timed_blocks": ft["blocks"],
@@ -1316,9 +1434,9 @@ def main():
     if args.trained_steps > 0 and not args.autograd and args.regime != "trained":
         # the headline workload in the TRAINED regime: scene-consistent targets, args.trained_steps training steps, then the same
         # timing rules (the resampled rounds spread along the rays and every row carries a gradient: DESIGN.md section 5)
-        tr = measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, False, min(args.min_seconds, 0.5),
-                     trained_steps=args.trained_steps)
-        trained = {"workload": tr["workload"], "steps_trained": -(-args.trained_steps // 2) * 2, "targets": "analytic street canyon (scene-consistent)",
+        tr = guard("trained block", lambda: measure(args, args.workload, args.mlp_dtype, rank, world, device, not args.no_roofline, False, min(args.min_seconds, 0.5),
+                                                    trained_steps=args.trained_steps))
+        trained = None if tr is None else {"workload": tr["workload"], "steps_trained": -(-args.trained_steps // 2) * 2, "targets": "analytic street canyon (scene-consistent)",
                    "value": round(tr["value"], 1), "unit": "rays/s", "ms_per_step": round(tr["ms_per_step"], 4),
                    "ms_per_step_min": round(tr["ms_min"], 4), "ms_per_step_max": round(tr["ms_max"], 4), "timed_blocks": tr["blocks"],
                    "quality": tr["quality"], "roofline": tr["roof"]}
@@ -1351,6 +1469,7 @@ def main():
                        "gradient_exchange": r["exchange_cost"], "exchange_variants": exchange_variants,
                        "ms_per_step_per_rank": r["per_rank_ms"],
                        "ms_per_step_rank_min_max": [min(r["per_rank_ms"]), max(r["per_rank_ms"])] if r["per_rank_ms"] else None,
+                       "fallbacks": FALLBACKS,
                        "launcher": "self (python bench.py --gpus N)" if os.environ.get("NR_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if world > 1 else None)},
             "roofline": r["roof"], "cpu_baseline": r["cpu"], "secondary": secondary, "trained": trained, "full_model": full_model,
         }

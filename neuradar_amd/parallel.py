@@ -7,6 +7,7 @@ their own large flat buckets (one collective per table, no DDP bucketing/copy), 
 are packed into a single fused bucket, and unused parameters (proposal_fields[0]) are simply
 all-reduced as zeros instead of DDP's find_unused_parameters bitmap exchange.
 """
+import datetime
 import os
 import weakref
 from typing import Iterable, List, Optional
@@ -37,8 +38,9 @@ class _nullcontext:
         return False
 
 
-def init_distributed(backend: Optional[str] = None) -> tuple:
-    """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
+def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] = None) -> tuple:
+    """(rank, world, local_rank) from the torchrun environment; no-op for a single process.  timeout_s: the process group's
+    collective timeout (None: the backend's default -- 10 minutes for RCCL, 30 for gloo)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,7 +51,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
             torch.cuda.set_device(local_rank)
         elif torch.cuda.is_available():
             torch.cuda.set_device(min(local_rank, torch.cuda.device_count() - 1))
-        dist.init_process_group(backend=backend)
+        kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=timeout_s)}
+        dist.init_process_group(backend=backend, **kw)
     return rank, world, local_rank
 
 

@@ -35,7 +35,7 @@ def test_launcher_stops_the_other_ranks_when_one_dies():
     """Rank 1 exits with code 7 while rank 0 hangs (stands for: waits in a collective): the launcher ends rank 0 and reports failure
     in seconds, not at the driver's time limit."""
     t0 = time.monotonic()
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", "--dist-backend", "gloo"],
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", "--dist-backend", "gloo", "--no-launch-retry"],
                        env=_env(NR_BENCH_FAIL_RANK="1", NR_BENCH_HANG_RANK="0"), cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "rank 1 exited with code 7" in r.stderr, (r.returncode, r.stderr[-1000:])
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -93,3 +93,42 @@ def test_bench_gpus_2_as_typed_runs_the_data_parallel_step_and_reports_the_excha
     assert "replicas identical on 2 ranks" in r.stderr
     print(f"2 ranks on one device: {d['ms_per_step']} ms/step; lists {mt['reduce_scatter_bytes_per_gpu'] / 1e6:.1f} MB vs dense "
           f"{mt['dense_reduce_scatter_would_be'] / 1e6:.1f} MB per GPU; bf16 variant {b['ms_per_step']} ms; off {ev['exchange_off']['ms_per_step']} ms")
+
+
+def test_launcher_runs_the_command_again_when_the_job_fails():
+    """A first multi-GPU run must not be lost to one refusing call: when the job fails (here: rank 1 exits with code 7 on the first
+    TWO attempts) the launcher runs the same command again on the next simpler gradient exchange, relays only the last attempt's
+    stdout -- one JSON line -- and the line names the attempts that failed.  --no-launch-retry: the first failure is final."""
+    args = [sys.executable, BENCH, "--gpus", "2", "--launch-check", "--dist-backend", "gloo"]
+    r = subprocess.run(args, env=_env(NR_BENCH_FAIL_RANK="1", NR_BENCH_FAIL_ATTEMPTS="2"), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["launch_attempt"] == 2 and len(d["fallbacks"]) == 2 and "exit code" in d["fallbacks"][0]["error"], d
+    assert "NR_SHARD_LISTS" in d["fallbacks"][0]["instead"] and "--table-exchange" in d["fallbacks"][1]["instead"]
+    assert r.stderr.count("once more with") == 2
+    r = subprocess.run(args + ["--no-launch-retry"], env=_env(NR_BENCH_FAIL_RANK="1", NR_BENCH_FAIL_ATTEMPTS="2"), cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "rank 1 exited with code 7" in r.stderr and "once more with" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_goes_on_with_a_simpler_exchange_when_a_block_fails_on_every_rank():
+    """The in-process half of the same insurance (the driver starts the ranks with torch.distributed.run: no launcher of ours to
+    try again): the row-list exchange raising on every rank (injected) -> the headline is measured on the sharded step with a dense
+    reduce-scatter; graph-segment capture raising -> eager launches; the line says both."""
+    cmd = [sys.executable, BENCH, "--gpus", "2", "--single-device", "--dist-backend", "gloo", "--steps", "4", "--warmup", "2",
+           "--secondary", "", "--full-model", "", "--trained-steps", "0", "--min-seconds", "0", "--no-cpu-baseline", "--no-roofline",
+           "--exchange-variants", "", "--check-replicas"]
+    r = subprocess.run(cmd, env=_env(NR_BENCH_INJECT="lists,segments"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = d["config"]
+    fb = cfg["fallbacks"]
+    assert len(fb) == 2 and fb[0]["failed"] == "headline block" and "NR_SHARD_LISTS=0" in fb[0]["instead"], fb
+    assert "graph segments" in fb[1]["failed"] and fb[1]["instead"] == "eager launches", fb
+    mt = cfg["gradient_exchange"]["main_table"]
+    assert cfg["gradient_exchange"]["main_table_mode"] == "shard" and not mt["gradient_half"].startswith("row lists"), mt
+    assert cfg["graph_segments_per_step"] == 0 and d["n_gpus"] == 2 and d["value"] > 0
+    assert "replicas identical on 2 ranks" in r.stderr
