@@ -26,7 +26,7 @@ extern "C" {
 
 #define NR_EINVAL (-1)
 #define NR_MAX_LAYERS 8
-#define NR_ABI_VERSION 27
+#define NR_ABI_VERSION 28
 #define NR_DTYPE_F32 0
 #define NR_DTYPE_BF16 1
 #define NR_DTYPE_F16 2
@@ -56,7 +56,8 @@ enum {
   NR_TUNE_FIELD_BWD_BLOCKS = 4,  /* blocks (= gradient slabs) of nr_field_bwd* (default 256 fp32 / 512 16-bit) */
   NR_TUNE_PDBWD_BLOCKS = 5,      /* blocks of nr_prop_density_bwd (default 256) */
   NR_TUNE_ADAM_BLOCKS = 6,       /* blocks of nr_adam_step* (default 4096) */
-  NR_TUNE_PW_MFMA_OFF = 7        /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+  NR_TUNE_PW_MFMA_OFF = 7,       /* 1: ConvTranspose2d on the generic pointwise kernels instead of the MFMA ones */
+  NR_TUNE_SHARED_SPLIT = 8       /* v28: threads per row of nr_hash_encode_bwd_shared: 1 (default), 2 or 4 share a row's 8 corners */
 };                               /* (v27: knobs 8 / 9 of v26 -- NR_TUNE_PROP_SHARED_* -- are gone: nothing read them) */
 int nr_init(void);
 int nr_set_tuning(int knob, int value);
@@ -121,6 +122,15 @@ int nr_hash_encode_bwd_shared(const float* x01, const float* std01, const float*
                               int features_per_level, int log2_hashmap_size, const float* grad_out, int64_t out_stride_n,
                               int64_t out_stride_l, float* grad_table, int64_t n, unsigned char* seen_grad,
                               nr_stream_t stream);
+
+/* v28: the same with the launch shape chosen by the caller: threads_per_row = 1, 2 or 4 threads share a row's 8 corners (blocks of
+ * 256 / 512 / 1 024 threads on the same 256-row tile and the same table: 1 / 2 / 4 waves per SIMD to hide the LDS round trips
+ * behind); 0 = the library's default (NR_TUNE_SHARED_SPLIT, else 1).  Same sums whatever the shape (integer addition).  Which
+ * is faster depends on what runs beside it: by itself 2 (-18 %), beside the step's proposal scatters 1. */
+int nr_hash_encode_bwd_shared_split(const float* x01, const float* std01, const float* scalings, int num_levels,
+                                    int features_per_level, int log2_hashmap_size, const float* grad_out, int64_t out_stride_n,
+                                    int64_t out_stride_l, float* grad_table, int64_t n, unsigned char* seen_grad,
+                                    int threads_per_row, nr_stream_t stream);
 
 /* The same scatter-add by TABLE SLICE OWNERSHIP, for tables a step hits densely (the proposal grids) and for incoherent rows
  * (lidar / radar rays), where the merging of nr_hash_encode_bwd finds little and the launch runs at the memory side's rate for

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NR_LIB_PATH") or os.path.join(CSRC, "libneuradar_hip.
 NR_MAX_LAYERS = 8
 NR_EINVAL = -1
 NR_LOSS_SLOTS = 1024
-NR_ABI_VERSION = 27
+NR_ABI_VERSION = 28
 NR_DTYPES = {"float32": 0, "bfloat16": 1, "float16": 2}  # nr_field_t.dtype
 # nr_amp state layout (include/neuradar_hip.h)
 NR_AMP_MAX_GROUPS, NR_AMP_SCALE, NR_AMP_GROWTH_TRACKER, NR_AMP_INV_SCALE, NR_AMP_SKIPPED_PREV, NR_AMP_SKIPPED_TOTAL = 8, 0, 1, 2, 3, 4
@@ -92,6 +92,7 @@ PROTOTYPES = {
     "nr_hash_encode_bwd_tuned": [P, P, P, I, I, I, P, L, L, P, L, I, I, P],
     "nr_hash_encode_bwd_marked": [P, P, P, I, I, I, P, L, L, P, L, I, I, P, P],
     "nr_hash_encode_bwd_shared": [P, P, P, I, I, I, P, L, L, P, L, P, P],
+    "nr_hash_encode_bwd_shared_split": [P, P, P, I, I, I, P, L, L, P, L, P, I, P],
     "nr_hash_encode_bwd_binned_workspace_bytes": [I, I, I, L],
     "nr_hash_encode_bwd_binned": [P, P, P, I, I, I, P, L, L, P, L, P, P],
     "nr_prop_density_scatter_binned": [P, P, P, I, I, I, P, L, L, P, P, I, L, P, P, L, P, P],
@@ -255,7 +256,8 @@ def lib() -> ctypes.CDLL:
 TUNING = (("NR_CONV7_BLOCKS", "persistent blocks of nr_conv7_fwd"), ("NR_BIN_BLOCKS_PER_CU", "bin blocks per half CU"),
           ("NR_SHARED_BLOCKS", "blocks of nr_hash_encode_bwd_shared"), ("NR_FIELD_FWD_BLOCKS", "blocks of nr_field_fwd*"),
           ("NR_FIELD_BWD_BLOCKS", "blocks of nr_field_bwd*"), ("NR_PDBWD_BLOCKS", "blocks of nr_prop_density_bwd"),
-          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"))
+          ("NR_ADAM_BLOCKS", "blocks of nr_adam_step*"), ("NR_PW_MFMA_OFF", "1: generic kernels for the transposed convolution"),
+          ("NR_SHARED_SPLIT", "threads per row of nr_hash_encode_bwd_shared* (1, 2, 4): overrides the caller's choice"))
 # variables earlier rounds read and this build ignores: setting one is an A/B run that compares identical code -- refuse it loudly
 RETIRED_ENV = {"NR_PW_MFMA": "use NR_PW_MFMA_OFF=1", "NR_PROP_SHARED_OFF": "no kernel ever read it (removed in ABI v27)",
                "NR_PROP_SHARED_BLOCKS": "no kernel ever read it (removed in ABI v27)"}

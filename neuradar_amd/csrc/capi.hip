@@ -52,6 +52,7 @@ extern "C" int nr_set_tuning(int knob, int value) {
     case NR_TUNE_PDBWD_BLOCKS: g_tuning.pdbwd_blocks = value; break;
     case NR_TUNE_ADAM_BLOCKS: g_tuning.adam_blocks = value; break;
     case NR_TUNE_PW_MFMA_OFF: g_tuning.pw_mfma_off = value; break;
+    case NR_TUNE_SHARED_SPLIT: g_tuning.shared_split = value; break;
     default: return NR_EINVAL;
   }
   return 0;

@@ -38,8 +38,17 @@ namespace {
 // 870 vs 698 us alone, step 2.70 vs 2.31 ms); two blocks per CU on a 3 328-slot table (alone 441 -> 292 us, in the step +2..5 %:
 // the bin blocks of the proposal scatters lose their LDS); the three scatters one after the other (+15 %); two features' sums in one
 // 64-bit integer (16 ds_add_u64 instead of 32 ds_add_u32 per row: alone -4 % / -1.5 %, step +-0).
-constexpr int kRows = 256;          // threads per block = rows per tile
-constexpr int kWaves = kRows / NR_WAVE;
+constexpr int kRows = 256;          // rows per tile
+// SPLIT (template parameter of the kernel; NR_TUNE_SHARED_SPLIT): a row's 8 corners shared out to SPLIT threads -- part p of the
+// block = threads [256 p, 256 p + 256) takes corners [p kCpt, p kCpt + kCpt) of row tid & 255.  The table allows one block per CU,
+// and with one thread per row that is ONE wave per SIMD with nothing to hide an LDS round trip behind.  Every part loads the row
+// and computes its cell (cheap, L1 hits); the addends, the segmented scan, the inserts and the adds -- the work -- are split, and
+// there are SPLIT waves per SIMD to overlap.  R6, same box: the kernel by itself 680 -> 558 (2) -> 544 us (4); in the step with the
+// three scatters side by side (one GPU) 2.13 -> 2.25 ms on a fresh model (the proposal scatters speed up, this kernel and the
+// Adam behind it -- the critical path -- fall back) and 2.11 -> 2.03-2.11 after 600 steps; with this scatter by itself first (the
+// data-parallel order: the main table's exchange follows it) 2.39 -> 2.33 fresh, 2.32 -> 2.14-2.22 after 600 steps.  Default: 1
+// beside the other scatters, 2 in the data-parallel order (fused_step sets the knob).
+constexpr int kWaves = kRows / NR_WAVE;  // waves per part
 #ifndef NR_SHARED_SLOTS
 #define NR_SHARED_SLOTS 3840
 #endif
@@ -76,21 +85,25 @@ __device__ unsigned long long g_shared_clocks[8];
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t key) { return __umulhi(key * 2654435761u, (uint32_t)kSlots); }
 
-template <bool MARK>
-__global__ void __launch_bounds__(kRows)
+template <bool MARK, int SPLIT>
+__global__ void __launch_bounds__(kRows * SPLIT)
 scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std, const float* __restrict__ scalings, int L,
                       int log2T, const float* __restrict__ gout, int64_t sl, float* __restrict__ gtable, int64_t n,
                       int64_t n_tiles, unsigned char* __restrict__ seen) {
-  constexpr int F = 4;
+  static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "corners per thread: 8, 4 or 2");
+  constexpr int F = 4, kThreads = kRows * SPLIT, kCpt = 8 / SPLIT;
   __shared__ __attribute__((aligned(16))) uint32_t keys[kSlots];
   __shared__ __attribute__((aligned(16))) uint32_t vals[kPlane * F];
   __shared__ uint16_t occ[kMaxOcc];
   __shared__ uint32_t count[2];
   __shared__ float wmax[kWaves];
-  const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1), wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & (NR_WAVE - 1), rtid = tid & (kRows - 1), part = tid / kRows, wave = rtid >> 6;
   const uint32_t mask = (1u << log2T) - 1u;
-  for (int i = tid; i < kSlots; i += kRows) keys[i] = kEmpty;
-  for (int i = tid; i < kPlane * F; i += kRows) vals[i] = 0u;
+#ifdef NR_SHARED_PRIO
+  __builtin_amdgcn_s_setprio(NR_SHARED_PRIO);
+#endif
+  for (int i = tid; i < kSlots; i += kThreads) keys[i] = kEmpty;
+  for (int i = tid; i < kPlane * F; i += kThreads) vals[i] = 0u;
   if (tid < 2) count[tid] = 0u;
   __syncthreads();
 
@@ -104,7 +117,7 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
   float px[3] = {0.0f, 0.0f, 0.0f}, pstd = 0.0f;
   float4 pg[kMaxLevels];
   auto fetch = [&](int64_t t) {
-    const int64_t row = t * kRows + tid;
+    const int64_t row = t * kRows + rtid;
     const bool in = row < n;
 #pragma unroll
     for (int a = 0; a < 3; ++a) px[a] = in ? x[row * 3 + a] : 0.0f;
@@ -150,8 +163,8 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       // `offset` on the ceil side (encodings.py:434,454-464); floor + 1 is the same vertex wherever its weight is not zero
       // (an integer coordinate has ceil = floor and offset 0: nothing is added on that side either way), and makes the 8
       // entries a function of the CELL alone -- what the merge across lanes below relies on
-      uint32_t idx[8];
-      float w[8];
+      uint32_t idx[kCpt];
+      float w[kCpt];
       int lo[3];
       {
         float o[3];
@@ -163,15 +176,16 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
           o[a] = p - fl;
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const bool hx = c & 1, hy = c & 2, hz = c & 4;
+        for (int c = 0; c < kCpt; ++c) {
+          const int cc = part * kCpt + c;  // (the corner's number: bit 0 / 1 / 2 = the high side in x / y / z)
+          const bool hx = cc & 1, hy = cc & 2, hz = cc & 4;
           idx[c] = nr_hash3(lo[0] + (hx ? 1 : 0), lo[1] + (hy ? 1 : 0), lo[2] + (hz ? 1 : 0), mask);
           w[c] = (hx ? o[0] : 1.0f - o[0]) * (hy ? o[1] : 1.0f - o[1]) * (hz ? o[2] : 1.0f - o[2]);
         }
       }
       // ---- block maximum -> fixed-point scale of (tile, level)
       float vmax = nr_wave_max_to_lane63(live && finite ? mag : 0.0f);
-      if (lane == NR_WAVE - 1) wmax[wave] = vmax;
+      if (lane == NR_WAVE - 1 && part == 0) wmax[wave] = vmax;
       NR_CLK(1)
       lds_barrier();  // A: the wave maxima are visible; the previous unit's flush is complete
       NR_CLK(2)
@@ -187,12 +201,12 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       if (live && !finite) {
         // inf / NaN gradients (an overflowed 16-bit operand upstream): straight to the table, like torch's index_put would
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < kCpt; ++c)
 #pragma unroll
           for (int f = 0; f < F; ++f) unsafeAtomicAdd(base + (int64_t)idx[c] * F + f, g[f] * w[c]);
         if (MARK)
 #pragma unroll
-          for (int c = 0; c < 8; ++c) seen[((int64_t)level << log2T) + idx[c]] = 1;
+          for (int c = 0; c < kCpt; ++c) seen[((int64_t)level << log2T) + idx[c]] = 1;
       }
       // ---- the row's 32 addends in fixed point, then merged across the wave's lanes: neighbouring lanes in ONE cell (camera
       // pixels at a coarse level -- or at every level while a fresh model's samples sit within a metre of the camera; samples
@@ -200,9 +214,9 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       // to the table.  Integer sums: the result is the same whatever is merged where; without the scan 64 lanes of a wave
       // queue on one LDS address (PMC: 4x the bank-conflict cycles of the bin pass, the insert phase 68 % of the kernel).
       const bool ins_row = live && finite;
-      int q[8][F];
+      int q[kCpt][F];
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
+      for (int c = 0; c < kCpt; ++c)
 #pragma unroll
         for (int f = 0; f < F; ++f) q[c][f] = ins_row ? (int)rintf(g[f] * w[c] * fix) : 0;
       int cell[3] = {ins_row ? lo[0] : INT_MIN + lane, ins_row ? lo[1] : INT_MIN + lane, ins_row ? lo[2] : INT_MIN + lane};
@@ -213,7 +227,7 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       if (heads != ~0ull) {  // (uniform) some run is longer than one lane
         int flag = head ? 1 : 0;
         auto scan_step = [&](auto ctrl, auto rowmask) {  // (nr_seg_scan_step: two vector instructions per element and in-row step)
-          nr_seg_scan_step<decltype(ctrl)::value, decltype(rowmask)::value, 8 * F>(&q[0][0], flag, lane);
+          nr_seg_scan_step<decltype(ctrl)::value, decltype(rowmask)::value, kCpt * F>(&q[0][0], flag, lane);
         };
         // (the scan stops once every lane has reached its run's head: the remaining steps would add nothing)
         do {
@@ -239,17 +253,17 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       NR_CLK(6)
       uint32_t nz = 0u;  // bit c: corner c has something to add
 #pragma unroll
-      for (int c = 0; c < 8; ++c) nz |= ((q[c][0] | q[c][1] | q[c][2] | q[c][3]) != 0 ? 1u : 0u) << c;
+      for (int c = 0; c < kCpt; ++c) nz |= ((q[c][0] | q[c][1] | q[c][2] | q[c][3]) != 0 ? 1u : 0u) << c;
       const bool ins = ins_row && tail;
-      uint32_t s[8], old[8];
+      uint32_t s[kCpt], old[kCpt];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < kCpt; ++c) {
         s[c] = slot_of(idx[c]);
         old[c] = (ins && ((nz >> c) & 1u)) ? atomicCAS(&keys[s[c]], kEmpty, idx[c]) : idx[c];  // ds_cmpst_rtn_b32
       }
       uint32_t claimed = 0u;  // bit c: this lane created the slot of corner c
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < kCpt; ++c) {
         const bool act = ins && ((nz >> c) & 1u);
         if (act && old[c] == kEmpty) claimed |= 1u << c;
         if (act && old[c] != kEmpty && old[c] != idx[c]) {  // taken by another vertex: linear probing
@@ -279,10 +293,10 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
         // One returning atomic per wave reserves the span of the list for all 8 corners of all its lanes; inside it the entries
         // go lane-major.  (Corner-major -- neighbouring rays' same-numbered corners, i.e. the vertices of one 64-byte table line, on
         // adjacent lanes of the flush -- was measured 6 % SLOWER per step, same call: 2.44 vs 2.28-2.32 ms.)
-        unsigned long long cm[8];
+        unsigned long long cm[kCpt];
         int total = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < kCpt; ++c) {
           cm[c] = __ballot((claimed >> c) & 1u);
           total += (int)__popcll(cm[c]);
         }
@@ -292,9 +306,9 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
           at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
           const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) at += (uint32_t)__popcll(cm[c] & below);
+          for (int c = 0; c < kCpt; ++c) at += (uint32_t)__popcll(cm[c] & below);
 #pragma unroll
-          for (int c = 0; c < 8; ++c)
+          for (int c = 0; c < kCpt; ++c)
             if ((claimed >> c) & 1u) occ[at++] = (uint16_t)s[c];
         }
       }
@@ -305,23 +319,23 @@ scatter_shared_kernel(const float* __restrict__ x, const float* __restrict__ std
       // reads issued together
       const uint32_t n_items = *cnt * F;
       if (tid == 0) count[(unit + 1u) & 1u] = 0u;  // (the other counter: last read in the previous unit's flush)
-      for (uint32_t item0 = (uint32_t)tid; item0 < n_items; item0 += kRows * 4) {
+      for (uint32_t item0 = (uint32_t)tid; item0 < n_items; item0 += kThreads * 4) {
         uint32_t sc[4], key[4];
         int q[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t item = item0 + (uint32_t)k * kRows;
+          const uint32_t item = item0 + (uint32_t)k * kThreads;
           sc[k] = item < n_items ? occ[item >> 2] : kEmpty;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t f = (item0 + (uint32_t)k * kRows) & 3u;
+          const uint32_t f = (item0 + (uint32_t)k * kThreads) & 3u;
           key[k] = sc[k] != kEmpty ? keys[sc[k]] : 0u;
           q[k] = sc[k] != kEmpty ? (int)vals[f * kPlane + sc[k]] : 0;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const uint32_t f = (item0 + (uint32_t)k * kRows) & 3u;
+          const uint32_t f = (item0 + (uint32_t)k * kThreads) & 3u;
           if (sc[k] == kEmpty) continue;
           vals[f * kPlane + sc[k]] = 0u;
           if (f == 0u) keys[sc[k]] = kEmpty;  // (the 4 lanes of a slot sit in one wave instruction: all have read the key)
@@ -375,9 +389,10 @@ extern "C" int nr_debug_shared_clocks(unsigned long long* out8, int reset) {
 }
 #endif
 
-extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
-                                         const float* grad_out, int64_t sn, int64_t sl, float* grad_table, int64_t n,
-                                         unsigned char* seen_grad, nr_stream_t stream) {
+extern "C" int nr_hash_encode_bwd_shared_split(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                               const float* grad_out, int64_t sn, int64_t sl, float* grad_table, int64_t n,
+                                               unsigned char* seen_grad, int threads_per_row, nr_stream_t stream) {
+  if (threads_per_row != 0 && threads_per_row != 1 && threads_per_row != 2 && threads_per_row != 4) return NR_EINVAL;
   if (n == 0) return 0;
   if (!x || !scalings || !grad_out || !grad_table || n < 0 || L < 1 || L > kMaxLevels || log2T < 1 || log2T > 30) return NR_EINVAL;
   // built for 4-float entries read as one float4 per row and level (the level-major [L, n, 4] gradient of the fused step)
@@ -387,14 +402,25 @@ extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const
   // beats two per CU by 4.5 % per step, same call (2.27 -> 2.17 ms fresh; 384 / 192 / 128 blocks: 2.24 / 2.20 / 2.45 ms)
   const int cap = nr_tuning().shared_blocks > 0 ? nr_tuning().shared_blocks : 256;
   const unsigned blocks = (unsigned)(tiles < cap ? tiles : cap);
-  if (seen_grad != nullptr)
-    hipLaunchKernelGGL(scatter_shared_kernel<true>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,
-                       sl, grad_table, n, tiles, seen_grad);
-  else
-    hipLaunchKernelGGL(scatter_shared_kernel<false>, dim3(blocks), dim3(kRows), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out,
-                       sl, grad_table, n, tiles, seen_grad);
+  int split = threads_per_row;  // (the A/B knob overrides the caller)
+  if (nr_tuning().shared_split == 1 || nr_tuning().shared_split == 2 || nr_tuning().shared_split == 4) split = nr_tuning().shared_split;
+  if (split == 0) split = 1;
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kRows * split), 0, nr_s(stream), x, std, scalings, L, log2T, grad_out, sl, grad_table, n,
+                       tiles, seen_grad);
+  };
+  const bool mark = seen_grad != nullptr;
+  if (split == 1) mark ? launch(scatter_shared_kernel<true, 1>) : launch(scatter_shared_kernel<false, 1>);
+  else if (split == 2) mark ? launch(scatter_shared_kernel<true, 2>) : launch(scatter_shared_kernel<false, 2>);
+  else mark ? launch(scatter_shared_kernel<true, 4>) : launch(scatter_shared_kernel<false, 4>);
   NR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int nr_hash_encode_bwd_shared(const float* x, const float* std, const float* scalings, int L, int F, int log2T,
+                                         const float* grad_out, int64_t sn, int64_t sl, float* grad_table, int64_t n,
+                                         unsigned char* seen_grad, nr_stream_t stream) {
+  return nr_hash_encode_bwd_shared_split(x, std, scalings, L, F, log2T, grad_out, sn, sl, grad_table, n, seen_grad, 0, stream);
 }
 
 extern "C" int nr_hash_mark_vertices(const float* x, const float* scalings, int L, int log2T, int64_t n, uint8_t* stamp, const float* epoch,

@@ -29,6 +29,7 @@ struct NrTuning {
   int pdbwd_blocks;        // NR_TUNE_PDBWD_BLOCKS: blocks of nr_prop_density_bwd
   int adam_blocks;         // NR_TUNE_ADAM_BLOCKS
   int pw_mfma_off;         // NR_TUNE_PW_MFMA_OFF: 1 = the transposed convolution on the generic pointwise kernels
+  int shared_split;        // NR_TUNE_SHARED_SPLIT: threads per row of nr_hash_encode_bwd_shared (1, 2 or 4; 0 = 1)
 };
 const NrTuning& nr_tuning();
 // The device's PARAMETER GENERATION word (capi.hip; allocated by nr_init, NULL before): bumped on the device by every launch that

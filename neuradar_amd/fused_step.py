@@ -775,9 +775,12 @@ class FusedTrainStep:
                             with torch.cuda.stream(adam_s):
                                 optimizers[0].step_buffer(level_pipeline_buffer, 1.0, part=(l_ * T4, (l_ + k_) * T4))
                         return 0
-                    return lib.nr_hash_encode_bwd_shared(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
-                                                         grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
-                                                         p(grid.hash_table.grad), nl, p(mark_seen), sp_)
+                    # threads per row (ABI v28): this scatter BY ITSELF is 18 % faster with two threads sharing a row's 8 corners
+                    # (two waves per SIMD on the one table a CU holds); beside the proposal scatters one thread per row wins
+                    # (same-box step times in grid_shared.hip's header)
+                    return lib.nr_hash_encode_bwd_shared_split(p(self.x01[lvl]), p(self.std[lvl]), p(grid.scalings), grid.num_levels, Fg,
+                                                               grid.log2_hashmap_size, p(self.g_feats[lvl]), Fg, nl * Fg,
+                                                               p(grid.hash_table.grad), nl, p(mark_seen), 2 if order == "main_first" else 1, sp_)
                 if mark_seen is not None and lvl == 2:
                     # the main table's scatter sets the optimizer's `seen` bytes itself: Adam then skips never-touched groups
                     # on the byte alone instead of reading 4 B of gradient per parameter of the whole table (FlatAdam.marked)

@@ -28,21 +28,28 @@ def _addends(x, sc, log2t, live):
     return out
 
 
-def _shared(x, std, sc, log2t, gout_rows, seen=None):
-    """gout_rows [n, L*4] -> grad_table [L << log2t, 4] through nr_hash_encode_bwd_shared (level-major gradient rows)."""
+def _shared(x, std, sc, log2t, gout_rows, seen=None, threads=None):
+    """gout_rows [n, L*4] -> grad_table [L << log2t, 4] through nr_hash_encode_bwd_shared (level-major gradient rows); threads:
+    nr_hash_encode_bwd_shared_split with that many threads per row."""
     from neuradar_amd import ops
 
     n, L = x.shape[0], sc.numel()
     g = gout_rows.view(n, L, 4).permute(1, 0, 2).contiguous()  # [L, n, 4]
     gt = torch.zeros(L << log2t, 4, device=DEV)
     lib, p = ops._lib.lib(), ops._p
-    ops.check(lib.nr_hash_encode_bwd_shared(p(x), p(std), p(sc), L, 4, log2t, p(g), 4, n * 4, p(gt), n, p(seen), ops._stream()), "shared")
+    if threads is None:
+        ops.check(lib.nr_hash_encode_bwd_shared(p(x), p(std), p(sc), L, 4, log2t, p(g), 4, n * 4, p(gt), n, p(seen), ops._stream()), "shared")
+    else:
+        ops.check(lib.nr_hash_encode_bwd_shared_split(p(x), p(std), p(sc), L, 4, log2t, p(g), 4, n * 4, p(gt), n, p(seen), threads, ops._stream()),
+                  "shared_split")
     return gt
 
 
+@pytest.mark.parametrize("threads", [None, 1, 2, 4])
 @pytest.mark.parametrize("case", ["uniform", "one_cell", "ragged_tiny_table", "grid_planes", "runs"])
-def test_shared_scatter_vs_oracle(case):
-    """Against torch.autograd of the oracle's gather.  uniform: distinct cells everywhere (a full table at the fine level);
+def test_shared_scatter_vs_oracle(case, threads):
+    """Against torch.autograd of the oracle's gather; threads: 1 / 2 / 4 threads sharing a row's 8 corners (ABI v28: blocks of 256 /
+    512 / 1 024 threads on the same tile and table), None = the v27 entry point.  uniform: distinct cells everywhere (a full table at the fine level);
     one_cell: all rows in ONE cell (256 lanes on 8 LDS addresses); ragged_tiny_table: n not a multiple of 256, a table of
     512 entries (many vertices share a slot chain); grid_planes: positions on exact cell boundaries (ceil == floor: two
     "corners" are one vertex); runs: runs of rows in one cell.  Tolerance: the kernel's own resolution -- an addend is rounded
@@ -68,7 +75,7 @@ def test_shared_scatter_vs_oracle(case):
     resc = 1.0 / torch.clamp(2.0 * sc[None, :] * std[:, None], min=1.0)  # neurad_encoding.py:309-316
     ref = hashgrid.encode(x, table, sc, 2**log2t).view(n, L, 4) * resc[:, :, None]
     (gref,) = torch.autograd.grad(ref, table, gout.view(n, L, 4))
-    gt = _shared(x.to(DEV), std.to(DEV), sc.to(DEV), log2t, gout.to(DEV)).cpu()
+    gt = _shared(x.to(DEV), std.to(DEV), sc.to(DEV), log2t, gout.to(DEV), threads=threads).cpu()
     # per entry: every addend is rounded to at most 2^-21 of the largest gradient entry (half a unit of 2^(e-21), 2^e the power
     # of two above its tile's largest entry), and the fp32 sums of either side carry ~1e-7 of the addends' magnitude
     n_add = _addends(x.to(DEV), sc.to(DEV), log2t, (gout.view(n, L, 4) != 0).any(dim=2).to(DEV)).cpu().double()[:, None]
@@ -79,8 +86,9 @@ def test_shared_scatter_vs_oracle(case):
     assert not bool(((gt != 0) & (gref == 0)).any()), "an entry was written that no row touches"
 
 
+@pytest.mark.parametrize("threads", [1, 2, 4])
 @pytest.mark.parametrize("rows", ["incoherent", "runs", "patch"])
-def test_shared_scatter_equals_merging_kernel_at_neuradar_size(rows):
+def test_shared_scatter_equals_merging_kernel_at_neuradar_size(rows, threads):
     """NeuRadar's main grid (8 levels x 2^22 entries x 4 floats), gradients with magnitudes over two decades: the two scatter
     implementations agree within the shared kernel's stated bound and to 1e-5 in relative L2; the shared kernel writes no
     entry the merging kernel leaves untouched."""
@@ -104,7 +112,7 @@ def test_shared_scatter_equals_merging_kernel_at_neuradar_size(rows):
     ops.check(lib.nr_hash_encode_bwd(p(x), p(std), p(sc), L, 4, log2t, p(gout), L * 4, 4, p(want), n, 0, st()), "merging")
     n_add = _addends(x, sc, log2t, torch.ones(n, L, dtype=torch.bool, device=DEV)).double()[:, None]
     seen = torch.zeros(L << log2t, device=DEV, dtype=torch.uint8)
-    got = _shared(x, std, sc, log2t, gout, seen=seen)
+    got = _shared(x, std, sc, log2t, gout, seen=seen, threads=threads)
     err = (got - want).abs()
     bound = 1e-4 * want.abs() + (n_add + 1.0) * (2.0 ** -21 + 2e-7) * float(gout.abs().max())
     assert bool((err <= bound).all()), f"{rows}: worst excess {float((err - bound).max()):.3e}"
@@ -172,3 +180,12 @@ def test_shared_scatter_argument_checks_empty_input_and_nonfinite_rows():
     assert lib.nr_hash_encode_bwd_shared(p(x), p(sd), p(sc), L, 4, log2t, p(g3), 4, n * 4, p(gt3), n, None, st()) == 0
     rows_bad = bad.any(dim=1)
     assert_close(gt2[~rows_bad].cpu(), gt3[~rows_bad].cpu(), rtol=1e-5, atol_scale=1e-6, what="finite rows beside non-finite ones")
+    # threads per row (ABI v28): 0 = the library's default, 1 / 2 / 4; anything else is refused; the non-finite rows take the same
+    # way whatever the shape
+    split = lambda t, g_, out: lib.nr_hash_encode_bwd_shared_split(p(x), p(sd), p(sc), L, 4, log2t, p(g_), 4, n * 4, p(out), n, None, t, st())  # noqa: E731
+    assert split(3, g, gt) != 0 and split(8, g, gt) != 0 and split(-1, g, gt) != 0
+    for t in (0, 2, 4):
+        gt4 = torch.zeros_like(gt)
+        assert split(t, g2, gt4) == 0
+        assert bool((~torch.isfinite(gt4) == bad).all())
+        assert_close(gt4[~rows_bad].cpu(), gt3[~rows_bad].cpu(), rtol=1e-5, atol_scale=1e-6, what=f"{t} threads per row: finite rows")
