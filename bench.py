@@ -754,10 +754,6 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
     segmented = 0  # world > 1: graph segments per step (0 = eager launches)
     if use_graph:
         try:
-            # (experiment: the step's own stream -- field backward, main scatter, main Adam: the critical chain -- captured at high
-            # priority, NR_CAPTURE_PRIORITY=-1)
-            cap_pr = int(os.environ.get("NR_CAPTURE_PRIORITY", "0"))
-            cap_stream = torch.cuda.Stream(priority=cap_pr) if cap_pr else None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -775,7 +771,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                 and (args.warmup % unroll == 0 or trained_steps > 0)
             if pair:
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, stream=cap_stream):
+                with torch.cuda.graph(g1):
                     for _ in range(unroll):
                         fwd_bwd()
                 graphs.append(("pair", g1))
@@ -784,7 +780,7 @@ def measure(args, workload, mlp_dtype, rank, world, device, want_roofline, want_
                 for _ in range(2 if slots is not None else 1):
                     k = slots["k"] if slots is not None else 0
                     g1 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1, stream=cap_stream):
+                    with torch.cuda.graph(g1):
                         fwd_bwd()
                     graphs.append((k, g1))
             graphs = dict(graphs)
